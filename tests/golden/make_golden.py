@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE model (/root/reference/net/MP_HSIR.py) on CPU.
+
+Runs only in the build container (the reference tree does not exist on the GPU box).  The
+reference is imported through two tiny stand-ins for packages the image lacks (tests/golden/
+refshim: timm.models.layers and clip); nothing from /root/reference is copied.  Every weight
+comes from tests/golden/detfill.py (crc32(key)-seeded), every input from `seeded_input`, so the
+fixtures hold only *outputs* (plus a few checksums) and stay small.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+The reference is run in float64 (module.double()) and results are stored rounded to float32:
+that is the reference's arithmetic with its own fp32 rounding noise (rel-L2 6e-7)
+removed, which lets the oracle be pinned at 1e-6 instead of 1e-5.  For the two full-width nets the
+plain fp32 run is sampled as well (`*_f32run_first4096`).
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+sys.path.insert(0, os.path.dirname(HERE))  # tests/ -> `golden.detfill`
+sys.path.insert(1, "/root/reference")
+warnings.filterwarnings("ignore")
+
+from golden.detfill import det_fill_, seeded_input, surrogate_clip_prompt  # noqa: E402
+from golden.cases import (TINY_CFG, TINY_CASES, BLOCK_CASES, FULL_CASES, GRAD_KEYS_FULL,  # noqa: E402
+                          sample_indices, cotangent)
+import net.MP_HSIR as ref  # noqa: E402  (the reference)
+
+torch.set_num_threads(8)
+F32 = np.float32
+
+
+def to_np(t):
+    return t.detach().to(torch.float32).cpu().numpy()
+
+
+def build_ref_net(cfg, dtype=torch.float64):
+    net = ref.MP_HSIR_Net(**cfg).eval()
+    det_fill_(net)
+    net = net.to(dtype)
+    net.text_prompt.clip_prompt = net.text_prompt.clip_prompt.to(dtype)
+    return net
+
+
+def task_tensor(task):
+    return torch.tensor(task, dtype=torch.long)
+
+
+def gen_tiny():
+    out = {}
+    nets = {}
+    for name, case in TINY_CASES.items():
+        cfg = dict(TINY_CFG, task_classes=case.get("task_classes", TINY_CFG["task_classes"]))
+        key = cfg["task_classes"]
+        if key not in nets:
+            nets[key] = build_ref_net(cfg)
+        net = nets[key]
+        x = seeded_input(name, case["shape"]).double()
+        with torch.no_grad():
+            y = net(x, task_tensor(case["task"]))
+        out[name + "/out"] = to_np(y)
+        print("tiny", name, tuple(y.shape), float(y.abs().mean()))
+    np.savez_compressed(os.path.join(HERE, "tiny_fwd.npz"), **out)
+
+
+def gen_tiny_grad():
+    """L1-after-clamp loss (train.py:58-61), eval mode (DropPath = identity), all param grads."""
+    net = build_ref_net(TINY_CFG)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    x = seeded_input("grad_x", (2, 8, 64, 64)).double()
+    clean = seeded_input("grad_clean", (2, 8, 64, 64)).double()
+    task = task_tensor([[1], [3]])
+    y = net(x, task)
+    loss = F.l1_loss(torch.clamp(y, 0, 1), clean)
+    loss.backward()
+    out = {"loss": np.array(float(loss)), "out": to_np(y)}
+    none_keys = []
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            none_keys.append(k)
+            continue
+        g = p.grad
+        out["norm/" + k] = np.array(float(g.norm()))
+        out["sum/" + k] = np.array(float(g.sum()))
+        idx = sample_indices(k, g.numel())
+        out["samp/" + k] = g.flatten()[idx].numpy()
+        if any(k.startswith(pref) for pref in GRAD_KEYS_FULL):
+            out["full/" + k] = to_np(g)
+    out["none_keys"] = np.array(none_keys)
+    print("tiny grad: loss", float(loss), "none:", none_keys)
+    np.savez_compressed(os.path.join(HERE, "tiny_grad.npz"), **out)
+
+    # two AdamW steps with the reference's optimizer settings (train.py:69: AdamW(lr) defaults)
+    net = build_ref_net(TINY_CFG)
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-4)
+    out = {}
+    losses = []
+    for step in range(2):
+        xs = seeded_input("adam_x%d" % step, (2, 8, 64, 64)).double()
+        cs = seeded_input("adam_c%d" % step, (2, 8, 64, 64)).double()
+        opt.zero_grad(set_to_none=True)
+        loss = F.l1_loss(torch.clamp(net(xs, task), 0, 1), cs)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    out["losses"] = np.array(losses)
+    ref0 = build_ref_net(TINY_CFG)
+    p0 = dict(ref0.named_parameters())
+    for k, p in net.named_parameters():
+        idx = sample_indices(k, p.numel())
+        out["delta_samp/" + k] = (p.detach() - p0[k].detach()).flatten()[idx].numpy()
+        out["delta_norm/" + k] = np.array(float((p.detach() - p0[k].detach()).norm()))
+    print("tiny adamw losses", losses)
+    np.savez_compressed(os.path.join(HERE, "tiny_adamw.npz"), **out)
+
+
+def gen_blocks():
+    out = {}
+    for name, c in BLOCK_CASES.items():
+        kind = c["kind"]
+        if kind == "pgsstb":
+            m = ref.PGSSTB(dim=c["C"], num_heads=c["heads"], input_resolution=[64, 64], window_size=8,
+                           shift_size=c["shift"], mlp_ratio=2.66, compress_ratio=c["cr"], prompt_len=128,
+                           drop_path=0.0, qkv_bias=True, bias=False).eval()
+            det_fill_(m)
+            m = m.double()
+            x = seeded_input(name, c["shape"], "normal").double().requires_grad_(c.get("grad", False))
+            cap = {}
+            if c.get("intermediates", False):
+                m.attn.register_forward_hook(lambda mod, i, o: cap.__setitem__("sa", o))
+                m.local_spectral_attn.register_forward_hook(lambda mod, i, o: cap.__setitem__("x1", o))
+                m.gobal_spectral_attn.register_forward_hook(lambda mod, i, o: cap.__setitem__("x2", o))
+                m.mlp.register_forward_hook(lambda mod, i, o: cap.__setitem__("mlp", o))
+            if c.get("grad", False):
+                for p in m.parameters():
+                    p.requires_grad_(True)
+                y = m(x)
+                (y * cotangent(name, y.shape).double()).sum().backward()
+                out[name + "/dx"] = to_np(x.grad)
+                for k, p in m.named_parameters():
+                    out[name + "/dparam/" + k] = to_np(p.grad)
+            else:
+                with torch.no_grad():
+                    y = m(x)
+            out[name + "/out"] = to_np(y)
+            for k, v in cap.items():
+                out[name + "/" + k] = to_np(v)
+        elif kind == "tvsp":
+            m = ref.TVSP(task_classes=c["T"], prompt_size=c["ps"], prompt_dim=c["D"], out_dim=c["D"]).eval()
+            det_fill_(m)
+            m = m.double()
+            B = c["shape"][0]
+            x = seeded_input(name, c["shape"], "normal").double()
+            w = F.one_hot(task_tensor(c["task"]), c["T"])
+            clip = (w.unsqueeze(-1) * surrogate_clip_prompt(c["T"]).double().unsqueeze(0)).mean(1)
+            assert clip.shape == (B, 512)
+            with torch.no_grad():
+                y = m(x, clip, w)
+            out[name + "/out"] = to_np(y)
+        elif kind == "fusion":
+            m = ref.PromptFusion(dim=c["D"] * 2, out_dim=c["D"], head=c["heads"]).eval()
+            det_fill_(m)
+            m = m.double()
+            x = seeded_input(name + ":x", c["shape"], "normal").double()
+            p = seeded_input(name + ":p", c["shape"], "normal").double()
+            with torch.no_grad():
+                y = m(x, p)
+            out[name + "/out"] = to_np(y)
+        print("block", name, tuple(y.shape), float(y.abs().mean()))
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **out)
+
+
+def psnr_ref(restored, clean):
+    """Band-wise PSNR as utils/val_utils.py:49-69 defines it (skimage absent: data_range=1 form)."""
+    r = np.clip(restored, 0, 1).astype(np.float64)
+    c = np.clip(clean, 0, 1).astype(np.float64)
+    mse = ((r - c) ** 2).mean(axis=(-1, -2))  # (B,C)
+    return float((10 * np.log10(1.0 / mse)).mean(axis=1).mean())
+
+
+def gen_full():
+    out = {}
+    for name, c in FULL_CASES.items():
+        clean = seeded_input(name + ":clean", c["shape"])
+        if c["recipe"] == "gaussian70":  # dataset_utils.py:293-298, test.py:554
+            degraded = clean + seeded_input(name + ":noise", c["shape"], "normal") * (70.0 / 255.0)
+        else:  # inpaint, dataset_utils.py:743-749: keep where rand > ratio (0.9)
+            mask = (seeded_input(name + ":mask", c["shape"]) > 0.9).float()
+            degraded = clean * mask
+        task = task_tensor(c["task"])
+        net = build_ref_net(c["cfg"])
+        with torch.no_grad():
+            y64 = net(degraded.double(), task)
+        net32 = build_ref_net(c["cfg"], torch.float32)
+        with torch.no_grad():
+            y32 = net32(degraded, task)
+        out[name + "/out"] = to_np(y64)
+        out[name + "/out_f32run_first4096"] = to_np(y32).reshape(-1)[:4096]
+        out[name + "/psnr_restored"] = np.array(psnr_ref(to_np(y64), clean.numpy()))
+        out[name + "/psnr_degraded"] = np.array(psnr_ref(degraded.numpy(), clean.numpy()))
+        rel = float((y64.float() - y32).norm() / y64.norm())
+        print("full", name, tuple(y64.shape), "psnr", out[name + "/psnr_restored"], "f32-vs-f64 rel", rel)
+    np.savez_compressed(os.path.join(HERE, "full.npz"), **out)
+
+
+def gen_keys():
+    """state_dict key/shape/dtype manifests for the two shipped configurations."""
+    import json
+    man = {}
+    for name, c in FULL_CASES.items():
+        net = ref.MP_HSIR_Net(**c["cfg"])
+        man[name] = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()}
+        man[name + ":nparams"] = sum(p.numel() for p in net.parameters())
+    net = ref.MP_HSIR_Net(**TINY_CFG)
+    man["tiny"] = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()}
+    with open(os.path.join(HERE, "state_dict_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["keys", "tiny", "grad", "blocks", "full"]
+    if "keys" in which:
+        gen_keys()
+    if "tiny" in which:
+        gen_tiny()
+    if "grad" in which:
+        gen_tiny_grad()
+    if "blocks" in which:
+        gen_blocks()
+    if "full" in which:
+        gen_full()
