@@ -1,0 +1,79 @@
+"""ctypes binding of libmphsir.so (include/mphsir.h).  No CPU fallback: if the HIP library is
+missing or does not load, every op raises -- build it with ``python mp-hsir_amd/build.py``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "libmphsir.so")
+_lib = None
+_is_emu = False
+
+c_void_p, c_int64, c_int32, c_int, c_float_p = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int,
+                                                ctypes.POINTER(ctypes.c_float))
+
+
+class GemmArgs(ctypes.Structure):
+    """mirror of struct mphsir_gemm_args"""
+    _fields_ = [("X", c_void_p), ("ldx", c_int64), ("W", c_void_p), ("w_batch_stride", c_int64),
+                ("rows_per_batch", c_int64), ("bias", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p),
+                ("Y", c_void_p), ("ldy", c_int64), ("M", c_int64), ("N", c_int64), ("K", c_int64),
+                ("epi", c_int), ("R", c_void_p), ("ldr", c_int64), ("SA", c_void_p), ("ldsa", c_int64),
+                ("gate", c_void_p), ("keep", c_void_p), ("H", c_int32), ("Wimg", c_int32), ("shift", c_int32)]
+
+
+_SYMBOLS = {
+    # name: (restype, argtypes)
+    "mphsir_version": (ctypes.c_char_p, []),
+    "mphsir_last_error": (ctypes.c_char_p, []),
+    "mphsir_device_arch": (c_int, [ctypes.c_char_p, c_int]),
+    "mphsir_kernel_name": (ctypes.c_char_p, [c_int]),
+    "mphsir_prof_enable": (c_int, [c_int]),
+    "mphsir_prof_read": (c_int, [ctypes.POINTER(c_int), c_float_p]),
+    "mphsir_gemm_tok": (c_int, [ctypes.POINTER(GemmArgs), c_int, c_void_p]),
+}
+
+
+def symbols():
+    """Every entry point include/mphsir.h declares (checked by tests/test_cabi.py)."""
+    return sorted(_SYMBOLS)
+
+
+def _bind(lib):
+    for name, (res, args) in _SYMBOLS.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load(path=None):
+    """Load (once) and return the library.  Raises RuntimeError if it cannot be loaded."""
+    global _lib, _is_emu
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _PATH
+    if not os.path.exists(p):
+        raise RuntimeError("mp-hsir_amd: HIP library %s not found -- run `python mp-hsir_amd/build.py` "
+                           "(there is no CPU fallback)" % p)
+    try:
+        lib = _bind(ctypes.CDLL(p))
+    except (OSError, AttributeError) as e:
+        raise RuntimeError("mp-hsir_amd: cannot load %s: %s" % (p, e))
+    _lib = lib
+    _is_emu = path is not None and "hipemu" in os.path.abspath(path)
+    return _lib
+
+
+def use_library_for_tests(path):
+    """TESTS ONLY: bind the ops to another build of the same sources (tests/hipemu)."""
+    return load(path)
+
+
+def is_emulated():
+    return _is_emu
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("mp-hsir_amd: %s failed (%d): %s" % (what, rc, load().mphsir_last_error().decode()))

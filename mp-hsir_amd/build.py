@@ -1,0 +1,65 @@
+"""Builds libmphsir.so (the C-ABI HIP library) for gfx950 with hipcc, in-tree.
+
+    python mp-hsir_amd/build.py            # -> mp-hsir_amd/libmphsir.so
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the .so is
+git-ignored but travels to the GPU box with the working tree.  Objects are cached per source on
+(mtime of the source and of every header).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libmphsir.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "mphsir.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, objdir, hdr_mtime, verbose):
+    obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_mtime):
+        return obj
+    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-8000:]))
+    if verbose and r.stderr.strip():
+        print(r.stderr[-4000:])
+    return obj
+
+
+def build(verbose=True, jobs=6):
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hm = _headers_mtime()
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, objdir, hm, verbose), srcs))
+    if os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(o) for o in objs):
+        return OUT
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-8000:])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(verbose="-q" not in sys.argv))

@@ -1,0 +1,91 @@
+// libmphsir: version / error text / launch timer.
+#include <string.h>
+
+#include <vector>
+
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+void clear_error() { g_err[0] = 0; }
+
+struct ProfLog {
+    int kid = -1;
+    std::vector<hipEvent_t> pool;   // start/stop pairs, reused
+    size_t used = 0;
+};
+static ProfLog g_prof;
+
+void prof_before(int kid, hipStream_t s) {
+    if (kid != g_prof.kid) return;
+    if (g_prof.used + 2 > g_prof.pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        g_prof.pool.push_back(a);
+        g_prof.pool.push_back(b);
+    }
+    (void)hipEventRecord(g_prof.pool[g_prof.used], s);
+}
+void prof_after(int kid, hipStream_t s) {
+    if (kid != g_prof.kid || g_prof.used + 2 > g_prof.pool.size()) return;
+    (void)hipEventRecord(g_prof.pool[g_prof.used + 1], s);
+    g_prof.used += 2;
+}
+
+}  // namespace mphsir
+
+extern "C" {
+
+const char* mphsir_version(void) { return "1.0.0-gfx950"; }
+const char* mphsir_last_error(void) { return mphsir::g_err; }
+
+int mphsir_device_arch(char* buf, int n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (!buf || n <= 0) return MPHSIR_EINVAL;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        mphsir::set_error("device_arch: no HIP device");
+        return MPHSIR_ELAUNCH;
+    }
+    strncpy(buf, prop.gcnArchName, (size_t)n - 1);
+    buf[n - 1] = 0;
+    return MPHSIR_OK;
+}
+
+const char* mphsir_kernel_name(int kid) {
+    static const char* names[] = {"gemm_tok", "win_attn", "dwconv_gram", "spectral_fold", "gated_mlp", "dwconv_gate"};
+    return (kid >= 0 && kid < (int)(sizeof(names) / sizeof(names[0]))) ? names[kid] : "?";
+}
+
+int mphsir_prof_enable(int kid) {
+    mphsir::g_prof.kid = kid;
+    mphsir::g_prof.used = 0;
+    return MPHSIR_OK;
+}
+
+int mphsir_prof_read(int* launches, float* total_ms) {
+    using mphsir::g_prof;
+    float sum = 0.f;
+    int n = 0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.pool[i + 1]) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, g_prof.pool[i], g_prof.pool[i + 1]) != hipSuccess) continue;
+        sum += ms;
+        ++n;
+    }
+    g_prof.used = 0;
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = sum;
+    return MPHSIR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+// gemm_tok: Y[M][N] = epi( pro(X)[M][K] @ W[N][K]^T ) on channels-last token matrices.
+//
+// Every 1x1 conv / Linear of the MP-HSIR path that is not inside a larger fused kernel goes through
+// here (reference call sites listed in include/mphsir.h).  One 256-thread workgroup computes a
+// 64-token x 64-channel tile: the token rows are staged through LDS in K-chunks (optionally
+// LayerNorm-ed on the way in), each wave owns one 16-channel column tile and streams its weight
+// rows straight from L2 as MFMA fragments (weights are tiny and shared by every workgroup), the
+// fp32 accumulators are staged through LDS so the epilogue and the global stores run on whole
+// 16-byte vectors along the channel axis.
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+constexpr int GT_BM = 64, GT_BN = 64, GT_KC = 64;
+
+struct GemmDev {
+    const void* X; long ldx;
+    const void* W; long wbs; long rpb;
+    const float* bias; const float* ln_w; const float* ln_b;
+    void* Y; long ldy;
+    int M, N, K;
+    const void* R; long ldr;
+    const void* SA; long ldsa;
+    const float* gate; const float* keep;
+    int H, Wimg, shift;
+};
+
+template <class T, int EPI, bool LN>
+__global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
+    typedef ElemTraits<T> TR;
+    constexpr int PAD = 16 / sizeof(T);
+    constexpr int LDA = GT_KC + PAD;
+    constexpr int LDC = GT_BN + 4;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)                                     // 16-byte aligned base
+    unsigned char* smem = reinterpret_cast<unsigned char*>(smem_v);
+    T* As = reinterpret_cast<T*>(smem);                                   // [64][LDA]
+    float* Cs = reinterpret_cast<float*>(smem);                           // [64][LDC] (aliases As)
+    float* stat = reinterpret_cast<float*>(smem + 64 * LDC * sizeof(float));   // mean[64], rstd[64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m0 = blockIdx.x * GT_BM, n0 = blockIdx.y * GT_BN;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* W = reinterpret_cast<const T*>(a.W) + (a.wbs ? (long)(m0 / a.rpb) * a.wbs : 0);
+    const int K = a.K;
+
+    if (LN) {   // per-row mean / rstd over K (two passes over the row; second pass hits L1/L2)
+        for (int r = wv * 16; r < wv * 16 + 16; ++r) {
+            const T* row = X + (long)(m0 + r) * a.ldx;
+            float s = 0.f;
+            for (int k = lane; k < K; k += 64) s += to_f32(row[k]);
+            const float mean = wave_sum(s) / (float)K;
+            float q = 0.f;
+            for (int k = lane; k < K; k += 64) { float d = to_f32(row[k]) - mean; q += d * d; }
+            const float var = wave_sum(q) / (float)K;
+            if (lane == 0) { stat[r] = mean; stat[64 + r] = rsqrtf(var + 1e-5f); }
+        }
+        __syncthreads();
+    }
+
+    const int ntile = n0 + wv * 16;            // this wave's 16 output channels
+    const bool active = ntile < a.N;           // wave-uniform
+    f32x4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int VEC = Vec16<T>::N;
+    for (int k0 = 0; k0 < K; k0 += GT_KC) {
+        const int kc = (K - k0) < GT_KC ? (K - k0) : GT_KC;    // 32 or 64
+        const int vpr = kc / VEC;                              // vectors per row
+        for (int v = tid; v < 64 * vpr; v += 256) {
+            const int r = v / vpr, c = (v % vpr) * VEC;
+            Vec16<T> x = load16<T>(X + (long)(m0 + r) * a.ldx + k0 + c);
+            if (LN) {
+                const float mean = stat[r], rstd = stat[64 + r];
+                for (int i = 0; i < VEC; ++i)
+                    x.set(i, (x.get(i) - mean) * rstd * a.ln_w[k0 + c + i] + a.ln_b[k0 + c + i]);
+            }
+            store16<T>(As + r * LDA + c, x);
+        }
+        __syncthreads();
+        if (active) {
+            for (int kk = 0; kk < kc; kk += TR::KCHUNK) {
+                const typename TR::frag_t wf = load_frag<T>(W, K, ntile, k0 + kk);
+                for (int mt = 0; mt < 4; ++mt) mma(acc[mt], load_frag<T>(As, LDA, mt * 16, kk), wf);
+            }
+        }
+        __syncthreads();
+    }
+
+    // accumulators -> LDS (fp32): lane holds rows (lane>>4)*4+r of tile mt, column lane&15
+    if (active)
+        for (int mt = 0; mt < 4; ++mt)
+            for (int r = 0; r < 4; ++r) Cs[(mt * 16 + (lane >> 4) * 4 + r) * LDC + wv * 16 + (lane & 15)] = acc[mt][r];
+    __syncthreads();
+
+    T* Y = reinterpret_cast<T*>(a.Y);
+    const T* R = reinterpret_cast<const T*>(a.R);
+    const T* SA = reinterpret_cast<const T*>(a.SA);
+    constexpr int G = GT_BN / VEC;
+    for (int idx = tid; idx < 64 * G; idx += 256) {
+        const int r = idx / G, c = (idx % G) * VEC, n = n0 + c, m = m0 + r;
+        if (n >= a.N) continue;
+        Vec16<T> out, res, sa;
+        if (EPI >= 1) res = load16<T>(R + (long)m * a.ldr + n);
+        float kf = 1.f;
+        const float* g = nullptr;
+        if (EPI == 2) {
+            sa = load16<T>(SA + (long)m * a.ldsa + n);
+            const int hw = a.H * a.Wimg, b = m / hw, p = m % hw, y = p / a.Wimg, x = p % a.Wimg;
+            const int ys = (y - a.shift + a.H) % a.H, xs = (x - a.shift + a.Wimg) % a.Wimg;   // shifted-frame coords
+            g = a.gate + ((long)b * (hw / 64) + (ys >> 3) * (a.Wimg >> 3) + (xs >> 3)) * a.N + n;
+            if (a.keep) kf = a.keep[b];
+        }
+        for (int i = 0; i < VEC; ++i) {
+            float v = Cs[r * LDC + c + i];
+            if (a.bias) v += a.bias[n + i];
+            if (EPI == 1) v += res.get(i);
+            if (EPI == 2) v = res.get(i) + kf * (sa.get(i) * g[i] + v);
+            out.set(i, v);
+        }
+        store16<T>(Y + (long)m * a.ldy + n, out);
+    }
+}
+
+template <class T, int EPI, bool LN>
+static int launch_gemm(const GemmDev& d, hipStream_t s) {
+    dim3 grid(d.M / GT_BM, (d.N + GT_BN - 1) / GT_BN);
+    const size_t shmem = 64 * (GT_BN + 4) * sizeof(float) + 128 * sizeof(float);
+    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TOK, (gemm_tok_kernel<T, EPI, LN>), grid, dim3(256), shmem, s, d);
+    return MPHSIR_OK;
+}
+
+template <class T>
+static int dispatch_gemm(const GemmDev& d, int epi, bool ln, hipStream_t s) {
+    switch (epi * 2 + (ln ? 1 : 0)) {
+        case 0: return launch_gemm<T, 0, false>(d, s);
+        case 1: return launch_gemm<T, 0, true>(d, s);
+        case 2: return launch_gemm<T, 1, false>(d, s);
+        case 3: return launch_gemm<T, 1, true>(d, s);
+        case 4: return launch_gemm<T, 2, false>(d, s);
+        case 5: return launch_gemm<T, 2, true>(d, s);
+    }
+    return MPHSIR_EINVAL;
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->X && a->W && a->Y, "gemm_tok: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "gemm_tok: dtype %d unsupported", dtype);
+    const int esz = dtype == MPHSIR_F32 ? 4 : 2;
+    MPHSIR_REQUIRE(a->M > 0 && a->M % 64 == 0, "gemm_tok: M=%lld must be a positive multiple of 64", (long long)a->M);
+    MPHSIR_REQUIRE(a->N > 0 && a->N % 16 == 0, "gemm_tok: N=%lld must be a multiple of 16", (long long)a->N);
+    MPHSIR_REQUIRE(a->K > 0 && a->K % 32 == 0, "gemm_tok: K=%lld must be a multiple of 32", (long long)a->K);
+    MPHSIR_REQUIRE(a->epi >= 0 && a->epi <= 2, "gemm_tok: epi %d unknown", a->epi);
+    MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->W) && aligned16(a->Y) && (a->ldx * esz) % 16 == 0 &&
+                       (a->ldy * esz) % 16 == 0, "gemm_tok: X/W/Y must be 16-byte aligned with 16-byte row pitch");
+    MPHSIR_REQUIRE((a->ln_w == nullptr) == (a->ln_b == nullptr), "gemm_tok: ln_w and ln_b go together");
+    if (a->epi >= 1)
+        MPHSIR_REQUIRE(a->R && aligned16(a->R) && (a->ldr * esz) % 16 == 0, "gemm_tok: epi %d needs an aligned R", a->epi);
+    if (a->epi == 2) {
+        MPHSIR_REQUIRE(a->SA && a->gate && aligned16(a->SA) && (a->ldsa * esz) % 16 == 0, "gemm_tok: epi 2 needs SA and gate");
+        MPHSIR_REQUIRE(a->H > 0 && a->Wimg > 0 && a->H % 8 == 0 && a->Wimg % 8 == 0 && a->M % ((int64_t)a->H * a->Wimg) == 0,
+                       "gemm_tok: epi 2 needs H,W multiples of 8 with M = B*H*W");
+        MPHSIR_REQUIRE(a->shift == 0 || a->shift == 4, "gemm_tok: shift must be 0 or 4");
+    }
+    if (a->w_batch_stride)
+        MPHSIR_REQUIRE(a->rows_per_batch > 0 && a->rows_per_batch % 64 == 0, "gemm_tok: rows_per_batch must be a multiple of 64");
+    GemmDev d{a->X, (long)a->ldx, a->W, (long)a->w_batch_stride, (long)a->rows_per_batch, a->bias, a->ln_w, a->ln_b,
+              a->Y, (long)a->ldy, (int)a->M, (int)a->N, (int)a->K, a->R, (long)a->ldr, a->SA, (long)a->ldsa,
+              a->gate, a->keep, a->H, a->Wimg, a->shift};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == MPHSIR_F32 ? dispatch_gemm<float>(d, a->epi, a->ln_w != nullptr, s)
+                               : dispatch_gemm<bf16_t>(d, a->epi, a->ln_w != nullptr, s);
+}

@@ -1,0 +1,112 @@
+// Device-side building blocks shared by every kernel of libmphsir (gfx950 / CDNA4 only).
+//
+//  * element types: float (exact-f32 parity path, v_mfma_f32_16x16x4_f32) and __bf16 (throughput
+//    path, v_mfma_f32_16x16x32_bf16); every kernel is a template over T and accumulates in fp32.
+//  * one MFMA "fragment" is 16 bytes per lane for both types: lane l holds elements
+//    k0 + EPL*(l>>4) .. +EPL-1 of row (l&15) of a K-contiguous operand.  For bf16 that is the
+//    native A/B map of the 16x16x32 instruction; for f32 the 4 elements feed 4 chained 16x16x4
+//    instructions (the k order inside a 16-wide chunk is permuted identically for A and B, which
+//    a dot product does not care about).
+//  * C/D map (both types): lane l holds D[(l>>4)*4 + r][l&15], r = 0..3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mphsir {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+constexpr int WAVE = 64;
+
+template <class T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    typedef f32x4 frag_t;     // 4 f32 per lane
+    typedef f32x4 vec4_t;     // 4 consecutive elements
+    static constexpr int EPL = 4;        // elements per lane per fragment
+    static constexpr int KCHUNK = 16;    // K covered by one fragment pair
+    static constexpr int DTYPE = 0;
+};
+template <> struct ElemTraits<bf16_t> {
+    typedef bf16x8 frag_t;
+    typedef bf16x4 vec4_t;
+    static constexpr int EPL = 8;
+    static constexpr int KCHUNK = 32;
+    static constexpr int DTYPE = 1;
+};
+
+template <class T> __device__ __forceinline__ constexpr int round_up_k(int k) {
+    return (k + ElemTraits<T>::KCHUNK - 1) / ElemTraits<T>::KCHUNK * ElemTraits<T>::KCHUNK;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// 16-byte fragment of a K-contiguous row-major operand (LDS or global): row0 + (lane&15), k0 + EPL*(lane>>4).
+template <class T>
+__device__ __forceinline__ typename ElemTraits<T>::frag_t load_frag(const T* base, int ld, int row0, int k0) {
+    const int l = lane_id();
+    const T* p = base + (size_t)(row0 + (l & 15)) * ld + k0 + ElemTraits<T>::EPL * (l >> 4);
+    return *reinterpret_cast<const typename ElemTraits<T>::frag_t*>(p);
+}
+
+// acc[16x16] += A-frag (rows of the first operand) x B-frag (rows of the second operand), over KCHUNK.
+__device__ __forceinline__ void mma(f32x4& acc, bf16x8 a, bf16x8 b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x4& acc, f32x4 a, f32x4 b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+template <class T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+template <class T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+
+// store 4 consecutive elements (from an accumulator column) -- 8 B (bf16) / 16 B (f32) aligned.
+template <class T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+    bf16x4 o;
+    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// 16-byte vector of T (8 bf16 / 4 f32) <-> fp32 registers, for coalesced global/LDS traffic.
+template <class T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+template <class T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <class T> __device__ __forceinline__ void store16(T* p, const Vec16<T>& x) {
+    *reinterpret_cast<decltype(x.v)*>(p) = x.v;
+}
+
+// exact (erf) GELU, the reference's nn.GELU()/F.gelu default.
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// wave-wide reductions by xor shuffles over the lanes selected by `mask_bits` (e.g. 1|2 = 4 lanes).
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+}  // namespace mphsir

@@ -1,0 +1,47 @@
+// Host-side plumbing shared by the C-ABI entry points: argument checks, error text, the optional
+// per-kernel launch timer, and the launch macro.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/mphsir.h"
+
+namespace mphsir {
+
+void set_error(const char* fmt, ...);
+void clear_error();
+
+// launch timer (mphsir_prof_*): brackets launches of one kernel id with events on the launch stream
+void prof_before(int kid, hipStream_t s);
+void prof_after(int kid, hipStream_t s);
+
+#define MPHSIR_REQUIRE(cond, ...)          \
+    do {                                   \
+        if (!(cond)) {                     \
+            mphsir::set_error(__VA_ARGS__); \
+            return MPHSIR_EINVAL;          \
+        }                                  \
+    } while (0)
+
+// Launches `kern` (a __global__ function, already instantiated) and reports launch errors.
+#define MPHSIR_LAUNCH(kid, kern, grid, block, shmem, stream, ...)                                   \
+    do {                                                                                            \
+        mphsir::prof_before(kid, stream);                                                           \
+        hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);                          \
+        mphsir::prof_after(kid, stream);                                                            \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) {                                                                     \
+            mphsir::set_error("%s: launch failed: %s", mphsir_kernel_name(kid), hipGetErrorString(e_)); \
+            return MPHSIR_ELAUNCH;                                                                  \
+        }                                                                                           \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// dynamic LDS above 64 KiB must be opted into per kernel function
+template <class K> inline void allow_big_lds(K kern, size_t bytes) {
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace mphsir
