@@ -70,6 +70,53 @@ typedef struct mphsir_gemm_args {
 } mphsir_gemm_args;
 int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* stream);
 
+/* ---- fused LayerNorm + shifted 8x8 window attention + local spectral-prompt gate -----------------
+ * Replaces, inside PGSSTB.forward (net/MP_HSIR.py:662-713): norm1 (:667), torch.roll(-shift) (:672),
+ * window_partition (:21-30,:677), Spatial_Attention.forward (:193-218) incl. the relative-position
+ * bias gather (:200-203) and the calculate_mask shift mask (:639-660, -100 across regions),
+ * window_reverse + roll(+shift) (:690-696), and the gate of PG_Spectral_Attention.forward (:132-152).
+ * X, SA: (B,H,W,C) channels-last cubes; SA = window-attention output back in image order.
+ * gate: [B*nW][C] fp32, one row per window in shifted-frame window order (window_partition order);
+ *       the reference's x1 is SA * gate[window] (:153), applied by mphsir_gemm_tok epi 2.
+ * Wqkv [3C][C] (attn.qkv.weight), bqkv [3C]; rpb = relative_position_bias_table [225][heads] fp32;
+ * Wproj [C][heads*HDP]: attn.proj.weight with every head's hd input columns zero-padded to
+ * HDP = mphsir_win_attn_hdp(hd, dtype); the spectral-prompt weights are the fp32 parameters as stored:
+ * Wprompt [128][C], prompt_param [128][r], Wq [r][r], Wkv [2r][r], Wdown [r][C], Wpproj [r][r] + bpproj
+ * [r], Wup [C][r].  H, W multiples of 8; shift 0 or 4; (C, C/heads) in {(32,32),(64,32),(64,64),
+ * (128,32),(128,64),(256,32),(96,48),(192,48),(192,96),(384,48)}.                                  */
+typedef struct mphsir_win_attn_args {
+    const void* X;
+    const float* ln_w; const float* ln_b;
+    const void* Wqkv; const float* bqkv;
+    const float* rpb;
+    const void* Wproj; const float* bproj;
+    const float* Wprompt; const float* prompt_param; const float* Wq; const float* Wkv;
+    const float* Wdown; const float* Wpproj; const float* bpproj; const float* Wup;
+    void* SA; float* gate;
+    int32_t B, H, W, C, heads, shift, r;
+} mphsir_win_attn_args;
+int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream);
+int mphsir_win_attn_hdp(int head_dim, int dtype);
+
+/* ---- fused LayerNorm + gated MLP + residual --------------------------------------------------
+ * Y = X + keep[b] * ( fc2( value * gelu_erf(gate) ) + b2 ),  [value|gate] = fc1(LayerNorm(X)) + b1
+ * Replaces PGSSTB's `x + drop_path(self.mlp(self.norm2(x)))` (net/MP_HSIR.py:719; GatedMlp :66-82:
+ * FIRST half of fc1 is the value, SECOND half goes through GELU; nn.LayerNorm :619).
+ * W1 is [2*HP][C]: rows 0..hid-1 = fc1.weight[0:hid] (value), rows HP..HP+hid-1 = fc1.weight[hid:2hid]
+ * (gate), everything else zero; b1 [2*HP] likewise; W2 is [C][HP] = fc2.weight zero-padded along K.
+ * HP = hid rounded up to a multiple of 32.  C in {32,64,96,128,192,256,384}; M % 64 == 0.
+ * Y may alias X.                                                                                 */
+typedef struct mphsir_mlp_args {
+    const void* X; int64_t ldx;
+    const float* ln_w; const float* ln_b;
+    const void* W1; const float* b1;
+    const void* W2; const float* b2;
+    const float* keep; int64_t rows_per_batch;   /* DropPath factor per sample, or NULL */
+    void* Y; int64_t ldy;
+    int64_t M; int32_t C, HP;
+} mphsir_mlp_args;
+int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream);
+
 /* ---- optional per-kernel launch timer (bench.py roofline leg) ----------------------------------
  * When enabled for kernel id `kid`, every launch of that kernel is bracketed by hipEvents on its
  * own stream.  read(): synchronises the recorded events, returns the number of launches and their

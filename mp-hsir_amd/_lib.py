@@ -22,6 +22,20 @@ class GemmArgs(ctypes.Structure):
                 ("gate", c_void_p), ("keep", c_void_p), ("H", c_int32), ("Wimg", c_int32), ("shift", c_int32)]
 
 
+class MlpArgs(ctypes.Structure):
+    """mirror of struct mphsir_mlp_args"""
+    _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("W1", c_void_p),
+                ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p), ("keep", c_void_p), ("rows_per_batch", c_int64),
+                ("Y", c_void_p), ("ldy", c_int64), ("M", c_int64), ("C", c_int32), ("HP", c_int32)]
+
+
+class WinAttnArgs(ctypes.Structure):
+    """mirror of struct mphsir_win_attn_args"""
+    _fields_ = [(n, c_void_p) for n in ("X", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "Wproj", "bproj", "Wprompt",
+                                         "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup", "SA", "gate")] + \
+               [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift", "r")]
+
+
 _SYMBOLS = {
     # name: (restype, argtypes)
     "mphsir_version": (ctypes.c_char_p, []),
@@ -31,6 +45,9 @@ _SYMBOLS = {
     "mphsir_prof_enable": (c_int, [c_int]),
     "mphsir_prof_read": (c_int, [ctypes.POINTER(c_int), c_float_p]),
     "mphsir_gemm_tok": (c_int, [ctypes.POINTER(GemmArgs), c_int, c_void_p]),
+    "mphsir_win_attn_fwd": (c_int, [ctypes.POINTER(WinAttnArgs), c_int, c_void_p]),
+    "mphsir_win_attn_hdp": (c_int, [c_int, c_int]),
+    "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
 }
 
 

@@ -1,0 +1,179 @@
+// gated_mlp_fwd: Y = X + keep * ( fc2( value * gelu(gate) ) ),  [value|gate] = fc1( LayerNorm(X) )
+//
+// The whole second half of a PGSSTB block (net/MP_HSIR.py:719 with GatedMlp :66-82 and norm2 :619)
+// in one kernel: the 2*hid-wide hidden activation never leaves the CU.  One 256-thread workgroup
+// owns 64 tokens; the LayerNorm-ed rows sit in LDS; each wave owns 16 tokens and walks the hidden
+// dimension in chunks of 32: two MFMA passes give value/gate for the chunk (D[hid][tok] layout, so
+// four consecutive hidden units of one token are one lane's accumulator -> gate applied in
+// registers, one 8/16-byte LDS store), then the chunk is immediately consumed as the K-slice of
+// fc2 into C/16 persistent fp32 accumulator tiles.  Weights stream from L2 as MFMA fragments.
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+struct MlpDev {
+    const void* X; long ldx;
+    const float* ln_w; const float* ln_b;
+    const void* W1; const float* b1;     // [2*HP][C], [2*HP]  (value rows then gate rows, zero padded)
+    const void* W2; const float* b2;     // [C][HP], [C]
+    const float* keep; long rpb;
+    void* Y; long ldy;
+    int M, HP;
+};
+
+template <class T, int C>
+__global__ __launch_bounds__(256) void gated_mlp_kernel(MlpDev a) {
+    typedef ElemTraits<T> TR;
+    typedef typename TR::frag_t frag_t;
+    constexpr int PAD = 16 / sizeof(T);
+    constexpr int LDX = C + PAD;
+    constexpr int LDH = 32 + PAD;
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NCT = C / 16;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    T* Xs = reinterpret_cast<T*>(smem_v);               // [64][LDX]  LN(x); later the output stage
+    T* Hs = Xs + 64 * LDX;                              // [4][16][LDH] per-wave hidden chunk
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m0 = blockIdx.x * 64;
+    const T* X = reinterpret_cast<const T*>(a.X);
+
+    // ---- LayerNorm into LDS: 4 adjacent lanes per token ------------------------------------
+    {
+        constexpr int NV = C / VEC;            // 16-byte vectors per row
+        constexpr int VPT = NV / 4;            // vectors per thread
+        const int r = tid >> 2, q = tid & 3;
+        const T* row = X + (long)(m0 + r) * a.ldx;
+        Vec16<T> xv[VPT];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            xv[i] = load16<T>(row + (q + 4 * i) * VEC);
+            for (int e = 0; e < VEC; ++e) s += xv[i].get(e);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            for (int e = 0; e < VEC; ++e) { float d = xv[i].get(e) - mean; d2 += d * d; }
+        d2 += __shfl_xor(d2, 1);
+        d2 += __shfl_xor(d2, 2);
+        const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
+            store16<T>(Xs + r * LDX + c0, o);
+        }
+    }
+    __syncthreads();
+
+    const T* W1 = reinterpret_cast<const T*>(a.W1);
+    const T* W2 = reinterpret_cast<const T*>(a.W2);
+    T* Hw = Hs + wv * 16 * LDH;
+    const int HP = a.HP;
+    f32x4 out[NCT];
+#pragma unroll
+    for (int i = 0; i < NCT; ++i) out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int j = 0; j < HP; j += 32) {
+        // fc1 for hidden units j..j+31 (value) and HP+j.. (gate), this wave's 16 tokens
+        f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0}, g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+#pragma unroll 4
+        for (int kk = 0; kk < C; kk += TR::KCHUNK) {
+            const frag_t bx = load_frag<T>(Xs, LDX, wv * 16, kk);
+            mma(v0, load_frag<T>(W1, C, j, kk), bx);
+            mma(v1, load_frag<T>(W1, C, j + 16, kk), bx);
+            mma(g0, load_frag<T>(W1, C, HP + j, kk), bx);
+            mma(g1, load_frag<T>(W1, C, HP + j + 16, kk), bx);
+        }
+        // lane: token lane&15, hidden rows (lane>>4)*4 + r
+        const int hr = (lane >> 4) * 4;
+        f32x4 h0, h1;
+        for (int r = 0; r < 4; ++r) {
+            h0[r] = (v0[r] + a.b1[j + hr + r]) * gelu_erf(g0[r] + a.b1[HP + j + hr + r]);
+            h1[r] = (v1[r] + a.b1[j + 16 + hr + r]) * gelu_erf(g1[r] + a.b1[HP + j + 16 + hr + r]);
+        }
+        store4<T>(Hw + (lane & 15) * LDH + hr, h0);
+        store4<T>(Hw + (lane & 15) * LDH + 16 + hr, h1);
+        __syncthreads();
+        // fc2 K-slice: out[co][tok] += W2[co][j..j+31] * H[tok][0..31]
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += TR::KCHUNK) {
+            const frag_t bh = load_frag<T>(Hw, LDH, 0, kk);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) mma(out[ct], load_frag<T>(W2, HP, ct * 16, j + kk), bh);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: (acc + b2) -> LDS stage (this wave's own rows), then coalesced residual + store
+    {
+        const int tok = wv * 16 + (lane & 15), cr = (lane >> 4) * 4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x4 o = out[ct];
+            for (int r = 0; r < 4; ++r) o[r] += a.b2[ct * 16 + cr + r];
+            store4<T>(Xs + tok * LDX + ct * 16 + cr, o);
+        }
+    }
+    __syncthreads();
+    T* Y = reinterpret_cast<T*>(a.Y);
+    constexpr int NV = C / VEC;
+    for (int idx = tid; idx < 64 * NV; idx += 256) {
+        const int r = idx / NV, c0 = (idx % NV) * VEC, m = m0 + r;
+        const float kf = a.keep ? a.keep[m / a.rpb] : 1.f;
+        const Vec16<T> x = load16<T>(X + (long)m * a.ldx + c0);
+        const Vec16<T> h = load16<T>(Xs + r * LDX + c0);
+        Vec16<T> o;
+        for (int e = 0; e < VEC; ++e) o.set(e, x.get(e) + kf * h.get(e));
+        store16<T>(Y + (long)m * a.ldy + c0, o);
+    }
+}
+
+template <class T, int C>
+static int launch_mlp(const MlpDev& d, hipStream_t s) {
+    constexpr int PAD = 16 / sizeof(T);
+    const size_t shmem = (64 * (C + PAD) + 4 * 16 * (32 + PAD)) * sizeof(T);
+    allow_big_lds(gated_mlp_kernel<T, C>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_kernel<T, C>), dim3(d.M / 64), dim3(256), shmem, s, d);
+    return MPHSIR_OK;
+}
+
+template <class T>
+static int dispatch_mlp(const MlpDev& d, int C, hipStream_t s) {
+    switch (C) {
+        case 32: return launch_mlp<T, 32>(d, s);
+        case 64: return launch_mlp<T, 64>(d, s);
+        case 96: return launch_mlp<T, 96>(d, s);
+        case 128: return launch_mlp<T, 128>(d, s);
+        case 192: return launch_mlp<T, 192>(d, s);
+        case 256: return launch_mlp<T, 256>(d, s);
+        case 384: return launch_mlp<T, 384>(d, s);
+    }
+    set_error("gated_mlp: C=%d not instantiated (32,64,96,128,192,256,384)", C);
+    return MPHSIR_EINVAL;
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->X && a->Y && a->W1 && a->W2 && a->b1 && a->b2 && a->ln_w && a->ln_b, "gated_mlp: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "gated_mlp: dtype %d unsupported", dtype);
+    const int esz = dtype == MPHSIR_F32 ? 4 : 2;
+    MPHSIR_REQUIRE(a->M > 0 && a->M % 64 == 0, "gated_mlp: M must be a positive multiple of 64");
+    MPHSIR_REQUIRE(a->HP > 0 && a->HP % 32 == 0, "gated_mlp: padded hidden width must be a multiple of 32");
+    MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->Y) && aligned16(a->W1) && aligned16(a->W2) &&
+                       (a->ldx * esz) % 16 == 0 && (a->ldy * esz) % 16 == 0, "gated_mlp: 16-byte alignment required");
+    if (a->keep) MPHSIR_REQUIRE(a->rows_per_batch > 0, "gated_mlp: keep needs rows_per_batch");
+    MlpDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->W1, a->b1, a->W2, a->b2, a->keep,
+             (long)(a->rows_per_batch > 0 ? a->rows_per_batch : a->M), a->Y, (long)a->ldy, (int)a->M, a->HP};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == MPHSIR_F32 ? dispatch_mlp<float>(d, a->C, s) : dispatch_mlp<bf16_t>(d, a->C, s);
+}

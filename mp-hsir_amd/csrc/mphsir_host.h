@@ -41,7 +41,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // dynamic LDS above 64 KiB must be opted into per kernel function
 template <class K> inline void allow_big_lds(K kern, size_t bytes) {
-    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 }  // namespace mphsir

@@ -1,0 +1,365 @@
+// win_attn_fwd: LayerNorm -> cyclic shift -> 8x8 window MSA -> proj, plus the local spectral-prompt gate.
+//
+// Replaces, per PGSSTB block (net/MP_HSIR.py:662-713): norm1 (:667), torch.roll (:672),
+// window_partition (:677), Spatial_Attention.forward (:193-218: qkv Linear, q*scale, QK^T,
+// relative-position bias gather, -100 shift mask, softmax, AV, proj), window_reverse + roll back
+// (:690-696) and the gate of PG_Spectral_Attention.forward (:132-152; the final `out*shortcut`
+// multiply, :153, is folded into gemm_tok's epilogue 2).
+//
+// One 256-thread workgroup = one window (64 tokens).  Roll/partition/reverse are address arithmetic
+// on the channels-last cube; the shift mask is computed from coordinates (no mask tensor).  Per head:
+//   (a) q,k [tok][hd] and v^T [hd][tok] by MFMA from the LN-ed tile in LDS (weights from L2);
+//   (b) S^T = K Q^T so that one lane owns one query column: softmax = in-lane max/sum over 16
+//       values + two xor-shuffles; P goes to LDS as the B operand of
+//   (c) O^T = V^T P^T, stored as [tok][hd], which is (d) the K-slice of the output projection,
+//       accumulated over heads in C/16 persistent fp32 tiles per wave.
+// After (a) every step is wave-local (wave w owns query rows 16w..16w+15).
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+struct WinAttnDev {
+    const void* X;
+    const float* ln_w; const float* ln_b;
+    const void* Wqkv; const float* bqkv;
+    const float* rpb;
+    const void* Wproj; const float* bproj;
+    const float* Wprompt; const float* Pp; const float* Wq; const float* Wkv; const float* Wdown;
+    const float* Wpproj; const float* bpproj; const float* Wup;
+    void* SA; float* gate;
+    int B, H, W, shift, r;
+};
+
+template <class T, int C, int HD> struct WinAttnCfg {
+    static constexpr int PAD = 16 / sizeof(T);
+    static constexpr int HEADS = C / HD;
+    static constexpr int HDP = (HD + ElemTraits<T>::KCHUNK - 1) / ElemTraits<T>::KCHUNK * ElemTraits<T>::KCHUNK;
+    static constexpr int LDX = C + (64 * (C + PAD) * sizeof(T) > 98304 ? 0 : PAD);   // drop the pad when LDS is tight
+    static constexpr int LDQ = HDP + PAD;
+    static constexpr int LDV = 64 + PAD;
+    static constexpr int LDP = 64 + PAD;
+    static constexpr size_t XS = 64 * LDX, QS = 64 * LDQ, VS = HD * LDV, PS = 64 * LDP;
+    static constexpr size_t T_ELEMS = XS + 2 * QS + VS + PS;
+    static constexpr size_t F_WORDS = 225 + 64;                      // bias column of one head, region ids
+    static constexpr size_t BYTES = T_ELEMS * sizeof(T) + F_WORDS * 4;
+    static_assert(BYTES <= 160 * 1024, "window-attention tile does not fit LDS");
+    static_assert((C + 128 + 8 * 32) * 4 <= 2 * QS * sizeof(T), "PG scratch must fit in the q/k tiles");
+    static_assert(C % 32 == 0 && HD % 16 == 0 && C % HD == 0, "unsupported width");
+};
+
+template <class T, int C, int HD>
+__global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
+    typedef ElemTraits<T> TR;
+    typedef typename TR::frag_t frag_t;
+    typedef WinAttnCfg<T, C, HD> CF;
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NCT = C / 16;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    T* Xs = reinterpret_cast<T*>(smem_v);
+    T* Qs = Xs + CF::XS;
+    T* Ks = Qs + CF::QS;
+    T* Vt = Ks + CF::QS;
+    T* Ps = Vt + CF::VS;
+    float* rpbs = reinterpret_cast<float*>(Ps + CF::PS);
+    int* reg = reinterpret_cast<int*>(rpbs + 225);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nwx = a.W >> 3, nW = (a.H >> 3) * nwx;
+    const int b = blockIdx.x / nW, wi = blockIdx.x % nW, wy = wi / nwx, wx = wi % nwx;
+    const T* X = reinterpret_cast<const T*>(a.X);
+
+    // token t=(ty,tx) of this window sits at shifted-frame (wy*8+ty, wx*8+tx) = image ((..+shift)%H, (..+shift)%W)
+    auto pixel_of = [&](int t) -> long {
+        const int ys = wy * 8 + (t >> 3), xs = wx * 8 + (t & 7);
+        const int y = (ys + a.shift) % a.H, x = (xs + a.shift) % a.W;
+        return ((long)b * a.H + y) * a.W + x;
+    };
+
+    // ---- LayerNorm(norm1) of the 64 tokens into LDS; 4 adjacent lanes per token -----------------
+    {
+        constexpr int NV = C / VEC, VPT = NV / 4;
+        const int t = tid >> 2, q = tid & 3;
+        const T* row = X + pixel_of(t) * C;
+        Vec16<T> xv[VPT];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            xv[i] = load16<T>(row + (q + 4 * i) * VEC);
+            for (int e = 0; e < VEC; ++e) s += xv[i].get(e);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            for (int e = 0; e < VEC; ++e) { float d = xv[i].get(e) - mean; d2 += d * d; }
+        d2 += __shfl_xor(d2, 1);
+        d2 += __shfl_xor(d2, 2);
+        const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
+            store16<T>(Xs + t * CF::LDX + c0, o);
+        }
+        if (tid < 64) {   // region id of token tid in the shifted frame (calculate_mask, :639-660)
+            const int ys = wy * 8 + (tid >> 3), xs = wx * 8 + (tid & 7);
+            const int ry = (ys >= a.H - 8) + (ys >= a.H - 4), rx = (xs >= a.W - 8) + (xs >= a.W - 4);
+            reg[tid] = a.shift ? 3 * ry + rx : 0;
+        }
+        if (CF::HDP != HD)   // zero the K-padding columns of q / k (= O) once
+            for (int i = tid; i < 2 * 64 * (CF::HDP - HD); i += 256) {
+                const int rr = i / (CF::HDP - HD), cc = HD + i % (CF::HDP - HD);
+                Qs[rr * CF::LDQ + cc] = from_f32<T>(0.f);   // rr in [0,128): Qs and Ks are contiguous
+            }
+    }
+
+    const T* Wqkv = reinterpret_cast<const T*>(a.Wqkv);
+    const T* Wp = reinterpret_cast<const T*>(a.Wproj);
+    const float scale = rsqrtf((float)HD);
+    f32x4 out[NCT];
+#pragma unroll
+    for (int i = 0; i < NCT; ++i) out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int h = 0; h < CF::HEADS; ++h) {
+        __syncthreads();   // Xs ready (h=0) / previous head's K, V^T, bias column no longer read
+        if (tid < 225) rpbs[tid] = a.rpb[tid * CF::HEADS + h];
+        // ---- (a) q, k, v^T for head h ---------------------------------------------------------
+        constexpr int TPW = HD / 16;                 // channel tiles per q/k/v
+        for (int u = wv; u < 3 * TPW * 2; u += 4) {
+            const int ct = u >> 1, th = u & 1, which = ct / TPW, cti = ct % TPW;
+            const int wrow = which * C + h * HD + cti * 16;
+            f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+            if (which < 2) {
+#pragma unroll 4
+                for (int kk = 0; kk < C; kk += TR::KCHUNK) {
+                    const frag_t wf = load_frag<T>(Wqkv, C, wrow, kk);
+                    mma(c0, wf, load_frag<T>(Xs, CF::LDX, th * 32, kk));
+                    mma(c1, wf, load_frag<T>(Xs, CF::LDX, th * 32 + 16, kk));
+                }
+                const int cr = cti * 16 + (lane >> 4) * 4;        // 4 consecutive channels of the head
+                const float sc = which == 0 ? scale : 1.f;
+                for (int r = 0; r < 4; ++r) {
+                    const float bb = a.bqkv[wrow + (lane >> 4) * 4 + r];
+                    c0[r] = (c0[r] + bb) * sc;
+                    c1[r] = (c1[r] + bb) * sc;
+                }
+                T* dst = which == 0 ? Qs : Ks;
+                store4<T>(dst + (th * 32 + (lane & 15)) * CF::LDQ + cr, c0);
+                store4<T>(dst + (th * 32 + 16 + (lane & 15)) * CF::LDQ + cr, c1);
+            } else {
+#pragma unroll 4
+                for (int kk = 0; kk < C; kk += TR::KCHUNK) {
+                    const frag_t wf = load_frag<T>(Wqkv, C, wrow, kk);
+                    mma(c0, load_frag<T>(Xs, CF::LDX, th * 32, kk), wf);
+                    mma(c1, load_frag<T>(Xs, CF::LDX, th * 32 + 16, kk), wf);
+                }
+                const float bb = a.bqkv[wrow + (lane & 15)];
+                for (int r = 0; r < 4; ++r) { c0[r] += bb; c1[r] += bb; }
+                T* vrow = Vt + (cti * 16 + (lane & 15)) * CF::LDV + (lane >> 4) * 4;   // 4 consecutive tokens
+                store4<T>(vrow + th * 32, c0);
+                store4<T>(vrow + th * 32 + 16, c1);
+            }
+        }
+        __syncthreads();
+
+        // ---- (b) S^T = K Q^T for this wave's 16 queries, + bias + mask, softmax over keys --------
+        f32x4 s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < CF::HDP; kk += TR::KCHUNK) {
+            const frag_t qf = load_frag<T>(Qs, CF::LDQ, wv * 16, kk);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) mma(s[kt], load_frag<T>(Ks, CF::LDQ, kt * 16, kk), qf);
+        }
+        const int qi = wv * 16 + (lane & 15), qy = qi >> 3, qx = qi & 7, qreg = reg[qi];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+            for (int r = 0; r < 4; ++r) {
+                const int kj = kt * 16 + (lane >> 4) * 4 + r;
+                float v = s[kt][r] + rpbs[(qy - (kj >> 3) + 7) * 15 + (qx - (kj & 7) + 7)];
+                if (reg[kj] != qreg) v += -100.0f;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+            for (int r = 0; r < 4; ++r) { const float e = expf(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 p = s[kt];
+            for (int r = 0; r < 4; ++r) p[r] *= inv;
+            store4<T>(Ps + qi * CF::LDP + kt * 16 + (lane >> 4) * 4, p);
+        }
+        __syncthreads();
+
+        // ---- (c) O^T = V^T P^T -> O [tok][hd] (over the q tile rows of this wave) ---------------
+#pragma unroll
+        for (int ct = 0; ct < TPW; ++ct) {
+            f32x4 o = {0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 64; kk += TR::KCHUNK)
+                mma(o, load_frag<T>(Vt, CF::LDV, ct * 16, kk), load_frag<T>(Ps, CF::LDP, wv * 16, kk));
+            store4<T>(Qs + qi * CF::LDQ + ct * 16 + (lane >> 4) * 4, o);
+        }
+        __syncthreads();
+
+        // ---- (d) out[co][tok] += Wproj[co][h*hd + :] * O[tok][:] -------------------------------
+#pragma unroll
+        for (int kk = 0; kk < CF::HDP; kk += TR::KCHUNK) {
+            const frag_t of = load_frag<T>(Qs, CF::LDQ, wv * 16, kk);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                mma(out[ct], load_frag<T>(Wp, CF::HEADS * CF::HDP, ct * 16, h * CF::HDP + kk), of);
+        }
+    }
+    __syncthreads();
+
+    // ---- proj bias, stage the 64 x C output tile in LDS (reusing the X tile) --------------------
+    {
+        const int tok = wv * 16 + (lane & 15), cr = (lane >> 4) * 4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x4 o = out[ct];
+            for (int r = 0; r < 4; ++r) o[r] += a.bproj[ct * 16 + cr + r];
+            store4<T>(Xs + tok * CF::LDX + ct * 16 + cr, o);
+        }
+    }
+    __syncthreads();
+    T* SA = reinterpret_cast<T*>(a.SA);
+    {
+        constexpr int NV = C / VEC;
+        for (int idx = tid; idx < 64 * NV; idx += 256) {
+            const int t = idx / NV, c0 = (idx % NV) * VEC;
+            store16<T>(SA + pixel_of(t) * C + c0, load16<T>(Xs + t * CF::LDX + c0));
+        }
+    }
+
+    // ---- local spectral-prompt gate (PG_Spectral_Attention, :132-152), fp32, tiny ----------------
+    float* mu = reinterpret_cast<float*>(Qs);     // [C]
+    float* lg = mu + C;                           // [128] prompt logits -> weights
+    float* sm = lg + 128;                         // small vectors, 32 floats apart
+    const int r = a.r;
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < 64; ++t) acc += to_f32(Xs[t * CF::LDX + c]);
+        mu[c] = acc * (1.0f / 64.0f);
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += a.Wprompt[tid * C + c] * mu[c];
+        lg[tid] = acc;
+    } else if (tid < 128 + r) {                   // d = linear_down(mu)
+        const int i = tid - 128;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += a.Wdown[i * C + c] * mu[c];
+        sm[32 + i] = acc;
+    }
+    __syncthreads();
+    if (wv == 0) {                                // softmax over the 128 prompt logits
+        const float l0 = lg[lane], l1 = lg[lane + 64];
+        float m = fmaxf(l0, l1);
+        for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float tot = wave_sum(e0 + e1);
+        lg[lane] = e0 / tot;
+        lg[lane + 64] = e1 / tot;
+    }
+    __syncthreads();
+    if (tid < r) {                                // s = w^T P
+        float acc = 0.f;
+        for (int p = 0; p < 128; ++p) acc += lg[p] * a.Pp[p * r + tid];
+        sm[tid] = acc;
+    } else if (tid >= 64 && tid < 64 + 2 * r) {   // kv = Wkv d
+        const int i = tid - 64;
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += a.Wkv[i * r + j] * sm[32 + j];
+        sm[64 + i] = acc;                         // k at sm[64..64+r), v at sm[64+r..64+2r)
+    }
+    __syncthreads();
+    if (tid < r) {                                // q = Wq s
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += a.Wq[tid * r + j] * sm[j];
+        sm[128 + tid] = acc;
+    }
+    __syncthreads();
+    if (tid < r) {                                // o_i = sum_j softmax_j(q_i k_j r^-1/2) v_j
+        const float qs = sm[128 + tid] * rsqrtf((float)r);
+        float m = -3.0e38f;
+        for (int j = 0; j < r; ++j) m = fmaxf(m, qs * sm[64 + j]);
+        float den = 0.f, num = 0.f;
+        for (int j = 0; j < r; ++j) { const float e = expf(qs * sm[64 + j] - m); den += e; num += e * sm[64 + r + j]; }
+        sm[160 + tid] = num / den;
+    }
+    __syncthreads();
+    if (tid < r) {                                // o2 = proj(o)
+        float acc = a.bpproj[tid];
+        for (int j = 0; j < r; ++j) acc += a.Wpproj[tid * r + j] * sm[160 + j];
+        sm[192 + tid] = acc;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {          // g = linear_up(o2)
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += a.Wup[c * r + j] * sm[192 + j];
+        a.gate[(long)blockIdx.x * C + c] = acc;
+    }
+}
+
+template <class T, int C, int HD>
+static int launch_win(const WinAttnDev& d, hipStream_t s) {
+    const size_t shmem = WinAttnCfg<T, C, HD>::BYTES;
+    allow_big_lds(win_attn_kernel<T, C, HD>, shmem);
+    const int nblk = d.B * (d.H / 8) * (d.W / 8);
+    MPHSIR_LAUNCH(MPHSIR_K_WIN_ATTN, (win_attn_kernel<T, C, HD>), dim3(nblk), dim3(256), shmem, s, d);
+    return MPHSIR_OK;
+}
+
+template <class T>
+static int dispatch_win(const WinAttnDev& d, int C, int HD, hipStream_t s) {
+#define MPHSIR_WIN_CASE(c, hd) if (C == c && HD == hd) return launch_win<T, c, hd>(d, s);
+    MPHSIR_WIN_CASE(32, 32) MPHSIR_WIN_CASE(64, 32) MPHSIR_WIN_CASE(64, 64) MPHSIR_WIN_CASE(128, 32)
+    MPHSIR_WIN_CASE(128, 64) MPHSIR_WIN_CASE(256, 32)
+    MPHSIR_WIN_CASE(96, 48) MPHSIR_WIN_CASE(192, 48) MPHSIR_WIN_CASE(192, 96) MPHSIR_WIN_CASE(384, 48)
+#undef MPHSIR_WIN_CASE
+    set_error("win_attn: (C=%d, head_dim=%d) not instantiated", C, HD);
+    return MPHSIR_EINVAL;
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_win_attn_hdp(int head_dim, int dtype) {
+    const int kc = dtype == MPHSIR_F32 ? 16 : 32;
+    return (head_dim + kc - 1) / kc * kc;
+}
+
+extern "C" int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->X && a->SA && a->gate && a->Wqkv && a->bqkv && a->rpb && a->Wproj && a->bproj && a->ln_w && a->ln_b,
+                   "win_attn: null pointer");
+    MPHSIR_REQUIRE(a->Wprompt && a->prompt_param && a->Wq && a->Wkv && a->Wdown && a->Wpproj && a->bpproj && a->Wup,
+                   "win_attn: null spectral-prompt weight");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "win_attn: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->H % 8 == 0 && a->W % 8 == 0, "win_attn: H,W must be multiples of 8");
+    MPHSIR_REQUIRE(a->shift == 0 || a->shift == 4, "win_attn: shift must be 0 or 4");
+    MPHSIR_REQUIRE(a->heads > 0 && a->C % a->heads == 0, "win_attn: C %% heads != 0");
+    MPHSIR_REQUIRE(a->r > 0 && a->r <= 32, "win_attn: low-rank width r=%d out of range (1..32)", a->r);
+    MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->SA) && aligned16(a->Wqkv) && aligned16(a->Wproj), "win_attn: 16-byte alignment required");
+    WinAttnDev d{a->X, a->ln_w, a->ln_b, a->Wqkv, a->bqkv, a->rpb, a->Wproj, a->bproj, a->Wprompt, a->prompt_param,
+                 a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->SA, a->gate, a->B, a->H, a->W, a->shift, a->r};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == MPHSIR_F32 ? dispatch_win<float>(d, a->C, a->C / a->heads, s)
+                               : dispatch_win<bf16_t>(d, a->C, a->C / a->heads, s);
+}

@@ -67,3 +67,75 @@ def gemm_tok(x, w, bias=None, ln=None, epi=0, res=None, sa=None, gate=None, keep
         a.H, a.Wimg, a.shift = geom
     _lib.check(lib.mphsir_gemm_tok(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gemm_tok")
     return y
+
+
+def round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+def pack_gated_mlp(fc1_w, fc1_b, fc2_w, dtype):
+    """(W1 [2*HP][C], b1 [2*HP] fp32, W2 [C][HP]) in the padded layout mphsir_gated_mlp_fwd reads."""
+    two_hid, C = fc1_w.shape
+    hid = two_hid // 2
+    HP = round_up(hid, 32)
+    W1 = torch.zeros((2 * HP, C), dtype=dtype, device=fc1_w.device)
+    W1[:hid] = fc1_w[:hid].to(dtype)
+    W1[HP:HP + hid] = fc1_w[hid:].to(dtype)
+    b1 = torch.zeros((2 * HP,), dtype=torch.float32, device=fc1_w.device)
+    b1[:hid] = fc1_b[:hid]
+    b1[HP:HP + hid] = fc1_b[hid:]
+    W2 = torch.zeros((C, HP), dtype=dtype, device=fc1_w.device)
+    W2[:, :hid] = fc2_w.to(dtype)
+    return W1, b1, W2
+
+
+def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, out=None):
+    """x (M,C) row-major view -> x + keep * mlp(LN(x)); weights from pack_gated_mlp."""
+    lib = _lib.load()
+    _check(x, W1, W2, b1, b2, ln_w, ln_b, keep)
+    M, ldx = _rows(x)
+    C = x.shape[1]
+    HP = W2.shape[1]
+    assert W1.shape == (2 * HP, C) and W1.dtype == x.dtype and W2.dtype == x.dtype
+    y = out if out is not None else torch.empty((M, C), dtype=x.dtype, device=x.device)
+    a = _lib.MlpArgs()
+    a.X, a.ldx, a.ln_w, a.ln_b = _p(x), ldx, _p(ln_w), _p(ln_b)
+    a.W1, a.b1, a.W2, a.b2 = _p(W1), _p(b1), _p(W2), _p(b2)
+    a.keep, a.rows_per_batch = _p(keep), rows_per_batch
+    a.Y, a.ldy, a.M, a.C, a.HP = _p(y), _rows(y)[1], M, C, HP
+    _lib.check(lib.mphsir_gated_mlp_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gated_mlp_fwd")
+    return y
+
+
+def pack_win_proj(proj_w, heads, dtype):
+    """attn.proj.weight (C, C) -> [C][heads*HDP] with each head's input columns zero-padded to HDP."""
+    C = proj_w.shape[0]
+    hd = C // heads
+    hdp = _lib.load().mphsir_win_attn_hdp(hd, _DT[dtype])
+    if hdp == hd:
+        return proj_w.to(dtype).contiguous()
+    out = torch.zeros((C, heads, hdp), dtype=dtype, device=proj_w.device)
+    out[:, :, :hd] = proj_w.reshape(C, heads, hd).to(dtype)
+    return out.reshape(C, heads * hdp)
+
+
+def win_attn_fwd(x, ln_w, ln_b, Wqkv, bqkv, rpb, Wproj, bproj, pg, heads, shift):
+    """x (B,H,W,C) contiguous.  pg = dict of the fp32 local_spectral_attn parameters.
+    Returns (sa (B,H,W,C), gate (B*nW, C) fp32)."""
+    lib = _lib.load()
+    _check(x, Wqkv, Wproj, *pg.values())
+    B, H, W, C = x.shape
+    assert x.is_contiguous() and Wqkv.shape == (3 * C, C) and Wqkv.dtype == x.dtype and Wproj.dtype == x.dtype
+    sa = torch.empty_like(x)
+    gate = torch.empty((B * (H // 8) * (W // 8), C), dtype=torch.float32, device=x.device)
+    a = _lib.WinAttnArgs()
+    a.X, a.ln_w, a.ln_b = _p(x), _p(ln_w), _p(ln_b)
+    a.Wqkv, a.bqkv, a.rpb, a.Wproj, a.bproj = _p(Wqkv), _p(bqkv), _p(rpb), _p(Wproj), _p(bproj)
+    a.Wprompt, a.prompt_param = _p(pg["linear_prompt.weight"]), _p(pg["prompt_param"])
+    a.Wq, a.Wkv, a.Wdown = _p(pg["q.weight"]), _p(pg["kv.weight"]), _p(pg["linear_down.weight"])
+    a.Wpproj, a.bpproj, a.Wup = _p(pg["proj.weight"]), _p(pg["proj.bias"]), _p(pg["linear_up.weight"])
+    a.SA, a.gate = _p(sa), _p(gate)
+    a.B, a.H, a.W, a.C, a.heads, a.shift = B, H, W, C, heads, shift
+    a.r = pg["linear_down.weight"].shape[0]
+    _lib.check(lib.mphsir_win_attn_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "win_attn_fwd")
+    return sa, gate

@@ -58,3 +58,61 @@ def test_gemm_tok_per_sample_combine(dtype):
     gimg = torch.roll(O.from_windows(gw, B, H, W), shifts=(shift, shift), dims=(1, 2))
     ref = res.double().reshape(B, H, W, C) + keep.double().reshape(B, 1, 1, 1) * (sa.double().reshape(B, H, W, C) * gimg + acc)
     assert rel_l2(y.reshape(B, H, W, C), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,hid", [(32, 85), (96, 255), (128, 340)])
+def test_gated_mlp(dtype, C, hid):
+    from mp_hsir_amd import ops
+    M = 128
+    x = rnd((M, C), 1, dtype)
+    P = {"fc1.weight": rnd((2 * hid, C), 2, scale=C ** -0.5), "fc1.bias": 0.1 * rnd((2 * hid,), 3),
+         "fc2.weight": rnd((C, hid), 4, scale=hid ** -0.5), "fc2.bias": 0.1 * rnd((C,), 5)}
+    lnw, lnb = 1 + 0.1 * rnd((C,), 6), 0.1 * rnd((C,), 7)
+    keep = torch.tensor([1.0, 1.5])
+    W1, b1, W2 = ops.pack_gated_mlp(P["fc1.weight"], P["fc1.bias"], P["fc2.weight"], dtype)
+    y = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, P["fc2.bias"], keep=keep, rows_per_batch=64)
+    Pd = {k: (v.to(dtype) if k.endswith("weight") else v).double() for k, v in P.items()}
+    xn = O.layer_norm_c(x.double(), lnw.double(), lnb.double())
+    ref = x.double() + keep.double().repeat_interleave(64)[:, None] * O.gated_mlp(Pd, "", xn)
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+def _block_params(manifest_entry, prefix, seed_shift=0):
+    from util import params_from_manifest
+    return params_from_manifest(manifest_entry, prefix, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("man,prefix,heads,shift,shape", [
+    ("tiny", "encoder_level1.blocks.1.", 1, 4, (1, 16, 24, 32)),
+    ("natural_mode0", "encoder_level1.blocks.1.", 2, 4, (2, 16, 16, 64)),
+    ("natural_mode0", "refinement.blocks.0.", 2, 0, (1, 8, 16, 128)),
+    ("remote_mode8", "encoder_level1.blocks.1.", 2, 4, (1, 16, 8, 96)),
+])
+def test_win_attn(dtype, man, prefix, heads, shift, shape, manifest):
+    from mp_hsir_amd import ops
+    P = _block_params(manifest[man], prefix)
+    B, H, W, C = shape
+    x = rnd(shape, 11, dtype)
+    wq = P["attn.qkv.weight"].to(dtype)
+    wp = P["attn.proj.weight"].to(dtype)
+    pg = {k[len("local_spectral_attn."):]: v.contiguous() for k, v in P.items() if k.startswith("local_spectral_attn.")}
+    pg["prompt_param"] = pg["prompt_param"].reshape(128, -1).contiguous()
+    sa, gate = ops.win_attn_fwd(x, P["norm1.weight"], P["norm1.bias"], wq, P["attn.qkv.bias"],
+                                P["attn.relative_position_bias_table"], ops.pack_win_proj(P["attn.proj.weight"], heads, dtype),
+                                P["attn.proj.bias"], pg, heads, shift)
+    # oracle on the same (dtype-rounded) weights, fp64 arithmetic
+    Pd = {k: v.double() for k, v in P.items()}
+    Pd["attn.qkv.weight"], Pd["attn.proj.weight"] = wq.double(), wp.double()
+    xn = O.layer_norm_c(x.double(), Pd["norm1.weight"], Pd["norm1.bias"])
+    if shift:
+        xn = torch.roll(xn, (-4, -4), (1, 2))
+    mask = O.shift_mask(H, W, torch.float64) if shift else None
+    saw = O.spatial_attention(Pd, "attn.", O.to_windows(xn), heads, mask)
+    g_ref = O.pg_spectral_gate(Pd, "local_spectral_attn.", saw)
+    sa_ref = O.from_windows(saw, B, H, W)
+    if shift:
+        sa_ref = torch.roll(sa_ref, (4, 4), (1, 2))
+    assert rel_l2(sa, sa_ref) < TOL[dtype] * (2 if dtype == torch.bfloat16 else 1)
+    assert rel_l2(gate, g_ref) < TOL[dtype] * (4 if dtype == torch.bfloat16 else 1)
