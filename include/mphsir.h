@@ -98,6 +98,50 @@ typedef struct mphsir_win_attn_args {
 int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream);
 int mphsir_win_attn_hdp(int head_dim, int dtype);
 
+/* ---- global "spectral" channel attention: pass A, fold, (pass B = mphsir_gemm_tok) ----------------
+ * Reference: Spectral_Attention.forward (net/MP_HSIR.py:96-114) == Attention.forward (:301-322,
+ * dup :406-427) and CrossAttention.forward (:234-249).  With t = conv1x1(x) computed by
+ * mphsir_gemm_tok, mphsir_dwconv_gram applies the depthwise 3x3 (qkv_dwconv / q_dwconv / kv_dwconv),
+ * writes v, and reduces q,k over the pixels into per-workgroup partials of the per-head Gram
+ * G_h = q_h k_h^T (hd x hd) and of sum(q^2), sum(k^2) -- q and k never reach HBM.
+ * Tq/Tk/Tv: row-major [B*H*W][ld*] views of the 1x1-conv output whose first channel is the first
+ * q / k / v channel (self-attention: t, t+C, t+2C with ld = 3C; cross attention: two tensors).
+ * wq/wk/wv: the matching depthwise taps as fp32 [9][ldw] (tap-major, channel-contiguous).
+ * V: [B*H*W][ldvo].  Gpart: [B][nsplit][heads][hd][hd] fp32, Spart: [B][nsplit][2][C] fp32;
+ * nsplit (workgroups per sample) must divide H*W/64.  Deterministic: no atomics.
+ * mphsir_spectral_fold: per (sample, head) sums the partials in split order, applies F.normalize
+ * (eps 1e-12, :104-105), temperature (:107), row softmax (:108) and folds project_out (:113):
+ * M[b] = Wo * blockdiag_h(softmax(...)), written as [B][C][C] in the compute dtype -- the per-sample
+ * weight of the pass-B mphsir_gemm_tok over V.  (C, C/heads) as for win_attn plus (32,16),(64,16),(128,16). */
+typedef struct mphsir_gram_args {
+    const void* Tq; int64_t ldq; const void* Tk; int64_t ldk; const void* Tv; int64_t ldv;
+    const float* wq; const float* wk; const float* wv; int64_t ldw;
+    void* V; int64_t ldvo;
+    float* Gpart; float* Spart;
+    int32_t B, H, W, C, heads, nsplit;
+} mphsir_gram_args;
+int mphsir_dwconv_gram(const mphsir_gram_args* a, int dtype, void* stream);
+typedef struct mphsir_fold_args {
+    const float* Gpart; const float* Spart;
+    const float* temperature;   /* [heads] */
+    const float* Wo;            /* project_out.weight [C][C] fp32 */
+    void* M;                    /* [B][C][C] compute dtype */
+    int32_t B, C, heads, nsplit;
+} mphsir_fold_args;
+int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* stream);
+
+/* ---- depthwise 3x3 + GELU gate of the GDFN feed-forward ------------------------------------------
+ * U[:, c] = gelu_erf(dw(T)[:, c]) * dw(T)[:, HP + c]   (FFN/FeedForward.forward :261-263, :387-389:
+ * gelu on the FIRST half).  T [B*H*W][2*HP] (ldt), w9 fp32 [9][2*HP] (ldw), U [B*H*W][HP] (ldu);
+ * HP = hidden width zero-padded to a multiple of 32 on both halves.                                */
+typedef struct mphsir_gate_args {
+    const void* T; int64_t ldt;
+    const float* w9; int64_t ldw;
+    void* U; int64_t ldu;
+    int32_t B, H, W, HP;
+} mphsir_gate_args;
+int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* stream);
+
 /* ---- fused LayerNorm + gated MLP + residual --------------------------------------------------
  * Y = X + keep[b] * ( fc2( value * gelu_erf(gate) ) + b2 ),  [value|gate] = fc1(LayerNorm(X)) + b1
  * Replaces PGSSTB's `x + drop_path(self.mlp(self.norm2(x)))` (net/MP_HSIR.py:719; GatedMlp :66-82:

@@ -36,6 +36,25 @@ class WinAttnArgs(ctypes.Structure):
                [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift", "r")]
 
 
+class GramArgs(ctypes.Structure):
+    """mirror of struct mphsir_gram_args"""
+    _fields_ = [("Tq", c_void_p), ("ldq", c_int64), ("Tk", c_void_p), ("ldk", c_int64), ("Tv", c_void_p), ("ldv", c_int64),
+                ("wq", c_void_p), ("wk", c_void_p), ("wv", c_void_p), ("ldw", c_int64), ("V", c_void_p), ("ldvo", c_int64),
+                ("Gpart", c_void_p), ("Spart", c_void_p)] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nsplit")]
+
+
+class FoldArgs(ctypes.Structure):
+    """mirror of struct mphsir_fold_args"""
+    _fields_ = [("Gpart", c_void_p), ("Spart", c_void_p), ("temperature", c_void_p), ("Wo", c_void_p), ("M", c_void_p)] + \
+               [(n, c_int32) for n in ("B", "C", "heads", "nsplit")]
+
+
+class GateArgs(ctypes.Structure):
+    """mirror of struct mphsir_gate_args"""
+    _fields_ = [("T", c_void_p), ("ldt", c_int64), ("w9", c_void_p), ("ldw", c_int64), ("U", c_void_p), ("ldu", c_int64)] + \
+               [(n, c_int32) for n in ("B", "H", "W", "HP")]
+
+
 _SYMBOLS = {
     # name: (restype, argtypes)
     "mphsir_version": (ctypes.c_char_p, []),
@@ -47,6 +66,9 @@ _SYMBOLS = {
     "mphsir_gemm_tok": (c_int, [ctypes.POINTER(GemmArgs), c_int, c_void_p]),
     "mphsir_win_attn_fwd": (c_int, [ctypes.POINTER(WinAttnArgs), c_int, c_void_p]),
     "mphsir_win_attn_hdp": (c_int, [c_int, c_int]),
+    "mphsir_dwconv_gram": (c_int, [ctypes.POINTER(GramArgs), c_int, c_void_p]),
+    "mphsir_spectral_fold": (c_int, [ctypes.POINTER(FoldArgs), c_int, c_void_p]),
+    "mphsir_dwconv_gate": (c_int, [ctypes.POINTER(GateArgs), c_int, c_void_p]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
 }
 

@@ -1,0 +1,297 @@
+// Global ("spectral") channel attention, the north-star kernel family.
+//
+// Reference op sequence (Spectral_Attention.forward net/MP_HSIR.py:96-114, == Attention/MDTA :301-322,
+// and CrossAttention.forward :234-249):  t = dwconv3x3(conv1x1(x));  q,k,v = split(t);
+// q,k L2-normalised over the H*W pixels;  A_h = softmax(q_h k_h^T * temperature_h)  (hd x hd per head);
+// out = project_out(A v).   Folded form: out = M_b v with the per-sample matrix
+// M_b = W_o * blockdiag_h(A_h), so only the raw Gram  G_h = sum_p q_h[:,p] k_h[:,p]^T  and the two
+// sum-of-squares vectors need a pass over the pixels.
+//
+//   dwconv_gram   pass A: depthwise 3x3 of the 1x1-conv output (q,k,v sources may be different
+//                 tensors -> cross attention), v written once, q/k kept on-chip (transposed tile in LDS)
+//                 and reduced into per-workgroup Gram / sum-of-squares partials by MFMA with
+//                 K = pixels.  Deterministic split-K: fixed tile -> workgroup map, no atomics.
+//   spectral_fold per (sample, head): ordered reduction of the partials, F.normalize (eps 1e-12)
+//                 scaling, temperature, row softmax, fold with project_out -> M_b (compute dtype).
+//   pass B        is mphsir_gemm_tok with the per-sample weight M_b (epi 2 adds the PGSSTB branch sum).
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+struct GramDev {
+    const void* Tq; long ldq; const void* Tk; long ldk; const void* Tv; long ldv;   // 1x1-conv outputs [B*H*W][ld]
+    const float* wq; const float* wk; const float* wv; long ldw;                      // depthwise taps [9][ldw] fp32
+    void* V; long ldvo;                                                               // [B*H*W][ldvo] out
+    float* Gpart;   // [B][nsplit][HEADS][HD][HD]
+    float* Spart;   // [B][nsplit][2][C]
+    int B, H, W, nsplit;
+};
+
+// depthwise 3x3 (zero padding) at pixel (y,x) for VEC consecutive channels starting at c0
+template <class T>
+__device__ __forceinline__ void dw3x3_vec(const T* base, long ld, const float* w9, long ldw, int c0, int y, int x,
+                                          int H, int W, float* acc) {
+    constexpr int VEC = Vec16<T>::N;
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            const Vec16<T> t = load16<T>(base + ((long)yy * W + xx) * ld + c0);
+            const float* w = w9 + ((dy + 1) * 3 + (dx + 1)) * ldw + c0;
+            for (int e = 0; e < VEC; ++e) acc[e] += t.get(e) * w[e];
+        }
+    }
+}
+
+template <class T, int C, int HD>
+__global__ __launch_bounds__(256) void dwconv_gram_kernel(GramDev a) {
+    typedef ElemTraits<T> TR;
+    constexpr int PAD = 16 / sizeof(T);
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int HEADS = C / HD;
+    constexpr int LDT = 64 + PAD;
+    constexpr int NT = HD / 16;                          // Gram tiles per side
+    constexpr int SLOTS = (NT * NT + 3) / 4;             // tiles per wave
+    constexpr int VPH = HD / VEC;                        // channel vectors per head
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    T* qT = reinterpret_cast<T*>(smem_v);                // [HD][LDT]  q_h^T : channel-major, pixel-contiguous
+    T* kT = qT + HD * LDT;                               // [HD][LDT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
+    const int HW = a.H * a.W, tiles = HW / 64, tpw = tiles / a.nsplit;
+    const long img = (long)b * HW;
+    const T* Tq = reinterpret_cast<const T*>(a.Tq) + img * a.ldq;
+    const T* Tk = reinterpret_cast<const T*>(a.Tk) + img * a.ldk;
+    const T* Tv = reinterpret_cast<const T*>(a.Tv) + img * a.ldv;
+    T* V = reinterpret_cast<T*>(a.V) + img * a.ldvo;
+
+    f32x4 g[HEADS][SLOTS];
+    float ssq[HEADS];                                    // thread t < 2*HD owns row t of [q_h; k_h]
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+        ssq[h] = 0.f;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) g[h][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int tile = sp * tpw; tile < (sp + 1) * tpw; ++tile) {
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+            // depthwise conv of q_h, k_h (-> LDS, transposed) and v_h (-> HBM) for 64 pixels
+            for (int idx = tid; idx < 64 * VPH; idx += 256) {
+                const int pi = idx / VPH, cv = idx % VPH, c0 = h * HD + cv * VEC;
+                const int p = tile * 64 + pi, y = p / a.W, x = p % a.W;
+                float acc[VEC];
+                dw3x3_vec<T>(Tq, a.ldq, a.wq, a.ldw, c0, y, x, a.H, a.W, acc);
+                for (int e = 0; e < VEC; ++e) qT[(cv * VEC + e) * LDT + pi] = from_f32<T>(acc[e]);
+                dw3x3_vec<T>(Tk, a.ldk, a.wk, a.ldw, c0, y, x, a.H, a.W, acc);
+                for (int e = 0; e < VEC; ++e) kT[(cv * VEC + e) * LDT + pi] = from_f32<T>(acc[e]);
+                dw3x3_vec<T>(Tv, a.ldv, a.wv, a.ldw, c0, y, x, a.H, a.W, acc);
+                Vec16<T> vo;
+                for (int e = 0; e < VEC; ++e) vo.set(e, acc[e]);
+                store16<T>(V + (long)p * a.ldvo + c0, vo);
+            }
+            __syncthreads();
+            if (tid < 2 * HD) {   // sum of squares of the (rounded) rows: the values the Gram sees
+                const T* row = qT + tid * LDT;       // rows HD..2HD-1 are kT
+                float s = 0.f;
+                for (int i = 0; i < 64; ++i) { const float v = to_f32(row[i]); s += v * v; }
+                ssq[h] += s;
+            }
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int t = wv + 4 * s;            // wave-uniform
+                if (t < NT * NT) {
+                    const int ti = t / NT, tj = t % NT;
+#pragma unroll
+                    for (int kk = 0; kk < 64; kk += TR::KCHUNK)
+                        mma(g[h][s], load_frag<T>(qT, LDT, ti * 16, kk), load_frag<T>(kT, LDT, tj * 16, kk));
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    float* Gp = a.Gpart + (long)blockIdx.x * HEADS * HD * HD;
+    float* Sp = a.Spart + (long)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int t = wv + 4 * s;
+            if (t < NT * NT) {
+                const int ti = t / NT, tj = t % NT;
+                for (int r = 0; r < 4; ++r)
+                    Gp[(h * HD + ti * 16 + (lane >> 4) * 4 + r) * HD + tj * 16 + (lane & 15)] = g[h][s][r];
+            }
+        }
+        if (tid < 2 * HD) Sp[(tid / HD) * C + h * HD + tid % HD] = ssq[h];
+    }
+}
+
+struct FoldDev {
+    const float* Gpart; const float* Spart; int nsplit;
+    const float* temperature;   // [HEADS]
+    const float* Wo;            // project_out weight [C][C] fp32
+    void* Mout;                 // [B][C][C] compute dtype
+    int B, C, HD;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void spectral_fold_kernel(FoldDev a) {
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    const int HD = a.HD, C = a.C, HEADS = C / HD;
+    float* G = reinterpret_cast<float*>(smem_v);      // [HD][HD] -> attention probabilities
+    float* nq = G + HD * HD;                          // [HD]
+    float* nk = nq + HD;                              // [HD]
+    const int tid = threadIdx.x, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
+
+    for (int i = tid; i < HD * HD; i += 256) {        // ordered (deterministic) reduction over the splits
+        float s = 0.f;
+        for (int sp = 0; sp < a.nsplit; ++sp) s += a.Gpart[(((long)b * a.nsplit + sp) * HEADS + h) * HD * HD + i];
+        G[i] = s;
+    }
+    if (tid < 2 * HD) {
+        float s = 0.f;
+        for (int sp = 0; sp < a.nsplit; ++sp) s += a.Spart[((long)b * a.nsplit + sp) * 2 * C + (tid / HD) * C + h * HD + tid % HD];
+        nq[tid] = fmaxf(sqrtf(s), 1e-12f);            // F.normalize eps (nk follows nq in memory)
+    }
+    __syncthreads();
+    if (tid < HD) {                                   // row softmax of G/(nq nk^T) * temperature
+        const float tq = a.temperature[h] / nq[tid];
+        float m = -3.0e38f;
+        for (int j = 0; j < HD; ++j) m = fmaxf(m, G[tid * HD + j] * tq / nk[j]);
+        float den = 0.f;
+        for (int j = 0; j < HD; ++j) { const float e = expf(G[tid * HD + j] * tq / nk[j] - m); G[tid * HD + j] = e; den += e; }
+        const float inv = 1.0f / den;
+        for (int j = 0; j < HD; ++j) G[tid * HD + j] *= inv;
+    }
+    __syncthreads();
+    T* M = reinterpret_cast<T*>(a.Mout) + (long)b * C * C;
+    for (int o = tid; o < C * HD; o += 256) {         // M[co][h*HD+j] = sum_i Wo[co][h*HD+i] A[i][j]
+        const int co = o / HD, j = o % HD;
+        const float* w = a.Wo + (long)co * C + h * HD;
+        float s = 0.f;
+        for (int i = 0; i < HD; ++i) s += w[i] * G[i * HD + j];
+        M[(long)co * C + h * HD + j] = from_f32<T>(s);
+    }
+}
+
+struct GateDev {
+    const void* Tin; long ldt;          // [B*H*W][2*HP]
+    const float* w9; long ldw;          // [9][2*HP]
+    void* U; long ldu;                  // [B*H*W][HP]
+    int B, H, W, HP;
+};
+
+// GDFN middle (FFN/FeedForward.forward net/MP_HSIR.py:261-263, :387-389): u = gelu(dw(t)[:HP]) * dw(t)[HP:]
+template <class T>
+__global__ __launch_bounds__(256) void dwconv_gate_kernel(GateDev a) {
+    constexpr int VEC = Vec16<T>::N;
+    const int vpp = a.HP / VEC, HW = a.H * a.W;
+    const long total = (long)a.B * HW * vpp;
+    const T* Tin = reinterpret_cast<const T*>(a.Tin);
+    T* U = reinterpret_cast<T*>(a.U);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long pix = idx / vpp;
+        const int c0 = (int)(idx % vpp) * VEC, b = (int)(pix / HW), p = (int)(pix % HW), y = p / a.W, x = p % a.W;
+        const T* base = Tin + (long)b * HW * a.ldt;
+        float v1[VEC], v2[VEC];
+        dw3x3_vec<T>(base, a.ldt, a.w9, a.ldw, c0, y, x, a.H, a.W, v1);
+        dw3x3_vec<T>(base, a.ldt, a.w9, a.ldw, a.HP + c0, y, x, a.H, a.W, v2);
+        Vec16<T> o;
+        for (int e = 0; e < VEC; ++e) o.set(e, gelu_erf(v1[e]) * v2[e]);
+        store16<T>(U + pix * a.ldu + c0, o);
+    }
+}
+
+template <class T, int C, int HD>
+static int launch_gram(const GramDev& d, hipStream_t s) {
+    constexpr int PAD = 16 / sizeof(T);
+    const size_t shmem = 2 * HD * (64 + PAD) * sizeof(T);
+    allow_big_lds(dwconv_gram_kernel<T, C, HD>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GRAM, (dwconv_gram_kernel<T, C, HD>), dim3(d.B * d.nsplit), dim3(256), shmem, s, d);
+    return MPHSIR_OK;
+}
+
+template <class T>
+static int dispatch_gram(const GramDev& d, int C, int HD, hipStream_t s) {
+#define MPHSIR_GRAM_CASE(c, hd) if (C == c && HD == hd) return launch_gram<T, c, hd>(d, s);
+    MPHSIR_GRAM_CASE(32, 16) MPHSIR_GRAM_CASE(64, 16) MPHSIR_GRAM_CASE(128, 16)
+    MPHSIR_GRAM_CASE(32, 32) MPHSIR_GRAM_CASE(64, 32) MPHSIR_GRAM_CASE(64, 64) MPHSIR_GRAM_CASE(128, 32)
+    MPHSIR_GRAM_CASE(128, 64) MPHSIR_GRAM_CASE(256, 32)
+    MPHSIR_GRAM_CASE(96, 48) MPHSIR_GRAM_CASE(192, 48) MPHSIR_GRAM_CASE(192, 96) MPHSIR_GRAM_CASE(384, 48)
+#undef MPHSIR_GRAM_CASE
+    set_error("dwconv_gram: (C=%d, head_dim=%d) not instantiated", C, HD);
+    return MPHSIR_EINVAL;
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_dwconv_gram(const mphsir_gram_args* a, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->Tq && a->Tk && a->Tv && a->wq && a->wk && a->wv && a->V && a->Gpart && a->Spart, "dwconv_gram: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "dwconv_gram: dtype %d unsupported", dtype);
+    const int esz = dtype == MPHSIR_F32 ? 4 : 2;
+    MPHSIR_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && ((int64_t)a->H * a->W) % 64 == 0, "dwconv_gram: H*W must be a multiple of 64");
+    MPHSIR_REQUIRE(a->heads > 0 && a->C % a->heads == 0, "dwconv_gram: C %% heads != 0");
+    const int tiles = a->H * a->W / 64;
+    MPHSIR_REQUIRE(a->nsplit > 0 && tiles % a->nsplit == 0, "dwconv_gram: nsplit=%d must divide the %d pixel tiles", a->nsplit, tiles);
+    MPHSIR_REQUIRE(aligned16(a->Tq) && aligned16(a->Tk) && aligned16(a->Tv) && aligned16(a->V) && (a->ldq * esz) % 16 == 0 &&
+                       (a->ldk * esz) % 16 == 0 && (a->ldv * esz) % 16 == 0 && (a->ldvo * esz) % 16 == 0,
+                   "dwconv_gram: 16-byte alignment required");
+    GramDev d{a->Tq, (long)a->ldq, a->Tk, (long)a->ldk, a->Tv, (long)a->ldv, a->wq, a->wk, a->wv, (long)a->ldw,
+              a->V, (long)a->ldvo, a->Gpart, a->Spart, a->B, a->H, a->W, a->nsplit};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == MPHSIR_F32 ? dispatch_gram<float>(d, a->C, a->C / a->heads, s)
+                               : dispatch_gram<bf16_t>(d, a->C, a->C / a->heads, s);
+}
+
+extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->Gpart && a->Spart && a->temperature && a->Wo && a->M, "spectral_fold: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "spectral_fold: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold: bad shape");
+    const int HD = a->C / a->heads;
+    MPHSIR_REQUIRE(HD <= 128, "spectral_fold: head_dim %d > 128", HD);
+    FoldDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->M, a->B, a->C, HD};
+    const size_t shmem = ((size_t)HD * HD + 2 * HD) * sizeof(float);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MPHSIR_F32) {
+        allow_big_lds(spectral_fold_kernel<float>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<float>), dim3(a->B * a->heads), dim3(256), shmem, s, d);
+    } else {
+        allow_big_lds(spectral_fold_kernel<bf16_t>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<bf16_t>), dim3(a->B * a->heads), dim3(256), shmem, s, d);
+    }
+    return MPHSIR_OK;
+}
+
+extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->T && a->w9 && a->U, "dwconv_gate: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "dwconv_gate: dtype %d unsupported", dtype);
+    const int esz = dtype == MPHSIR_F32 ? 4 : 2;
+    MPHSIR_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->HP > 0 && a->HP % 8 == 0, "dwconv_gate: bad shape");
+    MPHSIR_REQUIRE(aligned16(a->T) && aligned16(a->U) && (a->ldt * esz) % 16 == 0 && (a->ldu * esz) % 16 == 0, "dwconv_gate: 16-byte alignment required");
+    GateDev d{a->T, (long)a->ldt, a->w9, (long)a->ldw, a->U, (long)a->ldu, a->B, a->H, a->W, a->HP};
+    const long total = (long)a->B * a->H * a->W * (a->HP / (16 / esz));
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MPHSIR_F32)
+        MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    return MPHSIR_OK;
+}

@@ -139,3 +139,66 @@ def win_attn_fwd(x, ln_w, ln_b, Wqkv, bqkv, rpb, Wproj, bproj, pg, heads, shift)
     a.r = pg["linear_down.weight"].shape[0]
     _lib.check(lib.mphsir_win_attn_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "win_attn_fwd")
     return sa, gate
+
+
+def pack_dw(w):
+    """depthwise conv weight (C,1,3,3) -> fp32 [9][C] tap-major."""
+    return w.reshape(w.shape[0], 9).t().contiguous().float()
+
+
+def choose_nsplit(B, H, W):
+    """workgroups per sample for dwconv_gram: aim for >= ~512 workgroups, must divide H*W/64."""
+    tiles = H * W // 64
+    n = tiles
+    while n > 1 and B * n > 1024 and n % 2 == 0:
+        n //= 2
+    return n
+
+
+def dwconv_gram(tq, tk, tv, wq, wk, wv, ldw, B, H, W, C, heads, nsplit=None):
+    """tq/tk/tv: 2-D row-major views [B*H*W, >=C] of the 1x1-conv output starting at the first q/k/v
+    channel; wq/wk/wv fp32 tap-major views with row pitch ldw.  Returns (v (M,C), Gpart, Spart, nsplit)."""
+    lib = _lib.load()
+    _check(tq, tk, tv, wq, wk, wv)
+    M = B * H * W
+    nsplit = nsplit or choose_nsplit(B, H, W)
+    hd = C // heads
+    v = torch.empty((M, C), dtype=tq.dtype, device=tq.device)
+    gp = torch.empty((B, nsplit, heads, hd, hd), dtype=torch.float32, device=tq.device)
+    sp = torch.empty((B, nsplit, 2, C), dtype=torch.float32, device=tq.device)
+    a = _lib.GramArgs()
+    a.Tq, a.ldq, a.Tk, a.ldk, a.Tv, a.ldv = _p(tq), tq.stride(0), _p(tk), tk.stride(0), _p(tv), tv.stride(0)
+    a.wq, a.wk, a.wv, a.ldw = _p(wq), _p(wk), _p(wv), ldw
+    a.V, a.ldvo, a.Gpart, a.Spart = _p(v), C, _p(gp), _p(sp)
+    a.B, a.H, a.W, a.C, a.heads, a.nsplit = B, H, W, C, heads, nsplit
+    _lib.check(lib.mphsir_dwconv_gram(ctypes.byref(a), _DT[tq.dtype], _stream(tq)), "dwconv_gram")
+    return v, gp, sp, nsplit
+
+
+def spectral_fold(gp, sp, temperature, Wo, dtype):
+    """-> per-sample folded matrix M (B, C, C) in `dtype`."""
+    lib = _lib.load()
+    _check(gp, sp, temperature, Wo)
+    B, nsplit, heads, hd, _ = gp.shape
+    C = heads * hd
+    assert Wo.dtype == torch.float32 and Wo.is_contiguous() and temperature.is_contiguous()
+    Mo = torch.empty((B, C, C), dtype=dtype, device=gp.device)
+    a = _lib.FoldArgs()
+    a.Gpart, a.Spart, a.temperature, a.Wo, a.M = _p(gp), _p(sp), _p(temperature), _p(Wo), _p(Mo)
+    a.B, a.C, a.heads, a.nsplit = B, C, heads, nsplit
+    _lib.check(lib.mphsir_spectral_fold(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold")
+    return Mo
+
+
+def dwconv_gate(t, w9, B, H, W):
+    """t (M, 2*HP) -> gelu(dw(t)[:, :HP]) * dw(t)[:, HP:]  (M, HP)."""
+    lib = _lib.load()
+    _check(t, w9)
+    M, ldt = _rows(t)
+    HP = t.shape[1] // 2
+    u = torch.empty((M, HP), dtype=t.dtype, device=t.device)
+    a = _lib.GateArgs()
+    a.T, a.ldt, a.w9, a.ldw, a.U, a.ldu = _p(t), ldt, _p(w9), w9.stride(0), _p(u), HP
+    a.B, a.H, a.W, a.HP = B, H, W, HP
+    _lib.check(lib.mphsir_dwconv_gate(ctypes.byref(a), _DT[t.dtype], _stream(t)), "dwconv_gate")
+    return u

@@ -1,0 +1,172 @@
+"""Kernel parity checks shared by the CPU-emulator tests (tests/test_emu_kernels.py) and the real
+MI355X tests (tests/test_gpu_kernels.py): each check drives the C ABI through mp_hsir_amd.ops on
+device `dev` and compares with the fp64 oracle on the same (dtype-rounded) weights."""
+import torch
+
+from oracle import mp_hsir_oracle as O
+from util import params_from_manifest, rel_l2 as _rel
+
+DTYPES = [torch.float32, torch.bfloat16]
+# fp32: exact-f32 MFMA / fp32 VALU vs fp64 oracle.  bf16: storage rounding of activations (2^-9 per
+# element per stage) -- the reference's own bf16 autocast deviates 1e-2 from its fp32.
+TOL = {torch.float32: 2e-6, torch.bfloat16: 1.5e-2}
+
+GEMM_CASES = [(64, 64, 32, False, 0), (128, 96, 96, True, 0), (64, 48, 192, False, 1), (128, 32, 64, True, 1)]
+MLP_CASES = [(32, 85), (96, 255), (128, 340)]
+WIN_CASES = [
+    ("tiny", "encoder_level1.blocks.1.", 1, 4, (1, 16, 24, 32)),
+    ("natural_mode0", "encoder_level1.blocks.1.", 2, 4, (2, 16, 16, 64)),
+    ("natural_mode0", "refinement.blocks.0.", 2, 0, (1, 8, 16, 128)),
+    ("remote_mode8", "encoder_level1.blocks.1.", 2, 4, (1, 16, 8, 96)),
+]
+SPEC_CASES = [(32, 2, (2, 8, 16), 1), (64, 2, (1, 16, 16), 2), (96, 2, (1, 8, 8), 1), (128, 2, (1, 8, 16), 2)]
+
+_DEV = ["cpu"]
+
+
+def rel_l2(a, b):
+    return _rel(torch.as_tensor(a).detach().cpu(), torch.as_tensor(b).detach().cpu())
+
+
+def rnd(shape, seed, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(_DEV[0])
+
+
+def _use(dev):
+    _DEV[0] = dev
+
+
+def check_gemm_tok(dev, dtype, M, N, K, ln, epi):
+    _use(dev)
+    from mp_hsir_amd import ops
+    x, w = rnd((M, K), 1, dtype), rnd((N, K), 2, dtype, K ** -0.5)
+    bias = rnd((N,), 3)
+    lnw, lnb = 1 + 0.1 * rnd((K,), 4), 0.1 * rnd((K,), 5)
+    res = rnd((M, N), 6, dtype)
+    y = ops.gemm_tok(x, w, bias=bias, ln=(lnw, lnb) if ln else None, epi=epi, res=res if epi else None)
+    xd = x.double().cpu()
+    if ln:
+        xd = O.layer_norm_c(xd, lnw.double().cpu(), lnb.double().cpu())
+        if dtype == torch.bfloat16:
+            xd = xd.to(dtype).double().cpu()
+    ref = xd @ w.double().cpu().t() + bias.double().cpu() + (res.double().cpu() if epi else 0)
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+def check_gemm_tok_per_sample_combine(dev, dtype):
+    """epi 2 with a per-sample weight: the folded channel attention + PGSSTB branch sum."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W, C, shift = 2, 16, 16, 32, 4
+    M = B * H * W
+    v, Wb = rnd((M, C), 1, dtype), rnd((B, C, C), 2, dtype, C ** -0.5)
+    res, sa = rnd((M, C), 3, dtype), rnd((M, C), 4, dtype)
+    gate = rnd((B * (H // 8) * (W // 8), C), 5)
+    keep = torch.tensor([1.25, 0.0]).to(dev)
+    y = ops.gemm_tok(v, Wb, epi=2, res=res, sa=sa, gate=gate, keep=keep, geom=(H, W, shift))
+    acc = torch.einsum("bnk,bck->bnc", v.double().cpu().reshape(B, H * W, C), Wb.double().cpu()).reshape(B, H, W, C)
+    # gate lives in the shifted window frame: expand to windows, un-window, roll back
+    gw = gate.double().cpu()[:, None, :].expand(-1, 64, -1)
+    gimg = torch.roll(O.from_windows(gw, B, H, W), shifts=(shift, shift), dims=(1, 2))
+    ref = res.double().cpu().reshape(B, H, W, C) + keep.double().cpu().reshape(B, 1, 1, 1) * (sa.double().cpu().reshape(B, H, W, C) * gimg + acc)
+    assert rel_l2(y.reshape(B, H, W, C), ref) < TOL[dtype]
+
+
+def check_gated_mlp(dev, dtype, C, hid):
+    _use(dev)
+    from mp_hsir_amd import ops
+    M = 128
+    x = rnd((M, C), 1, dtype)
+    P = {"fc1.weight": rnd((2 * hid, C), 2, scale=C ** -0.5), "fc1.bias": 0.1 * rnd((2 * hid,), 3),
+         "fc2.weight": rnd((C, hid), 4, scale=hid ** -0.5), "fc2.bias": 0.1 * rnd((C,), 5)}
+    lnw, lnb = 1 + 0.1 * rnd((C,), 6), 0.1 * rnd((C,), 7)
+    keep = torch.tensor([1.0, 1.5]).to(dev)
+    W1, b1, W2 = ops.pack_gated_mlp(P["fc1.weight"], P["fc1.bias"], P["fc2.weight"], dtype)
+    y = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, P["fc2.bias"], keep=keep, rows_per_batch=64)
+    Pd = {k: (v.to(dtype) if k.endswith("weight") else v).double().cpu() for k, v in P.items()}
+    xn = O.layer_norm_c(x.double().cpu(), lnw.double().cpu(), lnb.double().cpu())
+    ref = x.double().cpu() + keep.double().cpu().repeat_interleave(64)[:, None] * O.gated_mlp(Pd, "", xn)
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+def _block_params(manifest_entry, prefix):
+    return {k: v.to(_DEV[0]) for k, v in params_from_manifest(manifest_entry, prefix, dtype=torch.float32).items()}
+
+
+def check_win_attn(dev, dtype, man, prefix, heads, shift, shape, manifest):
+    _use(dev)
+    from mp_hsir_amd import ops
+    P = _block_params(manifest[man], prefix)
+    B, H, W, C = shape
+    x = rnd(shape, 11, dtype)
+    wq = P["attn.qkv.weight"].to(dtype)
+    wp = P["attn.proj.weight"].to(dtype)
+    pg = {k[len("local_spectral_attn."):]: v.contiguous() for k, v in P.items() if k.startswith("local_spectral_attn.")}
+    pg["prompt_param"] = pg["prompt_param"].reshape(128, -1).contiguous()
+    sa, gate = ops.win_attn_fwd(x, P["norm1.weight"], P["norm1.bias"], wq, P["attn.qkv.bias"],
+                                P["attn.relative_position_bias_table"], ops.pack_win_proj(P["attn.proj.weight"], heads, dtype),
+                                P["attn.proj.bias"], pg, heads, shift)
+    # oracle on the same (dtype-rounded) weights, fp64 arithmetic
+    Pd = {k: v.double().cpu() for k, v in P.items()}
+    Pd["attn.qkv.weight"], Pd["attn.proj.weight"] = wq.double().cpu(), wp.double().cpu()
+    xn = O.layer_norm_c(x.double().cpu(), Pd["norm1.weight"], Pd["norm1.bias"])
+    if shift:
+        xn = torch.roll(xn, (-4, -4), (1, 2))
+    mask = O.shift_mask(H, W, torch.float64) if shift else None
+    saw = O.spatial_attention(Pd, "attn.", O.to_windows(xn), heads, mask)
+    g_ref = O.pg_spectral_gate(Pd, "local_spectral_attn.", saw)
+    sa_ref = O.from_windows(saw, B, H, W)
+    if shift:
+        sa_ref = torch.roll(sa_ref, (4, 4), (1, 2))
+    assert rel_l2(sa, sa_ref) < TOL[dtype] * (2 if dtype == torch.bfloat16 else 1)
+    assert rel_l2(gate, g_ref) < TOL[dtype] * (4 if dtype == torch.bfloat16 else 1)
+
+
+def check_spectral_attention_chain(dev, dtype, C, heads, shape, nsplit):
+    """gemm_tok (1x1 qkv) -> dwconv_gram -> spectral_fold -> gemm_tok (per-sample M) == oracle spectral_attention"""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    x = rnd((B, H, W, C), 21, dtype)
+    P = {"qkv.weight": rnd((3 * C, C, 1, 1), 22, scale=C ** -0.5), "qkv_dwconv.weight": rnd((3 * C, 1, 3, 3), 23, scale=1 / 3),
+         "project_out.weight": rnd((C, C, 1, 1), 24, scale=C ** -0.5), "temperature": 1 + 0.3 * rnd((heads, 1, 1), 25)}
+    wqkv = P["qkv.weight"].reshape(3 * C, C).to(dtype)
+    t = ops.gemm_tok(x.reshape(-1, C), wqkv)
+    w9 = ops.pack_dw(P["qkv_dwconv.weight"])
+    v, gp, sp, ns = ops.dwconv_gram(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], w9[:, :C], w9[:, C:2 * C], w9[:, 2 * C:],
+                                    3 * C, B, H, W, C, heads, nsplit=nsplit)
+    Mb = ops.spectral_fold(gp, sp, P["temperature"].reshape(heads).contiguous(),
+                           P["project_out.weight"].reshape(C, C).contiguous(), dtype)
+    y = ops.gemm_tok(v, Mb)
+    Pd = {k: v_.double().cpu() for k, v_ in P.items()}
+    Pd["qkv.weight"] = wqkv.double().cpu().reshape(3 * C, C, 1, 1)
+    ref = O.spectral_attention(Pd, "", x.double().cpu(), heads)
+    assert rel_l2(y.reshape(B, H, W, C), ref) < TOL[dtype] * (2 if dtype == torch.bfloat16 else 1)
+
+
+def check_gdfn_chain(dev, dtype):
+    """gemm_tok(LN + project_in) -> dwconv_gate -> gemm_tok(project_out + residual) == x + gdfn(LN(x))"""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W, C, hid = 1, 8, 16, 64, 170
+    HP = ops.round_up(hid, 32)
+    x = rnd((B, H, W, C), 31, dtype)
+    P = {"project_in.weight": rnd((2 * hid, C, 1, 1), 32, scale=C ** -0.5), "dwconv.weight": rnd((2 * hid, 1, 3, 3), 33, scale=1 / 3),
+         "project_out.weight": rnd((C, hid, 1, 1), 34, scale=hid ** -0.5)}
+    lnw, lnb = 1 + 0.1 * rnd((C,), 35), 0.1 * rnd((C,), 36)
+    w_in = torch.zeros((2 * HP, C), dtype=dtype, device=dev)
+    w_in[:hid], w_in[HP:HP + hid] = P["project_in.weight"].reshape(2 * hid, C)[:hid].to(dtype), P["project_in.weight"].reshape(2 * hid, C)[hid:].to(dtype)
+    w9 = torch.zeros((9, 2 * HP), device=dev)
+    w9s = ops.pack_dw(P["dwconv.weight"])
+    w9[:, :hid], w9[:, HP:HP + hid] = w9s[:, :hid], w9s[:, hid:]
+    w_out = torch.zeros((C, HP), dtype=dtype, device=dev)
+    w_out[:, :hid] = P["project_out.weight"].reshape(C, hid).to(dtype)
+    x2 = x.reshape(-1, C)
+    t = ops.gemm_tok(x2, w_in, ln=(lnw, lnb))
+    u = ops.dwconv_gate(t, w9, B, H, W)
+    y = ops.gemm_tok(u, w_out, epi=1, res=x2)
+    Pd = {"project_in.weight": P["project_in.weight"].to(dtype).double().cpu(), "dwconv.weight": P["dwconv.weight"].double().cpu(),
+          "project_out.weight": P["project_out.weight"].to(dtype).double().cpu()}
+    ref = x.double().cpu() + O.gdfn(Pd, "", O.layer_norm_c(x.double().cpu(), lnw.double().cpu(), lnb.double().cpu()))
+    assert rel_l2(y.reshape(B, H, W, C), ref) < TOL[dtype] * (2 if dtype == torch.bfloat16 else 1)

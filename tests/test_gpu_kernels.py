@@ -1,0 +1,73 @@
+"""Parity of the HIP kernels on a real MI355X, called through the C ABI (libmphsir.so), against the
+fp64 oracle on the same seeded inputs.  Same checks as tests/test_emu_kernels.py, device = cuda."""
+import os
+
+import pytest
+import torch
+
+import kernel_checks as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _real_library():
+    import mp_hsir_amd._lib as L
+    L._lib = None
+    L._is_emu = False
+    lib = L.load()
+    buf = (b" " * 64)
+    import ctypes
+    cbuf = ctypes.create_string_buffer(64)
+    assert lib.mphsir_device_arch(cbuf, 64) == 0
+    assert cbuf.value.decode().startswith("gfx950"), cbuf.value
+    assert not L.is_emulated()
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("M,N,K_,ln,epi", K.GEMM_CASES + [(4096, 192, 64, True, 0), (2048, 128, 352, False, 1)])
+def test_gemm_tok(dtype, M, N, K_, ln, epi):
+    K.check_gemm_tok("cuda", dtype, M, N, K_, ln, epi)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+def test_gemm_tok_per_sample_combine(dtype):
+    K.check_gemm_tok_per_sample_combine("cuda", dtype)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,hid", K.MLP_CASES + [(64, 170), (192, 510), (256, 680), (384, 1021)])
+def test_gated_mlp(dtype, C, hid):
+    K.check_gated_mlp("cuda", dtype, C, hid)
+
+
+GPU_WIN_CASES = K.WIN_CASES + [
+    ("natural_mode0", "encoder_level2.blocks.1.", 4, 4, (2, 32, 32, 128)),
+    ("natural_mode0", "latent.blocks.1.", 8, 4, (2, 16, 16, 256)),
+    ("natural_mode0", "refinement.blocks.1.", 2, 4, (1, 64, 64, 128)),
+    ("remote_mode8", "encoder_level2.blocks.1.", 4, 4, (1, 32, 32, 192)),
+    ("remote_mode8", "latent.blocks.0.", 8, 0, (1, 16, 16, 384)),
+    ("remote_mode8", "refinement.blocks.1.", 2, 4, (1, 32, 32, 192)),
+]
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("man,prefix,heads,shift,shape", GPU_WIN_CASES)
+def test_win_attn(dtype, man, prefix, heads, shift, shape, manifest):
+    K.check_win_attn("cuda", dtype, man, prefix, heads, shift, shape, manifest)
+
+
+GPU_SPEC_CASES = K.SPEC_CASES + [(64, 2, (2, 64, 64), 16), (128, 4, (1, 32, 32), 4), (256, 8, (2, 16, 16), 2),
+                                 (128, 2, (1, 64, 64), 8), (192, 2, (1, 32, 32), 4), (384, 8, (1, 16, 16), 1),
+                                 (64, 4, (1, 32, 32), 2), (128, 8, (1, 32, 32), 2)]
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,heads,shape,nsplit", GPU_SPEC_CASES)
+def test_spectral_attention_chain(dtype, C, heads, shape, nsplit):
+    K.check_spectral_attention_chain("cuda", dtype, C, heads, shape, nsplit)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+def test_gdfn_chain(dtype):
+    K.check_gdfn_chain("cuda", dtype)
