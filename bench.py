@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native MP-HSIR hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric "HSI patches/sec (fwd+bwd) 64x64x31 bf16", configs[2]): natural-scene
+MP_HSIR_Net(31,31,64,T=6), random init, synthetic 64x64x31 patches generated on the GPU, batch 32 per GPU,
+bf16 compute, one *full* training step per "step": forward, L1-after-clamp loss, backward, gradient
+all-reduce (RCCL, N>1), fused AdamW.  Weak scaling: per-GPU batch fixed.  Rank 0 prints one JSON line.
+
+Extra objects on the line:
+  roofline     the dominant HIP kernel of the step: algorithmic FLOPs (or bytes) per launch / its mean
+               launch duration, measured live with HIP events on the launch stream (mphsir_prof_*).
+  cpu_baseline the CPU oracle (a port of the reference's op sequence, oracle/mp_hsir_oracle.py) timed
+               on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PEAK_MFMA_TF = {"bf16": 2500.0, "f32": 157.3}
+RIDGE = 312.0                  # FLOP/B, bf16 dense MFMA peak / HBM peak
+
+KERNEL_IDS = {"gemm_tok": 0, "win_attn": 1, "dwconv_gram": 2, "spectral_fold": 3, "gated_mlp": 4, "dwconv_gate": 5,
+              "flat_adamw": 6}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--forward-only", action="store_true", help="diagnostic: time inference only (not the headline metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch=2, iters=2):
+    """fwd+bwd of the CPU oracle on a bounded sample: `iters` training-shaped iterations of `batch` patches."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import mp_hsir_oracle as O
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    torch.manual_seed(2024)
+    net = MP_HSIR_Net()
+    P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()
+         if not k.endswith("attn_mask")}
+    cfg = O.make_cfg()
+    clip = net.clip_prompts
+    x = torch.rand(batch, 31, 64, 64)
+    c = torch.rand(batch, 31, 64, 64)
+    task = torch.randint(0, 6, (batch, 1))
+    cores = torch.get_num_threads()
+    times = []
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        loss = O.l1_after_clamp(O.mp_hsir_forward(P, cfg, x, task, clip), c)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / iters
+    return {"value": round(batch / t, 4), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": "%d fwd+bwd iterations of batch %d, natural 64x64x31, fp32, torch CPU oracle (1 warm-up)" % (iters, batch)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    from mp_hsir_amd import _lib, ops
+    from mp_hsir_amd.data import SyntheticPatchSource
+    from mp_hsir_amd.engine import DataParallelEngine
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    lib = _lib.load()
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(2024)
+    net = MP_HSIR_Net(compute_dtype=dt).to(dev)
+    src = SyntheticPatchSource(31, 64, args.batch, 6, dev, 2024, rank)
+    if args.forward_only:
+        net.eval()
+        def step():
+            _, x, c, p = src.next()
+            with torch.no_grad():
+                return net(x, p)
+    else:
+        net.train()
+        eng = DataParallelEngine(net, lr=2e-4)
+        def step():
+            _, x, c, p = src.next()
+            return eng.train_step(x, c, p)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt_s = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_s = float(t)
+    value = world * args.batch * args.steps / dt_s
+
+    roofline = None
+    if not args.no_roofline:
+        # algorithmic work per step and per kernel (one accounted step), then per-kernel HIP-event timing
+        ops.ACCOUNT = {}
+        step()
+        torch.cuda.synchronize()
+        acct, ops.ACCOUNT = ops.ACCOUNT, None
+        per = {}
+        for name, kid in KERNEL_IDS.items():
+            if name not in acct and name != "flat_adamw":
+                continue
+            lib.mphsir_prof_enable(kid)
+            for _ in range(2):
+                step()
+            n, ms = ctypes.c_int(0), ctypes.c_float(0)
+            lib.mphsir_prof_read(ctypes.byref(n), ctypes.byref(ms))
+            lib.mphsir_prof_enable(-1)
+            if n.value:
+                per[name] = (n.value / 2.0, ms.value / 2.0)        # launches / step, ms / step
+        dom = max((k for k in per if k in acct), key=lambda k: per[k][1])
+        launches, ms = per[dom]
+        _, flops, nbytes = acct[dom]
+        ai = flops / max(nbytes, 1.0)
+        if ai >= RIDGE:
+            ach, peak, unit, bound = flops / (ms * 1e-3) / 1e12, PEAK_MFMA_TF[args.dtype], "TFLOP/s", "mfma"
+        else:
+            ach, peak, unit, bound = nbytes / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": launches,
+                    "avg_launch_us": round(ms * 1e3 / launches, 2), "flops_per_step": flops, "bytes_per_step": nbytes,
+                    "tflops_equiv": round(flops / (ms * 1e-3) / 1e12, 2),
+                    "kernel_ms_per_step": {k: round(v[1], 3) for k, v in sorted(per.items())}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = {
+            "metric": "hsi_patches_per_sec_fwd" if args.forward_only else "hsi_patches_per_sec_fwd_bwd",
+            "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_s / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "natural-scene MP_HSIR_Net(31,31,64,T=6) %s, 64x64x31 patches, batch %d/GPU, %s"
+                                   % ("forward" if args.forward_only else "training step fwd+bwd+allreduce+AdamW",
+                                      args.batch, "dp%d" % world),
+                       "global_batch": world * args.batch, "patch": "64x64x31", "parallelism": "dp%d" % world,
+                       "backward": "torch-op recompute composites (HIP backward kernels pending)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

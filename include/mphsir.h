@@ -161,6 +161,13 @@ typedef struct mphsir_mlp_args {
 } mphsir_mlp_args;
 int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream);
 
+/* ---- fused AdamW over the flat parameter arena ---------------------------------------------------
+ * One decoupled-weight-decay Adam step on n contiguous fp32 parameters (n % 4 == 0) with gradient g,
+ * moments m, v; g is multiplied by grad_scale first (1/world_size after a sum all-reduce).
+ * Semantics = torch.optim.AdamW as the reference configures it (train.py:69); step is 1-based.     */
+int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+
 /* ---- optional per-kernel launch timer (bench.py roofline leg) ----------------------------------
  * When enabled for kernel id `kid`, every launch of that kernel is bracketed by hipEvents on its
  * own stream.  read(): synchronises the recorded events, returns the number of launches and their
@@ -171,6 +178,7 @@ int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream);
 #define MPHSIR_K_SPECTRAL_FOLD 3
 #define MPHSIR_K_GATED_MLP 4
 #define MPHSIR_K_DWCONV_GATE 5
+#define MPHSIR_K_FLAT_ADAMW 6
 #define MPHSIR_K_COUNT 16
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -69,6 +69,8 @@ _SYMBOLS = {
     "mphsir_dwconv_gram": (c_int, [ctypes.POINTER(GramArgs), c_int, c_void_p]),
     "mphsir_spectral_fold": (c_int, [ctypes.POINTER(FoldArgs), c_int, c_void_p]),
     "mphsir_dwconv_gate": (c_int, [ctypes.POINTER(GateArgs), c_int, c_void_p]),
+    "mphsir_flat_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,
+                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int32, ctypes.c_float, c_void_p]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
 }
 

@@ -1,0 +1,128 @@
+"""Data-parallel training engine: one process per GPU, RCCL all-reduce of gradients over xGMI.
+
+Re-expresses what the reference gets implicitly from pytorch-lightning (train.py:118
+``pl.Trainer(devices=..., strategy="auto")`` -> DDP + AdamW, train.py:69) in an MI355X-first way:
+
+  * parameters, gradients and the two Adam moments live in four flat fp32 arenas (nn.Parameters are
+    views, so state_dict is untouched); 58 MB / 128 MB for the two shipped models -- trivial next to
+    288 GB of HBM, so there is exactly one copy of each and no re-bucketing copies;
+  * gradients are summed with `torch.distributed.all_reduce` (backend "nccl" = RCCL) directly on
+    slices of the gradient arena, a few large buckets (default 32 MiB: a ring over 7 xGMI links is
+    per-link bound, so few large messages beat many small ones), each issued from a
+    post-accumulate-grad hook as soon as its last gradient is written, i.e. overlapped with the
+    rest of backward; the arena is laid out in reverse registration order so buckets fill
+    front-to-back during backward;
+  * the 1/world mean, weight decay and the Adam update are one HIP kernel over the arena
+    (mphsir_flat_adamw);
+  * parameters that never receive a gradient (the reference has 8: TVSP.text_linear/clip_linear,
+    SURVEY Q3) are detected on the first step and kept out of the arenas -- the reference's AdamW
+    skips them too (grad is None), so no weight decay is applied to them.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def l1_after_clamp(restored, clean):
+    """reference training_step loss (train.py:58-61): clamp to [0,1] then nn.L1Loss."""
+    return (restored.clamp(0, 1) - clean).abs().mean()
+
+
+class DataParallelEngine:
+    def __init__(self, net, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, bucket_mb=32, process_group=None,
+                 loss_fn=l1_after_clamp):
+        self.net, self.lr, self.betas, self.eps, self.wd = net, lr, betas, eps, weight_decay
+        self.loss_fn = loss_fn
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self.step_count = 0
+        self.arena = None
+        self._pending = []
+
+    # ---- arenas ---------------------------------------------------------------------------------
+    def _build_arenas(self):
+        params = [p for p in self.net.parameters() if p.requires_grad]
+        used = [p for p in params if p.grad is not None]
+        self.unused = [p for p in params if p.grad is None]
+        used = used[::-1]                                   # backward produces gradients roughly in reverse order
+        offs, total = [], 0
+        for p in used:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4               # keep every tensor 16-byte aligned
+        dev = used[0].device
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.buckets = []                                   # (start, end, number of tensors)
+        start, count = 0, 0
+        for p, o in zip(used, offs):
+            n = p.numel()
+            self.flat_p[o:o + n].copy_(p.data.reshape(-1))
+            self.flat_g[o:o + n].copy_(p.grad.reshape(-1))
+            p.data = self.flat_p[o:o + n].view(p.shape)
+            p.grad = self.flat_g[o:o + n].view(p.shape)
+            count += 1
+            end = o + (n + 3) // 4 * 4
+            if end - start >= self.bucket_elems:
+                self.buckets.append([start, end, count])
+                start, count = end, 0
+        if count:
+            self.buckets.append([start, total, count])
+        self.arena = (used, offs, total)
+        if self.world > 1:
+            dist.broadcast(self.flat_p, 0, group=self.pg)   # DDP's initial parameter broadcast, one message
+            for p in self.unused:
+                dist.broadcast(p.data, 0, group=self.pg)
+            bucket_of = {}
+            bi = 0
+            for p, o in zip(used, offs):
+                while o >= self.buckets[bi][1]:
+                    bi += 1
+                bucket_of[p] = bi
+            self._remaining = [b[2] for b in self.buckets]
+            for p in used:
+                p.register_post_accumulate_grad_hook(self._make_hook(bucket_of[p]))
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            self._remaining[bi] -= 1
+            if self._remaining[bi] == 0:
+                s, e, _ = self.buckets[bi]
+                self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
+        return hook
+
+    # ---- one optimisation step ---------------------------------------------------------------------
+    def train_step(self, degraded, clean, prompt, lr=None):
+        first = self.arena is None
+        if not first:
+            self.flat_g.zero_()
+            if self.world > 1:
+                self._remaining = [b[2] for b in self.buckets]
+        restored = self.net(degraded, prompt)
+        loss = self.loss_fn(restored, clean)
+        loss.backward()
+        if first:
+            self._build_arenas()
+            if self.world > 1:
+                for s, e, _ in self.buckets:
+                    self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
+        for h in self._pending:
+            h.wait()
+        self._pending = []
+        self.step_count += 1
+        ops.flat_adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr if lr is None else lr, self.step_count,
+                       self.betas[0], self.betas[1], self.eps, self.wd, 1.0 / self.world)
+        return loss.detach()
+
+
+def warmup_cosine_lr(epoch, base_lr, epochs, eta_min=1e-6):
+    """LinearWarmupCosineAnnealingLR(warmup=int(0.1*epochs), max=epochs, eta_min=1e-6) stepped per epoch,
+    as train.py:71-85 configures it (closed form, utils/schedulers.py:332-346).  lr(0) = 0."""
+    import math
+    wu = int(0.1 * epochs)
+    if epoch < wu:
+        return epoch * base_lr / (wu - 1) if wu > 1 else 0.0
+    return eta_min + 0.5 * (base_lr - eta_min) * (1 + math.cos(math.pi * (epoch - wu) / (epochs - wu)))

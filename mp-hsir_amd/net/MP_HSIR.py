@@ -1,0 +1,451 @@
+"""MP_HSIR_Net on MI355X: the reference's module surface over hand-written HIP kernels.
+
+Drop-in for the reference's ``net/MP_HSIR.py`` (ZhehuiWu/MP-HSIR): same class name, constructor
+signature, ``forward(inp_img (B,C,H,W), task_id)`` contract and ``state_dict`` keys/shapes/dtypes
+(658 entries for the natural-scene model, see tests/test_state_dict.py), so the reference's
+checkpoints load with ``load_state_dict`` and its train.py/test.py can import this module instead.
+
+What is different is everything underneath.  The modules below only *hold* parameters under the
+reference's names; ``forward`` never calls them.  Activations are channels-last (B,H,W,C) in the
+compute dtype (fp32 = parity path, bf16 = throughput path) and every PGSSTB block is six launches
+of libmphsir (include/mphsir.h):
+
+    win_attn      LN1 + shift + window MSA + proj + spectral-prompt gate   (ref :667-696, :132-152)
+    gemm_tok      1x1 qkv conv of the global spectral branch              (ref :98)
+    dwconv_gram   depthwise 3x3 + per-head Gram / norms, v out            (ref :98-107)
+    spectral_fold normalise, temperature, softmax, fold project_out        (ref :104-113)
+    gemm_tok      M_b v + shortcut + DropPath*(sa*gate + .)                (ref :110-113, :715-718)
+    gated_mlp     LN2 + fc1 + GELU gate + fc2 + DropPath residual          (ref :719)
+
+Dense 3x3 convs, pixel (un)shuffle, concatenation and the two interpolations of TVSP are PyTorch-ROCm
+glue.  There is no CPU path: without libmphsir.so, forward raises.
+
+`file:line` citations are relative to the reference repository's net/MP_HSIR.py.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .. import autograd_ops as AG
+
+WINDOW = 8
+PROMPT_LEN = 128
+
+# the task sentences fed to the CLIP text encoder (reference :484-506) -- model definition data
+_TASK_PROMPTS = {
+    "gaussianN": "A hyperspectral image corrupted by Gaussian noise.",
+    "complexN": "A hyperspectral image affected by complex noise patterns.",
+    "blur": "A hyperspectral image degraded by Gasussian blur.",
+    "sr": "A hyperspectral image with reduced spatial resolution.",
+    "inpaint": "A hyperspectral image compressed to a certain ratio.",
+    "haze": "A hyperspectral image degraded by atmospheric haze.",
+    "bandmiss": "A hyperspectral image with missing spectral bands.",
+    "cassi": "A hyperspectral image modulated by a coded aperture and compressed into a snapshot measurement.",
+}
+_TASK_SETS = {6: ("gaussianN", "complexN", "blur", "sr", "inpaint", "bandmiss"),
+              7: ("gaussianN", "complexN", "blur", "sr", "inpaint", "haze", "bandmiss"),
+              1: ("cassi",)}
+
+
+def _hidden(dim, factor):
+    return int(dim * factor)
+
+
+class _Cache:
+    """Per-module cache of weights converted/padded for the kernels, keyed on the compute dtype and
+    on the version counters of the source parameters (in-place updates, load_state_dict) plus the
+    package-wide epoch that raw-pointer optimizers bump (ops.bump_weight_epoch)."""
+
+    def __init__(self):
+        self.key = None
+        self.val = None
+
+    def get(self, params, dtype, build):
+        key = (dtype, ops.weight_epoch(), tuple(p._version for p in params), params[0].device)
+        if key != self.key:
+            with torch.no_grad():
+                self.val = build()
+            self.key = key
+        return self.val
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter holders (names = reference attribute names; forward is never called on them)
+# --------------------------------------------------------------------------------------------------
+class GatedMlp(nn.Module):                                                         # ref :66-82
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features * 2)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Spectral_Attention(nn.Module):                                               # ref :85-114
+    def __init__(self, dim, num_heads, bias=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.temperature = nn.Parameter(torch.ones(num_heads, 1, 1))
+        self.qkv = nn.Conv2d(dim, dim * 3, 1, bias=bias)
+        self.qkv_dwconv = nn.Conv2d(dim * 3, dim * 3, 3, padding=1, groups=dim * 3, bias=bias)
+        self.project_out = nn.Conv2d(dim, dim, 1, bias=bias)
+        self._cache = _Cache()
+
+    def packed(self, dtype):
+        ps = [self.qkv.weight, self.qkv_dwconv.weight, self.project_out.weight, self.temperature]
+        C = self.project_out.weight.shape[0]
+
+        def build():
+            return dict(wqkv=self.qkv.weight.reshape(3 * C, C).to(dtype).contiguous(),
+                        w9=ops.pack_dw(self.qkv_dwconv.weight),
+                        wo=self.project_out.weight.reshape(C, C).float().contiguous(),
+                        temp=self.temperature.reshape(-1).float().contiguous())
+        return self._cache.get(ps, dtype, build)
+
+
+Attention = Spectral_Attention      # the reference defines the same MDTA math twice more (:289, :394)
+
+
+class PG_Spectral_Attention(nn.Module):                                            # ref :116-155
+    def __init__(self, dim, compress_ratio, num_heads, prompt_len, bias=False):
+        super().__init__()
+        r = dim // compress_ratio
+        self.num_heads = num_heads
+        self.linear_down = nn.Linear(dim, r, bias=bias)
+        self.linear_up = nn.Linear(r, dim, bias=bias)
+        self.linear_prompt = nn.Linear(dim, prompt_len, bias=bias)
+        self.prompt_param = nn.Parameter(torch.rand(1, 1, prompt_len, r))
+        self.q = nn.Linear(r, r, bias=bias)
+        self.kv = nn.Linear(r, 2 * r, bias=bias)
+        self.proj = nn.Linear(r, r)
+
+
+class Spatial_Attention(nn.Module):                                                # ref :158-218
+    def __init__(self, dim, window_size, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        n = 2 * window_size - 1
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(n * n, num_heads))
+        t = torch.arange(window_size * window_size)
+        ty, tx = t // window_size, t % window_size
+        index = (ty[:, None] - ty[None, :] + window_size - 1) * n + (tx[:, None] - tx[None, :] + window_size - 1)
+        self.register_buffer("relative_position_index", index)
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+
+
+def shifted_window_mask(H, W, window=WINDOW, shift=WINDOW // 2):
+    """(nW,64,64) fp32: 0 where two tokens of a shifted window share a region, -100 otherwise (ref
+    calculate_mask :639-660).  Only kept as the `attn_mask` buffer for state_dict parity: the kernel
+    derives the mask from coordinates."""
+    def reg(n):
+        c = torch.arange(n)
+        return (c >= n - window).long() + (c >= n - shift).long()
+    ids = 3 * reg(H)[:, None] + reg(W)[None, :]
+    ids = ids.reshape(H // window, window, W // window, window).permute(0, 2, 1, 3).reshape(-1, window * window)
+    return (ids[:, None, :] != ids[:, :, None]).float() * -100.0
+
+
+class PGSSTB(nn.Module):                                                           # ref :601-723
+    def __init__(self, dim, num_heads, input_resolution=(64, 64), window_size=8, shift_size=0, drop_path=0.0,
+                 mlp_ratio=4., compress_ratio=8, prompt_len=128, qkv_bias=True, bias=False):
+        super().__init__()
+        assert window_size == WINDOW and qkv_bias and shift_size in (0, WINDOW // 2)
+        self.dim, self.num_heads, self.shift_size = dim, num_heads, shift_size
+        self.input_resolution = list(input_resolution)
+        self.drop_prob = float(drop_path)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = GatedMlp(dim, _hidden(dim, mlp_ratio))
+        self.attn = Spatial_Attention(dim, window_size, num_heads)
+        self.register_buffer("attn_mask", shifted_window_mask(*self.input_resolution) if shift_size > 0 else None)
+        self.gobal_spectral_attn = Spectral_Attention(dim, num_heads, bias)      # (sic) reference spelling
+        self.local_spectral_attn = PG_Spectral_Attention(dim, compress_ratio, num_heads, prompt_len, bias)
+        self._cache = _Cache()
+
+    def packed(self, dtype):
+        a, m, pg = self.attn, self.mlp, self.local_spectral_attn
+        ps = [a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, a.relative_position_bias_table,
+              m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, self.norm1.weight, self.norm1.bias,
+              self.norm2.weight, self.norm2.bias] + list(pg.parameters())
+
+        def build():
+            W1, b1, W2 = ops.pack_gated_mlp(m.fc1.weight, m.fc1.bias, m.fc2.weight, dtype)
+            f = lambda t: t.detach().float().contiguous()
+            return dict(
+                wqkv=a.qkv.weight.to(dtype).contiguous(), bqkv=f(a.qkv.bias),
+                wproj=ops.pack_win_proj(a.proj.weight, self.num_heads, dtype), bproj=f(a.proj.bias),
+                rpb=f(a.relative_position_bias_table), W1=W1, b1=b1, W2=W2, b2=f(m.fc2.bias),
+                ln1=(f(self.norm1.weight), f(self.norm1.bias)), ln2=(f(self.norm2.weight), f(self.norm2.bias)),
+                pg={"linear_prompt.weight": f(pg.linear_prompt.weight), "prompt_param": f(pg.prompt_param.reshape(PROMPT_LEN, -1)),
+                    "q.weight": f(pg.q.weight), "kv.weight": f(pg.kv.weight), "linear_down.weight": f(pg.linear_down.weight),
+                    "proj.weight": f(pg.proj.weight), "proj.bias": f(pg.proj.bias), "linear_up.weight": f(pg.linear_up.weight)})
+        return self._cache.get(ps, dtype, build)
+
+    def drop_path_factors(self, B, device):
+        """timm DropPath semantics: per-sample Bernoulli(keep)/keep, drawn independently for the two
+        residual branches (ref :718-719); None in eval mode or when the rate is 0."""
+        if not self.training or self.drop_prob == 0.0:
+            return None, None
+        keep = 1.0 - self.drop_prob
+        m = torch.empty((2, B), dtype=torch.float32, device=device).bernoulli_(keep) / keep
+        return m[0].contiguous(), m[1].contiguous()
+
+    def forward(self, x, text_prompt=None):
+        """x: channels-last (B,H,W,C) in the compute dtype."""
+        k1, k2 = self.drop_path_factors(x.shape[0], x.device)
+        return AG.pgsstb(self, x, k1, k2)
+
+
+class BaseBlock(nn.Module):                                                        # ref :727-761
+    def __init__(self, dim=96, window_size=8, input_resolution=(64, 64), depth=6, num_head=6, mlp_ratio=2,
+                 compress_ratio=8, prompt_len=128, qkv_bias=True, qk_scale=None, drop_path=(), bias=False):
+        super().__init__()
+        self.blocks = nn.ModuleList(
+            PGSSTB(dim, num_head, input_resolution, window_size, 0 if i % 2 == 0 else window_size // 2, drop_path[i],
+                   mlp_ratio, compress_ratio, prompt_len, qkv_bias, bias) for i in range(depth))
+
+    def forward(self, x, text_prompt=None):
+        y = x
+        for blk in self.blocks:
+            y = blk(y)
+        return y + x
+
+
+class _LN(nn.Module):
+    """holder for LayerNorm(dim, 'WithBias').body.{weight,bias}                     ref :341-370"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.body = nn.Module()
+        self.body.weight = nn.Parameter(torch.ones(dim))
+        self.body.bias = nn.Parameter(torch.zeros(dim))
+
+    def pair(self):
+        return self.body.weight.detach().float().contiguous(), self.body.bias.detach().float().contiguous()
+
+
+class FeedForward(nn.Module):                                                      # ref :251-265 == :374-391
+    def __init__(self, dim, ffn_expansion_factor, bias=False):
+        super().__init__()
+        hid = _hidden(dim, ffn_expansion_factor)
+        self.project_in = nn.Conv2d(dim, hid * 2, 1, bias=bias)
+        self.dwconv = nn.Conv2d(hid * 2, hid * 2, 3, padding=1, groups=hid * 2, bias=bias)
+        self.project_out = nn.Conv2d(hid, dim, 1, bias=bias)
+        self._cache = _Cache()
+
+    def packed(self, dtype):
+        ps = [self.project_in.weight, self.dwconv.weight, self.project_out.weight]
+
+        def build():
+            two_hid, D = self.project_in.weight.shape[:2]
+            hid = two_hid // 2
+            HP = ops.round_up(hid, 32)
+            dev = self.project_in.weight.device
+            w_in = torch.zeros((2 * HP, D), dtype=dtype, device=dev)
+            wi = self.project_in.weight.reshape(two_hid, D)
+            w_in[:hid], w_in[HP:HP + hid] = wi[:hid].to(dtype), wi[hid:].to(dtype)
+            w9 = torch.zeros((9, 2 * HP), dtype=torch.float32, device=dev)
+            w9s = ops.pack_dw(self.dwconv.weight)
+            w9[:, :hid], w9[:, HP:HP + hid] = w9s[:, :hid], w9s[:, hid:]
+            w_out = torch.zeros((D, HP), dtype=dtype, device=dev)
+            w_out[:, :hid] = self.project_out.weight.reshape(D, hid).to(dtype)
+            return dict(w_in=w_in, w9=w9, w_out=w_out)
+        return self._cache.get(ps, dtype, build)
+
+
+FFN = FeedForward
+
+
+class CrossAttention(nn.Module):                                                   # ref :220-249
+    def __init__(self, dim, num_heads, bias=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.temperature = nn.Parameter(torch.ones(num_heads, 1, 1))
+        self.kv = nn.Conv2d(dim, dim * 2, 1, bias=bias)
+        self.kv_dwconv = nn.Conv2d(dim * 2, dim * 2, 3, padding=1, groups=dim * 2, bias=bias)
+        self.q = nn.Conv2d(dim, dim, 1, bias=bias)
+        self.q_dwconv = nn.Conv2d(dim, dim, 3, padding=1, groups=dim, bias=bias)
+        self.project_out = nn.Conv2d(dim, dim, 1, bias=bias)
+        self._cache = _Cache()
+
+    def packed(self, dtype):
+        ps = [self.kv.weight, self.kv_dwconv.weight, self.q.weight, self.q_dwconv.weight, self.project_out.weight, self.temperature]
+        D = self.q.weight.shape[0]
+
+        def build():
+            return dict(wq=self.q.weight.reshape(D, D).to(dtype).contiguous(),
+                        wkv=self.kv.weight.reshape(2 * D, D).to(dtype).contiguous(),
+                        w9=torch.cat([ops.pack_dw(self.q_dwconv.weight), ops.pack_dw(self.kv_dwconv.weight)], 1).contiguous(),
+                        wo=self.project_out.weight.reshape(D, D).float().contiguous(),
+                        temp=self.temperature.reshape(-1).float().contiguous())
+        return self._cache.get(ps, dtype, build)
+
+
+class CrossTransformer(nn.Module):                                                 # ref :267-287
+    def __init__(self, dim, num_heads, ffn_expansion_factor, bias=False, LayerNorm_type="WithBias", cross_residual=True):
+        super().__init__()
+        assert LayerNorm_type == "WithBias" and cross_residual
+        self.norm11, self.norm12 = _LN(dim), _LN(dim)
+        self.attn = CrossAttention(dim, num_heads, bias)
+        self.norm2 = _LN(dim)
+        self.ffn = FFN(dim, ffn_expansion_factor, bias)
+
+
+class TransformerBlock(nn.Module):                                                 # ref :466-479
+    def __init__(self, dim, num_heads, ffn_expansion_factor, bias=False, LayerNorm_type="WithBias"):
+        super().__init__()
+        assert LayerNorm_type == "WithBias"
+        self.norm1 = _LN(dim)
+        self.attn = Attention(dim, num_heads, bias)
+        self.norm2 = _LN(dim)
+        self.ffn = FeedForward(dim, ffn_expansion_factor, bias)
+
+
+class Text_Prompt(nn.Module):                                                      # ref :481-535
+    def __init__(self, task_classes=7, clip_prompt=None):
+        super().__init__()
+        if task_classes not in _TASK_SETS:
+            raise ValueError("task_classes must be 6 or 7")
+        self.task_text_prompts = [_TASK_PROMPTS[k] for k in _TASK_SETS[task_classes]]
+        self.task_classes = task_classes
+        if clip_prompt is None:
+            clip_prompt = self._encode_with_clip()
+        assert tuple(clip_prompt.shape) == (task_classes, 512), clip_prompt.shape
+        self.clip_prompt = clip_prompt.detach().float()      # plain attribute, not in state_dict
+
+    def _encode_with_clip(self):
+        try:
+            import clip  # OpenAI CLIP, as the reference uses it (:512-515)
+            model, _ = clip.load("ViT-B/32", device="cpu")
+            with torch.no_grad():
+                return model.encode_text(clip.tokenize(self.task_text_prompts)).float()
+        except ImportError:
+            warnings.warn("OpenAI `clip` is not installed: using a seeded surrogate for the (T,512) text "
+                          "embeddings.  Pass clip_prompt=... to MP_HSIR_Net to inject the real ones.")
+            g = torch.Generator().manual_seed(2024)
+            v = torch.randn((self.task_classes, 512), generator=g)
+            return v / v.norm(dim=-1, keepdim=True) * 8.0
+
+    def forward(self, x, de_class=None):
+        T = self.task_classes
+        table = self.clip_prompt.to(x.device)
+        if de_class.dim() > 1:
+            w = F.one_hot(de_class, T).float().mean(dim=1)      # training path: mean of one-hots (:519-523)
+        else:
+            w = F.one_hot(de_class, T)                           # test path: int64 one-hot (:525)
+        clip = (w.unsqueeze(-1) * table.unsqueeze(0)).mean(dim=1)
+        return clip, w
+
+    def get_clip_prompt(self):
+        return self.clip_prompt
+
+
+class TVSP(nn.Module):                                                             # ref :538-583
+    def __init__(self, task_classes=6, prompt_size=64, prompt_dim=96, out_dim=96, clip_prompts=None):
+        super().__init__()
+        self.task_classes, self.prompt_size, self.prompt_dim = task_classes, prompt_size, prompt_dim
+        self.text_linear = nn.Linear(512, prompt_dim)         # in the state_dict, unused in forward (Q3)
+        self.visual_prompt = nn.Parameter(torch.randn(1, prompt_dim, prompt_size, prompt_size))
+        self.clip_linear = nn.Linear(512, prompt_dim)         # likewise
+        self.text_prompt_learnable = nn.Parameter(torch.randn(1, task_classes, prompt_dim, 1, 1))
+        self.cross_transformer = CrossTransformer(prompt_dim, 2, 2.66, False, "WithBias")
+        self.conv_last = nn.Conv2d(prompt_dim, out_dim, 3, padding=1, bias=False)
+
+    def forward(self, x, clip_prompt=None, prompt_weights=None):
+        """x: channels-last (B,H,W,D) (only its shape is used, as in the reference)."""
+        return AG.tvsp(self, x, clip_prompt, prompt_weights)
+
+
+class PromptFusion(nn.Module):                                                     # ref :587-599
+    def __init__(self, dim=96, out_dim=48, head=6, ffn_expansion_factor=2.66, bias=False):
+        super().__init__()
+        self.transformer = TransformerBlock(dim, head, ffn_expansion_factor, bias, "WithBias")
+        self.conv = nn.Conv2d(dim, out_dim, 1, bias=bias)
+
+    def forward(self, x, prompt):
+        return AG.prompt_fusion(self, x, prompt)
+
+
+class OverlapPatchEmbed(nn.Module):                                                # ref :454-463
+    def __init__(self, in_c=3, embed_dim=48, bias=False):
+        super().__init__()
+        self.proj = nn.Conv2d(in_c, embed_dim, 3, padding=1, bias=bias)
+
+
+class Downsample(nn.Module):                                                       # ref :432-440
+    def __init__(self, n_feat):
+        super().__init__()
+        self.body = nn.Sequential(nn.Conv2d(n_feat, n_feat // 2, 3, padding=1, bias=False), nn.PixelUnshuffle(2))
+
+
+class Upsample(nn.Module):                                                         # ref :442-450
+    def __init__(self, n_feat):
+        super().__init__()
+        self.body = nn.Sequential(nn.Conv2d(n_feat, n_feat * 2, 3, padding=1, bias=False), nn.PixelShuffle(2))
+
+
+class MP_HSIR_Net(nn.Module):                                                      # ref :763-844
+    def __init__(self, in_channel=31, out_channel=31, dim=64, num_blocks=[2, 4, 6], window_size=[8, 8, 8],
+                 task_classes=6, num_refinement_blocks=4, heads=[2, 4, 8], ffn_expansion_factor=2.66, bias=False,
+                 clip_prompt=None, compute_dtype=None):
+        super().__init__()
+        assert list(window_size) == [8, 8, 8], "the kernels are built for 8x8 windows (the only shipped setting)"
+        nb = list(num_blocks)
+        self.patch_embed = OverlapPatchEmbed(in_channel, dim)
+        dpr = [x.item() for x in torch.linspace(0, 0.1, sum(nb))]
+        self.text_prompt = Text_Prompt(task_classes=task_classes, clip_prompt=clip_prompt)
+        self.clip_prompts = self.text_prompt.get_clip_prompt()
+        self.prompt1 = TVSP(task_classes, 64, dim, dim)
+        self.prompt2 = TVSP(task_classes, 32, dim * 2, dim * 2)
+        self.fusion1 = PromptFusion(dim * 2, dim, 4, 2.66, False)
+        self.fusion2 = PromptFusion(dim * 4, dim * 2, 8, 2.66, False)
+
+        def stage(c, res, depth, head, cr, rates):
+            return BaseBlock(c, 8, [res, res], depth, head, ffn_expansion_factor, cr, PROMPT_LEN, True, None, rates, bias)
+        r1, r2, r3 = dpr[:nb[0]], dpr[nb[0]:nb[0] + nb[1]], dpr[nb[0] + nb[1]:]
+        self.encoder_level1 = stage(dim, 64, nb[0], heads[0], 8, r1)
+        self.down1_2 = Downsample(dim)
+        self.encoder_level2 = stage(dim * 2, 32, nb[1], heads[1], 16, r2)
+        self.down2_3 = Downsample(dim * 2)
+        self.latent = stage(dim * 4, 16, nb[2], heads[2], 32, r3)
+        self.up3_2 = Upsample(dim * 4)
+        self.reduce_chan_level2 = nn.Conv2d(dim * 4, dim * 2, 1, bias=bias)
+        self.decoder_level2 = stage(dim * 2, 32, nb[1], heads[1], 16, r2)
+        self.up2_1 = Upsample(dim * 2)
+        self.decoder_level1 = stage(dim * 2, 64, nb[0], heads[0], 8, r1)
+        self.refinement = stage(dim * 2, 64, num_refinement_blocks, heads[0], 8, r2)
+        self.output = nn.Conv2d(dim * 2, out_channel, 3, padding=1, bias=bias)
+        self.prompts = None
+        self.compute_dtype = compute_dtype
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (exact-f32 MFMA, parity path), torch.bfloat16, or None = follow autocast."""
+        self.compute_dtype = dtype
+        return self
+
+    def _dtype(self):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        if torch.is_autocast_enabled():
+            return torch.bfloat16     # the reference trains with fp16 autocast (train.py:118); bf16 here
+        return torch.float32
+
+    def forward(self, inp_img, task_id=None):
+        dt = self._dtype()
+        clip, w = self.text_prompt(inp_img, task_id)
+        x_in = inp_img.to(dt).permute(0, 2, 3, 1).contiguous()                     # channels-last from here on
+        e1 = self.encoder_level1(AG.conv3x3(x_in, self.patch_embed.proj.weight))
+        e2 = self.encoder_level2(AG.pixel_unshuffle2(AG.conv3x3(e1, self.down1_2.body[0].weight)))
+        lat = self.latent(AG.pixel_unshuffle2(AG.conv3x3(e2, self.down2_3.body[0].weight)))
+        d2_in = AG.pixel_shuffle2(AG.conv3x3(lat, self.up3_2.body[0].weight))
+        f2 = self.fusion2(e2, self.prompt2(e2, clip, w))
+        d2 = self.decoder_level2(AG.conv1x1(torch.cat([d2_in, f2], -1), self.reduce_chan_level2.weight))
+        d1_in = AG.pixel_shuffle2(AG.conv3x3(d2, self.up2_1.body[0].weight))
+        f1 = self.fusion1(e1, self.prompt1(e1, clip, w))
+        r = self.refinement(self.decoder_level1(torch.cat([d1_in, f1], -1)))
+        out = AG.conv3x3(r, self.output.weight).permute(0, 3, 1, 2).to(inp_img.dtype) + inp_img
+        return out

@@ -8,6 +8,17 @@ from . import _lib
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
+# optional algorithmic work accounting (bench.py roofline leg): kernel name -> [launches, flops, bytes]
+ACCOUNT = None
+
+
+def _acct(name, flops, nbytes):
+    if ACCOUNT is not None:
+        a = ACCOUNT.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += nbytes
+
 
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -66,6 +77,8 @@ def gemm_tok(x, w, bias=None, ln=None, epi=0, res=None, sa=None, gate=None, keep
     if geom is not None:
         a.H, a.Wimg, a.shift = geom
     _lib.check(lib.mphsir_gemm_tok(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gemm_tok")
+    es = x.element_size()
+    _acct("gemm_tok", 2.0 * M * N * K, (M * K + M * N * (1 + (res is not None) + (sa is not None))) * es + w.numel() * es)
     return y
 
 
@@ -104,6 +117,7 @@ def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, ou
     a.keep, a.rows_per_batch = _p(keep), rows_per_batch
     a.Y, a.ldy, a.M, a.C, a.HP = _p(y), _rows(y)[1], M, C, HP
     _lib.check(lib.mphsir_gated_mlp_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gated_mlp_fwd")
+    _acct("gated_mlp", 6.0 * M * C * HP, 2.0 * M * C * x.element_size() + 3.0 * C * HP * x.element_size())
     return y
 
 
@@ -138,6 +152,8 @@ def win_attn_fwd(x, ln_w, ln_b, Wqkv, bqkv, rpb, Wproj, bproj, pg, heads, shift)
     a.B, a.H, a.W, a.C, a.heads, a.shift = B, H, W, C, heads, shift
     a.r = pg["linear_down.weight"].shape[0]
     _lib.check(lib.mphsir_win_attn_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "win_attn_fwd")
+    M = B * H * W
+    _acct("win_attn", M * (8.0 * C * C + 4.0 * 64 * C), 2.0 * M * C * x.element_size() + gate.numel() * 4 + 4.0 * C * C * x.element_size())
     return sa, gate
 
 
@@ -172,6 +188,7 @@ def dwconv_gram(tq, tk, tv, wq, wk, wv, ldw, B, H, W, C, heads, nsplit=None):
     a.V, a.ldvo, a.Gpart, a.Spart = _p(v), C, _p(gp), _p(sp)
     a.B, a.H, a.W, a.C, a.heads, a.nsplit = B, H, W, C, heads, nsplit
     _lib.check(lib.mphsir_dwconv_gram(ctypes.byref(a), _DT[tq.dtype], _stream(tq)), "dwconv_gram")
+    _acct("dwconv_gram", M * (54.0 * C + 2.0 * C * hd), 4.0 * M * C * tq.element_size() + gp.numel() * 4 + sp.numel() * 4)
     return v, gp, sp, nsplit
 
 
@@ -187,6 +204,7 @@ def spectral_fold(gp, sp, temperature, Wo, dtype):
     a.Gpart, a.Spart, a.temperature, a.Wo, a.M = _p(gp), _p(sp), _p(temperature), _p(Wo), _p(Mo)
     a.B, a.C, a.heads, a.nsplit = B, C, heads, nsplit
     _lib.check(lib.mphsir_spectral_fold(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold")
+    _acct("spectral_fold", 2.0 * B * C * C * hd, gp.numel() * 4 + sp.numel() * 4 + C * C * 4 + Mo.numel() * Mo.element_size())
     return Mo
 
 
@@ -201,4 +219,28 @@ def dwconv_gate(t, w9, B, H, W):
     a.T, a.ldt, a.w9, a.ldw, a.U, a.ldu = _p(t), ldt, _p(w9), w9.stride(0), _p(u), HP
     a.B, a.H, a.W, a.HP = B, H, W, HP
     _lib.check(lib.mphsir_dwconv_gate(ctypes.byref(a), _DT[t.dtype], _stream(t)), "dwconv_gate")
+    _acct("dwconv_gate", M * HP * 40.0, 3.0 * M * HP * t.element_size())
     return u
+
+
+_WEIGHT_EPOCH = [0]
+
+
+def weight_epoch():
+    return _WEIGHT_EPOCH[0]
+
+
+def bump_weight_epoch():
+    """Call after updating parameters through raw pointers (the flat-arena optimizer kernel): the
+    per-module packed-weight caches key on this counter as well as on tensor version counters."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def flat_adamw(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    """In-place AdamW step on flat fp32 arenas (length a multiple of 4)."""
+    lib = _lib.load()
+    _check(p, g, m, v)
+    assert p.dtype == torch.float32 and p.is_contiguous() and p.numel() == g.numel() == m.numel() == v.numel()
+    _lib.check(lib.mphsir_flat_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                                     grad_scale, _stream(p)), "flat_adamw")
+    bump_weight_epoch()

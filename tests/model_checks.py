@@ -1,0 +1,89 @@
+"""Whole-network checks shared by the emulator (CPU) and GPU test files."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from golden.cases import TINY_CFG, TINY_CASES, FULL_CASES
+from golden.detfill import det_fill_, seeded_input, surrogate_clip_prompt
+from util import rel_l2
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build_net(cfg, dev, dtype=torch.float32):
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    net = MP_HSIR_Net(**cfg, clip_prompt=surrogate_clip_prompt(cfg["task_classes"])).eval()
+    det_fill_(net)
+    return net.to(dev).set_compute_dtype(dtype)
+
+
+def check_tiny_forward(dev, name, dtype=torch.float32, tol=2e-5):
+    case = TINY_CASES[name]
+    cfg = dict(TINY_CFG, task_classes=case.get("task_classes", TINY_CFG["task_classes"]))
+    net = build_net(cfg, dev, dtype)
+    x = seeded_input(name, case["shape"]).to(dev)
+    with torch.no_grad():
+        y = net(x, torch.tensor(case["task"]).to(dev))
+    want = np.load(os.path.join(GOLDEN, "tiny_fwd.npz"))[name + "/out"]
+    err = rel_l2(y.float().cpu(), want)
+    assert err < tol, (name, err)
+    return err
+
+
+def full_case_inputs(name):
+    c = FULL_CASES[name]
+    clean = seeded_input(name + ":clean", c["shape"])
+    if c["recipe"] == "gaussian70":
+        degraded = clean + seeded_input(name + ":noise", c["shape"], "normal") * (70.0 / 255.0)
+    else:
+        degraded = clean * (seeded_input(name + ":mask", c["shape"]) > 0.9).float()
+    return c, clean, degraded
+
+
+def psnr(restored, clean):
+    r = restored.detach().double().cpu().clamp(0, 1)
+    c = clean.detach().double().cpu().clamp(0, 1)
+    mse = ((r - c) ** 2).mean(dim=(-1, -2))
+    return float((10.0 * torch.log10(1.0 / mse)).mean(dim=1).mean())
+
+
+def check_full_forward(dev, name, dtype=torch.float32, tol=1e-3, dpsnr=0.01):
+    c, clean, degraded = full_case_inputs(name)
+    net = build_net(c["cfg"], dev, dtype)
+    with torch.no_grad():
+        y = net(degraded.to(dev), torch.tensor(c["task"]).to(dev))
+    g = np.load(os.path.join(GOLDEN, "full.npz"))
+    err = rel_l2(y.float().cpu(), g[name + "/out"])
+    dp = abs(psnr(y, clean) - float(g[name + "/psnr_restored"]))
+    assert err < tol and dp < dpsnr, (name, err, dp)
+    return err, dp
+
+
+def check_tiny_gradients(dev, dtype=torch.float32, tol=1e-4):
+    """L1-after-clamp loss and every parameter gradient of the tiny net vs the reference (tiny_grad.npz)."""
+    from golden.cases import GRAD_KEYS_FULL, sample_indices
+    net = build_net(TINY_CFG, dev, dtype)
+    x = seeded_input("grad_x", (2, 8, 64, 64)).to(dev)
+    clean = seeded_input("grad_clean", (2, 8, 64, 64)).to(dev)
+    task = torch.tensor([[1], [3]]).to(dev)
+    y = net(x, task)
+    loss = (y.clamp(0, 1) - clean).abs().mean()
+    loss.backward()
+    g = np.load(os.path.join(GOLDEN, "tiny_grad.npz"))
+    assert abs(float(loss) - float(g["loss"])) < tol * 10, (float(loss), float(g["loss"]))
+    none_keys = set(str(k) for k in g["none_keys"])
+    worst = 0.0
+    for k, p in net.named_parameters():
+        if k in none_keys:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        want = float(g["norm/" + k])
+        err = abs(float(p.grad.float().norm()) - want) / (want + 1e-20)
+        if any(k.startswith(pref) for pref in GRAD_KEYS_FULL):
+            err = max(err, rel_l2(p.grad.float().cpu(), g["full/" + k]))
+        worst = max(worst, err)
+        assert err < tol, (k, err)
+    return worst
