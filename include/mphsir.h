@@ -161,6 +161,17 @@ typedef struct mphsir_mlp_args {
 } mphsir_mlp_args;
 int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream);
 
+/* ---- plain depthwise 3x3 (backward building blocks) ----------------------------------------------
+ * mphsir_dwconv3x3: Y[p][c] = sum_taps X[p+tap][c] * w9[tap][c] (zero padding); flip=1 uses the spatially
+ * flipped taps = gradient w.r.t. the input of the same depthwise conv applied to dY.
+ * mphsir_dwconv3x3_wgrad: partial[blk][tap][c] = sum over the pixels of block blk of X[p+tap][c]*dY[p][c];
+ * the caller sums the nblk partials (fixed order -> deterministic).  w9 / partial are fp32, tap-major.
+ * Gradients of every nn.Conv2d(groups=channels) on the path (net/MP_HSIR.py:92,227,230,257,382).        */
+int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int64_t ldw, void* Y, int64_t ldy,
+                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t flip, int dtype, void* stream);
+int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY, int64_t lddy, float* partial, int32_t nblk,
+                           int32_t B, int32_t H, int32_t W, int32_t C, int dtype, void* stream);
+
 /* ---- fused AdamW over the flat parameter arena ---------------------------------------------------
  * One decoupled-weight-decay Adam step on n contiguous fp32 parameters (n % 4 == 0) with gradient g,
  * moments m, v; g is multiplied by grad_scale first (1/world_size after a sum all-reduce).
@@ -179,6 +190,8 @@ int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, f
 #define MPHSIR_K_GATED_MLP 4
 #define MPHSIR_K_DWCONV_GATE 5
 #define MPHSIR_K_FLAT_ADAMW 6
+#define MPHSIR_K_DWCONV 7
+#define MPHSIR_K_DWCONV_WGRAD 8
 #define MPHSIR_K_COUNT 16
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -14,6 +14,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from . import ops
+
 WINDOW, SHIFT, PROMPT_LEN = 8, 4, 128
 
 
@@ -25,8 +27,35 @@ def pw(x, w4):
     return x @ w4.reshape(w4.shape[0], -1).to(x.dtype).t()
 
 
+class _DwConv3x3(torch.autograd.Function):
+    """depthwise 3x3 through the HIP kernels: forward, backward-data (flipped taps) and weight gradient.
+    (MIOpen's bf16 channels-last depthwise backward falls back to naive kernels: 75 % of a training step.)"""
+
+    @staticmethod
+    def forward(ctx, x, w4):
+        w9 = ops.pack_dw(w4)
+        ctx.save_for_backward(x, w9)
+        ctx.wshape = w4.shape
+        return ops.dwconv3x3(x, w9)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w9 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.dwconv3x3(dy, w9, flip=True) if ctx.needs_input_grad[0] else None
+        dw = ops.dwconv3x3_wgrad(x, dy).t().reshape(ctx.wshape) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
 def dw3(x, w4):
-    return F.conv2d(x.permute(0, 3, 1, 2), w4.to(x.dtype), None, 1, 1, 1, w4.shape[0]).permute(0, 2, 3, 1)
+    return _DwConv3x3.apply(x.contiguous(), w4)
+
+
+def _pad_halves(w, hp):
+    """(2*hid, ...) -> (2*hp, ...): each half zero-padded to hp rows (the kernels' padded GDFN layout)."""
+    hid = w.shape[0] // 2
+    z = w.new_zeros((hp - hid,) + tuple(w.shape[1:]))
+    return torch.cat([w[:hid], z, w[hid:], z], 0)
 
 
 def to_windows(x):
@@ -82,9 +111,12 @@ def cross_attention(P, pre, xq, xkv, heads):
 
 
 def gdfn(P, pre, x):
-    t = dw3(pw(x, P[pre + "project_in.weight"]), P[pre + "dwconv.weight"])
-    hid = t.shape[-1] // 2
-    return pw(F.gelu(t[..., :hid].float()).to(x.dtype) * t[..., hid:], P[pre + "project_out.weight"])
+    w_in, w_dw, w_out = P[pre + "project_in.weight"], P[pre + "dwconv.weight"], P[pre + "project_out.weight"]
+    hid = w_in.shape[0] // 2
+    hp = (hid + 31) // 32 * 32
+    t = dw3(pw(x, _pad_halves(w_in, hp)), _pad_halves(w_dw, hp))
+    u = F.gelu(t[..., :hp].float()).to(x.dtype) * t[..., hp:]
+    return pw(u, F.pad(w_out.reshape(w_out.shape[0], hid), (0, hp - hid)))
 
 
 def gated_mlp(P, pre, x):

@@ -4,6 +4,8 @@ missing or does not load, every op raises -- build it with ``python mp-hsir_amd/
 import ctypes
 import os
 
+import torch  # noqa: F401  -- must come first: libmphsir.so binds to the HIP runtime PyTorch-ROCm already loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.path.join(_HERE, "libmphsir.so")
 _lib = None
@@ -69,6 +71,10 @@ _SYMBOLS = {
     "mphsir_dwconv_gram": (c_int, [ctypes.POINTER(GramArgs), c_int, c_void_p]),
     "mphsir_spectral_fold": (c_int, [ctypes.POINTER(FoldArgs), c_int, c_void_p]),
     "mphsir_dwconv_gate": (c_int, [ctypes.POINTER(GateArgs), c_int, c_void_p]),
+    "mphsir_dwconv3x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                 c_int32, c_int, c_void_p]),
+    "mphsir_dwconv3x3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                       c_int32, c_int, c_void_p]),
     "mphsir_flat_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,
                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int32, ctypes.c_float, c_void_p]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),

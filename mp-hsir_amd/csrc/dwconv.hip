@@ -1,0 +1,149 @@
+// Plain depthwise 3x3 on channels-last cubes: forward / backward-data (same kernel, taps flipped) and
+// the weight gradient (two-stage deterministic reduction over pixels).
+//
+// Used by the backward pass of every `*_dwconv` of the reference (nn.Conv2d(..., groups=channels),
+// net/MP_HSIR.py:92,227,230,257,382): d/dx of a depthwise correlation is the depthwise correlation of
+// dy with the spatially flipped taps; d/dw[tap][c] = sum over pixels of x[pixel+tap][c] * dy[pixel][c].
+// Pure HBM/L2 streaming: 16 B per lane along the channel axis, fp32 accumulation.
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+struct DwDev {
+    const void* X; long ldx; const float* w9; long ldw; void* Y; long ldy;
+    int B, H, W, C, flip;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(DwDev a) {
+    constexpr int VEC = Vec16<T>::N;
+    const int cv = a.C / VEC, HW = a.H * a.W;
+    const long total = (long)a.B * HW * cv;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    T* Y = reinterpret_cast<T*>(a.Y);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long pix = idx / cv;
+        const int c0 = (int)(idx % cv) * VEC, b = (int)(pix / HW), p = (int)(pix % HW), y = p / a.W, x = p % a.W;
+        const T* base = X + (long)b * HW * a.ldx;
+        float acc[VEC];
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= a.H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= a.W) continue;
+                const int tap = a.flip ? (1 - dy) * 3 + (1 - dx) : (dy + 1) * 3 + (dx + 1);
+                const Vec16<T> t = load16<T>(base + ((long)yy * a.W + xx) * a.ldx + c0);
+                const float* w = a.w9 + tap * a.ldw + c0;
+                for (int e = 0; e < VEC; ++e) acc[e] += t.get(e) * w[e];
+            }
+        }
+        Vec16<T> o;
+        for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+        store16<T>(Y + pix * a.ldy + c0, o);
+    }
+}
+
+struct DwWgDev {
+    const void* X; long ldx; const void* dY; long lddy; float* part;   // part [nblk][9][C]
+    int B, H, W, C, nblk;
+};
+
+// block = 64 channel vectors (lanes) x 4 pixel groups (waves); grid = (nblk, ceil(C/VEC/64))
+template <class T>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwWgDev a) {
+    constexpr int VEC = Vec16<T>::N;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    float* red = reinterpret_cast<float*>(smem_v);        // [4][64][9*VEC]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cvec = blockIdx.y * 64 + lane, c0 = cvec * VEC;
+    const bool live = c0 < a.C;
+    const int HW = a.H * a.W;
+    const long P = (long)a.B * HW, per = (P + a.nblk - 1) / a.nblk;
+    const long p_lo = (long)blockIdx.x * per, p_hi = (p_lo + per < P) ? p_lo + per : P;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* dY = reinterpret_cast<const T*>(a.dY);
+    float acc[9][VEC];
+    for (int t = 0; t < 9; ++t)
+        for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
+    if (live)
+        for (long pix = p_lo + wv; pix < p_hi; pix += 4) {
+            const int b = (int)(pix / HW), p = (int)(pix % HW), y = p / a.W, x = p % a.W;
+            const Vec16<T> g = load16<T>(dY + pix * a.lddy + c0);
+            const T* base = X + (long)b * HW * a.ldx;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= a.H) continue;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= a.W) continue;
+                    const Vec16<T> t = load16<T>(base + ((long)yy * a.W + xx) * a.ldx + c0);
+                    for (int e = 0; e < VEC; ++e) acc[(dy + 1) * 3 + (dx + 1)][e] += t.get(e) * g.get(e);
+                }
+            }
+        }
+    float* mine = red + ((wv * 64 + lane) * 9) * VEC;
+    for (int t = 0; t < 9; ++t)
+        for (int e = 0; e < VEC; ++e) mine[t * VEC + e] = acc[t][e];
+    __syncthreads();
+    if (wv == 0 && live) {
+        float* out = a.part + (long)blockIdx.x * 9 * a.C;
+        for (int t = 0; t < 9; ++t)
+            for (int e = 0; e < VEC; ++e) {
+                float s = 0.f;
+                for (int w = 0; w < 4; ++w) s += red[((w * 64 + lane) * 9 + t) * VEC + e];   // fixed order
+                out[t * a.C + c0 + e] = s;
+            }
+    }
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int64_t ldw, void* Y, int64_t ldy,
+                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t flip, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(X && w9 && Y, "dwconv3x3: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "dwconv3x3: dtype %d unsupported", dtype);
+    const int esz = dtype == MPHSIR_F32 ? 4 : 2, vec = 16 / esz;
+    MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0, "dwconv3x3: C must be a multiple of %d", vec);
+    MPHSIR_REQUIRE(aligned16(X) && aligned16(Y) && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0, "dwconv3x3: 16-byte alignment required");
+    DwDev d{X, (long)ldx, w9, (long)ldw, Y, (long)ldy, B, H, W, C, flip};
+    long blocks = ((long)B * H * W * (C / vec) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MPHSIR_F32)
+        MPHSIR_LAUNCH(MPHSIR_K_DWCONV, (dwconv3x3_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_DWCONV, (dwconv3x3_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    return MPHSIR_OK;
+}
+
+extern "C" int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY, int64_t lddy, float* partial, int32_t nblk,
+                                      int32_t B, int32_t H, int32_t W, int32_t C, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(X && dY && partial, "dwconv3x3_wgrad: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "dwconv3x3_wgrad: dtype %d unsupported", dtype);
+    const int esz = dtype == MPHSIR_F32 ? 4 : 2, vec = 16 / esz;
+    MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0 && nblk > 0, "dwconv3x3_wgrad: bad shape");
+    MPHSIR_REQUIRE(aligned16(X) && aligned16(dY) && (ldx * esz) % 16 == 0 && (lddy * esz) % 16 == 0, "dwconv3x3_wgrad: 16-byte alignment required");
+    DwWgDev d{X, (long)ldx, dY, (long)lddy, partial, B, H, W, C, nblk};
+    const size_t shmem = 4 * 64 * 9 * vec * sizeof(float);
+    dim3 grid(nblk, (C / vec + 63) / 64);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MPHSIR_F32) {
+        allow_big_lds(dwconv3x3_wgrad_kernel<float>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_DWCONV_WGRAD, (dwconv3x3_wgrad_kernel<float>), grid, dim3(256), shmem, s, d);
+    } else {
+        allow_big_lds(dwconv3x3_wgrad_kernel<bf16_t>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_DWCONV_WGRAD, (dwconv3x3_wgrad_kernel<bf16_t>), grid, dim3(256), shmem, s, d);
+    }
+    return MPHSIR_OK;
+}

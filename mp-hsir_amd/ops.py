@@ -244,3 +244,30 @@ def flat_adamw(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
     _lib.check(lib.mphsir_flat_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                      grad_scale, _stream(p)), "flat_adamw")
     bump_weight_epoch()
+
+
+def dwconv3x3(x, w9, flip=False):
+    """x (B,H,W,C) channels-last (last dim contiguous, row pitch = stride of W axis); w9 fp32 [9][C] view."""
+    lib = _lib.load()
+    _check(x, w9)
+    B, H, W, C = x.shape
+    assert x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and x.stride(0) == H * x.stride(1)
+    y = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    _lib.check(lib.mphsir_dwconv3x3(_p(x), x.stride(2), _p(w9), w9.stride(0), _p(y), C, B, H, W, C, int(flip),
+                                    _DT[x.dtype], _stream(x)), "dwconv3x3")
+    _acct("dwconv3x3", 18.0 * B * H * W * C, 2.0 * B * H * W * C * x.element_size())
+    return y
+
+
+def dwconv3x3_wgrad(x, dy, nblk=None):
+    """-> fp32 [9][C] = sum_p x[p+tap] * dy[p]."""
+    lib = _lib.load()
+    _check(x, dy)
+    B, H, W, C = x.shape
+    assert x.stride(3) == 1 and dy.stride(3) == 1 and dy.shape == x.shape
+    nblk = nblk or max(1, min(1024, B * H * W // 128))
+    part = torch.empty((nblk, 9, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mphsir_dwconv3x3_wgrad(_p(x), x.stride(2), _p(dy), dy.stride(2), _p(part), nblk, B, H, W, C,
+                                          _DT[x.dtype], _stream(x)), "dwconv3x3_wgrad")
+    _acct("dwconv3x3_wgrad", 18.0 * B * H * W * C, 2.0 * B * H * W * C * x.element_size())
+    return part.sum(dim=0)

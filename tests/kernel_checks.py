@@ -170,3 +170,24 @@ def check_gdfn_chain(dev, dtype):
           "project_out.weight": P["project_out.weight"].to(dtype).double().cpu()}
     ref = x.double().cpu() + O.gdfn(Pd, "", O.layer_norm_c(x.double().cpu(), lnw.double().cpu(), lnb.double().cpu()))
     assert rel_l2(y.reshape(B, H, W, C), ref) < TOL[dtype] * (2 if dtype == torch.bfloat16 else 1)
+
+
+def check_dwconv_plain(dev, dtype, shape):
+    """forward, backward-data (flipped taps) and weight gradient of the depthwise 3x3 vs torch autograd (fp64)."""
+    _use(dev)
+    import torch.nn.functional as F
+    from mp_hsir_amd import ops
+    B, H, W, C = shape
+    x, dy = rnd(shape, 41, dtype), rnd(shape, 42, dtype)
+    w = rnd((C, 1, 3, 3), 43, scale=1 / 3)
+    w9 = ops.pack_dw(w)
+    y = ops.dwconv3x3(x, w9)
+    dx = ops.dwconv3x3(dy, w9, flip=True)
+    dw = ops.dwconv3x3_wgrad(x, dy, nblk=3)
+    xr = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.double().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1, 1, C)
+    yr.backward(dy.double().cpu().permute(0, 3, 1, 2))
+    assert rel_l2(y, yr.detach().permute(0, 2, 3, 1)) < TOL[dtype]
+    assert rel_l2(dx, xr.grad.permute(0, 2, 3, 1)) < TOL[dtype]
+    assert rel_l2(dw, wr.grad.reshape(C, 9).t()) < TOL[dtype]
