@@ -144,43 +144,50 @@ struct FoldDev {
     int B, C, HD;
 };
 
+// grid = (B*HEADS, C/FOLD_CO): every workgroup redoes the (tiny) reduction + softmax of its head and
+// folds FOLD_CO output rows of project_out, whose head slice is staged through LDS.
+constexpr int FOLD_CO = 32;
+
 template <class T>
 __global__ __launch_bounds__(256) void spectral_fold_kernel(FoldDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     const int HD = a.HD, C = a.C, HEADS = C / HD;
-    float* G = reinterpret_cast<float*>(smem_v);      // [HD][HD] -> attention probabilities
-    float* nq = G + HD * HD;                          // [HD]
+    float* G = reinterpret_cast<float*>(smem_v);      // [HD][HD+1] -> attention probabilities
+    const int LDG = HD + 1;
+    float* nq = G + HD * LDG;                         // [HD]
     float* nk = nq + HD;                              // [HD]
-    const int tid = threadIdx.x, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
+    float* Ws = nk + HD;                              // [FOLD_CO][HD+1] project_out rows of this workgroup
+    const int tid = threadIdx.x, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS, co0 = blockIdx.y * FOLD_CO;
 
     for (int i = tid; i < HD * HD; i += 256) {        // ordered (deterministic) reduction over the splits
         float s = 0.f;
         for (int sp = 0; sp < a.nsplit; ++sp) s += a.Gpart[(((long)b * a.nsplit + sp) * HEADS + h) * HD * HD + i];
-        G[i] = s;
+        G[(i / HD) * LDG + i % HD] = s;
     }
     if (tid < 2 * HD) {
         float s = 0.f;
         for (int sp = 0; sp < a.nsplit; ++sp) s += a.Spart[((long)b * a.nsplit + sp) * 2 * C + (tid / HD) * C + h * HD + tid % HD];
         nq[tid] = fmaxf(sqrtf(s), 1e-12f);            // F.normalize eps (nk follows nq in memory)
     }
+    for (int i = tid; i < FOLD_CO * HD; i += 256)
+        Ws[(i / HD) * LDG + i % HD] = a.Wo[(long)(co0 + i / HD) * C + h * HD + i % HD];
     __syncthreads();
     if (tid < HD) {                                   // row softmax of G/(nq nk^T) * temperature
         const float tq = a.temperature[h] / nq[tid];
         float m = -3.0e38f;
-        for (int j = 0; j < HD; ++j) m = fmaxf(m, G[tid * HD + j] * tq / nk[j]);
+        for (int j = 0; j < HD; ++j) m = fmaxf(m, G[tid * LDG + j] * tq / nk[j]);
         float den = 0.f;
-        for (int j = 0; j < HD; ++j) { const float e = expf(G[tid * HD + j] * tq / nk[j] - m); G[tid * HD + j] = e; den += e; }
+        for (int j = 0; j < HD; ++j) { const float e = expf(G[tid * LDG + j] * tq / nk[j] - m); G[tid * LDG + j] = e; den += e; }
         const float inv = 1.0f / den;
-        for (int j = 0; j < HD; ++j) G[tid * HD + j] *= inv;
+        for (int j = 0; j < HD; ++j) G[tid * LDG + j] *= inv;
     }
     __syncthreads();
     T* M = reinterpret_cast<T*>(a.Mout) + (long)b * C * C;
-    for (int o = tid; o < C * HD; o += 256) {         // M[co][h*HD+j] = sum_i Wo[co][h*HD+i] A[i][j]
-        const int co = o / HD, j = o % HD;
-        const float* w = a.Wo + (long)co * C + h * HD;
+    for (int o = tid; o < FOLD_CO * HD; o += 256) {   // M[co][h*HD+j] = sum_i Wo[co][h*HD+i] A[i][j]
+        const int cl = o / HD, j = o % HD;
         float s = 0.f;
-        for (int i = 0; i < HD; ++i) s += w[i] * G[i * HD + j];
-        M[(long)co * C + h * HD + j] = from_f32<T>(s);
+        for (int i = 0; i < HD; ++i) s += Ws[cl * LDG + i] * G[i * LDG + j];
+        M[(long)(co0 + cl) * C + h * HD + j] = from_f32<T>(s);
     }
 }
 
@@ -264,14 +271,15 @@ extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* 
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 128, "spectral_fold: head_dim %d > 128", HD);
     FoldDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->M, a->B, a->C, HD};
-    const size_t shmem = ((size_t)HD * HD + 2 * HD) * sizeof(float);
+    MPHSIR_REQUIRE(a->C % FOLD_CO == 0, "spectral_fold: C must be a multiple of %d", FOLD_CO);
+    const size_t shmem = ((size_t)HD * (HD + 1) + 2 * HD + (size_t)FOLD_CO * (HD + 1)) * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32) {
         allow_big_lds(spectral_fold_kernel<float>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<float>), dim3(a->B * a->heads), dim3(256), shmem, s, d);
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<float>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(256), shmem, s, d);
     } else {
         allow_big_lds(spectral_fold_kernel<bf16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<bf16_t>), dim3(a->B * a->heads), dim3(256), shmem, s, d);
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<bf16_t>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(256), shmem, s, d);
     }
     return MPHSIR_OK;
 }
