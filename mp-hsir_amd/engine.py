@@ -40,6 +40,14 @@ class DataParallelEngine:
         self.step_count = 0
         self.arena = None
         self._pending = []
+        if self.world > 1:      # DDP's initial parameter broadcast (rank 0 -> all), one flat message
+            ps = [p for p in net.parameters()]
+            flat = torch.cat([p.data.reshape(-1).float() for p in ps])
+            dist.broadcast(flat, 0, group=self.pg)
+            o = 0
+            for p in ps:
+                p.data.copy_(flat[o:o + p.numel()].view(p.shape))
+                o += p.numel()
 
     # ---- arenas ---------------------------------------------------------------------------------
     def _build_arenas(self):
@@ -73,9 +81,6 @@ class DataParallelEngine:
             self.buckets.append([start, total, count])
         self.arena = (used, offs, total)
         if self.world > 1:
-            dist.broadcast(self.flat_p, 0, group=self.pg)   # DDP's initial parameter broadcast, one message
-            for p in self.unused:
-                dist.broadcast(p.data, 0, group=self.pg)
             bucket_of = {}
             bi = 0
             for p, o in zip(used, offs):

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Evaluation script for the two BASELINE modes of the reference's test.py: mode 0 (Gaussian denoise,
+test.py:150-188, prompt id 0, sigma 70 default :554) and mode 8 (inpainting, test.py:440-469, prompt id 4,
+mask ratio 0.9 :562).  Batch-1 forward under no_grad, band-wise PSNR as utils/val_utils.py:49-69 defines it
+(clip to [0,1], data_range 1, mean over bands then images).  Test cubes are synthetic (no datasets
+offline); pass --ckpt_path to evaluate a Lightning checkpoint of the reference (`net.` key prefix).
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net  # noqa: E402
+
+
+def psnr_bandwise(restored, clean):
+    r = restored.detach().double().clamp(0, 1)
+    c = clean.detach().double().clamp(0, 1)
+    mse = ((r - c) ** 2).mean(dim=(-1, -2))
+    return float((10.0 * torch.log10(1.0 / mse)).mean(dim=1).mean())
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--cuda", type=int, default=0)                       # reference default 4 (test.py:543): box specific
+    p.add_argument("--seed", type=int, default=2024)
+    p.add_argument("--mode", type=int, default=0, help="Used to select degradation mode.")
+    p.add_argument("--gaussian_noise_sigma", type=int, default=70, help="Gaussian Noise intensity")
+    p.add_argument("--mask_ratio", type=float, default=0.9, help="Inpaint Mask Ratio")
+    p.add_argument("--select_bands", type=list, default=[27, 15, 9])
+    p.add_argument("--ckpt_path", type=str, default=None)
+    p.add_argument("--model", type=str, default="natural_scene", choices=["natural_scene", "remote_sensing"])
+    p.add_argument("--size", type=int, default=512, help="synthetic cube height/width (reference test cubes: 512)")
+    p.add_argument("--cubes", type=int, default=4)
+    p.add_argument("--precision", type=str, default="f32", choices=["bf16", "f32"])
+    return p
+
+
+def main():
+    o = build_parser().parse_args()
+    torch.manual_seed(o.seed)
+    dev = torch.device("cuda", o.cuda)
+    cfg = dict(in_channel=31, out_channel=31, dim=64, task_classes=6) if o.model == "natural_scene" else \
+        dict(in_channel=100, out_channel=100, dim=96, task_classes=7)
+    net = MP_HSIR_Net(**cfg, compute_dtype=torch.float32 if o.precision == "f32" else torch.bfloat16).to(dev).eval()
+    if o.ckpt_path:
+        state = torch.load(o.ckpt_path, map_location=dev)["state_dict"]
+        net.load_state_dict({k[4:]: v for k, v in state.items() if k.startswith("net.")}, strict=False)   # test.py:575
+    gen = torch.Generator(device=dev).manual_seed(o.seed)
+    total = 0.0
+    for i in range(o.cubes):
+        clean = torch.rand((1, cfg["in_channel"], o.size, o.size), generator=gen, device=dev)
+        if o.mode == 0:
+            degraded = clean + torch.randn(clean.shape, generator=gen, device=dev) * (o.gaussian_noise_sigma / 255.0)
+            prompt = torch.tensor([0], device=dev)
+        elif o.mode == 8:
+            degraded = clean * (torch.rand(clean.shape, generator=gen, device=dev) > o.mask_ratio).float()
+            prompt = torch.tensor([4], device=dev)
+        else:
+            raise SystemExit("only modes 0 and 8 are wired to synthetic data (SURVEY §8f row 2)")
+        with torch.no_grad():
+            restored = net(degraded, prompt)
+        p = psnr_bandwise(restored, clean.clamp(0, 1))
+        total += p
+        print("cube %d psnr %.2f" % (i, p))
+    print(("Denoise sigma=%d: psnr: %.2f" % (o.gaussian_noise_sigma, total / o.cubes)) if o.mode == 0 else
+          ("Inpaint mask ratio=%f: psnr: %.2f" % (o.mask_ratio, total / o.cubes)))
+
+
+if __name__ == "__main__":
+    main()

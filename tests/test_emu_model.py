@@ -1,0 +1,20 @@
+"""Whole-network checks on CPU through the emulated kernels: the boundary module's wiring (NHWC glue,
+weight packing, TVSP batch coupling, autograd plumbing) against the reference's golden outputs and
+gradients.  Slow (fibers), so only the two most informative cases run here; the rest are `-m gpu`."""
+import pytest
+
+import model_checks as M
+from emu import bind_emulator
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emu():
+    bind_emulator()
+
+
+def test_tiny_forward_b4_matches_reference():
+    assert M.check_tiny_forward("cpu", "t32_b4") < 2e-6
+
+
+def test_tiny_gradients_match_reference():
+    assert M.check_tiny_gradients("cpu") < 1e-4
