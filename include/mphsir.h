@@ -161,6 +161,23 @@ typedef struct mphsir_mlp_args {
 } mphsir_mlp_args;
 int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream);
 
+/* ---- backward (data) of the fused LayerNorm + gated MLP + residual ---------------------------------
+ * Given dY = dL/dY of mphsir_gated_mlp_fwd and DM = keep[b]*dY (= dY when DropPath is off), computes
+ * dX = dY + LN_backward(...) and writes the three token matrices the parameter gradients are plain
+ * token-reduction GEMMs / column sums of:  XN = LN(X) [M][C],  H = value*gelu(gate) [M][HP],
+ * DPRE = [dvalue | dgate] [M][2*HP]  (dW2 = DM^T H, dW1 = DPRE^T XN, db2 = colsum DM, db1 = colsum DPRE),
+ * plus per-workgroup partial sums part[M/64][2][C] of d(ln weight) and d(ln bias).
+ * W1/b1 as for the forward; W1T = W1 transposed [C][2*HP]; W2T = fc2.weight^T zero-padded [HP][C].
+ * fp32 supports C <= 256.  Autograd of train.py:58-67 for net/MP_HSIR.py:719.                       */
+typedef struct mphsir_mlp_bwd_args {
+    const void* X; const void* dY; const void* DM;
+    const float* ln_w; const float* ln_b;
+    const void* W1; const float* b1; const void* W1T; const void* W2T;
+    void* dX; void* XN; void* H; void* DPRE; float* part;
+    int64_t M; int32_t C, HP;
+} mphsir_mlp_bwd_args;
+int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream);
+
 /* ---- plain depthwise 3x3 (backward building blocks) ----------------------------------------------
  * mphsir_dwconv3x3: Y[p][c] = sum_taps X[p+tap][c] * w9[tap][c] (zero padding); flip=1 uses the spatially
  * flipped taps = gradient w.r.t. the input of the same depthwise conv applied to dY.
@@ -192,6 +209,7 @@ int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, f
 #define MPHSIR_K_FLAT_ADAMW 6
 #define MPHSIR_K_DWCONV 7
 #define MPHSIR_K_DWCONV_WGRAD 8
+#define MPHSIR_K_GATED_MLP_BWD 9
 #define MPHSIR_K_COUNT 16
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -157,7 +157,8 @@ def pg_gate(P, pre, xw):
     return o @ P[pre + "linear_up.weight"].float().t()
 
 
-def pgsstb(P, x, heads, shift, k1=None, k2=None):
+def pgsstb_attn(P, x, heads, shift, k1=None):
+    """first residual branch of the block: x + DropPath(local + global spectral of the window attention)."""
     B, H, W, C = x.shape
     xn = layer_norm(x, P["norm1.weight"], P["norm1.bias"])
     if shift:
@@ -174,10 +175,14 @@ def pgsstb(P, x, heads, shift, k1=None, k2=None):
     branch = img(local) + spectral_attention(P, "gobal_spectral_attn.", sa_img, heads)
     if k1 is not None:
         branch = branch * k1.reshape(B, 1, 1, 1).to(branch.dtype)
-    y = x + branch
+    return x + branch
+
+
+def mlp_branch(P, y, k2=None):
+    """second residual branch: y + DropPath(GatedMlp(LN2(y)))."""
     m = gated_mlp(P, "mlp.", layer_norm(y, P["norm2.weight"], P["norm2.bias"]))
     if k2 is not None:
-        m = m * k2.reshape(B, 1, 1, 1).to(m.dtype)
+        m = m * k2.reshape(-1, 1, 1, 1).to(m.dtype)
     return y + m
 
 

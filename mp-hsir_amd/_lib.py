@@ -57,6 +57,12 @@ class GateArgs(ctypes.Structure):
                [(n, c_int32) for n in ("B", "H", "W", "HP")]
 
 
+class MlpBwdArgs(ctypes.Structure):
+    """mirror of struct mphsir_mlp_bwd_args"""
+    _fields_ = [(n, c_void_p) for n in ("X", "dY", "DM", "ln_w", "ln_b", "W1", "b1", "W1T", "W2T", "dX", "XN", "H", "DPRE", "part")] + \
+               [("M", c_int64), ("C", c_int32), ("HP", c_int32)]
+
+
 _SYMBOLS = {
     # name: (restype, argtypes)
     "mphsir_version": (ctypes.c_char_p, []),
@@ -77,6 +83,7 @@ _SYMBOLS = {
                                        c_int32, c_int, c_void_p]),
     "mphsir_flat_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,
                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int32, ctypes.c_float, c_void_p]),
+    "mphsir_gated_mlp_bwd": (c_int, [ctypes.POINTER(MlpBwdArgs), c_int, c_void_p]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
 }
 

@@ -31,14 +31,14 @@ class _Recompute(torch.autograd.Function):
         return (None, None, None, None) + tuple(out)
 
 
-def _apply(fwd, comp, module, *inputs):
-    named = list(module.named_parameters())
+def _apply(fwd, comp, module, *inputs, only=None):
+    named = [(n, p) for n, p in module.named_parameters() if only is None or only(n)]
     names = tuple(n for n, _ in named)
     return _Recompute.apply(fwd, comp, names, len(inputs), *inputs, *[p for _, p in named])
 
 
 # ---- PGSSTB ---------------------------------------------------------------------------------------
-def _pgsstb_forward(blk, x, k1, k2):
+def _pgsstb_attn_forward(blk, x, k1):
     B, H, W, Cc = x.shape
     dt = x.dtype
     pk = blk.packed(dt)
@@ -54,14 +54,60 @@ def _pgsstb_forward(blk, x, k1, k2):
                                       3 * Cc, B, H, W, Cc, heads)
     Mb = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt)
     y = ops.gemm_tok(v, Mb, epi=2, res=x2, sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
-    z = ops.gated_mlp_fwd(y, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"], pk["W2"], pk["b2"], keep=k2,
-                          rows_per_batch=H * W, out=y)
-    return z.reshape(B, H, W, Cc)
+    return y.reshape(B, H, W, Cc)
+
+
+class _GatedMlp(torch.autograd.Function):
+    """z = y + keep*mlp(LN2(y)): HIP forward and HIP data-gradient; the parameter gradients are the
+    token-reduction GEMMs / column sums of the three matrices the backward kernel writes."""
+
+    @staticmethod
+    def forward(ctx, blk, k2, y, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b):
+        B, H, W, Cc = y.shape
+        pk = blk.packed(y.dtype)
+        ctx.blk, ctx.k2 = blk, k2
+        ctx.save_for_backward(y)
+        z = ops.gated_mlp_fwd(y.reshape(-1, Cc), pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"], pk["W2"], pk["b2"],
+                              keep=k2, rows_per_batch=H * W)
+        return z.reshape(B, H, W, Cc)
+
+    @staticmethod
+    def backward(ctx, dz):
+        (y,) = ctx.saved_tensors
+        blk, k2 = ctx.blk, ctx.k2
+        B, H, W, Cc = y.shape
+        dt = y.dtype
+        pk = blk.packed(dt)
+        dz2 = dz.reshape(-1, Cc).contiguous()
+        dm = dz2 if k2 is None else (dz.float() * k2.reshape(B, 1, 1, 1)).to(dt).reshape(-1, Cc)
+        dx, xn, h, dpre, part = ops.gated_mlp_bwd(y.reshape(-1, Cc), dz2, dm, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"],
+                                                  pk["W1T"], pk["W2T"])
+        hid = blk.mlp.fc2.weight.shape[1]
+        HP = h.shape[1]
+        dW2 = (dm.t() @ h)[:, :hid].float()
+        dW1p = (dpre.t() @ xn).float()
+        db1p = dpre.float().sum(0)
+        dln = part.sum(0)
+        return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1],
+                torch.cat([dW1p[:hid], dW1p[HP:HP + hid]], 0), torch.cat([db1p[:hid], db1p[HP:HP + hid]]),
+                dW2, dm.float().sum(0))
 
 
 def pgsstb(blk, x, k1, k2):
-    return _apply(lambda x_: _pgsstb_forward(blk, x_, k1, k2),
-                  lambda x_, P: C.pgsstb(P, x_, blk.num_heads, blk.shift_size > 0, k1, k2), blk, x)
+    heads, shifted = blk.num_heads, blk.shift_size > 0
+    y = _apply(lambda x_: _pgsstb_attn_forward(blk, x_, k1), lambda x_, P: C.pgsstb_attn(P, x_, heads, shifted, k1), blk, x,
+               only=lambda n: not (n.startswith("mlp.") or n.startswith("norm2.")))
+    if x.dtype == torch.float32 and x.shape[-1] > 256:      # fp32 LDS budget of the backward kernel
+        pk = blk.packed(x.dtype)
+
+        def fwd(y_):
+            B, H, W, Cc = y_.shape
+            return ops.gated_mlp_fwd(y_.reshape(-1, Cc), pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"], pk["W2"], pk["b2"],
+                                     keep=k2, rows_per_batch=H * W).reshape(B, H, W, Cc)
+        return _apply(fwd, lambda y_, P: C.mlp_branch(P, y_, k2), blk, y,
+                      only=lambda n: n.startswith("mlp.") or n.startswith("norm2."))
+    m = blk.mlp
+    return _GatedMlp.apply(blk, k2, y, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
 
 
 # ---- GDFN / channel attention sub-chains ------------------------------------------------------------

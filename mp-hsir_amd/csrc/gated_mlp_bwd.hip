@@ -1,0 +1,266 @@
+// gated_mlp_bwd: data gradient of  y = x + keep * fc2(value * gelu(gate)),  [value|gate] = fc1(LN(x)).
+//
+// Backward of PGSSTB's second residual branch (reference forward: net/MP_HSIR.py:719, GatedMlp :66-82,
+// norm2 :619).  Same tile structure as gated_mlp_fwd (64 tokens per workgroup, 16 per wave, hidden
+// dimension walked in chunks of 32, everything after the LayerNorm staging is wave-local):
+//   recompute value/gate for the chunk (fc1 on the LN-ed tile in LDS),
+//   dh   = dm W2            (dm = keep * dy staged in LDS, W2^T streamed from L2),
+//   dval = dh * gelu(gate),  dgate = dh * value * gelu'(gate)             (registers),
+//   dxn += [dval|dgate] W1   (C/16 persistent fp32 accumulator tiles per wave),
+// then LayerNorm backward per token and dx = dy + that.  h = value*gelu(gate), [dval|dgate] and LN(x)
+// are written out once so that the four weight gradients are plain token-reduction GEMMs
+// (dW2 = dm^T h, dW1 = [dval|dgate]^T xn, done by the caller with a library GEMM) and the bias / LN
+// parameter gradients are column sums (per-workgroup partials here, no atomics).
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+struct MlpBwdDev {
+    const void* X; const void* dY; const void* DM;   // [M][C] each (ld = C)
+    const float* ln_w; const float* ln_b;
+    const void* W1; const float* b1;                 // [2*HP][C], [2*HP]
+    const void* W1T;                                 // [C][2*HP]
+    const void* W2T;                                 // [HP][C]
+    void* dX;                                        // [M][C]
+    void* XN; void* H; void* DPRE;                   // [M][C], [M][HP], [M][2*HP]
+    float* part;                                     // [M/64][2][C]: d(ln weight), d(ln bias) partial sums
+    int M, HP;
+};
+
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+template <class T, int C>
+__global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
+    typedef ElemTraits<T> TR;
+    typedef typename TR::frag_t frag_t;
+    constexpr int PAD = 16 / sizeof(T);
+    constexpr int LDX = C + PAD;
+    constexpr int LDH = 64 + PAD;
+    constexpr int LDF = C + 4;                          // fp32 staging of dxn
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NCT = C / 16;
+    constexpr int NV = C / VEC, VPT = NV / 4;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    T* Xs = reinterpret_cast<T*>(smem_v);               // [64][LDX]  LN(x)
+    T* Ds = Xs + 64 * LDX;                              // [64][LDX]  dm = keep*dy
+    T* Hs = Ds + 64 * LDX;                              // [4][16][LDH]  per wave: [dval(32) | dgate(32)], also h staging
+    float* stat = reinterpret_cast<float*>(Hs + 4 * 16 * LDH);   // mean[64], rstd[64]
+    float* Fs = reinterpret_cast<float*>(smem_v);       // [64][LDF] fp32 dxn (aliases Xs|Ds after the main loop)
+    static_assert(64 * LDF * 4 <= 2 * 64 * LDX * sizeof(T), "fp32 dxn stage must fit in the two token tiles");
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m0 = blockIdx.x * 64;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* DM = reinterpret_cast<const T*>(a.DM);
+    const T* dY = reinterpret_cast<const T*>(a.dY);
+
+    // ---- stage LN(x) (also written to XN) and dm; 4 adjacent lanes per token --------------------
+    {
+        const int r = tid >> 2, q = tid & 3;
+        const T* row = X + (long)(m0 + r) * C;
+        Vec16<T> xv[VPT];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            xv[i] = load16<T>(row + (q + 4 * i) * VEC);
+            for (int e = 0; e < VEC; ++e) s += xv[i].get(e);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            for (int e = 0; e < VEC; ++e) { float d = xv[i].get(e) - mean; d2 += d * d; }
+        d2 += __shfl_xor(d2, 1);
+        d2 += __shfl_xor(d2, 2);
+        const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+        if (q == 0) { stat[r] = mean; stat[64 + r] = rstd; }
+        T* XN = reinterpret_cast<T*>(a.XN) + (long)(m0 + r) * C;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
+            store16<T>(Xs + r * LDX + c0, o);
+            store16<T>(XN + c0, o);
+            store16<T>(Ds + r * LDX + c0, load16<T>(DM + (long)(m0 + r) * C + c0));
+        }
+    }
+    __syncthreads();
+
+    const T* W1 = reinterpret_cast<const T*>(a.W1);
+    const T* W1T = reinterpret_cast<const T*>(a.W1T);
+    const T* W2T = reinterpret_cast<const T*>(a.W2T);
+    T* Hw = Hs + wv * 16 * LDH;
+    const int HP = a.HP;
+    T* Hout = reinterpret_cast<T*>(a.H);
+    T* Pout = reinterpret_cast<T*>(a.DPRE);
+    f32x4 out[NCT];
+#pragma unroll
+    for (int i = 0; i < NCT; ++i) out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int j = 0; j < HP; j += 32) {
+        f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0}, g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+        f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};          // dh tiles
+#pragma unroll 4
+        for (int kk = 0; kk < C; kk += TR::KCHUNK) {
+            const frag_t bx = load_frag<T>(Xs, LDX, wv * 16, kk);
+            const frag_t bd = load_frag<T>(Ds, LDX, wv * 16, kk);
+            mma(v0, load_frag<T>(W1, C, j, kk), bx);
+            mma(v1, load_frag<T>(W1, C, j + 16, kk), bx);
+            mma(g0, load_frag<T>(W1, C, HP + j, kk), bx);
+            mma(g1, load_frag<T>(W1, C, HP + j + 16, kk), bx);
+            mma(e0, load_frag<T>(W2T, C, j, kk), bd);
+            mma(e1, load_frag<T>(W2T, C, j + 16, kk), bd);
+        }
+        const int hr = (lane >> 4) * 4, tk = lane & 15;
+        f32x4 h0, h1, dv0, dv1, dg0, dg1;
+        for (int r = 0; r < 4; ++r) {
+            const float va = v0[r] + a.b1[j + hr + r], ga = g0[r] + a.b1[HP + j + hr + r];
+            const float vb = v1[r] + a.b1[j + 16 + hr + r], gb = g1[r] + a.b1[HP + j + 16 + hr + r];
+            const float ea = gelu_erf(ga), eb = gelu_erf(gb);
+            h0[r] = va * ea;            h1[r] = vb * eb;
+            dv0[r] = e0[r] * ea;        dv1[r] = e1[r] * eb;
+            dg0[r] = e0[r] * va * gelu_erf_grad(ga);
+            dg1[r] = e1[r] * vb * gelu_erf_grad(gb);
+        }
+        // h chunk -> HBM through the per-wave LDS buffer (whole 64-byte row segments per token)
+        store4<T>(Hw + tk * LDH + hr, h0);
+        store4<T>(Hw + tk * LDH + 16 + hr, h1);
+        __syncthreads();
+        {
+            constexpr int VPR = 32 / VEC;                    // vectors per 32-wide row segment
+            for (int i = lane; i < 16 * VPR; i += 64) {
+                const int t = i / VPR, c = (i % VPR) * VEC;
+                store16<T>(Hout + (long)(m0 + wv * 16 + t) * HP + j + c, load16<T>(Hw + t * LDH + c));
+            }
+        }
+        __syncthreads();
+        store4<T>(Hw + tk * LDH + hr, dv0);
+        store4<T>(Hw + tk * LDH + 16 + hr, dv1);
+        store4<T>(Hw + tk * LDH + 32 + hr, dg0);
+        store4<T>(Hw + tk * LDH + 48 + hr, dg1);
+        __syncthreads();
+        {
+            constexpr int VPR = 32 / VEC;
+            for (int i = lane; i < 16 * 2 * VPR; i += 64) {
+                const int t = i / (2 * VPR), seg = (i / VPR) & 1, c = (i % VPR) * VEC;
+                store16<T>(Pout + (long)(m0 + wv * 16 + t) * 2 * HP + seg * HP + j + c, load16<T>(Hw + t * LDH + seg * 32 + c));
+            }
+        }
+        // dxn[c][tok] += W1T[c][j..j+31] * dval + W1T[c][HP+j..] * dgate
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += TR::KCHUNK) {
+            const frag_t bv = load_frag<T>(Hw, LDH, 0, kk);
+            const frag_t bg = load_frag<T>(Hw, LDH, 0, 32 + kk);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                mma(out[ct], load_frag<T>(W1T, 2 * HP, ct * 16, j + kk), bv);
+                mma(out[ct], load_frag<T>(W1T, 2 * HP, ct * 16, HP + j + kk), bg);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- dxn -> fp32 LDS stage; LayerNorm backward; dx = dy + ...; parameter-gradient partials -----
+    {
+        const int tok = wv * 16 + (lane & 15), cr = (lane >> 4) * 4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+            *reinterpret_cast<f32x4*>(Fs + tok * LDF + ct * 16 + cr) = out[ct];
+    }
+    __syncthreads();
+    float* part = a.part + (long)blockIdx.x * 2 * C;
+    for (int c = tid; c < C; c += 256) {                 // d(ln bias)[c] = sum_tok dxn
+        float s = 0.f;
+        for (int t = 0; t < 64; ++t) s += Fs[t * LDF + c];
+        part[C + c] = s;
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 2, q = tid & 3;
+        const float mean = stat[r], rstd = stat[64 + r];
+        const T* xrow = X + (long)(m0 + r) * C;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            const Vec16<T> xv = load16<T>(xrow + c0);
+            for (int e = 0; e < VEC; ++e) {
+                const float gw = Fs[r * LDF + c0 + e] * a.ln_w[c0 + e], xh = (xv.get(e) - mean) * rstd;
+                s1 += gw;
+                s2 += gw * xh;
+            }
+        }
+        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+        s1 *= 1.0f / (float)C;
+        s2 *= 1.0f / (float)C;
+        T* dxrow = reinterpret_cast<T*>(a.dX) + (long)(m0 + r) * C;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            const Vec16<T> xv = load16<T>(xrow + c0);
+            const Vec16<T> dy = load16<T>(dY + (long)(m0 + r) * C + c0);
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) {
+                const float dxn = Fs[r * LDF + c0 + e], xh = (xv.get(e) - mean) * rstd;
+                o.set(e, dy.get(e) + rstd * (dxn * a.ln_w[c0 + e] - s1 - xh * s2));
+                Fs[r * LDF + c0 + e] = dxn * xh;          // for d(ln weight)
+            }
+            store16<T>(dxrow + c0, o);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {                 // d(ln weight)[c] = sum_tok dxn * xhat
+        float s = 0.f;
+        for (int t = 0; t < 64; ++t) s += Fs[t * LDF + c];
+        part[c] = s;
+    }
+}
+
+template <class T, int C>
+static int launch_mlp_bwd(const MlpBwdDev& d, hipStream_t s) {
+    constexpr int PAD = 16 / sizeof(T);
+    const size_t shmem = (2 * 64 * (C + PAD) + 4 * 16 * (64 + PAD)) * sizeof(T) + 128 * sizeof(float);
+    allow_big_lds(gated_mlp_bwd_kernel<T, C>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd_kernel<T, C>), dim3(d.M / 64), dim3(256), shmem, s, d);
+    return MPHSIR_OK;
+}
+
+template <class T>
+static int dispatch_mlp_bwd(const MlpBwdDev& d, int C, hipStream_t s) {
+    switch (C) {
+        case 32: return launch_mlp_bwd<T, 32>(d, s);
+        case 64: return launch_mlp_bwd<T, 64>(d, s);
+        case 96: return launch_mlp_bwd<T, 96>(d, s);
+        case 128: return launch_mlp_bwd<T, 128>(d, s);
+        case 192: return launch_mlp_bwd<T, 192>(d, s);
+        case 256: return launch_mlp_bwd<T, 256>(d, s);
+        case 384: return launch_mlp_bwd<T, 384>(d, s);
+    }
+    set_error("gated_mlp_bwd: C=%d not instantiated", C);
+    return MPHSIR_EINVAL;
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->X && a->dY && a->DM && a->ln_w && a->ln_b && a->W1 && a->b1 && a->W1T && a->W2T && a->dX && a->XN &&
+                       a->H && a->DPRE && a->part, "gated_mlp_bwd: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "gated_mlp_bwd: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(a->M > 0 && a->M % 64 == 0 && a->HP > 0 && a->HP % 32 == 0, "gated_mlp_bwd: M %% 64 and HP %% 32 must be 0");
+    MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->dY) && aligned16(a->DM) && aligned16(a->dX) && aligned16(a->XN) && aligned16(a->H) &&
+                       aligned16(a->DPRE) && aligned16(a->W1) && aligned16(a->W1T) && aligned16(a->W2T), "gated_mlp_bwd: 16-byte alignment required");
+    if (dtype == MPHSIR_F32) MPHSIR_REQUIRE(a->C <= 256, "gated_mlp_bwd: fp32 supports C <= 256 (LDS budget)");
+    MlpBwdDev d{a->X, a->dY, a->DM, a->ln_w, a->ln_b, a->W1, a->b1, a->W1T, a->W2T, a->dX, a->XN, a->H, a->DPRE, a->part,
+                (int)a->M, a->HP};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == MPHSIR_F32 ? dispatch_mlp_bwd<float>(d, a->C, s) : dispatch_mlp_bwd<bf16_t>(d, a->C, s);
+}

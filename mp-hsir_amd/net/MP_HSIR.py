@@ -179,6 +179,7 @@ class PGSSTB(nn.Module):                                                        
                 wqkv=a.qkv.weight.to(dtype).contiguous(), bqkv=f(a.qkv.bias),
                 wproj=ops.pack_win_proj(a.proj.weight, self.num_heads, dtype), bproj=f(a.proj.bias),
                 rpb=f(a.relative_position_bias_table), W1=W1, b1=b1, W2=W2, b2=f(m.fc2.bias),
+                W1T=W1.t().contiguous(), W2T=W2.t().contiguous(),
                 ln1=(f(self.norm1.weight), f(self.norm1.bias)), ln2=(f(self.norm2.weight), f(self.norm2.bias)),
                 pg={"linear_prompt.weight": f(pg.linear_prompt.weight), "prompt_param": f(pg.prompt_param.reshape(PROMPT_LEN, -1)),
                     "q.weight": f(pg.q.weight), "kv.weight": f(pg.kv.weight), "linear_down.weight": f(pg.linear_down.weight),

@@ -271,3 +271,26 @@ def dwconv3x3_wgrad(x, dy, nblk=None):
                                           _DT[x.dtype], _stream(x)), "dwconv3x3_wgrad")
     _acct("dwconv3x3_wgrad", 18.0 * B * H * W * C, 2.0 * B * H * W * C * x.element_size())
     return part.sum(dim=0)
+
+
+def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T):
+    """-> dx, xn, h, dpre, part (see include/mphsir.h).  x, dy, dm: contiguous (M,C)."""
+    lib = _lib.load()
+    _check(x, dy, dm, W1, W1T, W2T)
+    M, C = x.shape
+    HP = W2T.shape[0]
+    assert x.is_contiguous() and dy.is_contiguous() and dm.is_contiguous() and W1T.shape == (C, 2 * HP) and W2T.shape == (HP, C)
+    dev, dt = x.device, x.dtype
+    dx = torch.empty_like(x)
+    xn = torch.empty_like(x)
+    h = torch.empty((M, HP), dtype=dt, device=dev)
+    dpre = torch.empty((M, 2 * HP), dtype=dt, device=dev)
+    part = torch.empty((M // 64, 2, C), dtype=torch.float32, device=dev)
+    a = _lib.MlpBwdArgs()
+    a.X, a.dY, a.DM, a.ln_w, a.ln_b = _p(x), _p(dy), _p(dm), _p(ln_w), _p(ln_b)
+    a.W1, a.b1, a.W1T, a.W2T = _p(W1), _p(b1), _p(W1T), _p(W2T)
+    a.dX, a.XN, a.H, a.DPRE, a.part = _p(dx), _p(xn), _p(h), _p(dpre), _p(part)
+    a.M, a.C, a.HP = M, C, HP
+    _lib.check(lib.mphsir_gated_mlp_bwd(ctypes.byref(a), _DT[dt], _stream(x)), "gated_mlp_bwd")
+    _acct("gated_mlp_bwd", 12.0 * M * C * HP, (3.0 * M * C + 3.0 * M * HP + M * C) * x.element_size())
+    return dx, xn, h, dpre, part

@@ -191,3 +191,37 @@ def check_dwconv_plain(dev, dtype, shape):
     assert rel_l2(y, yr.detach().permute(0, 2, 3, 1)) < TOL[dtype]
     assert rel_l2(dx, xr.grad.permute(0, 2, 3, 1)) < TOL[dtype]
     assert rel_l2(dw, wr.grad.reshape(C, 9).t()) < TOL[dtype]
+
+
+def check_gated_mlp_bwd(dev, dtype, C, hid):
+    """HIP data-gradient kernel + token-reduction GEMMs vs autograd of the fp64 oracle."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    M = 128
+    x, dy = rnd((M, C), 1, dtype), rnd((M, C), 9, dtype)
+    P = {"fc1.weight": rnd((2 * hid, C), 2, scale=C ** -0.5), "fc1.bias": 0.1 * rnd((2 * hid,), 3),
+         "fc2.weight": rnd((C, hid), 4, scale=hid ** -0.5), "fc2.bias": 0.1 * rnd((C,), 5)}
+    lnw, lnb = 1 + 0.1 * rnd((C,), 6), 0.1 * rnd((C,), 7)
+    keep = torch.tensor([1.0, 1.5]).to(dev)
+    W1, b1, W2 = ops.pack_gated_mlp(P["fc1.weight"], P["fc1.bias"], P["fc2.weight"], dtype)
+    HP = W2.shape[1]
+    dm = (dy.float() * keep.repeat_interleave(64)[:, None]).to(dtype)
+    dx, xn, h, dpre, part = ops.gated_mlp_bwd(x, dy, dm, lnw, lnb, W1, b1, W1.t().contiguous(), W2.t().contiguous())
+    dW2 = (dm.float().t() @ h.float())[:, :hid]
+    dW1p = dpre.float().t() @ xn.float()
+    dW1 = torch.cat([dW1p[:hid], dW1p[HP:HP + hid]], 0)
+    db1p = dpre.float().sum(0)
+    db1 = torch.cat([db1p[:hid], db1p[HP:HP + hid]])
+    db2 = dm.float().sum(0)
+    dln = part.sum(0)
+    # oracle autograd
+    Pd = {k: (v.to(dtype) if k.endswith("weight") else v).double().cpu().requires_grad_(True) for k, v in P.items()}
+    xd = x.double().cpu().requires_grad_(True)
+    lw, lb = lnw.double().cpu().requires_grad_(True), lnb.double().cpu().requires_grad_(True)
+    y = xd + keep.double().cpu().repeat_interleave(64)[:, None] * O.gated_mlp(Pd, "", O.layer_norm_c(xd, lw, lb))
+    y.backward(dy.double().cpu())
+    tol = TOL[dtype] * (2 if dtype == torch.bfloat16 else 5)
+    assert rel_l2(dx, xd.grad) < tol
+    assert rel_l2(dW2, Pd["fc2.weight"].grad) < tol and rel_l2(dW1, Pd["fc1.weight"].grad) < tol
+    assert rel_l2(db1, Pd["fc1.bias"].grad) < tol and rel_l2(db2, Pd["fc2.bias"].grad) < tol
+    assert rel_l2(dln[0], lw.grad) < tol and rel_l2(dln[1], lb.grad) < tol

@@ -50,3 +50,9 @@ def test_gdfn_chain(dtype):
 @pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 5, 7, 96)])
 def test_dwconv_plain(dtype, shape):
     K.check_dwconv_plain("cpu", dtype, shape)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,hid", [(32, 85), (96, 255)])
+def test_gated_mlp_bwd(dtype, C, hid):
+    K.check_gated_mlp_bwd("cpu", dtype, C, hid)

@@ -77,3 +77,13 @@ def test_gdfn_chain(dtype):
 @pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 5, 7, 96), (4, 64, 64, 384), (2, 32, 32, 704)])
 def test_dwconv_plain(dtype, shape):
     K.check_dwconv_plain("cuda", dtype, shape)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,hid", [(32, 85), (96, 255), (64, 170), (128, 340), (256, 680), (192, 510)])
+def test_gated_mlp_bwd(dtype, C, hid):
+    K.check_gated_mlp_bwd("cuda", dtype, C, hid)
+
+
+def test_gated_mlp_bwd_c384_bf16():
+    K.check_gated_mlp_bwd("cuda", torch.bfloat16, 384, 1021)
