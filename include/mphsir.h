@@ -93,6 +93,8 @@ typedef struct mphsir_win_attn_args {
     const float* Wprompt; const float* prompt_param; const float* Wq; const float* Wkv;
     const float* Wdown; const float* Wpproj; const float* bpproj; const float* Wup;
     void* SA; float* gate;
+    float* mu;      /* optional [B*nW][C] fp32: per-window mean of SA (input of the gate; saved for backward) */
+    void* Oattn;    /* optional (B,H,W,C): softmax(QK^T)V before proj, image order (saved for backward)     */
     int32_t B, H, W, C, heads, shift, r;
 } mphsir_win_attn_args;
 int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream);
@@ -178,6 +180,33 @@ typedef struct mphsir_mlp_bwd_args {
 } mphsir_mlp_bwd_args;
 int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream);
 
+/* ---- backward of the window-attention side of a PGSSTB block --------------------------------------
+ * mphsir_combine_bwd: backward of mphsir_gemm_tok epi 2 (y = R + keep*(SA*gate[win] + acc), net/MP_HSIR.py
+ *   :715-718,:153): dOut = keep*dY (written only if keep != NULL), dSA = dOut*gate[win],
+ *   dgate[win][c] = sum over the window's 64 tokens of dOut*SA.  All cubes (B,H,W,C), image order.
+ * mphsir_win_attn_bwd: backward of the attention core of mphsir_win_attn_fwd (Spatial_Attention.forward
+ *   :193-218) for d_sa = dSA + dmu[win]/64 (dmu = gradient w.r.t. the window mean that feeds the gate).
+ *   Outputs: dQKV [B*nW*64][3C] and XNw = LN(x) [B*nW*64][C], both in window-token order (row = window*64 +
+ *   token), dSAt = the total d_sa (B,H,W,C), drpb [B*nW][225][heads] partials of the bias-table gradient.
+ *   The caller finishes with library GEMMs: d_xn = dQKV Wqkv, dWqkv = dQKV^T XNw, dbqkv = colsum dQKV,
+ *   dWproj = dSAt^T Oattn, dbproj = colsum dSAt.  WprojT = proj.weight^T [C][C].
+ *   mphsir_win_attn_bwd_fits(C, heads, dtype) tells whether the tile fits LDS (fp32: small widths only).
+ * mphsir_ln_bwd_win: dX = dRes + LayerNorm_backward(dXNw) where dXNw [B*nW*64][C] is in window-token order
+ *   (norm1 :667 + roll/partition :672-678 in reverse); part [B*nW][2][C] = partials of d(weight), d(bias). */
+int mphsir_combine_bwd(const void* dY, const void* SA, const float* gate, const float* keep, void* dOut, void* dSA,
+                       float* dgate, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
+typedef struct mphsir_win_attn_bwd_args {
+    const void* X; const void* dSA; const float* dmu;
+    const float* ln_w; const float* ln_b;
+    const void* Wqkv; const float* bqkv; const float* rpb; const void* WprojT;
+    void* dQKV; void* XNw; void* dSAt; float* drpb;
+    int32_t B, H, W, C, heads, shift;
+} mphsir_win_attn_bwd_args;
+int mphsir_win_attn_bwd(const mphsir_win_attn_bwd_args* a, int dtype, void* stream);
+int mphsir_win_attn_bwd_fits(int32_t C, int32_t heads, int dtype);
+int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const float* ln_w, void* dX, float* part,
+                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
+
 /* ---- plain depthwise 3x3 (backward building blocks) ----------------------------------------------
  * mphsir_dwconv3x3: Y[p][c] = sum_taps X[p+tap][c] * w9[tap][c] (zero padding); flip=1 uses the spatially
  * flipped taps = gradient w.r.t. the input of the same depthwise conv applied to dY.
@@ -210,6 +239,9 @@ int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, f
 #define MPHSIR_K_DWCONV 7
 #define MPHSIR_K_DWCONV_WGRAD 8
 #define MPHSIR_K_GATED_MLP_BWD 9
+#define MPHSIR_K_COMBINE_BWD 10
+#define MPHSIR_K_WIN_ATTN_BWD 11
+#define MPHSIR_K_LN_BWD_WIN 12
 #define MPHSIR_K_COUNT 16
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

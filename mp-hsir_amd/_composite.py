@@ -144,7 +144,11 @@ def window_attention(P, pre, xw, heads, mask):
 
 
 def pg_gate(P, pre, xw):
-    mu = xw.float().mean(dim=1)
+    return pg_gate_from_mean(P, pre, xw.float().mean(dim=1))
+
+
+def pg_gate_from_mean(P, pre, mu):
+    """the per-window gate as a function of the window mean (B*nW, C) -- tiny fp32 math."""
     r = P[pre + "linear_down.weight"].shape[0]
     w = torch.softmax(mu @ P[pre + "linear_prompt.weight"].float().t(), dim=-1)
     s = w @ P[pre + "prompt_param"].float().reshape(PROMPT_LEN, r)

@@ -34,7 +34,8 @@ class MlpArgs(ctypes.Structure):
 class WinAttnArgs(ctypes.Structure):
     """mirror of struct mphsir_win_attn_args"""
     _fields_ = [(n, c_void_p) for n in ("X", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "Wproj", "bproj", "Wprompt",
-                                         "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup", "SA", "gate")] + \
+                                         "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup", "SA", "gate",
+                                         "mu", "Oattn")] + \
                [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift", "r")]
 
 
@@ -63,6 +64,12 @@ class MlpBwdArgs(ctypes.Structure):
                [("M", c_int64), ("C", c_int32), ("HP", c_int32)]
 
 
+class WinAttnBwdArgs(ctypes.Structure):
+    """mirror of struct mphsir_win_attn_bwd_args"""
+    _fields_ = [(n, c_void_p) for n in ("X", "dSA", "dmu", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "WprojT", "dQKV", "XNw",
+                                         "dSAt", "drpb")] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift")]
+
+
 _SYMBOLS = {
     # name: (restype, argtypes)
     "mphsir_version": (ctypes.c_char_p, []),
@@ -83,6 +90,10 @@ _SYMBOLS = {
                                        c_int32, c_int, c_void_p]),
     "mphsir_flat_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,
                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int32, ctypes.c_float, c_void_p]),
+    "mphsir_combine_bwd": (c_int, [c_void_p] * 7 + [c_int32] * 5 + [c_int, c_void_p]),
+    "mphsir_win_attn_bwd": (c_int, [ctypes.POINTER(WinAttnBwdArgs), c_int, c_void_p]),
+    "mphsir_win_attn_bwd_fits": (c_int, [c_int32, c_int32, c_int]),
+    "mphsir_ln_bwd_win": (c_int, [c_void_p] * 6 + [c_int32] * 5 + [c_int, c_void_p]),
     "mphsir_gated_mlp_bwd": (c_int, [ctypes.POINTER(MlpBwdArgs), c_int, c_void_p]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
 }

@@ -93,15 +93,148 @@ class _GatedMlp(torch.autograd.Function):
                 dW2, dm.float().sum(0))
 
 
+def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, temperature, wo, heads, B, H, W):
+    """Backward of the folded channel attention  out = M_b v,  M_b = Wo blockdiag(softmax(normalised Gram)).
+
+    d_out (M,C); t_q/t_k/t_v: (B,H,W,*) views of the 1x1-conv outputs that fed dwconv_gram (channels-last,
+    C channels each); w9*: fp32 tap-major dw weights [9][C] views; v, gp, sp, Mb as saved by the forward.
+    Returns d(t_q), d(t_k), d(t_v) (B,H,W,C each), d(dw taps) [9][C] x3, d temperature (heads,), d Wo (C,C).
+    Heavy lifting: library batched GEMMs + the HIP depthwise kernels; the hd x hd softmax math is tiny fp32."""
+    C = v.shape[1]
+    N = H * W
+    hd = C // heads
+    dt = v.dtype
+    dO3, v3 = d_out.reshape(B, N, C), v.reshape(B, N, C)
+    dM = torch.bmm(dO3.transpose(1, 2), v3).float()                     # (B,C,C)
+    dv = torch.bmm(dO3, Mb)                                              # (B,N,C)
+    G = gp.sum(dim=1).requires_grad_(True)                               # (B,h,hd,hd)
+    S = sp.sum(dim=1)
+    sq = S[:, 0].reshape(B, heads, hd).clone().requires_grad_(True)
+    sk = S[:, 1].reshape(B, heads, hd).clone().requires_grad_(True)
+    temp = temperature.detach().reshape(heads).float().requires_grad_(True)
+    wo_ = wo.detach().reshape(C, C).float().requires_grad_(True)
+    with torch.enable_grad():
+        nq = sq.sqrt().clamp_min(1e-12)
+        nk = sk.sqrt().clamp_min(1e-12)
+        A = torch.softmax(G / (nq[..., :, None] * nk[..., None, :]) * temp.reshape(1, heads, 1, 1), dim=-1)
+        M = torch.einsum("ohi,bhij->bohj", wo_.reshape(C, heads, hd), A).reshape(B, C, C)
+    dG, dsq, dsk, dtemp, dwo = torch.autograd.grad(M, [G, sq, sk, temp, wo_], dM)
+    # q, k of the forward (never stored): one depthwise pass each
+    q = ops.dwconv3x3(t_q, w9q).reshape(B, N, C)
+    k = ops.dwconv3x3(t_k, w9k).reshape(B, N, C)
+    Nq = torch.zeros((B, C, C), dtype=torch.float32, device=v.device)
+    for h in range(heads):
+        Nq[:, h * hd:(h + 1) * hd, h * hd:(h + 1) * hd] = dG[:, h]
+    Nq = Nq.to(dt)
+    dq = torch.baddbmm(q * (2.0 * dsq).reshape(B, 1, C).to(dt), k, Nq.transpose(1, 2))
+    dk = torch.baddbmm(k * (2.0 * dsk).reshape(B, 1, C).to(dt), q, Nq)
+    dq4, dk4, dv4 = dq.reshape(B, H, W, C), dk.reshape(B, H, W, C), dv.reshape(B, H, W, C)
+    dtq = ops.dwconv3x3(dq4, w9q, flip=True)
+    dtk = ops.dwconv3x3(dk4, w9k, flip=True)
+    dtv = ops.dwconv3x3(dv4, w9v, flip=True)
+    dwq = ops.dwconv3x3_wgrad(t_q, dq4)
+    dwk = ops.dwconv3x3_wgrad(t_k, dk4)
+    dwv = ops.dwconv3x3_wgrad(t_v, dv4)
+    return dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo
+
+
+_PG_KEYS = ("linear_down.weight", "linear_up.weight", "linear_prompt.weight", "prompt_param", "q.weight", "kv.weight",
+            "proj.weight", "proj.bias")
+
+
+class _PgsstbAttn(torch.autograd.Function):
+    """First residual branch of a PGSSTB block: HIP forward (5 launches) and HIP/GEMM backward."""
+
+    @staticmethod
+    def forward(ctx, blk, k1, x, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, rpb, s_temp, s_qkv, s_dw, s_out, *pg):
+        B, H, W, Cc = x.shape
+        dt = x.dtype
+        pk = blk.packed(dt)
+        sp = blk.gobal_spectral_attn.packed(dt)
+        heads, shift = blk.num_heads, blk.shift_size
+        sa, gate, mu, oattn = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"],
+                                               pk["bproj"], pk["pg"], heads, shift, save=True)
+        sa2 = sa.reshape(-1, Cc)
+        t = ops.gemm_tok(sa2, sp["wqkv"])
+        w9 = sp["w9"]
+        v, gp, spart, _ = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
+                                          3 * Cc, B, H, W, Cc, heads)
+        Mb = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt)
+        y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
+        ctx.blk, ctx.k1 = blk, k1
+        ctx.save_for_backward(x, sa, gate, mu, oattn, t, v, gp, spart, Mb)
+        return y.reshape(B, H, W, Cc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sa, gate, mu, oattn, t, v, gp, spart, Mb = ctx.saved_tensors
+        blk, k1 = ctx.blk, ctx.k1
+        B, H, W, Cc = x.shape
+        dt = x.dtype
+        M = B * H * W
+        heads, shift = blk.num_heads, blk.shift_size
+        pk = blk.packed(dt)
+        sp = blk.gobal_spectral_attn.packed(dt)
+        dy = dy.contiguous()
+        # (1) branch sum  y = x + keep*(sa*gate + out)
+        d_out, d_sa, dgate = ops.combine_bwd(dy, sa, gate, k1, shift)
+        # (2) global spectral attention
+        t4 = t.reshape(B, H, W, 3 * Cc)
+        w9 = sp["w9"]
+        tq, tk, tv = t4[..., :Cc], t4[..., Cc:2 * Cc], t4[..., 2 * Cc:]
+        dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
+            d_out.reshape(M, Cc), tq, tk, tv, w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:], v, gp, spart, Mb,
+            blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W)
+        dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
+        d_sa = d_sa.reshape(M, Cc).addmm_(dt3, sp["wqkv"])                       # + dt Wqkv  (1x1 conv backward)
+        d_sqkv = (dt3.t() @ sa.reshape(M, Cc)).float().reshape(3 * Cc, Cc, 1, 1)
+        d_sdw = torch.cat([dwq, dwk, dwv], dim=1).t().reshape(3 * Cc, 1, 3, 3)
+        # (3) local spectral-prompt gate: tiny fp32 math on (B*nW, C), differentiated by autograd
+        pgm = blk.local_spectral_attn
+        leaves = {k: getattr_path(pgm, k).detach().requires_grad_(True) for k in _PG_KEYS}
+        mu_ = mu.detach().requires_grad_(True)
+        with torch.enable_grad():
+            g_ = C.pg_gate_from_mean(leaves, "", mu_)
+        grads = torch.autograd.grad(g_, [mu_] + [leaves[k] for k in _PG_KEYS], dgate)
+        dmu, dpg = grads[0].contiguous(), grads[1:]
+        # (4) window attention core
+        dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
+                                                 pk["rpb"], pk["wprojT"], heads, shift)
+        dxn = dqkv @ pk["wqkv"]
+        d_qkv_w = (dqkv.t() @ xnw).float()
+        d_qkv_b = dqkv.float().sum(0)
+        dsat2 = dsat.reshape(M, Cc)
+        d_proj_w = (dsat2.t() @ oattn.reshape(M, Cc)).float()
+        d_proj_b = dsat2.float().sum(0)
+        # (5) norm1 backward + the residual path
+        dx, part = ops.ln_bwd_win(x, dxn, dy, pk["ln1"][0], shift)
+        dln = part.sum(0)
+        return (None, None, dx, dln[0], dln[1], d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, drpb.sum(0),
+                dtemp.reshape(heads, 1, 1), d_sqkv, d_sdw, dwo.reshape(Cc, Cc, 1, 1)) + tuple(dpg)
+
+
+def getattr_path(mod, dotted):
+    for part in dotted.split("."):
+        mod = getattr(mod, part)
+    return mod
+
+
 def pgsstb(blk, x, k1, k2):
     heads, shifted = blk.num_heads, blk.shift_size > 0
-    y = _apply(lambda x_: _pgsstb_attn_forward(blk, x_, k1), lambda x_, P: C.pgsstb_attn(P, x_, heads, shifted, k1), blk, x,
-               only=lambda n: not (n.startswith("mlp.") or n.startswith("norm2.")))
-    if x.dtype == torch.float32 and x.shape[-1] > 256:      # fp32 LDS budget of the backward kernel
+    Cc = x.shape[-1]
+    if ops.win_attn_bwd_fits(Cc, heads, x.dtype):
+        a, s, pgm = blk.attn, blk.gobal_spectral_attn, blk.local_spectral_attn
+        y = _PgsstbAttn.apply(blk, k1, x, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                              a.relative_position_bias_table, s.temperature, s.qkv.weight, s.qkv_dwconv.weight,
+                              s.project_out.weight, *[getattr_path(pgm, k) for k in _PG_KEYS])
+    else:   # LDS budget of the backward kernel (fp32 at larger widths): differentiate the torch composite instead
+        y = _apply(lambda x_: _pgsstb_attn_forward(blk, x_, k1), lambda x_, P: C.pgsstb_attn(P, x_, heads, shifted, k1), blk, x,
+                   only=lambda n: not (n.startswith("mlp.") or n.startswith("norm2.")))
+    if x.dtype == torch.float32 and Cc > 256:      # fp32 LDS budget of the MLP backward kernel
         pk = blk.packed(x.dtype)
 
         def fwd(y_):
-            B, H, W, Cc = y_.shape
+            B, H, W, _ = y_.shape
             return ops.gated_mlp_fwd(y_.reshape(-1, Cc), pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"], pk["W2"], pk["b2"],
                                      keep=k2, rows_per_batch=H * W).reshape(B, H, W, Cc)
         return _apply(fwd, lambda y_, P: C.mlp_branch(P, y_, k2), blk, y,

@@ -1,0 +1,483 @@
+// Backward kernels of the first residual branch of a PGSSTB block (window attention side).
+//
+//   combine_bwd   backward of gemm_tok epi 2,  y = x + keep*(sa*gate[win] + out):
+//                 d_out = keep*dy, d_sa = d_out*gate[win], d_gate[win] = sum_tok d_out*sa   (ref :715-718, :153)
+//   win_attn_bwd  backward of the 8x8 window attention core (ref Spatial_Attention.forward :193-218):
+//                 per window and head recompute q,k,v and the probabilities from LN(x); dO = d_sa W_proj;
+//                 dP^T = V dO^T; dS = P o (dP - rowsum(dP o P)); dQ = scale dS K, dK = dS^T Q, dV = P^T dO.
+//                 Writes d[q|k|v] (window-token order), LN(x) (same order) and the total d_sa (image order),
+//                 so that every parameter gradient is a plain token-reduction GEMM / column sum done by
+//                 the caller, plus per-window partials of the relative-position-bias gradient.
+//   ln_bwd_win    d_x = d_res + LayerNorm_backward(d_xn) with d_xn in window-token order (un-shift /
+//                 un-window by address arithmetic), plus per-window partials of d(norm1 weight/bias).
+// All reductions are ordered (no atomics): results are bitwise reproducible.
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+struct WinGeom {
+    int B, H, W, shift;
+};
+
+__device__ __forceinline__ long win_pixel(const WinGeom& g, int blk, int t) {
+    const int nwx = g.W >> 3, nW = (g.H >> 3) * nwx;
+    const int b = blk / nW, wi = blk % nW, wy = wi / nwx, wx = wi % nwx;
+    const int ys = wy * 8 + (t >> 3), xs = wx * 8 + (t & 7);
+    return ((long)b * g.H + (ys + g.shift) % g.H) * g.W + (xs + g.shift) % g.W;
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct CombBwdDev {
+    const void* dY; const void* SA; const float* gate; const float* keep;
+    void* dOut;      // optional: keep*dy (written only when keep != NULL)
+    void* dSA;       // d_out * gate[win]
+    float* dgate;    // [B*nW][C]
+    WinGeom g; int C;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void combine_bwd_kernel(CombBwdDev a) {
+    constexpr int VEC = Vec16<T>::N;
+    const int C = a.C, tid = threadIdx.x, nv = C / VEC;
+    const int nW = (a.g.H >> 3) * (a.g.W >> 3), b = blockIdx.x / nW;
+    const float kf = a.keep ? a.keep[b] : 1.f;
+    const T* dY = reinterpret_cast<const T*>(a.dY);
+    const T* SA = reinterpret_cast<const T*>(a.SA);
+    T* dOut = reinterpret_cast<T*>(a.dOut);
+    T* dSA = reinterpret_cast<T*>(a.dSA);
+    const float* g = a.gate + (long)blockIdx.x * C;
+    for (int idx = tid; idx < 64 * nv; idx += 256) {
+        const int t = idx / nv, c0 = (idx % nv) * VEC;
+        const long p = win_pixel(a.g, blockIdx.x, t) * C + c0;
+        const Vec16<T> dy = load16<T>(dY + p);
+        Vec16<T> o, s;
+        for (int e = 0; e < VEC; ++e) {
+            const float d = from_f32<T>(kf * dy.get(e));     // rounded exactly as the stored d_out
+            o.set(e, d);
+            s.set(e, to_f32(from_f32<T>(d)) * g[c0 + e]);
+        }
+        if (a.keep && dOut) store16<T>(dOut + p, o);
+        store16<T>(dSA + p, s);
+    }
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < 64; ++t) {
+            const long p = win_pixel(a.g, blockIdx.x, t) * C + c;
+            acc += to_f32(from_f32<T>(kf * to_f32(dY[p]))) * to_f32(SA[p]);
+        }
+        a.dgate[(long)blockIdx.x * C + c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct WinBwdDev {
+    const void* X; const void* dSA; const float* dmu;
+    const float* ln_w; const float* ln_b;
+    const void* Wqkv; const float* bqkv; const float* rpb;
+    const void* WprojT;                 // [C][C]: WprojT[ci][co] = proj.weight[co][ci]
+    void* dQKV;                         // [B*nW*64][3C]  window-token order
+    void* XNw;                          // [B*nW*64][C]   LN(x), window-token order
+    void* dSAt;                         // (B,H,W,C) total d_sa (adds dmu/64), image order
+    float* drpb;                        // [B*nW][225][HEADS]
+    WinGeom g;
+};
+
+template <class T, int C, int HD> struct WinBwdCfg {
+    static constexpr int PAD = 16 / sizeof(T);
+    static constexpr int HEADS = C / HD;
+    static constexpr int KC = ElemTraits<T>::KCHUNK;
+    static constexpr int HDP = (HD + KC - 1) / KC * KC;
+    static constexpr int LDX = C + PAD;
+    static constexpr int LDQ = HDP + PAD;        // row-major [64][HDP]
+    static constexpr int LDT = 64 + PAD;         // transposed [HD][64] and the 64x64 tiles
+    static constexpr bool ALIAS = HDP >= 64;     // P^T, dS, dS^T reuse the Q, K, V tiles
+    static constexpr size_t XS = 64 * LDX, QS = 64 * LDQ, TS = HD * LDT, SS = 64 * LDT;
+    static constexpr size_t T_ELEMS = 2 * XS + 4 * QS + 3 * TS + (ALIAS ? 0 : 3 * SS);
+    static constexpr size_t BYTES = T_ELEMS * sizeof(T) + (225 + 64) * 4;
+    static constexpr bool FITS = BYTES <= 160 * 1024;
+};
+
+template <class T, int C, int HD>
+__global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
+    typedef ElemTraits<T> TR;
+    typedef typename TR::frag_t frag_t;
+    typedef WinBwdCfg<T, C, HD> CF;
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int TPW = HD / 16;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    T* Xs = reinterpret_cast<T*>(smem_v);        // LN(x)            [64][LDX]
+    T* Ds = Xs + CF::XS;                         // total d_sa       [64][LDX]
+    T* Qr = Ds + CF::XS;                         // q (scaled)       [64][LDQ]
+    T* Kr = Qr + CF::QS;                         // k                [64][LDQ]
+    T* Vr = Kr + CF::QS;                         // v                [64][LDQ]
+    T* Or = Vr + CF::QS;                         // dO_h             [64][LDQ]
+    T* Qt = Or + CF::QS;                         // q^T              [HD][LDT]
+    T* Kt = Qt + CF::TS;                         // k^T
+    T* Ot = Kt + CF::TS;                         // dO_h^T
+    T* Pt = CF::ALIAS ? Qr : Ot + CF::TS;        // P^T   [key][q]   [64][LDT]
+    T* dS = CF::ALIAS ? Kr : Pt + CF::SS;        // dS    [q][key]
+    T* dSt = CF::ALIAS ? Vr : dS + CF::SS;       // dS^T  [key][q]
+    float* rpbs = reinterpret_cast<float*>(Xs + CF::T_ELEMS);
+    int* reg = reinterpret_cast<int*>(rpbs + 225);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* dSA = reinterpret_cast<const T*>(a.dSA);
+    const long row0 = (long)blockIdx.x * 64;
+
+    // ---- stage LN(x) and the total d_sa; write both side outputs -----------------------------------
+    {
+        constexpr int NV = C / VEC, VPT = NV / 4;
+        const int t = tid >> 2, q = tid & 3;
+        const long pix = win_pixel(a.g, blockIdx.x, t);
+        const T* row = X + pix * C;
+        Vec16<T> xv[VPT];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            xv[i] = load16<T>(row + (q + 4 * i) * VEC);
+            for (int e = 0; e < VEC; ++e) s += xv[i].get(e);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            for (int e = 0; e < VEC; ++e) { float d = xv[i].get(e) - mean; d2 += d * d; }
+        d2 += __shfl_xor(d2, 1);
+        d2 += __shfl_xor(d2, 2);
+        const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+        T* xnw = reinterpret_cast<T*>(a.XNw) + (row0 + t) * C;
+        T* dst = reinterpret_cast<T*>(a.dSAt) + pix * C;
+        const float* dmu = a.dmu + (long)blockIdx.x * C;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
+            store16<T>(Xs + t * CF::LDX + c0, o);
+            store16<T>(xnw + c0, o);
+            Vec16<T> d = load16<T>(dSA + pix * C + c0);
+            for (int e = 0; e < VEC; ++e) d.set(e, d.get(e) + dmu[c0 + e] * (1.0f / 64.0f));
+            store16<T>(Ds + t * CF::LDX + c0, d);
+            store16<T>(dst + c0, d);
+        }
+        if (tid < 64) {
+            const int nwx = a.g.W >> 3, nW = (a.g.H >> 3) * nwx, wi = blockIdx.x % nW;
+            const int ys = (wi / nwx) * 8 + (tid >> 3), xs = (wi % nwx) * 8 + (tid & 7);
+            const int ry = (ys >= a.g.H - 8) + (ys >= a.g.H - 4), rx = (xs >= a.g.W - 8) + (xs >= a.g.W - 4);
+            reg[tid] = a.g.shift ? 3 * ry + rx : 0;
+        }
+        if (CF::HDP != HD)   // zero K-padding columns of the four row-major tiles once
+            for (int i = tid; i < 4 * 64 * (CF::HDP - HD); i += 256) {
+                const int rr = i / (CF::HDP - HD), cc = HD + i % (CF::HDP - HD);
+                Qr[rr * CF::LDQ + cc] = from_f32<T>(0.f);
+            }
+    }
+
+    const T* Wqkv = reinterpret_cast<const T*>(a.Wqkv);
+    const T* WpT = reinterpret_cast<const T*>(a.WprojT);
+    T* dQKV = reinterpret_cast<T*>(a.dQKV);
+    const float scale = rsqrtf((float)HD);
+
+    for (int h = 0; h < CF::HEADS; ++h) {
+        __syncthreads();
+        if (CF::ALIAS && CF::HDP != HD)   // the aliased 64x64 tiles overwrote the zero padding of q,k,v
+            for (int i = tid; i < 3 * 64 * (CF::HDP - HD); i += 256) {
+                const int rr = i / (CF::HDP - HD), cc = HD + i % (CF::HDP - HD);
+                Qr[rr * CF::LDQ + cc] = from_f32<T>(0.f);
+            }
+        if (tid < 225) rpbs[tid] = a.rpb[tid * CF::HEADS + h];
+        // ---- (a) recompute q,k,v (row-major, q/k also transposed) and dO_h = d_sa W_proj[:, head] ------
+        for (int u = wv; u < 4 * TPW * 2; u += 4) {
+            const int ct = u >> 1, th = u & 1, which = ct / TPW, cti = ct % TPW;
+            f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+            const int wrow = (which < 3 ? which * C : 0) + h * HD + cti * 16;
+            const T* Wsrc = which < 3 ? Wqkv : WpT;
+            const T* Bsrc = which < 3 ? Xs : Ds;
+#pragma unroll 4
+            for (int kk = 0; kk < C; kk += TR::KCHUNK) {
+                const frag_t wf = load_frag<T>(Wsrc, C, wrow, kk);
+                mma(c0, wf, load_frag<T>(Bsrc, CF::LDX, th * 32, kk));
+                mma(c1, wf, load_frag<T>(Bsrc, CF::LDX, th * 32 + 16, kk));
+            }
+            const int cr = cti * 16 + (lane >> 4) * 4;
+            if (which < 3) {
+                const float sc = which == 0 ? scale : 1.f;
+                for (int r = 0; r < 4; ++r) {
+                    const float bb = a.bqkv[wrow + (lane >> 4) * 4 + r];
+                    c0[r] = (c0[r] + bb) * sc;
+                    c1[r] = (c1[r] + bb) * sc;
+                }
+            }
+            T* rowm = which == 0 ? Qr : which == 1 ? Kr : which == 2 ? Vr : Or;
+            store4<T>(rowm + (th * 32 + (lane & 15)) * CF::LDQ + cr, c0);
+            store4<T>(rowm + (th * 32 + 16 + (lane & 15)) * CF::LDQ + cr, c1);
+            if (which != 2) {
+                T* tr = which == 0 ? Qt : which == 1 ? Kt : Ot;
+                for (int r = 0; r < 4; ++r) {
+                    tr[(cr + r) * CF::LDT + th * 32 + (lane & 15)] = from_f32<T>(c0[r]);
+                    tr[(cr + r) * CF::LDT + th * 32 + 16 + (lane & 15)] = from_f32<T>(c1[r]);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- (b) P^T (recomputed softmax) and dP^T = V dO^T for this wave's 16 queries -------------------
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kk = 0; kk < CF::HDP; kk += TR::KCHUNK) {
+            const frag_t qf = load_frag<T>(Qr, CF::LDQ, wv * 16, kk);
+            const frag_t of = load_frag<T>(Or, CF::LDQ, wv * 16, kk);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                mma(s[kt], load_frag<T>(Kr, CF::LDQ, kt * 16, kk), qf);
+                mma(dp[kt], load_frag<T>(Vr, CF::LDQ, kt * 16, kk), of);
+            }
+        }
+        const int qi = wv * 16 + (lane & 15), qy = qi >> 3, qx = qi & 7, qreg = reg[qi];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+            for (int r = 0; r < 4; ++r) {
+                const int kj = kt * 16 + (lane >> 4) * 4 + r;
+                float v = s[kt][r] + rpbs[(qy - (kj >> 3) + 7) * 15 + (qx - (kj & 7) + 7)];
+                if (reg[kj] != qreg) v += -100.0f;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+            for (int r = 0; r < 4; ++r) { const float e = expf(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+            for (int r = 0; r < 4; ++r) { s[kt][r] *= inv; dot += s[kt][r] * dp[kt][r]; }
+        dot += __shfl_xor(dot, 16);
+        dot += __shfl_xor(dot, 32);
+        if (CF::ALIAS) __syncthreads();          // every wave is done reading q,k,v before they are overwritten
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 ds;
+            for (int r = 0; r < 4; ++r) ds[r] = s[kt][r] * (dp[kt][r] - dot);
+            store4<T>(dS + qi * CF::LDT + kt * 16 + (lane >> 4) * 4, ds);
+            for (int r = 0; r < 4; ++r) {
+                const int kj = kt * 16 + (lane >> 4) * 4 + r;
+                Pt[kj * CF::LDT + qi] = from_f32<T>(s[kt][r]);
+                dSt[kj * CF::LDT + qi] = from_f32<T>(ds[r]);
+            }
+        }
+        __syncthreads();
+
+        // ---- (c) dQ = scale dS K, dK = dS^T Q, dV = P^T dO  (this wave's 16 tokens) ------------------------
+        {
+            const long row = row0 + wv * 16 + (lane & 15);
+            T* out = dQKV + row * (3 * C) + h * HD + (lane >> 4) * 4;
+#pragma unroll
+            for (int ct = 0; ct < TPW; ++ct) {
+                f32x4 dq = {0, 0, 0, 0}, dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < 64; kk += TR::KCHUNK) {
+                    mma(dq, load_frag<T>(Kt, CF::LDT, ct * 16, kk), load_frag<T>(dS, CF::LDT, wv * 16, kk));
+                    mma(dk, load_frag<T>(Qt, CF::LDT, ct * 16, kk), load_frag<T>(dSt, CF::LDT, wv * 16, kk));
+                    mma(dv, load_frag<T>(Ot, CF::LDT, ct * 16, kk), load_frag<T>(Pt, CF::LDT, wv * 16, kk));
+                }
+                for (int r = 0; r < 4; ++r) dq[r] *= scale;
+                store4<T>(out + ct * 16, dq);
+                store4<T>(out + C + ct * 16, dk);
+                store4<T>(out + 2 * C + ct * 16, dv);
+            }
+        }
+        // relative-position-bias gradient: table entry (dy,dx) collects dS over its (8-|dy|)(8-|dx|) pairs
+        if (tid < 225) {
+            const int oy = tid / 15 - 7, ox = tid % 15 - 7;
+            float acc = 0.f;
+            for (int ky = (oy < 0 ? -oy : 0); ky < (oy > 0 ? 8 - oy : 8); ++ky)
+                for (int kx = (ox < 0 ? -ox : 0); kx < (ox > 0 ? 8 - ox : 8); ++kx)
+                    acc += to_f32(dS[((ky + oy) * 8 + kx + ox) * CF::LDT + ky * 8 + kx]);
+            a.drpb[((long)blockIdx.x * 225 + tid) * CF::HEADS + h] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct LnBwdDev {
+    const void* X; const void* dXNw; const void* dRes; const float* ln_w;
+    void* dX; float* part;      // part [B*nW][2][C]
+    WinGeom g; int C;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void ln_bwd_win_kernel(LnBwdDev a) {
+    constexpr int VEC = Vec16<T>::N;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    const int C = a.C, LDF = C + 4, tid = threadIdx.x;
+    float* Fs = reinterpret_cast<float*>(smem_v);          // [64][LDF] d_xn, then d_xn * xhat
+    float* stat = Fs + 64 * LDF;                           // mean, rstd, s1, s2 per token
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* dXN = reinterpret_cast<const T*>(a.dXNw) + (long)blockIdx.x * 64 * C;
+    const T* dRes = reinterpret_cast<const T*>(a.dRes);
+    T* dX = reinterpret_cast<T*>(a.dX);
+    const int nv = C / VEC;
+    const int t = tid >> 2, q = tid & 3;
+    const long pix = win_pixel(a.g, blockIdx.x, t);
+    // pass 1: statistics of x, and the two LN-backward row sums
+    float s = 0.f;
+    for (int i = q; i < nv; i += 4) {
+        const Vec16<T> xv = load16<T>(X + pix * C + i * VEC);
+        for (int e = 0; e < VEC; ++e) s += xv.get(e);
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    const float mean = s / (float)C;
+    float d2 = 0.f;
+    for (int i = q; i < nv; i += 4) {
+        const Vec16<T> xv = load16<T>(X + pix * C + i * VEC);
+        for (int e = 0; e < VEC; ++e) { const float d = xv.get(e) - mean; d2 += d * d; }
+    }
+    d2 += __shfl_xor(d2, 1); d2 += __shfl_xor(d2, 2);
+    const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = q; i < nv; i += 4) {
+        const Vec16<T> xv = load16<T>(X + pix * C + i * VEC);
+        const Vec16<T> g = load16<T>(dXN + (long)t * C + i * VEC);
+        for (int e = 0; e < VEC; ++e) {
+            const int c = i * VEC + e;
+            const float gw = g.get(e) * a.ln_w[c], xh = (xv.get(e) - mean) * rstd;
+            s1 += gw; s2 += gw * xh;
+            Fs[t * LDF + c] = g.get(e);
+        }
+    }
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+    s1 *= 1.0f / (float)C; s2 *= 1.0f / (float)C;
+    __syncthreads();
+    float* part = a.part + (long)blockIdx.x * 2 * C;
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int tt = 0; tt < 64; ++tt) acc += Fs[tt * LDF + c];
+        part[C + c] = acc;
+    }
+    __syncthreads();
+    for (int i = q; i < nv; i += 4) {
+        const Vec16<T> xv = load16<T>(X + pix * C + i * VEC);
+        const Vec16<T> dr = load16<T>(dRes + pix * C + i * VEC);
+        Vec16<T> o;
+        for (int e = 0; e < VEC; ++e) {
+            const int c = i * VEC + e;
+            const float dxn = Fs[t * LDF + c], xh = (xv.get(e) - mean) * rstd;
+            o.set(e, dr.get(e) + rstd * (dxn * a.ln_w[c] - s1 - xh * s2));
+            Fs[t * LDF + c] = dxn * xh;
+        }
+        store16<T>(dX + pix * C + i * VEC, o);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int tt = 0; tt < 64; ++tt) acc += Fs[tt * LDF + c];
+        part[c] = acc;
+    }
+}
+
+template <class T, int C, int HD>
+static int launch_win_bwd(const WinBwdDev& d, hipStream_t s) {
+    typedef WinBwdCfg<T, C, HD> CF;
+    if constexpr (!CF::FITS) {
+        set_error("win_attn_bwd: (C=%d, head_dim=%d) needs %d bytes of LDS in this dtype", C, HD, (int)CF::BYTES);
+        return MPHSIR_EINVAL;
+    } else {
+        allow_big_lds(win_attn_bwd_kernel<T, C, HD>, CF::BYTES);
+        const int nblk = d.g.B * (d.g.H / 8) * (d.g.W / 8);
+        MPHSIR_LAUNCH(MPHSIR_K_WIN_ATTN_BWD, (win_attn_bwd_kernel<T, C, HD>), dim3(nblk), dim3(256), CF::BYTES, s, d);
+        return MPHSIR_OK;
+    }
+}
+
+template <class T>
+static int dispatch_win_bwd(const WinBwdDev& d, int C, int HD, hipStream_t s) {
+#define MPHSIR_WINB_CASE(c, hd) if (C == c && HD == hd) return launch_win_bwd<T, c, hd>(d, s);
+    MPHSIR_WINB_CASE(32, 32) MPHSIR_WINB_CASE(64, 32) MPHSIR_WINB_CASE(64, 64) MPHSIR_WINB_CASE(128, 32)
+    MPHSIR_WINB_CASE(128, 64) MPHSIR_WINB_CASE(256, 32)
+    MPHSIR_WINB_CASE(96, 48) MPHSIR_WINB_CASE(192, 48) MPHSIR_WINB_CASE(192, 96) MPHSIR_WINB_CASE(384, 48)
+#undef MPHSIR_WINB_CASE
+    set_error("win_attn_bwd: (C=%d, head_dim=%d) not instantiated", C, HD);
+    return MPHSIR_EINVAL;
+}
+
+static bool geom_ok(int B, int H, int W, int shift) {
+    return B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && (shift == 0 || shift == 4);
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_combine_bwd(const void* dY, const void* SA, const float* gate, const float* keep, void* dOut, void* dSA,
+                                  float* dgate, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(dY && SA && gate && dSA && dgate, "combine_bwd: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "combine_bwd: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(geom_ok(B, H, W, shift) && C > 0 && C % 8 == 0, "combine_bwd: bad geometry");
+    MPHSIR_REQUIRE(aligned16(dY) && aligned16(SA) && aligned16(dSA) && (!dOut || aligned16(dOut)), "combine_bwd: 16-byte alignment required");
+    CombBwdDev d{dY, SA, gate, keep, dOut, dSA, dgate, WinGeom{B, H, W, shift}, C};
+    const int nblk = B * (H / 8) * (W / 8);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MPHSIR_F32)
+        MPHSIR_LAUNCH(MPHSIR_K_COMBINE_BWD, (combine_bwd_kernel<float>), dim3(nblk), dim3(256), 0, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_COMBINE_BWD, (combine_bwd_kernel<bf16_t>), dim3(nblk), dim3(256), 0, s, d);
+    return MPHSIR_OK;
+}
+
+extern "C" int mphsir_win_attn_bwd(const mphsir_win_attn_bwd_args* a, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->X && a->dSA && a->dmu && a->ln_w && a->ln_b && a->Wqkv && a->bqkv && a->rpb && a->WprojT && a->dQKV &&
+                       a->XNw && a->dSAt && a->drpb, "win_attn_bwd: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "win_attn_bwd: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(geom_ok(a->B, a->H, a->W, a->shift) && a->heads > 0 && a->C % a->heads == 0, "win_attn_bwd: bad geometry");
+    WinBwdDev d{a->X, a->dSA, a->dmu, a->ln_w, a->ln_b, a->Wqkv, a->bqkv, a->rpb, a->WprojT, a->dQKV, a->XNw, a->dSAt, a->drpb,
+                WinGeom{a->B, a->H, a->W, a->shift}};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == MPHSIR_F32 ? dispatch_win_bwd<float>(d, a->C, a->C / a->heads, s)
+                               : dispatch_win_bwd<bf16_t>(d, a->C, a->C / a->heads, s);
+}
+
+extern "C" int mphsir_win_attn_bwd_fits(int32_t C, int32_t heads, int dtype) {
+    using namespace mphsir;
+    const int hd = C / heads, kc = dtype == MPHSIR_F32 ? 16 : 32, esz = dtype == MPHSIR_F32 ? 4 : 2, pad = 16 / esz;
+    const int hdp = (hd + kc - 1) / kc * kc;
+    const size_t elems = 2 * 64 * (size_t)(C + pad) + 4 * 64 * (size_t)(hdp + pad) + 3 * (size_t)hd * (64 + pad) +
+                         (hdp >= 64 ? 0 : 3 * 64 * (size_t)(64 + pad));
+    return elems * esz + (225 + 64) * 4 <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const float* ln_w, void* dX, float* part,
+                                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(X && dXNw && dRes && ln_w && dX && part, "ln_bwd_win: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "ln_bwd_win: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(geom_ok(B, H, W, shift) && C > 0 && C % 32 == 0 && C <= 512, "ln_bwd_win: bad geometry");
+    MPHSIR_REQUIRE(aligned16(X) && aligned16(dXNw) && aligned16(dRes) && aligned16(dX), "ln_bwd_win: 16-byte alignment required");
+    LnBwdDev d{X, dXNw, dRes, ln_w, dX, part, WinGeom{B, H, W, shift}, C};
+    const size_t shmem = (64 * (size_t)(C + 4) + 256) * sizeof(float);
+    const int nblk = B * (H / 8) * (W / 8);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MPHSIR_F32) {
+        allow_big_lds(ln_bwd_win_kernel<float>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_kernel<float>), dim3(nblk), dim3(256), shmem, s, d);
+    } else {
+        allow_big_lds(ln_bwd_win_kernel<bf16_t>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_kernel<bf16_t>), dim3(nblk), dim3(256), shmem, s, d);
+    }
+    return MPHSIR_OK;
+}

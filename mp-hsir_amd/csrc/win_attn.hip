@@ -28,6 +28,8 @@ struct WinAttnDev {
     const float* Wprompt; const float* Pp; const float* Wq; const float* Wkv; const float* Wdown;
     const float* Wpproj; const float* bpproj; const float* Wup;
     void* SA; float* gate;
+    float* mu;      // optional [B*nW][C]: window mean of SA (training: input of the gate's autograd)
+    void* Oattn;    // optional (B,H,W,C): attention output before proj, image order (training: dWproj)
     int B, H, W, shift, r;
 };
 
@@ -214,6 +216,14 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
             store4<T>(Qs + qi * CF::LDQ + ct * 16 + (lane >> 4) * 4, o);
         }
         __syncthreads();
+        if (a.Oattn) {   // training: keep softmax(QK^T)V (before proj) for the proj weight gradient
+            constexpr int VPH = HD / VEC;
+            T* Oa = reinterpret_cast<T*>(a.Oattn);
+            for (int idx = tid; idx < 64 * VPH; idx += 256) {
+                const int t = idx / VPH, c0 = (idx % VPH) * VEC;
+                store16<T>(Oa + pixel_of(t) * C + h * HD + c0, load16<T>(Qs + t * CF::LDQ + c0));
+            }
+        }
 
         // ---- (d) out[co][tok] += Wproj[co][h*hd + :] * O[tok][:] -------------------------------
 #pragma unroll
@@ -255,6 +265,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         float acc = 0.f;
         for (int t = 0; t < 64; ++t) acc += to_f32(Xs[t * CF::LDX + c]);
         mu[c] = acc * (1.0f / 64.0f);
+        if (a.mu) a.mu[(long)blockIdx.x * C + c] = mu[c];
     }
     __syncthreads();
     if (tid < 128) {
@@ -358,7 +369,7 @@ extern "C" int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, voi
     MPHSIR_REQUIRE(a->r > 0 && a->r <= 32, "win_attn: low-rank width r=%d out of range (1..32)", a->r);
     MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->SA) && aligned16(a->Wqkv) && aligned16(a->Wproj), "win_attn: 16-byte alignment required");
     WinAttnDev d{a->X, a->ln_w, a->ln_b, a->Wqkv, a->bqkv, a->rpb, a->Wproj, a->bproj, a->Wprompt, a->prompt_param,
-                 a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->SA, a->gate, a->B, a->H, a->W, a->shift, a->r};
+                 a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->SA, a->gate, a->mu, a->Oattn, a->B, a->H, a->W, a->shift, a->r};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == MPHSIR_F32 ? dispatch_win<float>(d, a->C, a->C / a->heads, s)
                                : dispatch_win<bf16_t>(d, a->C, a->C / a->heads, s);

@@ -178,6 +178,7 @@ class PGSSTB(nn.Module):                                                        
             return dict(
                 wqkv=a.qkv.weight.to(dtype).contiguous(), bqkv=f(a.qkv.bias),
                 wproj=ops.pack_win_proj(a.proj.weight, self.num_heads, dtype), bproj=f(a.proj.bias),
+                wprojT=a.proj.weight.t().to(dtype).contiguous(),
                 rpb=f(a.relative_position_bias_table), W1=W1, b1=b1, W2=W2, b2=f(m.fc2.bias),
                 W1T=W1.t().contiguous(), W2T=W2.t().contiguous(),
                 ln1=(f(self.norm1.weight), f(self.norm1.bias)), ln2=(f(self.norm2.weight), f(self.norm2.bias)),

@@ -133,9 +133,9 @@ def pack_win_proj(proj_w, heads, dtype):
     return out.reshape(C, heads * hdp)
 
 
-def win_attn_fwd(x, ln_w, ln_b, Wqkv, bqkv, rpb, Wproj, bproj, pg, heads, shift):
+def win_attn_fwd(x, ln_w, ln_b, Wqkv, bqkv, rpb, Wproj, bproj, pg, heads, shift, save=False):
     """x (B,H,W,C) contiguous.  pg = dict of the fp32 local_spectral_attn parameters.
-    Returns (sa (B,H,W,C), gate (B*nW, C) fp32)."""
+    Returns (sa (B,H,W,C), gate (B*nW, C) fp32) and, with save=True, also (mu (B*nW,C) fp32, o_attn (B,H,W,C))."""
     lib = _lib.load()
     _check(x, Wqkv, Wproj, *pg.values())
     B, H, W, C = x.shape
@@ -149,11 +149,17 @@ def win_attn_fwd(x, ln_w, ln_b, Wqkv, bqkv, rpb, Wproj, bproj, pg, heads, shift)
     a.Wq, a.Wkv, a.Wdown = _p(pg["q.weight"]), _p(pg["kv.weight"]), _p(pg["linear_down.weight"])
     a.Wpproj, a.bpproj, a.Wup = _p(pg["proj.weight"]), _p(pg["proj.bias"]), _p(pg["linear_up.weight"])
     a.SA, a.gate = _p(sa), _p(gate)
+    mu = oattn = None
+    if save:
+        mu, oattn = torch.empty_like(gate), torch.empty_like(x)
+        a.mu, a.Oattn = _p(mu), _p(oattn)
     a.B, a.H, a.W, a.C, a.heads, a.shift = B, H, W, C, heads, shift
     a.r = pg["linear_down.weight"].shape[0]
     _lib.check(lib.mphsir_win_attn_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "win_attn_fwd")
     M = B * H * W
     _acct("win_attn", M * (8.0 * C * C + 4.0 * 64 * C), 2.0 * M * C * x.element_size() + gate.numel() * 4 + 4.0 * C * C * x.element_size())
+    if save:
+        return sa, gate, mu, oattn
     return sa, gate
 
 
@@ -294,3 +300,57 @@ def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T):
     _lib.check(lib.mphsir_gated_mlp_bwd(ctypes.byref(a), _DT[dt], _stream(x)), "gated_mlp_bwd")
     _acct("gated_mlp_bwd", 12.0 * M * C * HP, (3.0 * M * C + 3.0 * M * HP + M * C) * x.element_size())
     return dx, xn, h, dpre, part
+
+
+def combine_bwd(dy, sa, gate, keep, shift):
+    """dy, sa (B,H,W,C) -> (d_out (= dy when keep is None), d_sa, dgate (B*nW,C) fp32)."""
+    lib = _lib.load()
+    _check(dy, sa, gate, keep)
+    B, H, W, C = dy.shape
+    assert dy.is_contiguous() and sa.is_contiguous()
+    d_out = torch.empty_like(dy) if keep is not None else dy
+    d_sa = torch.empty_like(dy)
+    dgate = torch.empty_like(gate)
+    _lib.check(lib.mphsir_combine_bwd(_p(dy), _p(sa), _p(gate), _p(keep), _p(d_out) if keep is not None else None, _p(d_sa),
+                                      _p(dgate), B, H, W, C, shift, _DT[dy.dtype], _stream(dy)), "combine_bwd")
+    _acct("combine_bwd", 4.0 * dy.numel(), 4.0 * dy.numel() * dy.element_size())
+    return d_out, d_sa, dgate
+
+
+def win_attn_bwd_fits(C, heads, dtype):
+    return bool(_lib.load().mphsir_win_attn_bwd_fits(C, heads, _DT[dtype]))
+
+
+def win_attn_bwd(x, dsa, dmu, ln_w, ln_b, Wqkv, bqkv, rpb, WprojT, heads, shift):
+    """-> dqkv (M,3C) and xn (M,C) in window-token order, dsa_total (B,H,W,C), drpb (B*nW,225,heads) fp32."""
+    lib = _lib.load()
+    _check(x, dsa, dmu, Wqkv, WprojT)
+    B, H, W, C = x.shape
+    M = B * H * W
+    assert x.is_contiguous() and dsa.is_contiguous() and WprojT.shape == (C, C)
+    dqkv = torch.empty((M, 3 * C), dtype=x.dtype, device=x.device)
+    xnw = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    dsat = torch.empty_like(x)
+    drpb = torch.empty((M // 64, 225, heads), dtype=torch.float32, device=x.device)
+    a = _lib.WinAttnBwdArgs()
+    a.X, a.dSA, a.dmu, a.ln_w, a.ln_b = _p(x), _p(dsa), _p(dmu), _p(ln_w), _p(ln_b)
+    a.Wqkv, a.bqkv, a.rpb, a.WprojT = _p(Wqkv), _p(bqkv), _p(rpb), _p(WprojT)
+    a.dQKV, a.XNw, a.dSAt, a.drpb = _p(dqkv), _p(xnw), _p(dsat), _p(drpb)
+    a.B, a.H, a.W, a.C, a.heads, a.shift = B, H, W, C, heads, shift
+    _lib.check(lib.mphsir_win_attn_bwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "win_attn_bwd")
+    _acct("win_attn_bwd", M * (8.0 * C * C + 10.0 * 64 * C), 7.0 * M * C * x.element_size())
+    return dqkv, xnw, dsat, drpb
+
+
+def ln_bwd_win(x, dxn_w, dres, ln_w, shift):
+    """dx = dres + LN_backward(dxn_w) (dxn_w in window-token order) -> (dx (B,H,W,C), part (B*nW,2,C))."""
+    lib = _lib.load()
+    _check(x, dxn_w, dres, ln_w)
+    B, H, W, C = x.shape
+    assert x.is_contiguous() and dxn_w.is_contiguous() and dres.is_contiguous()
+    dx = torch.empty_like(x)
+    part = torch.empty((B * H * W // 64, 2, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mphsir_ln_bwd_win(_p(x), _p(dxn_w), _p(dres), _p(ln_w), _p(dx), _p(part), B, H, W, C, shift,
+                                     _DT[x.dtype], _stream(x)), "ln_bwd_win")
+    _acct("ln_bwd_win", 10.0 * x.numel(), 4.0 * x.numel() * x.element_size())
+    return dx, part

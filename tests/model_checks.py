@@ -87,3 +87,35 @@ def check_tiny_gradients(dev, dtype=torch.float32, tol=1e-4):
         worst = max(worst, err)
         assert err < tol, (k, err)
     return worst
+
+
+def check_block_gradients(dev, name="nat_enc1", dtype=torch.float32, tol=2e-4):
+    """one stand-alone PGSSTB (golden blocks.npz, grads from the reference): out, dx and every parameter gradient."""
+    import json
+    from golden.cases import BLOCK_CASES, cotangent
+    from golden.detfill import det_value
+    from mp_hsir_amd.net.MP_HSIR import PGSSTB
+    c = BLOCK_CASES[name]
+    blk = PGSSTB(c["C"], c["heads"], [64, 64], 8, c["shift"], 0.0, 2.66, c["cr"], 128).eval()
+    with torch.no_grad():
+        for k, p in blk.named_parameters():
+            p.copy_(det_value(k, p.shape).float())
+    blk = blk.to(dev)
+    x = seeded_input(name, c["shape"], "normal").to(dev).permute(0, 2, 3, 1).contiguous().to(dtype).requires_grad_(True)
+    from mp_hsir_amd import ops
+    ops.ACCOUNT = {}
+    y = blk(x)
+    g = np.load(os.path.join(GOLDEN, "blocks.npz"))
+    e_out = rel_l2(y.detach().float().cpu().permute(0, 3, 1, 2), g[name + "/out"])
+    cot = cotangent(name, c["shape"]).to(dev).permute(0, 2, 3, 1).to(dtype)
+    (y * cot).sum().backward()
+    acct, ops.ACCOUNT = ops.ACCOUNT, None
+    for kname in ("win_attn_bwd", "combine_bwd", "ln_bwd_win", "gated_mlp_bwd", "dwconv3x3_wgrad"):
+        assert kname in acct, "backward did not run the HIP kernel " + kname
+    worst = max(e_out, rel_l2(x.grad.float().cpu().permute(0, 3, 1, 2), g[name + "/dx"]))
+    for k, p in blk.named_parameters():
+        err = rel_l2(p.grad.float().cpu(), g[name + "/dparam/" + k])
+        worst = max(worst, err)
+        assert err < tol, (k, err)
+    assert worst < tol, worst
+    return worst

@@ -18,3 +18,8 @@ def test_tiny_forward_b4_matches_reference():
 
 def test_tiny_gradients_match_reference():
     assert M.check_tiny_gradients("cpu") < 1e-4
+
+
+def test_block_gradients_match_reference():
+    """stand-alone PGSSTB (C=64, 2 heads, shifted): HIP backward kernels vs the reference's dx / dparams."""
+    assert M.check_block_gradients("cpu") < 2e-5

@@ -70,3 +70,33 @@ def test_batch_coupling_and_large_cube():
         big = net(torch.rand(1, 31, 256, 256, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"))
     assert torch.isfinite(y16).all() and torch.isfinite(big).all() and big.shape == (1, 31, 256, 256)
     assert not torch.allclose(y1[0], y16[0])
+
+
+def test_block_gradients_fp32():
+    assert M.check_block_gradients("cuda", "nat_enc1", torch.float32) < 2e-5
+
+
+def test_block_gradients_bf16():
+    print("bf16 block-gradient worst rel-L2", M.check_block_gradients("cuda", "nat_enc1", torch.bfloat16, tol=6e-2))
+
+
+def test_tiny_net_gradients_fp32():
+    assert M.check_tiny_gradients("cuda") < 1e-4
+
+
+def test_training_step_bf16_natural_runs_and_learns():
+    """three engine steps of the natural-scene net at batch 4: finite loss, parameters move, loss not exploding."""
+    from mp_hsir_amd.data import SyntheticPatchSource
+    from mp_hsir_amd.engine import DataParallelEngine
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    torch.manual_seed(0)
+    net = MP_HSIR_Net(compute_dtype=torch.bfloat16).cuda().train()
+    w0 = net.output.weight.detach().clone()
+    eng = DataParallelEngine(net, lr=2e-4)
+    src = SyntheticPatchSource(31, 64, 4, 6, "cuda", 2024, 0)
+    losses = []
+    for _ in range(3):
+        _, x, c, p = src.next()
+        losses.append(float(eng.train_step(x, c, p)))
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < 2 * losses[0]
+    assert not torch.equal(net.output.weight.detach(), w0) and len(eng.unused) == 8      # SURVEY Q3
