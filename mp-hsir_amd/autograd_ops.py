@@ -86,11 +86,11 @@ class _GatedMlp(torch.autograd.Function):
         HP = h.shape[1]
         dW2 = (dm.t() @ h)[:, :hid].float()
         dW1p = (dpre.t() @ xn).float()
-        db1p = dpre.float().sum(0)
+        db1p = torch.sum(dpre, dim=0, dtype=torch.float32)
         dln = part.sum(0)
         return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1],
                 torch.cat([dW1p[:hid], dW1p[HP:HP + hid]], 0), torch.cat([db1p[:hid], db1p[HP:HP + hid]]),
-                dW2, dm.float().sum(0))
+                dW2, torch.sum(dm, dim=0, dtype=torch.float32))
 
 
 def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, temperature, wo, heads, B, H, W):
@@ -119,13 +119,32 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, te
         A = torch.softmax(G / (nq[..., :, None] * nk[..., None, :]) * temp.reshape(1, heads, 1, 1), dim=-1)
         M = torch.einsum("ohi,bhij->bohj", wo_.reshape(C, heads, hd), A).reshape(B, C, C)
     dG, dsq, dsk, dtemp, dwo = torch.autograd.grad(M, [G, sq, sk, temp, wo_], dM)
-    # q, k of the forward (never stored): one depthwise pass each
-    q = ops.dwconv3x3(t_q, w9q).reshape(B, N, C)
-    k = ops.dwconv3x3(t_k, w9k).reshape(B, N, C)
+    # q, k of the forward (never stored) are recomputed by the depthwise kernel; when q|k|v are adjacent channel
+    # slices of one tensor (self-attention) every depthwise pass runs once over the joint channel range.
+    joint = (t_q.data_ptr() + C * t_q.element_size() == t_k.data_ptr() and t_k.data_ptr() + C * t_k.element_size() == t_v.data_ptr()
+             and t_q.stride() == t_k.stride() == t_v.stride() and w9q.data_ptr() + 4 * C == w9k.data_ptr()
+             and w9k.data_ptr() + 4 * C == w9v.data_ptr())
     Nq = torch.zeros((B, C, C), dtype=torch.float32, device=v.device)
     for h in range(heads):
         Nq[:, h * hd:(h + 1) * hd, h * hd:(h + 1) * hd] = dG[:, h]
     Nq = Nq.to(dt)
+    if joint:
+        ld = t_q.stride(2)
+        t_all = torch.as_strided(t_q, (B, H, W, 3 * C), t_q.stride())
+        w9_all = torch.as_strided(w9q, (9, 3 * C), w9q.stride())
+        qk = ops.dwconv3x3(torch.as_strided(t_q, (B, H, W, 2 * C), t_q.stride()), torch.as_strided(w9q, (9, 2 * C), w9q.stride()))
+        q, k = qk[..., :C].reshape(B, N, C), qk[..., C:].reshape(B, N, C)
+        dall = torch.empty((B, N, 3 * C), dtype=dt, device=v.device)
+        torch.baddbmm(q * (2.0 * dsq).reshape(B, 1, C).to(dt), k, Nq.transpose(1, 2), out=dall[..., :C])
+        torch.baddbmm(k * (2.0 * dsk).reshape(B, 1, C).to(dt), q, Nq, out=dall[..., C:2 * C])
+        dall[..., 2 * C:] = dv
+        dall4 = dall.reshape(B, H, W, 3 * C)
+        dt_all = ops.dwconv3x3(dall4, w9_all, flip=True)
+        dw_all = ops.dwconv3x3_wgrad(t_all, dall4)
+        return (dt_all[..., :C], dt_all[..., C:2 * C], dt_all[..., 2 * C:], dw_all[:, :C], dw_all[:, C:2 * C], dw_all[:, 2 * C:],
+                dtemp, dwo)
+    q = ops.dwconv3x3(t_q, w9q).reshape(B, N, C)
+    k = ops.dwconv3x3(t_k, w9k).reshape(B, N, C)
     dq = torch.baddbmm(q * (2.0 * dsq).reshape(B, 1, C).to(dt), k, Nq.transpose(1, 2))
     dk = torch.baddbmm(k * (2.0 * dsk).reshape(B, 1, C).to(dt), q, Nq)
     dq4, dk4, dv4 = dq.reshape(B, H, W, C), dk.reshape(B, H, W, C), dv.reshape(B, H, W, C)
@@ -185,7 +204,10 @@ class _PgsstbAttn(torch.autograd.Function):
         dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
             d_out.reshape(M, Cc), tq, tk, tv, w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:], v, gp, spart, Mb,
             blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W)
-        dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
+        if dtq.data_ptr() + Cc * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * Cc:
+            dt3 = torch.as_strided(dtq, (M, 3 * Cc), (3 * Cc, 1))
+        else:
+            dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
         d_sa = d_sa.reshape(M, Cc).addmm_(dt3, sp["wqkv"])                       # + dt Wqkv  (1x1 conv backward)
         d_sqkv = (dt3.t() @ sa.reshape(M, Cc)).float().reshape(3 * Cc, Cc, 1, 1)
         d_sdw = torch.cat([dwq, dwk, dwv], dim=1).t().reshape(3 * Cc, 1, 3, 3)
@@ -202,10 +224,10 @@ class _PgsstbAttn(torch.autograd.Function):
                                                  pk["rpb"], pk["wprojT"], heads, shift)
         dxn = dqkv @ pk["wqkv"]
         d_qkv_w = (dqkv.t() @ xnw).float()
-        d_qkv_b = dqkv.float().sum(0)
+        d_qkv_b = torch.sum(dqkv, dim=0, dtype=torch.float32)
         dsat2 = dsat.reshape(M, Cc)
         d_proj_w = (dsat2.t() @ oattn.reshape(M, Cc)).float()
-        d_proj_b = dsat2.float().sum(0)
+        d_proj_b = torch.sum(dsat2, dim=0, dtype=torch.float32)
         # (5) norm1 backward + the residual path
         dx, part = ops.ln_bwd_win(x, dxn, dy, pk["ln1"][0], shift)
         dln = part.sum(0)
