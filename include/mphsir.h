@@ -207,6 +207,14 @@ int mphsir_win_attn_bwd_fits(int32_t C, int32_t heads, int dtype);
 int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const float* ln_w, void* dX, float* part,
                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
 
+/* ---- token-reduction GEMM (weight gradients) --------------------------------------------------------
+ * Cpart[b][s][n1][n2] = sum over the s-th token range of A[b][m][n1] * B[b][m][n2]  (fp32 partials;
+ * the caller sums the nsplit partials in order).  A: [batch][M][lda], B: [batch][M][ldb] token-major
+ * views (batch strides in elements).  This is dW = dY^T X of every Linear / 1x1 conv on the path and the
+ * per-sample dM = d_out^T v of the folded channel attention (autograd of net/MP_HSIR.py, train.py:58-67). */
+int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
+                   float* Cpart, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int dtype, void* stream);
+
 /* ---- plain depthwise 3x3 (backward building blocks) ----------------------------------------------
  * mphsir_dwconv3x3: Y[p][c] = sum_taps X[p+tap][c] * w9[tap][c] (zero padding); flip=1 uses the spatially
  * flipped taps = gradient w.r.t. the input of the same depthwise conv applied to dY.
@@ -242,6 +250,7 @@ int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, f
 #define MPHSIR_K_COMBINE_BWD 10
 #define MPHSIR_K_WIN_ATTN_BWD 11
 #define MPHSIR_K_LN_BWD_WIN 12
+#define MPHSIR_K_GEMM_TN 13
 #define MPHSIR_K_COUNT 16
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

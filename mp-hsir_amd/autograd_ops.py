@@ -84,8 +84,8 @@ class _GatedMlp(torch.autograd.Function):
                                                   pk["W1T"], pk["W2T"])
         hid = blk.mlp.fc2.weight.shape[1]
         HP = h.shape[1]
-        dW2 = (dm.t() @ h)[:, :hid].float()
-        dW1p = (dpre.t() @ xn).float()
+        dW2 = ops.gemm_tn(dm, h)[:, :hid]
+        dW1p = ops.gemm_tn(dpre, xn)
         db1p = torch.sum(dpre, dim=0, dtype=torch.float32)
         dln = part.sum(0)
         return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1],
@@ -105,7 +105,7 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, te
     hd = C // heads
     dt = v.dtype
     dO3, v3 = d_out.reshape(B, N, C), v.reshape(B, N, C)
-    dM = torch.bmm(dO3.transpose(1, 2), v3).float()                     # (B,C,C)
+    dM = ops.gemm_tn(dO3, v3)                                           # (B,C,C) fp32
     dv = torch.bmm(dO3, Mb)                                              # (B,N,C)
     G = gp.sum(dim=1).requires_grad_(True)                               # (B,h,hd,hd)
     S = sp.sum(dim=1)
@@ -209,7 +209,7 @@ class _PgsstbAttn(torch.autograd.Function):
         else:
             dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
         d_sa = d_sa.reshape(M, Cc).addmm_(dt3, sp["wqkv"])                       # + dt Wqkv  (1x1 conv backward)
-        d_sqkv = (dt3.t() @ sa.reshape(M, Cc)).float().reshape(3 * Cc, Cc, 1, 1)
+        d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
         d_sdw = torch.cat([dwq, dwk, dwv], dim=1).t().reshape(3 * Cc, 1, 3, 3)
         # (3) local spectral-prompt gate: tiny fp32 math on (B*nW, C), differentiated by autograd
         pgm = blk.local_spectral_attn
@@ -223,10 +223,10 @@ class _PgsstbAttn(torch.autograd.Function):
         dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
                                                  pk["rpb"], pk["wprojT"], heads, shift)
         dxn = dqkv @ pk["wqkv"]
-        d_qkv_w = (dqkv.t() @ xnw).float()
+        d_qkv_w = ops.gemm_tn(dqkv, xnw)
         d_qkv_b = torch.sum(dqkv, dim=0, dtype=torch.float32)
         dsat2 = dsat.reshape(M, Cc)
-        d_proj_w = (dsat2.t() @ oattn.reshape(M, Cc)).float()
+        d_proj_w = ops.gemm_tn(dsat2, oattn.reshape(M, Cc))
         d_proj_b = torch.sum(dsat2, dim=0, dtype=torch.float32)
         # (5) norm1 backward + the residual path
         dx, part = ops.ln_bwd_win(x, dxn, dy, pk["ln1"][0], shift)
@@ -345,7 +345,7 @@ class _Conv1x1(torch.autograd.Function):
         dy2, x2 = dy.reshape(-1, N), x.reshape(-1, K)
         dx = ops.gemm_tok(dy2.contiguous(), w.reshape(N, K).t().to(x.dtype).contiguous()).reshape(x.shape) \
             if ctx.needs_input_grad[0] and N % 32 == 0 and K % 16 == 0 else (dy2 @ w.reshape(N, K).to(dy.dtype)).reshape(x.shape)
-        dw = (dy2.float().t() @ x2.float()).reshape(w.shape) if ctx.needs_input_grad[1] else None
+        dw = ops.gemm_tn(dy2.contiguous(), x2).reshape(w.shape) if ctx.needs_input_grad[1] else None
         return dx, dw
 
 

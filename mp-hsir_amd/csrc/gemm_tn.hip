@@ -1,0 +1,98 @@
+// gemm_tn: token-reduction GEMM  C[n1][n2] = sum_m A[m][n1] * B[m][n2]   (A, B token-major, C fp32)
+//
+// Every parameter gradient of a Linear / 1x1 conv on the path is of this form (dW = dY^T X over all
+// tokens of the local batch), and so is the per-sample dM = d_out^T v of the folded
+// channel attention.  M (tokens) is 1e5..1e6 while N1, N2 <= ~1.4k, so the work is split over M:
+// grid = (output tiles of 64x64, nsplit, batch); each workgroup walks its token range in 64-row steps,
+// transposing both operand tiles into LDS (the MFMA K axis must be lane-contiguous) and accumulating
+// its 64x64 tile in registers; partial tiles go to Cpart[batch][split][N1][N2] and are summed by the
+// caller in split order: deterministic, no atomics.  HBM-bound (AI = 32..64 FLOP/B); tiles of one
+// token range are adjacent in blockIdx so operand re-reads hit L2.
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+struct TnDev {
+    const void* A; long lda; long abs;
+    const void* B; long ldb; long bbs;
+    float* Cp;
+    long M; int N1, N2, nsplit;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
+    typedef ElemTraits<T> TR;
+    constexpr int PAD = 16 / sizeof(T);
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int KT = 64, LDT = KT + PAD;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    T* At = reinterpret_cast<T*>(smem_v);        // [64 n1][LDT]
+    T* Bt = At + 64 * LDT;                       // [64 n2][LDT]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t2n = (a.N2 + 63) / 64;
+    const int n1_0 = (blockIdx.x / t2n) * 64, n2_0 = (blockIdx.x % t2n) * 64;
+    const int sp = blockIdx.y, bz = blockIdx.z;
+    const long per = ((a.M + a.nsplit - 1) / a.nsplit + KT - 1) / KT * KT;
+    const long m_lo = (long)sp * per, m_hi = (m_lo + per < a.M) ? m_lo + per : a.M;
+    const T* A = reinterpret_cast<const T*>(a.A) + (long)bz * a.abs;
+    const T* B = reinterpret_cast<const T*>(a.B) + (long)bz * a.bbs;
+
+    f32x4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int VPR = 64 / VEC;                // vectors per 64-column row segment
+    for (long m0 = m_lo; m0 < m_hi; m0 += KT) {
+        for (int v = tid; v < KT * VPR; v += 256) {
+            const int r = v / VPR, c = (v % VPR) * VEC;
+            const long m = m0 + r;
+            Vec16<T> xa, xb;
+            const bool okm = m < m_hi;
+            if (okm && n1_0 + c < a.N1) xa = load16<T>(A + m * a.lda + n1_0 + c);
+            else for (int e = 0; e < VEC; ++e) xa.set(e, 0.f);
+            if (okm && n2_0 + c < a.N2) xb = load16<T>(B + m * a.ldb + n2_0 + c);
+            else for (int e = 0; e < VEC; ++e) xb.set(e, 0.f);
+            for (int e = 0; e < VEC; ++e) {
+                At[(c + e) * LDT + r] = xa.v[e];
+                Bt[(c + e) * LDT + r] = xb.v[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += TR::KCHUNK) {
+            const typename TR::frag_t af = load_frag<T>(At, LDT, wv * 16, kk);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) mma(acc[nt], af, load_frag<T>(Bt, LDT, nt * 16, kk));
+        }
+        __syncthreads();
+    }
+    float* Cp = a.Cp + (((long)bz * a.nsplit + sp) * a.N1) * a.N2;
+    for (int nt = 0; nt < 4; ++nt)
+        for (int r = 0; r < 4; ++r) {
+            const int n1 = n1_0 + wv * 16 + (lane >> 4) * 4 + r, n2 = n2_0 + nt * 16 + (lane & 15);
+            if (n1 < a.N1 && n2 < a.N2) Cp[(long)n1 * a.N2 + n2] = acc[nt][r];
+        }
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
+                              float* Cpart, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(A && B && Cpart, "gemm_tn: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "gemm_tn: dtype %d unsupported", dtype);
+    const int esz = dtype == MPHSIR_F32 ? 4 : 2, vec = 16 / esz;
+    MPHSIR_REQUIRE(M > 0 && N1 > 0 && N2 > 0 && N1 % vec == 0 && N2 % vec == 0 && nsplit > 0 && batch > 0 && nsplit < 65536 && batch < 65536,
+                   "gemm_tn: bad shape (N1, N2 must be multiples of %d)", vec);
+    MPHSIR_REQUIRE(aligned16(A) && aligned16(B) && (lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0 &&
+                       (a_batch_stride * esz) % 16 == 0 && (b_batch_stride * esz) % 16 == 0, "gemm_tn: 16-byte alignment required");
+    TnDev d{A, (long)lda, (long)a_batch_stride, B, (long)ldb, (long)b_batch_stride, Cpart, (long)M, N1, N2, nsplit};
+    dim3 grid(((N1 + 63) / 64) * ((N2 + 63) / 64), nsplit, batch);
+    const size_t shmem = 2 * 64 * (64 + vec) * esz;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MPHSIR_F32)
+        MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_kernel<float>), grid, dim3(256), shmem, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_kernel<bf16_t>), grid, dim3(256), shmem, s, d);
+    return MPHSIR_OK;
+}

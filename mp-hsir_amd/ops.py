@@ -354,3 +354,24 @@ def ln_bwd_win(x, dxn_w, dres, ln_w, shift):
                                      _DT[x.dtype], _stream(x)), "ln_bwd_win")
     _acct("ln_bwd_win", 10.0 * x.numel(), 4.0 * x.numel() * x.element_size())
     return dx, part
+
+
+def gemm_tn(a, b, nsplit=None):
+    """sum over tokens of a[m,:]^T b[m,:].  a (M,N1), b (M,N2) row-major views -> fp32 (N1,N2);
+    batched: a (Bt,M,N1), b (Bt,M,N2) -> (Bt,N1,N2)."""
+    lib = _lib.load()
+    _check(a, b)
+    batched = a.dim() == 3
+    Bt = a.shape[0] if batched else 1
+    M, N1, N2 = a.shape[-2], a.shape[-1], b.shape[-1]
+    assert a.stride(-1) == 1 and b.stride(-1) == 1 and b.shape[-2] == M and a.dtype == b.dtype
+    if nsplit is None:
+        tiles = ((N1 + 63) // 64) * ((N2 + 63) // 64) * Bt
+        nsplit = max(1, min(M // 512, max(1, 1536 // tiles)))
+    part = torch.empty((Bt, nsplit, N1, N2), dtype=torch.float32, device=a.device)
+    _lib.check(lib.mphsir_gemm_tn(_p(a), a.stride(-2), a.stride(0) if batched else 0, _p(b), b.stride(-2),
+                                  b.stride(0) if batched else 0, _p(part), M, N1, N2, nsplit, Bt, _DT[a.dtype], _stream(a)),
+               "gemm_tn")
+    _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size() + part.numel() * 4.0)
+    out = part.sum(dim=1) if nsplit > 1 else part[:, 0]
+    return out if batched else out[0]

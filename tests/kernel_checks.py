@@ -225,3 +225,19 @@ def check_gated_mlp_bwd(dev, dtype, C, hid):
     assert rel_l2(dW2, Pd["fc2.weight"].grad) < tol and rel_l2(dW1, Pd["fc1.weight"].grad) < tol
     assert rel_l2(db1, Pd["fc1.bias"].grad) < tol and rel_l2(db2, Pd["fc2.bias"].grad) < tol
     assert rel_l2(dln[0], lw.grad) < tol and rel_l2(dln[1], lb.grad) < tol
+
+
+def check_gemm_tn(dev, dtype, M, N1, N2, nsplit, batch):
+    _use(dev)
+    from mp_hsir_amd import ops
+    shape_a = (batch, M, N1) if batch else (M, N1)
+    shape_b = (batch, M, N2) if batch else (M, N2)
+    a, b = rnd(shape_a, 51, dtype), rnd(shape_b, 52, dtype)
+    c = ops.gemm_tn(a, b, nsplit=nsplit)
+    ref = a.double().cpu().transpose(-1, -2) @ b.double().cpu()
+    assert rel_l2(c, ref) < (3e-6 if dtype == torch.float32 else 1e-2)
+    # strided views (column slices of a wider matrix), as the backward uses them
+    wide = rnd((M, N1 + 24), 53, dtype)
+    if not batch:
+        c2 = ops.gemm_tn(wide[:, 8:8 + N1], b, nsplit=nsplit)
+        assert rel_l2(c2, wide[:, 8:8 + N1].double().cpu().t() @ b.double().cpu()) < (3e-6 if dtype == torch.float32 else 1e-2)

@@ -87,3 +87,10 @@ def test_gated_mlp_bwd(dtype, C, hid):
 
 def test_gated_mlp_bwd_c384_bf16():
     K.check_gated_mlp_bwd("cuda", torch.bfloat16, 384, 1021)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("M,N1,N2,nsplit,batch", [(256, 64, 64, 2, 0), (200, 96, 32, 3, 0), (128, 32, 32, 1, 2),
+                                                   (131072, 704, 128, None, 0), (4096, 128, 128, None, 32), (32768, 384, 128, None, 0)])
+def test_gemm_tn(dtype, M, N1, N2, nsplit, batch):
+    K.check_gemm_tn("cuda", dtype, M, N1, N2, nsplit, batch)
