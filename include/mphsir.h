@@ -226,6 +226,10 @@ int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int64_t ldw, v
 int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY, int64_t lddy, float* partial, int32_t nblk,
                            int32_t B, int32_t H, int32_t W, int32_t C, int dtype, void* stream);
 
+/* backward of the GDFN gate u = gelu_erf(T[:, :HP]) * T[:, HP:] (FFN/FeedForward.forward :263, :389):
+ * given dU [M][HP] writes U (recomputed, for d project_out) and dT [M][2*HP].                          */
+int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void* dT, int64_t M, int32_t HP, int dtype, void* stream);
+
 /* ---- fused AdamW over the flat parameter arena ---------------------------------------------------
  * One decoupled-weight-decay Adam step on n contiguous fp32 parameters (n % 4 == 0) with gradient g,
  * moments m, v; g is multiplied by grad_scale first (1/world_size after a sum all-reduce).
@@ -251,6 +255,7 @@ int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, f
 #define MPHSIR_K_WIN_ATTN_BWD 11
 #define MPHSIR_K_LN_BWD_WIN 12
 #define MPHSIR_K_GEMM_TN 13
+#define MPHSIR_K_GDFN_GATE_BWD 14
 #define MPHSIR_K_COUNT 16
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -96,6 +96,7 @@ _SYMBOLS = {
     "mphsir_ln_bwd_win": (c_int, [c_void_p] * 6 + [c_int32] * 5 + [c_int, c_void_p]),
     "mphsir_gemm_tn": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_int32,
                                c_int32, c_int32, c_int, c_void_p]),
+    "mphsir_gdfn_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "mphsir_gated_mlp_bwd": (c_int, [ctypes.POINTER(MlpBwdArgs), c_int, c_void_p]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
 }

@@ -302,6 +302,158 @@ def _transformer_block_forward(tb, t):
     return _gdfn_res(tb.ffn, tb.norm2, a, B, H, W).reshape(B, H, W, D)
 
 
+def _ln_vjp(x2, w, b, dxn):
+    """LayerNorm over channels (torch kernels): returns (d x, d weight, d bias) for upstream dxn, and LN(x)."""
+    xl = x2.detach().requires_grad_(True)
+    wl, bl = w.detach().requires_grad_(True), b.detach().requires_grad_(True)
+    with torch.enable_grad():
+        xn = F.layer_norm(xl.float(), (xl.shape[-1],), wl.float(), bl.float(), 1e-5).to(x2.dtype)
+    return torch.autograd.grad(xn, [xl, wl, bl], dxn)
+
+
+def _ln_fwd(x2, w, b):
+    return F.layer_norm(x2.float(), (x2.shape[-1],), w.float(), b.float(), 1e-5).to(x2.dtype)
+
+
+def _unpad_halves(w, hid, HP):
+    return torch.cat([w[:hid], w[HP:HP + hid]], 0)
+
+
+class _GdfnRes(torch.autograd.Function):
+    """y = a + project_out(gelu(x1) * x2), [x1|x2] = dwconv(project_in(LN(a)))   (ref FFN :251-265 / FeedForward
+    :374-391 inside the pre-norm residual of :286 / :477).  HIP forward; backward = HIP depthwise / gate /
+    token-reduction kernels + library GEMMs for the two data gradients."""
+
+    @staticmethod
+    def forward(ctx, ffn, ln, geom, a2, ln_w, ln_b, w_in, w_dw, w_out):
+        B, H, W = geom
+        pf = ffn.packed(a2.dtype)
+        t = ops.gemm_tok(a2, pf["w_in"], ln=ln.pair())
+        u = ops.dwconv_gate(t, pf["w9"], B, H, W)
+        y = ops.gemm_tok(u, pf["w_out"], epi=1, res=a2)
+        ctx.ffn, ctx.ln, ctx.geom = ffn, ln, geom
+        ctx.save_for_backward(a2, t)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, t = ctx.saved_tensors
+        ffn, ln, (B, H, W) = ctx.ffn, ctx.ln, ctx.geom
+        pf = ffn.packed(a2.dtype)
+        HP = pf["w_out"].shape[1]
+        hid = ffn.project_out.weight.shape[1]
+        D = a2.shape[1]
+        dy = dy.contiguous()
+        t4 = t.reshape(B, H, W, 2 * HP)
+        tdw = ops.dwconv3x3(t4, pf["w9"]).reshape(-1, 2 * HP)
+        du = dy @ pf["w_out"]                                              # (M,HP)
+        u, dtdw = ops.gdfn_gate_bwd(tdw, du)
+        d_out_w = ops.gemm_tn(dy, u)[:, :hid].reshape(D, hid, 1, 1)
+        dtdw4 = dtdw.reshape(B, H, W, 2 * HP)
+        dt_ = ops.dwconv3x3(dtdw4, pf["w9"], flip=True).reshape(-1, 2 * HP)
+        d_dw = _unpad_halves(ops.dwconv3x3_wgrad(t4, dtdw4).t(), hid, HP).reshape(2 * hid, 1, 3, 3)
+        lw, lb = ln.body.weight, ln.body.bias
+        xn = _ln_fwd(a2, lw, lb)
+        d_in_w = _unpad_halves(ops.gemm_tn(dt_, xn), hid, HP).reshape(2 * hid, D, 1, 1)
+        da, dlw, dlb = _ln_vjp(a2, lw, lb, dt_ @ pf["w_in"])
+        return None, None, None, dy + da, dlw, dlb, d_in_w, d_dw, d_out_w
+
+
+def _gdfn_res_ag(ffn, ln, a2, B, H, W):
+    return _GdfnRes.apply(ffn, ln, (B, H, W), a2, ln.body.weight, ln.body.bias, ffn.project_in.weight, ffn.dwconv.weight,
+                          ffn.project_out.weight)
+
+
+class _SelfChannelAttnRes(torch.autograd.Function):
+    """a = t + M_b v  with q,k,v from dwconv(qkv(LN(t)))   (ref Attention :289-322 inside :476)."""
+
+    @staticmethod
+    def forward(ctx, attn, ln, geom, t2, ln_w, ln_b, w_qkv, w_dw, w_out, temp):
+        B, H, W = geom
+        D = t2.shape[1]
+        dt = t2.dtype
+        pa = attn.packed(dt)
+        q = ops.gemm_tok(t2, pa["wqkv"], ln=ln.pair())
+        w9 = pa["w9"]
+        v, gp, sp, _ = ops.dwconv_gram(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
+                                       B, H, W, D, attn.num_heads)
+        Mb = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt)
+        a = ops.gemm_tok(v, Mb, epi=1, res=t2)
+        ctx.attn, ctx.ln, ctx.geom = attn, ln, geom
+        ctx.save_for_backward(t2, q, v, gp, sp, Mb)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        t2, q, v, gp, sp, Mb = ctx.saved_tensors
+        attn, ln, (B, H, W) = ctx.attn, ctx.ln, ctx.geom
+        D = t2.shape[1]
+        M = t2.shape[0]
+        pa = attn.packed(t2.dtype)
+        w9 = pa["w9"]
+        da = da.contiguous()
+        q4 = q.reshape(B, H, W, 3 * D)
+        dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
+            da, q4[..., :D], q4[..., D:2 * D], q4[..., 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb,
+            attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
+        if dtq.data_ptr() + D * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * D:
+            dt3 = torch.as_strided(dtq, (M, 3 * D), (3 * D, 1))
+        else:
+            dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * D)
+        lw, lb = ln.body.weight, ln.body.bias
+        xn = _ln_fwd(t2, lw, lb)
+        d_qkv = ops.gemm_tn(dt3, xn).reshape(3 * D, D, 1, 1)
+        dt_in, dlw, dlb = _ln_vjp(t2, lw, lb, dt3 @ pa["wqkv"])
+        d_dw = torch.cat([dwq, dwk, dwv], dim=1).t().reshape(3 * D, 1, 3, 3)
+        return None, None, None, da + dt_in, dlw, dlb, d_qkv, d_dw, dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1)
+
+
+class _CrossChannelAttnRes(torch.autograd.Function):
+    """a = x_q + M_b v, q from x_q, k/v from x_kv   (ref CrossAttention :220-249 inside :282)."""
+
+    @staticmethod
+    def forward(ctx, ct, geom, text2, vis2, n11w, n11b, n12w, n12b, w_q, w_kv, w_qdw, w_kvdw, w_out, temp):
+        B, H, W = geom
+        D = text2.shape[1]
+        dt = text2.dtype
+        pa = ct.attn.packed(dt)
+        tq = ops.gemm_tok(text2, pa["wq"], ln=ct.norm11.pair())
+        tkv = ops.gemm_tok(vis2, pa["wkv"], ln=ct.norm12.pair())
+        w9 = pa["w9"]
+        v, gp, sp, _ = ops.dwconv_gram(tq, tkv[:, :D], tkv[:, D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
+                                       B, H, W, D, ct.attn.num_heads)
+        Mb = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt)
+        a = ops.gemm_tok(v, Mb, epi=1, res=text2)
+        ctx.ct, ctx.geom = ct, geom
+        ctx.save_for_backward(text2, vis2, tq, tkv, v, gp, sp, Mb)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        text2, vis2, tq, tkv, v, gp, sp, Mb = ctx.saved_tensors
+        ct, (B, H, W) = ctx.ct, ctx.geom
+        attn = ct.attn
+        D = text2.shape[1]
+        M = text2.shape[0]
+        pa = attn.packed(text2.dtype)
+        w9 = pa["w9"]
+        da = da.contiguous()
+        tq4, tkv4 = tq.reshape(B, H, W, D), tkv.reshape(B, H, W, 2 * D)
+        dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
+            da, tq4, tkv4[..., :D], tkv4[..., D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb,
+            attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
+        dtq2 = dtq.reshape(M, D)
+        dkv = torch.cat([dtk, dtv], dim=-1).reshape(M, 2 * D)
+        xq = _ln_fwd(text2, ct.norm11.body.weight, ct.norm11.body.bias)
+        xv = _ln_fwd(vis2, ct.norm12.body.weight, ct.norm12.body.bias)
+        d_wq = ops.gemm_tn(dtq2, xq).reshape(D, D, 1, 1)
+        d_wkv = ops.gemm_tn(dkv, xv).reshape(2 * D, D, 1, 1)
+        dtext, d11w, d11b = _ln_vjp(text2, ct.norm11.body.weight, ct.norm11.body.bias, dtq2 @ pa["wq"])
+        dvis, d12w, d12b = _ln_vjp(vis2, ct.norm12.body.weight, ct.norm12.body.bias, dkv @ pa["wkv"])
+        return (None, None, da + dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.t().reshape(D, 1, 3, 3),
+                torch.cat([dwk, dwv], dim=1).t().reshape(2 * D, 1, 3, 3), dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1))
+
+
 def tvsp(mod, x, clip_prompt, prompt_weights):
     """TVSP.forward (ref :572-583) with the batch-coupling broadcast of SURVEY Q1 made explicit:
     text[b,i,j,d] = L[b,d] * clip[floor(i*B/ps), floor(j*512/ps)]."""
@@ -314,8 +466,11 @@ def tvsp(mod, x, clip_prompt, prompt_weights):
     text = (clip_map[None, :, :, None] * L[:, None, None, :]).to(dt).contiguous()
     vis = mod.visual_prompt.permute(0, 2, 3, 1).expand(B, ps, ps, D).to(dt).contiguous()
     ct = mod.cross_transformer
-    y = _apply(lambda t_, v_: _cross_transformer_forward(ct, t_, v_),
-               lambda t_, v_, P: C.cross_transformer(P, t_, v_, ct.attn.num_heads), ct, text, vis)
+    at = ct.attn
+    a = _CrossChannelAttnRes.apply(ct, (B, ps, ps), text.reshape(-1, D), vis.reshape(-1, D), ct.norm11.body.weight,
+                                   ct.norm11.body.bias, ct.norm12.body.weight, ct.norm12.body.bias, at.q.weight, at.kv.weight,
+                                   at.q_dwconv.weight, at.kv_dwconv.weight, at.project_out.weight, at.temperature)
+    y = _gdfn_res_ag(ct.ffn, ct.norm2, a, B, ps, ps).reshape(B, ps, ps, D)
     if (H, W) != (ps, ps):                                                             # ref :580
         y = F.interpolate(y.permute(0, 3, 1, 2), (H, W), mode="bilinear").permute(0, 2, 3, 1).contiguous()
     return conv3x3(y, mod.conv_last.weight)
@@ -323,9 +478,12 @@ def tvsp(mod, x, clip_prompt, prompt_weights):
 
 def prompt_fusion(mod, x, prompt):
     t = torch.cat([x, prompt], dim=-1)
+    B, H, W, D = t.shape
     tb = mod.transformer
-    y = _apply(lambda t_: _transformer_block_forward(tb, t_),
-               lambda t_, P: C.transformer_block(P, t_, tb.attn.num_heads), tb, t)
+    at = tb.attn
+    a = _SelfChannelAttnRes.apply(at, tb.norm1, (B, H, W), t.reshape(-1, D), tb.norm1.body.weight, tb.norm1.body.bias,
+                                  at.qkv.weight, at.qkv_dwconv.weight, at.project_out.weight, at.temperature)
+    y = _gdfn_res_ag(tb.ffn, tb.norm2, a, B, H, W).reshape(B, H, W, D)
     return conv1x1(y, mod.conv.weight)
 
 

@@ -103,7 +103,62 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwWgDev a) {
     }
 }
 
+struct GateBwdDev {
+    const void* T; const void* dU; void* U; void* dT; long M; int HP;
+};
+
+__device__ __forceinline__ float gelu_grad_erf(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+// backward of u = gelu(x1) * x2 with [x1|x2] = T[:, :HP], T[:, HP:]  (FFN/FeedForward :263, :389); also re-emits u
+template <class T>
+__global__ __launch_bounds__(256) void gdfn_gate_bwd_kernel(GateBwdDev a) {
+    constexpr int VEC = Vec16<T>::N;
+    const int vpr = a.HP / VEC;
+    const long total = a.M * vpr;
+    const T* Tin = reinterpret_cast<const T*>(a.T);
+    const T* dU = reinterpret_cast<const T*>(a.dU);
+    T* U = reinterpret_cast<T*>(a.U);
+    T* dT = reinterpret_cast<T*>(a.dT);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / vpr;
+        const int c0 = (int)(idx % vpr) * VEC;
+        const Vec16<T> x1 = load16<T>(Tin + m * 2 * a.HP + c0), x2 = load16<T>(Tin + m * 2 * a.HP + a.HP + c0);
+        const Vec16<T> du = load16<T>(dU + m * a.HP + c0);
+        Vec16<T> u, d1, d2;
+        for (int e = 0; e < VEC; ++e) {
+            const float g = gelu_erf(x1.get(e));
+            u.set(e, g * x2.get(e));
+            d1.set(e, du.get(e) * x2.get(e) * gelu_grad_erf(x1.get(e)));
+            d2.set(e, du.get(e) * g);
+        }
+        store16<T>(U + m * a.HP + c0, u);
+        store16<T>(dT + m * 2 * a.HP + c0, d1);
+        store16<T>(dT + m * 2 * a.HP + a.HP + c0, d2);
+    }
+}
+
 }  // namespace mphsir
+
+extern "C" int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void* dT, int64_t M, int32_t HP, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(T && dU && U && dT, "gdfn_gate_bwd: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "gdfn_gate_bwd: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(M > 0 && HP > 0 && HP % 8 == 0, "gdfn_gate_bwd: bad shape");
+    MPHSIR_REQUIRE(aligned16(T) && aligned16(dU) && aligned16(U) && aligned16(dT), "gdfn_gate_bwd: 16-byte alignment required");
+    GateBwdDev d{T, dU, U, dT, (long)M, HP};
+    const int vec = dtype == MPHSIR_F32 ? 4 : 8;
+    long blocks = (M * (HP / vec) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MPHSIR_F32)
+        MPHSIR_LAUNCH(MPHSIR_K_GDFN_GATE_BWD, (gdfn_gate_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_GDFN_GATE_BWD, (gdfn_gate_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    return MPHSIR_OK;
+}
 
 extern "C" int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int64_t ldw, void* Y, int64_t ldy,
                                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t flip, int dtype, void* stream) {

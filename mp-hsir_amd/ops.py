@@ -375,3 +375,15 @@ def gemm_tn(a, b, nsplit=None):
     _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size() + part.numel() * 4.0)
     out = part.sum(dim=1) if nsplit > 1 else part[:, 0]
     return out if batched else out[0]
+
+
+def gdfn_gate_bwd(t, du):
+    """t (M,2*HP), du (M,HP) contiguous -> (u (M,HP), dt (M,2*HP))."""
+    lib = _lib.load()
+    _check(t, du)
+    M, HP = du.shape
+    assert t.shape == (M, 2 * HP) and t.is_contiguous() and du.is_contiguous()
+    u, dt_ = torch.empty_like(du), torch.empty_like(t)
+    _lib.check(lib.mphsir_gdfn_gate_bwd(_p(t), _p(du), _p(u), _p(dt_), M, HP, _DT[t.dtype], _stream(t)), "gdfn_gate_bwd")
+    _acct("gdfn_gate_bwd", 30.0 * M * HP, 7.0 * M * HP * t.element_size())
+    return u, dt_
