@@ -128,6 +128,7 @@ typedef struct mphsir_fold_args {
     const float* temperature;   /* [heads] */
     const float* Wo;            /* project_out.weight [C][C] fp32 */
     void* M;                    /* [B][C][C] compute dtype */
+    void* MT;                   /* optional [B][C][C]: M transposed (saved for backward) */
     int32_t B, C, heads, nsplit;
 } mphsir_fold_args;
 int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* stream);
@@ -207,6 +208,30 @@ int mphsir_win_attn_bwd_fits(int32_t C, int32_t heads, int dtype);
 int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const float* ln_w, void* dX, float* part,
                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
 
+/* ---- backward of the two small per-sample / per-window stages -----------------------------------------
+ * mphsir_spectral_fold_bwd: backward of mphsir_spectral_fold.  dM [B][C][C] fp32 = gradient w.r.t. M_b.  Outputs:
+ *   W2 [B][2C][2C] (compute dtype) such that [dq | dk] = [q | k] W2_b^T is one mphsir_gemm_tok with a per-sample
+ *   weight (rows c: [diag(2 d sum q^2) | dG blocks], rows C+c: [dG^T blocks | diag(2 d sum k^2)]);
+ *   dWo [B][C][C] fp32 per-sample parts of d project_out.weight (sum over B); dtemp [B][heads] parts of d temperature.
+ * mphsir_pg_gate_bwd: backward of the local spectral-prompt gate for every window: dmu [nW][C] and the factor rows
+ *   L [nW][KL] = [dgate | d o2 | d kv | d q | w | d logit | d d | 0], R [nW][KR] = [o2 | o | 1 | d | s | d s | mu | 0]
+ *   (KL >= C+5r+256, KR >= 5r+1+C, multiples of 4): L^T R over the windows (mphsir_gemm_tn, fp32) holds every
+ *   parameter gradient of PG_Spectral_Attention (net/MP_HSIR.py:122-129) as a sub-block.                        */
+typedef struct mphsir_fold_bwd_args {
+    const float* Gpart; const float* Spart; const float* temperature; const float* Wo; const float* dM;
+    void* W2; float* dWo; float* dtemp;
+    int32_t B, C, heads, nsplit;
+} mphsir_fold_bwd_args;
+int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype, void* stream);
+typedef struct mphsir_pg_bwd_args {
+    const float* mu; const float* dgate;
+    const float* Wprompt; const float* prompt_param; const float* Wq; const float* Wkv; const float* Wdown;
+    const float* Wpproj; const float* bpproj; const float* Wup;
+    float* dmu; float* L; float* R;
+    int32_t nW, C, r, KL, KR;
+} mphsir_pg_bwd_args;
+int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream);
+
 /* ---- token-reduction GEMM (weight gradients) --------------------------------------------------------
  * Cpart[b][s][n1][n2] = sum over the s-th token range of A[b][m][n1] * B[b][m][n2]  (fp32 partials;
  * the caller sums the nsplit partials in order).  A: [batch][M][lda], B: [batch][M][ldb] token-major
@@ -256,7 +281,9 @@ int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, f
 #define MPHSIR_K_LN_BWD_WIN 12
 #define MPHSIR_K_GEMM_TN 13
 #define MPHSIR_K_GDFN_GATE_BWD 14
-#define MPHSIR_K_COUNT 16
+#define MPHSIR_K_FOLD_BWD 15
+#define MPHSIR_K_PG_GATE_BWD 16
+#define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);
 const char* mphsir_kernel_name(int kid);

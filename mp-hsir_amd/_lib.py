@@ -48,7 +48,8 @@ class GramArgs(ctypes.Structure):
 
 class FoldArgs(ctypes.Structure):
     """mirror of struct mphsir_fold_args"""
-    _fields_ = [("Gpart", c_void_p), ("Spart", c_void_p), ("temperature", c_void_p), ("Wo", c_void_p), ("M", c_void_p)] + \
+    _fields_ = [("Gpart", c_void_p), ("Spart", c_void_p), ("temperature", c_void_p), ("Wo", c_void_p), ("M", c_void_p),
+                ("MT", c_void_p)] + \
                [(n, c_int32) for n in ("B", "C", "heads", "nsplit")]
 
 
@@ -68,6 +69,18 @@ class WinAttnBwdArgs(ctypes.Structure):
     """mirror of struct mphsir_win_attn_bwd_args"""
     _fields_ = [(n, c_void_p) for n in ("X", "dSA", "dmu", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "WprojT", "dQKV", "XNw",
                                          "dSAt", "drpb")] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift")]
+
+
+class FoldBwdArgs(ctypes.Structure):
+    """mirror of struct mphsir_fold_bwd_args"""
+    _fields_ = [(n, c_void_p) for n in ("Gpart", "Spart", "temperature", "Wo", "dM", "W2", "dWo", "dtemp")] + \
+               [(n, c_int32) for n in ("B", "C", "heads", "nsplit")]
+
+
+class PgBwdArgs(ctypes.Structure):
+    """mirror of struct mphsir_pg_bwd_args"""
+    _fields_ = [(n, c_void_p) for n in ("mu", "dgate", "Wprompt", "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup",
+                                         "dmu", "L", "R")] + [(n, c_int32) for n in ("nW", "C", "r", "KL", "KR")]
 
 
 _SYMBOLS = {
@@ -96,6 +109,8 @@ _SYMBOLS = {
     "mphsir_ln_bwd_win": (c_int, [c_void_p] * 6 + [c_int32] * 5 + [c_int, c_void_p]),
     "mphsir_gemm_tn": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_int32,
                                c_int32, c_int32, c_int, c_void_p]),
+    "mphsir_spectral_fold_bwd": (c_int, [ctypes.POINTER(FoldBwdArgs), c_int, c_void_p]),
+    "mphsir_pg_gate_bwd": (c_int, [ctypes.POINTER(PgBwdArgs), c_void_p]),
     "mphsir_gdfn_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "mphsir_gated_mlp_bwd": (c_int, [ctypes.POINTER(MlpBwdArgs), c_int, c_void_p]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),

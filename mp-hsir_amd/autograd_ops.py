@@ -93,68 +93,44 @@ class _GatedMlp(torch.autograd.Function):
                 dW2, torch.sum(dm, dim=0, dtype=torch.float32))
 
 
-def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, temperature, wo, heads, B, H, W):
+def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, MbT, temperature, wo, heads, B, H, W):
     """Backward of the folded channel attention  out = M_b v,  M_b = Wo blockdiag(softmax(normalised Gram)).
 
     d_out (M,C); t_q/t_k/t_v: (B,H,W,*) views of the 1x1-conv outputs that fed dwconv_gram (channels-last,
-    C channels each); w9*: fp32 tap-major dw weights [9][C] views; v, gp, sp, Mb as saved by the forward.
+    C channels each); w9*: fp32 tap-major dw weights [9][C] views; v, gp, sp, Mb, MbT as saved by the forward.
     Returns d(t_q), d(t_k), d(t_v) (B,H,W,C each), d(dw taps) [9][C] x3, d temperature (heads,), d Wo (C,C).
-    Heavy lifting: library batched GEMMs + the HIP depthwise kernels; the hd x hd softmax math is tiny fp32."""
+    All HIP: dM = d_out^T v (gemm_tn), fold backward (one launch), [dq|dk] and dv as per-sample token GEMMs,
+    depthwise backward (data + taps)."""
     C = v.shape[1]
     N = H * W
-    hd = C // heads
+    M = B * N
     dt = v.dtype
-    dO3, v3 = d_out.reshape(B, N, C), v.reshape(B, N, C)
-    dM = ops.gemm_tn(dO3, v3)                                           # (B,C,C) fp32
-    dv = torch.bmm(dO3, Mb)                                              # (B,N,C)
-    G = gp.sum(dim=1).requires_grad_(True)                               # (B,h,hd,hd)
-    S = sp.sum(dim=1)
-    sq = S[:, 0].reshape(B, heads, hd).clone().requires_grad_(True)
-    sk = S[:, 1].reshape(B, heads, hd).clone().requires_grad_(True)
-    temp = temperature.detach().reshape(heads).float().requires_grad_(True)
-    wo_ = wo.detach().reshape(C, C).float().requires_grad_(True)
-    with torch.enable_grad():
-        nq = sq.sqrt().clamp_min(1e-12)
-        nk = sk.sqrt().clamp_min(1e-12)
-        A = torch.softmax(G / (nq[..., :, None] * nk[..., None, :]) * temp.reshape(1, heads, 1, 1), dim=-1)
-        M = torch.einsum("ohi,bhij->bohj", wo_.reshape(C, heads, hd), A).reshape(B, C, C)
-    dG, dsq, dsk, dtemp, dwo = torch.autograd.grad(M, [G, sq, sk, temp, wo_], dM)
+    dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C))                      # (B,C,C) fp32
+    W2, dwo, dtemp = ops.spectral_fold_bwd(gp, sp, temperature.detach().reshape(heads).float().contiguous(),
+                                           wo.detach().reshape(C, C).float().contiguous(), dM, dt)
     # q, k of the forward (never stored) are recomputed by the depthwise kernel; when q|k|v are adjacent channel
     # slices of one tensor (self-attention) every depthwise pass runs once over the joint channel range.
     joint = (t_q.data_ptr() + C * t_q.element_size() == t_k.data_ptr() and t_k.data_ptr() + C * t_k.element_size() == t_v.data_ptr()
              and t_q.stride() == t_k.stride() == t_v.stride() and w9q.data_ptr() + 4 * C == w9k.data_ptr()
              and w9k.data_ptr() + 4 * C == w9v.data_ptr())
-    Nq = torch.zeros((B, C, C), dtype=torch.float32, device=v.device)
-    for h in range(heads):
-        Nq[:, h * hd:(h + 1) * hd, h * hd:(h + 1) * hd] = dG[:, h]
-    Nq = Nq.to(dt)
+    dall = torch.empty((M, 3 * C), dtype=dt, device=v.device)
     if joint:
-        ld = t_q.stride(2)
+        qk = ops.dwconv3x3(torch.as_strided(t_q, (B, H, W, 2 * C), t_q.stride()), torch.as_strided(w9q, (9, 2 * C), w9q.stride()))
+    else:
+        qk = torch.cat([ops.dwconv3x3(t_q, w9q), ops.dwconv3x3(t_k, w9k)], dim=-1)
+    ops.gemm_tok(qk.reshape(M, 2 * C), W2, out=dall[:, :2 * C])                       # [dq | dk]
+    ops.gemm_tok(d_out, MbT, out=dall[:, 2 * C:])                                     # dv = d_out M_b
+    dall4 = dall.reshape(B, H, W, 3 * C)
+    if joint:
         t_all = torch.as_strided(t_q, (B, H, W, 3 * C), t_q.stride())
         w9_all = torch.as_strided(w9q, (9, 3 * C), w9q.stride())
-        qk = ops.dwconv3x3(torch.as_strided(t_q, (B, H, W, 2 * C), t_q.stride()), torch.as_strided(w9q, (9, 2 * C), w9q.stride()))
-        q, k = qk[..., :C].reshape(B, N, C), qk[..., C:].reshape(B, N, C)
-        dall = torch.empty((B, N, 3 * C), dtype=dt, device=v.device)
-        torch.baddbmm(q * (2.0 * dsq).reshape(B, 1, C).to(dt), k, Nq.transpose(1, 2), out=dall[..., :C])
-        torch.baddbmm(k * (2.0 * dsk).reshape(B, 1, C).to(dt), q, Nq, out=dall[..., C:2 * C])
-        dall[..., 2 * C:] = dv
-        dall4 = dall.reshape(B, H, W, 3 * C)
         dt_all = ops.dwconv3x3(dall4, w9_all, flip=True)
         dw_all = ops.dwconv3x3_wgrad(t_all, dall4)
         return (dt_all[..., :C], dt_all[..., C:2 * C], dt_all[..., 2 * C:], dw_all[:, :C], dw_all[:, C:2 * C], dw_all[:, 2 * C:],
                 dtemp, dwo)
-    q = ops.dwconv3x3(t_q, w9q).reshape(B, N, C)
-    k = ops.dwconv3x3(t_k, w9k).reshape(B, N, C)
-    dq = torch.baddbmm(q * (2.0 * dsq).reshape(B, 1, C).to(dt), k, Nq.transpose(1, 2))
-    dk = torch.baddbmm(k * (2.0 * dsk).reshape(B, 1, C).to(dt), q, Nq)
-    dq4, dk4, dv4 = dq.reshape(B, H, W, C), dk.reshape(B, H, W, C), dv.reshape(B, H, W, C)
-    dtq = ops.dwconv3x3(dq4, w9q, flip=True)
-    dtk = ops.dwconv3x3(dk4, w9k, flip=True)
-    dtv = ops.dwconv3x3(dv4, w9v, flip=True)
-    dwq = ops.dwconv3x3_wgrad(t_q, dq4)
-    dwk = ops.dwconv3x3_wgrad(t_k, dk4)
-    dwv = ops.dwconv3x3_wgrad(t_v, dv4)
-    return dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo
+    dq4, dk4, dv4 = dall4[..., :C], dall4[..., C:2 * C], dall4[..., 2 * C:]
+    return (ops.dwconv3x3(dq4, w9q, flip=True), ops.dwconv3x3(dk4, w9k, flip=True), ops.dwconv3x3(dv4, w9v, flip=True),
+            ops.dwconv3x3_wgrad(t_q, dq4), ops.dwconv3x3_wgrad(t_k, dk4), ops.dwconv3x3_wgrad(t_v, dv4), dtemp, dwo)
 
 
 _PG_KEYS = ("linear_down.weight", "linear_up.weight", "linear_prompt.weight", "prompt_param", "q.weight", "kv.weight",
@@ -178,15 +154,15 @@ class _PgsstbAttn(torch.autograd.Function):
         w9 = sp["w9"]
         v, gp, spart, _ = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
                                           3 * Cc, B, H, W, Cc, heads)
-        Mb = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt)
+        Mb, MbT = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt, transposed=True)
         y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
         ctx.blk, ctx.k1 = blk, k1
-        ctx.save_for_backward(x, sa, gate, mu, oattn, t, v, gp, spart, Mb)
+        ctx.save_for_backward(x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT)
         return y.reshape(B, H, W, Cc)
 
     @staticmethod
     def backward(ctx, dy):
-        x, sa, gate, mu, oattn, t, v, gp, spart, Mb = ctx.saved_tensors
+        x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT = ctx.saved_tensors
         blk, k1 = ctx.blk, ctx.k1
         B, H, W, Cc = x.shape
         dt = x.dtype
@@ -202,7 +178,7 @@ class _PgsstbAttn(torch.autograd.Function):
         w9 = sp["w9"]
         tq, tk, tv = t4[..., :Cc], t4[..., Cc:2 * Cc], t4[..., 2 * Cc:]
         dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
-            d_out.reshape(M, Cc), tq, tk, tv, w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:], v, gp, spart, Mb,
+            d_out.reshape(M, Cc), tq, tk, tv, w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:], v, gp, spart, Mb, MbT,
             blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W)
         if dtq.data_ptr() + Cc * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * Cc:
             dt3 = torch.as_strided(dtq, (M, 3 * Cc), (3 * Cc, 1))
@@ -211,14 +187,9 @@ class _PgsstbAttn(torch.autograd.Function):
         d_sa = d_sa.reshape(M, Cc).addmm_(dt3, sp["wqkv"])                       # + dt Wqkv  (1x1 conv backward)
         d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
         d_sdw = torch.cat([dwq, dwk, dwv], dim=1).t().reshape(3 * Cc, 1, 3, 3)
-        # (3) local spectral-prompt gate: tiny fp32 math on (B*nW, C), differentiated by autograd
-        pgm = blk.local_spectral_attn
-        leaves = {k: getattr_path(pgm, k).detach().requires_grad_(True) for k in _PG_KEYS}
-        mu_ = mu.detach().requires_grad_(True)
-        with torch.enable_grad():
-            g_ = C.pg_gate_from_mean(leaves, "", mu_)
-        grads = torch.autograd.grad(g_, [mu_] + [leaves[k] for k in _PG_KEYS], dgate)
-        dmu, dpg = grads[0].contiguous(), grads[1:]
+        # (3) local spectral-prompt gate: one launch per block + one token-reduction GEMM over the windows
+        dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"])
+        dpg = tuple(gpg[k].reshape(getattr_path(blk.local_spectral_attn, k).shape) for k in _PG_KEYS)
         # (4) window attention core
         dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
                                                  pk["rpb"], pk["wprojT"], heads, shift)
@@ -377,15 +348,15 @@ class _SelfChannelAttnRes(torch.autograd.Function):
         w9 = pa["w9"]
         v, gp, sp, _ = ops.dwconv_gram(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
                                        B, H, W, D, attn.num_heads)
-        Mb = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt)
+        Mb, MbT = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
         a = ops.gemm_tok(v, Mb, epi=1, res=t2)
         ctx.attn, ctx.ln, ctx.geom = attn, ln, geom
-        ctx.save_for_backward(t2, q, v, gp, sp, Mb)
+        ctx.save_for_backward(t2, q, v, gp, sp, Mb, MbT)
         return a
 
     @staticmethod
     def backward(ctx, da):
-        t2, q, v, gp, sp, Mb = ctx.saved_tensors
+        t2, q, v, gp, sp, Mb, MbT = ctx.saved_tensors
         attn, ln, (B, H, W) = ctx.attn, ctx.ln, ctx.geom
         D = t2.shape[1]
         M = t2.shape[0]
@@ -394,7 +365,7 @@ class _SelfChannelAttnRes(torch.autograd.Function):
         da = da.contiguous()
         q4 = q.reshape(B, H, W, 3 * D)
         dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
-            da, q4[..., :D], q4[..., D:2 * D], q4[..., 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb,
+            da, q4[..., :D], q4[..., D:2 * D], q4[..., 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
             attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
         if dtq.data_ptr() + D * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * D:
             dt3 = torch.as_strided(dtq, (M, 3 * D), (3 * D, 1))
@@ -422,15 +393,15 @@ class _CrossChannelAttnRes(torch.autograd.Function):
         w9 = pa["w9"]
         v, gp, sp, _ = ops.dwconv_gram(tq, tkv[:, :D], tkv[:, D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
                                        B, H, W, D, ct.attn.num_heads)
-        Mb = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt)
+        Mb, MbT = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
         a = ops.gemm_tok(v, Mb, epi=1, res=text2)
         ctx.ct, ctx.geom = ct, geom
-        ctx.save_for_backward(text2, vis2, tq, tkv, v, gp, sp, Mb)
+        ctx.save_for_backward(text2, vis2, tq, tkv, v, gp, sp, Mb, MbT)
         return a
 
     @staticmethod
     def backward(ctx, da):
-        text2, vis2, tq, tkv, v, gp, sp, Mb = ctx.saved_tensors
+        text2, vis2, tq, tkv, v, gp, sp, Mb, MbT = ctx.saved_tensors
         ct, (B, H, W) = ctx.ct, ctx.geom
         attn = ct.attn
         D = text2.shape[1]
@@ -440,7 +411,7 @@ class _CrossChannelAttnRes(torch.autograd.Function):
         da = da.contiguous()
         tq4, tkv4 = tq.reshape(B, H, W, D), tkv.reshape(B, H, W, 2 * D)
         dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
-            da, tq4, tkv4[..., :D], tkv4[..., D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb,
+            da, tq4, tkv4[..., :D], tkv4[..., D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
             attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
         dtq2 = dtq.reshape(M, D)
         dkv = torch.cat([dtk, dtv], dim=-1).reshape(M, 2 * D)

@@ -1,0 +1,344 @@
+// Backward of the two "tiny math" stages of a PGSSTB block, one launch each instead of ~40 library ops:
+//
+//   spectral_fold_bwd  backward of mphsir_spectral_fold for one (sample, head) per workgroup: from dM = dL/dM_b it
+//       recomputes the hd x hd attention A and produces dG, d(sum q^2), d(sum k^2), d temperature and the
+//       per-sample part of d project_out.  dG and the norm terms are emitted as ONE per-sample matrix
+//       W2_b [2C][2C] so that  [dq | dk] = [q | k] W2_b^T  is a single token GEMM (mphsir_gemm_tok):
+//           rows c      (q gradients): [ diag(2 dsq) | Nq   ],  Nq[c][c'] = dG_h[i][j] inside head blocks
+//           rows C + c' (k gradients): [ Nq^T        | diag(2 dsk) ]
+//       (reference forward: Spectral_Attention.forward net/MP_HSIR.py:104-113).
+//   pg_gate_bwd  backward of the local spectral-prompt gate (PG_Spectral_Attention.forward :132-152) per window:
+//       d mu and the per-window left/right factor rows whose token-reduction product (ONE mphsir_gemm_tn over the
+//       windows) contains every parameter gradient of the branch as a sub-block.
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+struct FoldBwdDev {
+    const float* Gpart; const float* Spart; int nsplit;
+    const float* temperature; const float* Wo;
+    const float* dM;            // [B][C][C] fp32
+    void* W2;                   // [B][2C][2C] compute dtype
+    float* dWo;                 // [B][C][C] fp32 per-sample partial (column block of this head written by its WG)
+    float* dtemp;               // [B][HEADS]
+    int B, C, HD;
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    const int HD = a.HD, C = a.C, HEADS = C / HD, LDG = HD + 1;
+    float* G = reinterpret_cast<float*>(smem_v);      // raw Gram           [HD][LDG]
+    float* A = G + HD * LDG;                          // probabilities      [HD][LDG]
+    float* D = A + HD * LDG;                          // dA -> dGtilde      [HD][LDG]
+    float* nq = D + HD * LDG;                         // [HD] (clamped norms)   nk follows
+    float* nk = nq + HD;
+    float* sq = nk + HD;                              // [2*HD] raw sums of squares
+    float* dn = sq + 2 * HD;                          // [2*HD] d nq, d nk
+    float* red = dn + 2 * HD;                         // [HD] row reductions
+    const int tid = threadIdx.x, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
+    const float temp = a.temperature[h];
+
+    for (int i = tid; i < HD * HD; i += 256) {
+        float s = 0.f;
+        for (int sp = 0; sp < a.nsplit; ++sp) s += a.Gpart[(((long)b * a.nsplit + sp) * HEADS + h) * HD * HD + i];
+        G[(i / HD) * LDG + i % HD] = s;
+    }
+    if (tid < 2 * HD) {
+        float s = 0.f;
+        for (int sp = 0; sp < a.nsplit; ++sp) s += a.Spart[((long)b * a.nsplit + sp) * 2 * C + (tid / HD) * C + h * HD + tid % HD];
+        sq[tid] = s;
+        nq[tid] = fmaxf(sqrtf(s), 1e-12f);
+    }
+    __syncthreads();
+    if (tid < HD) {                                   // A = softmax_rows(G / (nq nk^T) * temp)
+        const float tq = temp / nq[tid];
+        float m = -3.0e38f;
+        for (int j = 0; j < HD; ++j) m = fmaxf(m, G[tid * LDG + j] * tq / nk[j]);
+        float den = 0.f;
+        for (int j = 0; j < HD; ++j) { const float e = expf(G[tid * LDG + j] * tq / nk[j] - m); A[tid * LDG + j] = e; den += e; }
+        const float inv = 1.0f / den;
+        for (int j = 0; j < HD; ++j) A[tid * LDG + j] *= inv;
+    }
+    __syncthreads();
+    const float* dM = a.dM + (long)b * C * C;
+    for (int o = tid; o < HD * HD; o += 256) {        // dA[i][j] = sum_co Wo[co][hHD+i] dM[co][hHD+j]
+        const int i = o / HD, j = o % HD;
+        float s = 0.f;
+        for (int co = 0; co < C; ++co) s += a.Wo[(long)co * C + h * HD + i] * dM[(long)co * C + h * HD + j];
+        D[i * LDG + j] = s;
+    }
+    float* dWo = a.dWo + (long)b * C * C;
+    for (int o = tid; o < C * HD; o += 256) {         // dWo_b[co][hHD+i] = sum_j dM[co][hHD+j] A[i][j]
+        const int co = o / HD, i = o % HD;
+        float s = 0.f;
+        for (int j = 0; j < HD; ++j) s += dM[(long)co * C + h * HD + j] * A[i * LDG + j];
+        dWo[(long)co * C + h * HD + i] = s;
+    }
+    __syncthreads();
+    if (tid < HD) {                                   // softmax backward per row; logits = Gtilde * temp
+        const int i = tid;
+        float rs = 0.f;
+        for (int j = 0; j < HD; ++j) rs += A[i * LDG + j] * D[i * LDG + j];
+        float dt = 0.f, dnq = 0.f;
+        for (int j = 0; j < HD; ++j) {
+            const float dl = A[i * LDG + j] * (D[i * LDG + j] - rs);
+            const float gt = G[i * LDG + j] / (nq[i] * nk[j]);
+            dt += dl * gt;
+            const float dgt = dl * temp;
+            dnq -= dgt * gt / nq[i];
+            D[i * LDG + j] = dgt;                     // keep dGtilde
+        }
+        red[i] = dt;
+        dn[i] = dnq;
+    }
+    __syncthreads();
+    if (tid < HD) {                                   // d nk[j] = -sum_i dGtilde[i][j] * Gtilde[i][j] / nk[j]
+        const int j = tid;
+        float s = 0.f;
+        for (int i = 0; i < HD; ++i) s -= D[i * LDG + j] * G[i * LDG + j] / (nq[i] * nk[j]) / nk[j];
+        dn[HD + j] = s;
+    }
+    if (tid == 0) {
+        float s = 0.f;
+        for (int i = 0; i < HD; ++i) s += red[i];
+        a.dtemp[b * HEADS + h] = s;
+    }
+    __syncthreads();
+    // W2_b rows of this head: q rows hHD+i and k rows C+hHD+j, all 2C columns
+    T* W2 = reinterpret_cast<T*>(a.W2) + (long)b * 4 * C * C;
+    const int C2 = 2 * C;
+    for (int o = tid; o < HD * C2; o += 256) {
+        const int i = o / C2, col = o % C2;           // q-gradient row
+        float v = 0.f;
+        if (col < C) {
+            if (col == h * HD + i) v = sq[i] > 1e-24f ? dn[i] / nq[i] : 0.f;         // 2 * dsq = dnq / nq
+        } else {
+            const int cp = col - C - h * HD;
+            if (cp >= 0 && cp < HD) v = D[i * LDG + cp] / (nq[i] * nk[cp]);           // dG[i][j]
+        }
+        W2[(long)(h * HD + i) * C2 + col] = from_f32<T>(v);
+    }
+    for (int o = tid; o < HD * C2; o += 256) {
+        const int j = o / C2, col = o % C2;           // k-gradient row
+        float v = 0.f;
+        if (col < C) {
+            const int ci = col - h * HD;
+            if (ci >= 0 && ci < HD) v = D[ci * LDG + j] / (nq[ci] * nk[j]);           // Nq^T
+        } else if (col == C + h * HD + j) {
+            v = sq[HD + j] > 1e-24f ? dn[HD + j] / nk[j] : 0.f;
+        }
+        W2[(long)(C + h * HD + j) * C2 + col] = from_f32<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct PgBwdDev {
+    const float* mu; const float* dgate;
+    const float* Wprompt; const float* Pp; const float* Wq; const float* Wkv; const float* Wdown;
+    const float* Wpproj; const float* bpproj; const float* Wup;
+    float* dmu;                 // [nW][C]
+    float* L; float* R;         // [nW][KL], [nW][KR]
+    int nW, C, r, KL, KR;
+};
+
+__global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* mu = reinterpret_cast<float*>(smem_v);     // [C]
+    float* dg = mu + C;                               // [C]
+    float* w = dg + C;                                // [128] prompt weights
+    float* dl = w + 128;                              // [128] d logits
+    float* sm = dl + 128;                             // small vectors, 32 apart (r <= 32)
+    float* s_ = sm, *d_ = sm + 32, *kv = sm + 64, *q_ = sm + 128, *o_ = sm + 160, *o2 = sm + 192;
+    float* do2 = sm + 224, *do_ = sm + 256, *dq = sm + 288, *dkv = sm + 320, *dd = sm + 384, *ds = sm + 416;
+    float* At = sm + 448;                             // [r][r] attention probabilities (r*r <= 1024)
+    const long win = blockIdx.x;
+    for (int c = tid; c < C; c += 256) { mu[c] = a.mu[win * C + c]; dg[c] = a.dgate[win * C + c]; }
+    __syncthreads();
+    // ---- forward recompute -------------------------------------------------------------------------
+    if (tid < 128) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += a.Wprompt[tid * C + c] * mu[c];
+        w[tid] = acc;
+    } else if (tid < 128 + r) {
+        const int i = tid - 128;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += a.Wdown[i * C + c] * mu[c];
+        d_[i] = acc;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const float l0 = w[lane], l1 = w[lane + 64];
+        float m = fmaxf(l0, l1);
+        for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float tot = wave_sum(e0 + e1);
+        w[lane] = e0 / tot;
+        w[lane + 64] = e1 / tot;
+    }
+    __syncthreads();
+    if (tid < r) {
+        float acc = 0.f;
+        for (int p = 0; p < 128; ++p) acc += w[p] * a.Pp[p * r + tid];
+        s_[tid] = acc;
+    } else if (tid >= 64 && tid < 64 + 2 * r) {
+        const int i = tid - 64;
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += a.Wkv[i * r + j] * d_[j];
+        kv[i] = acc;
+    }
+    __syncthreads();
+    if (tid < r) {
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += a.Wq[tid * r + j] * s_[j];
+        q_[tid] = acc;
+    }
+    __syncthreads();
+    const float sc = rsqrtf((float)r);
+    if (tid < r) {
+        const float qs = q_[tid] * sc;
+        float m = -3.0e38f;
+        for (int j = 0; j < r; ++j) m = fmaxf(m, qs * kv[j]);
+        float den = 0.f, num = 0.f;
+        for (int j = 0; j < r; ++j) { const float e = expf(qs * kv[j] - m); At[tid * r + j] = e; den += e; num += e * kv[r + j]; }
+        for (int j = 0; j < r; ++j) At[tid * r + j] /= den;
+        o_[tid] = num / den;
+    }
+    __syncthreads();
+    if (tid < r) {
+        float acc = a.bpproj[tid];
+        for (int j = 0; j < r; ++j) acc += a.Wpproj[tid * r + j] * o_[j];
+        o2[tid] = acc;
+    }
+    // ---- backward --------------------------------------------------------------------------------------
+    if (tid >= 64 && tid < 64 + r) {                  // do2 = Wup^T dg
+        const int i = tid - 64;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc += a.Wup[c * r + i] * dg[c];
+        do2[i] = acc;
+    }
+    __syncthreads();
+    if (tid < r) {                                    // do = Wpproj^T do2
+        float acc = 0.f;
+        for (int i = 0; i < r; ++i) acc += a.Wpproj[i * r + tid] * do2[i];
+        do_[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < r) {                                    // row i: dS_ij = A_ij (do_i v_j - sum_j' A_ij' do_i v_j'); dq_i = sc sum_j dS_ij k_j
+        const int i = tid;
+        float rs = 0.f;
+        for (int j = 0; j < r; ++j) rs += At[i * r + j] * do_[i] * kv[r + j];
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += At[i * r + j] * (do_[i] * kv[r + j] - rs) * kv[j];
+        dq[i] = acc * sc;
+    }
+    __syncthreads();
+    if (tid < r) {                                    // column j: dk_j = sc sum_i dS_ij q_i ; dv_j = sum_i A_ij do_i
+        const int j = tid;
+        float dk = 0.f, dv = 0.f;
+        for (int i = 0; i < r; ++i) {
+            float rs = 0.f;
+            for (int jj = 0; jj < r; ++jj) rs += At[i * r + jj] * do_[i] * kv[r + jj];
+            dk += At[i * r + j] * (do_[i] * kv[r + j] - rs) * q_[i];
+            dv += At[i * r + j] * do_[i];
+        }
+        dkv[j] = dk * sc;
+        dkv[r + j] = dv;
+    }
+    __syncthreads();
+    if (tid < r) {                                    // dd = Wkv^T dkv ; ds = Wq^T dq
+        float acc = 0.f, acc2 = 0.f;
+        for (int m = 0; m < 2 * r; ++m) acc += a.Wkv[m * r + tid] * dkv[m];
+        for (int i = 0; i < r; ++i) acc2 += a.Wq[i * r + tid] * dq[i];
+        dd[tid] = acc;
+        ds[tid] = acc2;
+    }
+    __syncthreads();
+    if (tid < 128) {                                  // dw[p] = Pp[p] . ds
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += a.Pp[tid * r + j] * ds[j];
+        dl[tid] = acc;
+    }
+    __syncthreads();
+    if (wv == 0) {                                    // dlogit = w (dw - sum w dw)
+        const float t0 = w[lane] * dl[lane], t1 = w[lane + 64] * dl[lane + 64];
+        const float tot = wave_sum(t0 + t1);
+        const float a0 = w[lane] * (dl[lane] - tot), a1 = w[lane + 64] * (dl[lane + 64] - tot);
+        dl[lane] = a0;
+        dl[lane + 64] = a1;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {              // dmu = Wprompt^T dlogit + Wdown^T dd
+        float acc = 0.f;
+        for (int p = 0; p < 128; ++p) acc += a.Wprompt[p * C + c] * dl[p];
+        for (int i = 0; i < r; ++i) acc += a.Wdown[i * C + c] * dd[i];
+        a.dmu[win * C + c] = acc;
+    }
+    // ---- factor rows: L = [dg(C) | do2(r) | dkv(2r) | dq(r) | w(128) | dlogit(128) | dd(r) | 0..],
+    //                   R = [o2(r) | o(r) | 1 | d(r) | s(r) | ds(r) | mu(C) | 0..]
+    float* L = a.L + win * a.KL;
+    float* R = a.R + win * a.KR;
+    for (int c = tid; c < a.KL; c += 256) {
+        float v = 0.f;
+        int o = c;
+        if (o < C) v = dg[o];
+        else if ((o -= C) < r) v = do2[o];
+        else if ((o -= r) < 2 * r) v = dkv[o];
+        else if ((o -= 2 * r) < r) v = dq[o];
+        else if ((o -= r) < 128) v = w[o];
+        else if ((o -= 128) < 128) v = dl[o];
+        else if ((o -= 128) < r) v = dd[o];
+        L[c] = v;
+    }
+    for (int c = tid; c < a.KR; c += 256) {
+        float v = 0.f;
+        int o = c;
+        if (o < r) v = o2[o];
+        else if ((o -= r) < r) v = o_[o];
+        else if ((o -= r) < 1) v = 1.f;
+        else if ((o -= 1) < r) v = d_[o];
+        else if ((o -= r) < r) v = s_[o];
+        else if ((o -= r) < r) v = ds[o];
+        else if ((o -= r) < C) v = mu[o];
+        R[c] = v;
+    }
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->Gpart && a->Spart && a->temperature && a->Wo && a->dM && a->W2 && a->dWo && a->dtemp, "spectral_fold_bwd: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "spectral_fold_bwd: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold_bwd: bad shape");
+    const int HD = a->C / a->heads;
+    MPHSIR_REQUIRE(HD <= 96, "spectral_fold_bwd: head_dim %d > 96", HD);
+    FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->W2, a->dWo, a->dtemp, a->B, a->C, HD};
+    const size_t shmem = (3 * (size_t)HD * (HD + 1) + 7 * HD) * sizeof(float);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MPHSIR_F32) {
+        allow_big_lds(spectral_fold_bwd_kernel<float>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<float>), dim3(a->B * a->heads), dim3(256), shmem, s, d);
+    } else {
+        allow_big_lds(spectral_fold_bwd_kernel<bf16_t>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<bf16_t>), dim3(a->B * a->heads), dim3(256), shmem, s, d);
+    }
+    return MPHSIR_OK;
+}
+
+extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->mu && a->dgate && a->Wprompt && a->prompt_param && a->Wq && a->Wkv && a->Wdown && a->Wpproj && a->bpproj &&
+                       a->Wup && a->dmu && a->L && a->R, "pg_gate_bwd: null pointer");
+    MPHSIR_REQUIRE(a->nW > 0 && a->C > 0 && a->r > 0 && a->r <= 32, "pg_gate_bwd: bad shape");
+    MPHSIR_REQUIRE(a->KL >= a->C + 5 * a->r + 256 && a->KR >= 5 * a->r + 1 + a->C, "pg_gate_bwd: factor widths too small");
+    PgBwdDev d{a->mu, a->dgate, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->dmu, a->L, a->R,
+               a->nW, a->C, a->r, a->KL, a->KR};
+    const size_t shmem = (2 * (size_t)a->C + 256 + 448 + 1024) * sizeof(float);
+    MPHSIR_LAUNCH(MPHSIR_K_PG_GATE_BWD, pg_gate_bwd_kernel, dim3(a->nW), dim3(256), shmem, reinterpret_cast<hipStream_t>(stream), d);
+    return MPHSIR_OK;
+}

@@ -141,6 +141,7 @@ struct FoldDev {
     const float* temperature;   // [HEADS]
     const float* Wo;            // project_out weight [C][C] fp32
     void* Mout;                 // [B][C][C] compute dtype
+    void* MTout;                // optional [B][C][C]: M^T (training: dv = d_out M is a token GEMM with weight M^T)
     int B, C, HD;
 };
 
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256) void spectral_fold_kernel(FoldDev a) {
         float s = 0.f;
         for (int i = 0; i < HD; ++i) s += Ws[cl * LDG + i] * G[i * LDG + j];
         M[(long)(co0 + cl) * C + h * HD + j] = from_f32<T>(s);
+        if (a.MTout) reinterpret_cast<T*>(a.MTout)[(long)b * C * C + (long)(h * HD + j) * C + co0 + cl] = from_f32<T>(s);
     }
 }
 
@@ -270,7 +272,7 @@ extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* 
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold: bad shape");
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 128, "spectral_fold: head_dim %d > 128", HD);
-    FoldDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->M, a->B, a->C, HD};
+    FoldDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->M, a->MT, a->B, a->C, HD};
     MPHSIR_REQUIRE(a->C % FOLD_CO == 0, "spectral_fold: C must be a multiple of %d", FOLD_CO);
     const size_t shmem = ((size_t)HD * (HD + 1) + 2 * HD + (size_t)FOLD_CO * (HD + 1)) * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

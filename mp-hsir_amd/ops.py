@@ -198,8 +198,8 @@ def dwconv_gram(tq, tk, tv, wq, wk, wv, ldw, B, H, W, C, heads, nsplit=None):
     return v, gp, sp, nsplit
 
 
-def spectral_fold(gp, sp, temperature, Wo, dtype):
-    """-> per-sample folded matrix M (B, C, C) in `dtype`."""
+def spectral_fold(gp, sp, temperature, Wo, dtype, transposed=False):
+    """-> per-sample folded matrix M (B, C, C) in `dtype` (and M^T when transposed=True)."""
     lib = _lib.load()
     _check(gp, sp, temperature, Wo)
     B, nsplit, heads, hd, _ = gp.shape
@@ -208,10 +208,12 @@ def spectral_fold(gp, sp, temperature, Wo, dtype):
     Mo = torch.empty((B, C, C), dtype=dtype, device=gp.device)
     a = _lib.FoldArgs()
     a.Gpart, a.Spart, a.temperature, a.Wo, a.M = _p(gp), _p(sp), _p(temperature), _p(Wo), _p(Mo)
+    MT = torch.empty_like(Mo) if transposed else None
+    a.MT = _p(MT)
     a.B, a.C, a.heads, a.nsplit = B, C, heads, nsplit
     _lib.check(lib.mphsir_spectral_fold(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold")
     _acct("spectral_fold", 2.0 * B * C * C * hd, gp.numel() * 4 + sp.numel() * 4 + C * C * 4 + Mo.numel() * Mo.element_size())
-    return Mo
+    return (Mo, MT) if transposed else Mo
 
 
 def dwconv_gate(t, w9, B, H, W):
@@ -387,3 +389,55 @@ def gdfn_gate_bwd(t, du):
     _lib.check(lib.mphsir_gdfn_gate_bwd(_p(t), _p(du), _p(u), _p(dt_), M, HP, _DT[t.dtype], _stream(t)), "gdfn_gate_bwd")
     _acct("gdfn_gate_bwd", 30.0 * M * HP, 7.0 * M * HP * t.element_size())
     return u, dt_
+
+
+def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype):
+    """-> W2 (B,2C,2C) in `dtype`, dWo (C,C) fp32, dtemp (heads,) fp32."""
+    lib = _lib.load()
+    _check(gp, sp, temperature, Wo, dM)
+    B, nsplit, heads, hd, _ = gp.shape
+    C = heads * hd
+    assert dM.shape == (B, C, C) and dM.dtype == torch.float32 and dM.is_contiguous()
+    W2 = torch.empty((B, 2 * C, 2 * C), dtype=dtype, device=gp.device)
+    dWo = torch.empty((B, C, C), dtype=torch.float32, device=gp.device)
+    dtemp = torch.empty((B, heads), dtype=torch.float32, device=gp.device)
+    a = _lib.FoldBwdArgs()
+    a.Gpart, a.Spart, a.temperature, a.Wo, a.dM = _p(gp), _p(sp), _p(temperature), _p(Wo), _p(dM)
+    a.W2, a.dWo, a.dtemp = _p(W2), _p(dWo), _p(dtemp)
+    a.B, a.C, a.heads, a.nsplit = B, C, heads, nsplit
+    _lib.check(lib.mphsir_spectral_fold_bwd(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold_bwd")
+    _acct("spectral_fold_bwd", 4.0 * B * C * C * hd, 3.0 * B * C * C * 4)
+    return W2, dWo.sum(dim=0), dtemp.sum(dim=0)
+
+
+def pg_gate_bwd(mu, dgate, pg):
+    """mu, dgate (nW,C) fp32; pg = fp32 parameter dict (as for win_attn_fwd) -> dmu (nW,C) and the dict of
+    parameter gradients of the local spectral-prompt branch."""
+    lib = _lib.load()
+    _check(mu, dgate, *pg.values())
+    nW, C = mu.shape
+    r = pg["linear_down.weight"].shape[0]
+    KL, KR = round_up(C + 5 * r + 256, 4), round_up(5 * r + 1 + C, 4)
+    dmu = torch.empty_like(mu)
+    L = torch.empty((nW, KL), dtype=torch.float32, device=mu.device)
+    R = torch.empty((nW, KR), dtype=torch.float32, device=mu.device)
+    a = _lib.PgBwdArgs()
+    a.mu, a.dgate = _p(mu), _p(dgate)
+    a.Wprompt, a.prompt_param = _p(pg["linear_prompt.weight"]), _p(pg["prompt_param"])
+    a.Wq, a.Wkv, a.Wdown = _p(pg["q.weight"]), _p(pg["kv.weight"]), _p(pg["linear_down.weight"])
+    a.Wpproj, a.bpproj, a.Wup = _p(pg["proj.weight"]), _p(pg["proj.bias"]), _p(pg["linear_up.weight"])
+    a.dmu, a.L, a.R = _p(dmu), _p(L), _p(R)
+    a.nW, a.C, a.r, a.KL, a.KR = nW, C, r, KL, KR
+    _lib.check(lib.mphsir_pg_gate_bwd(ctypes.byref(a), _stream(mu)), "pg_gate_bwd")
+    P = gemm_tn(L, R)
+    g = {
+        "linear_up.weight": P[0:C, 0:r],
+        "proj.weight": P[C:C + r, r:2 * r],
+        "proj.bias": P[C:C + r, 2 * r],
+        "kv.weight": P[C + r:C + 3 * r, 2 * r + 1:3 * r + 1],
+        "q.weight": P[C + 3 * r:C + 4 * r, 3 * r + 1:4 * r + 1],
+        "prompt_param": P[C + 4 * r:C + 4 * r + 128, 4 * r + 1:5 * r + 1],
+        "linear_prompt.weight": P[C + 4 * r + 128:C + 4 * r + 256, 5 * r + 1:5 * r + 1 + C],
+        "linear_down.weight": P[C + 4 * r + 256:C + 5 * r + 256, 5 * r + 1:5 * r + 1 + C],
+    }
+    return dmu, g
