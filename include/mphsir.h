@@ -161,6 +161,7 @@ typedef struct mphsir_mlp_args {
     const float* keep; int64_t rows_per_batch;   /* DropPath factor per sample, or NULL */
     void* Y; int64_t ldy;
     int64_t M; int32_t C, HP;
+    int32_t tiles_per_wave;                      /* tuning: 0 = auto, 1 or 2 token tiles (of 16) per wave */
 } mphsir_mlp_args;
 int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream);
 

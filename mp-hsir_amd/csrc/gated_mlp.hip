@@ -20,6 +20,7 @@ struct MlpDev {
     const float* keep; long rpb;
     void* Y; long ldy;
     int M, HP;
+    int tpw;      // token tiles per wave: 0 = auto, 1, 2
 };
 
 template <class T, int C>
@@ -135,8 +136,181 @@ __global__ __launch_bounds__(256) void gated_mlp_kernel(MlpDev a) {
     }
 }
 
+// ---- version with the weight chunks staged through LDS (shared by the 4 waves) ------------------------
+// The direct version above streams every weight fragment from L1/L2 per wave (4x redundant, L1-bandwidth
+// bound).  Here each 32-wide hidden chunk of fc1 (32 value + 32 gate rows, K = C) and of fc2 (C rows, K = 32)
+// is loaded once per workgroup with coalesced 16-byte loads, and each wave owns TT token tiles (BM = 64*TT)
+// so every weight fragment read from LDS feeds TT MFMAs.
+template <class T, int C, int TT> struct MlpLdsCfg {
+    static constexpr int PAD = 16 / sizeof(T);
+    static constexpr int BM = 64 * TT;
+    static constexpr int LDX = C + PAD, LDH = 32 + PAD;
+    static constexpr size_t ELEMS = (size_t)BM * LDX + 64 * LDX + (size_t)C * LDH + 4 * 16 * TT * LDH;
+    static constexpr size_t BYTES = ELEMS * sizeof(T);
+    static constexpr bool FITS = BYTES <= 160 * 1024;
+};
+
+template <class T, int C, int TT>
+__global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
+    typedef ElemTraits<T> TR;
+    typedef typename TR::frag_t frag_t;
+    typedef MlpLdsCfg<T, C, TT> CF;
+    constexpr int LDX = CF::LDX, LDH = CF::LDH, BM = CF::BM;
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int NCT = C / 16;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    T* Xs = reinterpret_cast<T*>(smem_v);               // [BM][LDX]
+    T* W1s = Xs + BM * LDX;                             // [64][LDX]  value rows 0..31, gate rows 32..63
+    T* W2s = W1s + 64 * LDX;                            // [C][LDH]
+    T* Hs = W2s + C * LDH;                              // [4][16*TT][LDH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m0 = blockIdx.x * BM;
+    const T* X = reinterpret_cast<const T*>(a.X);
+
+    // ---- LayerNorm into LDS: 4 adjacent lanes per token, TT passes ---------------------------------
+    for (int pass = 0; pass < TT; ++pass) {
+        constexpr int NV = C / VEC, VPT = NV / 4;
+        const int r = pass * 64 + (tid >> 2), q = tid & 3;
+        const T* row = X + (long)(m0 + r) * a.ldx;
+        Vec16<T> xv[VPT];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            xv[i] = load16<T>(row + (q + 4 * i) * VEC);
+            for (int e = 0; e < VEC; ++e) s += xv[i].get(e);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            for (int e = 0; e < VEC; ++e) { float d = xv[i].get(e) - mean; d2 += d * d; }
+        d2 += __shfl_xor(d2, 1);
+        d2 += __shfl_xor(d2, 2);
+        const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
+            store16<T>(Xs + r * LDX + c0, o);
+        }
+    }
+
+    const T* W1 = reinterpret_cast<const T*>(a.W1);
+    const T* W2 = reinterpret_cast<const T*>(a.W2);
+    T* Hw = Hs + wv * 16 * TT * LDH;
+    const int HP = a.HP;
+    f32x4 out[TT][NCT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) out[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int j = 0; j < HP; j += 32) {
+        __syncthreads();                                   // previous chunk's weight tiles fully consumed (and Xs staged)
+        {
+            constexpr int VPR = C / VEC;
+            for (int v = tid; v < 64 * VPR; v += 256) {
+                const int r = v / VPR, c = (v % VPR) * VEC;
+                const long srow = r < 32 ? j + r : HP + j + (r - 32);
+                store16<T>(W1s + r * LDX + c, load16<T>(W1 + srow * C + c));
+            }
+            constexpr int VPH = 32 / VEC;
+            for (int v = tid; v < C * VPH; v += 256) {
+                const int r = v / VPH, c = (v % VPH) * VEC;
+                store16<T>(W2s + r * LDH + c, load16<T>(W2 + (long)r * HP + j + c));
+            }
+        }
+        __syncthreads();
+        f32x4 vv[TT][2], gg[TT][2];
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            for (int u = 0; u < 2; ++u) { vv[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; gg[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 2
+        for (int kk = 0; kk < C; kk += TR::KCHUNK) {
+            const frag_t wv0 = load_frag<T>(W1s, LDX, 0, kk), wv1 = load_frag<T>(W1s, LDX, 16, kk);
+            const frag_t wg0 = load_frag<T>(W1s, LDX, 32, kk), wg1 = load_frag<T>(W1s, LDX, 48, kk);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const frag_t bx = load_frag<T>(Xs, LDX, (wv * TT + t) * 16, kk);
+                mma(vv[t][0], wv0, bx);
+                mma(vv[t][1], wv1, bx);
+                mma(gg[t][0], wg0, bx);
+                mma(gg[t][1], wg1, bx);
+            }
+        }
+        const int hr = (lane >> 4) * 4;
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+            for (int u = 0; u < 2; ++u) {
+                f32x4 h;
+                for (int r = 0; r < 4; ++r)
+                    h[r] = (vv[t][u][r] + a.b1[j + u * 16 + hr + r]) * gelu_erf(gg[t][u][r] + a.b1[HP + j + u * 16 + hr + r]);
+                store4<T>(Hw + (t * 16 + (lane & 15)) * LDH + u * 16 + hr, h);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += TR::KCHUNK) {
+            frag_t bh[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) bh[t] = load_frag<T>(Hw, LDH, t * 16, kk);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const frag_t w2 = load_frag<T>(W2s, LDH, ct * 16, kk);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) mma(out[t][ct], w2, bh[t]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: (acc + b2) -> LDS stage (own rows), then coalesced residual + store -----------------
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const int tok = (wv * TT + t) * 16 + (lane & 15), cr = (lane >> 4) * 4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            f32x4 o = out[t][ct];
+            for (int r = 0; r < 4; ++r) o[r] += a.b2[ct * 16 + cr + r];
+            store4<T>(Xs + tok * LDX + ct * 16 + cr, o);
+        }
+    }
+    __syncthreads();
+    T* Y = reinterpret_cast<T*>(a.Y);
+    constexpr int NV = C / VEC;
+    for (int idx = tid; idx < BM * NV; idx += 256) {
+        const int r = idx / NV, c0 = (idx % NV) * VEC, m = m0 + r;
+        const float kf = a.keep ? a.keep[m / a.rpb] : 1.f;
+        const Vec16<T> x = load16<T>(X + (long)m * a.ldx + c0);
+        const Vec16<T> h = load16<T>(Xs + r * LDX + c0);
+        Vec16<T> o;
+        for (int e = 0; e < VEC; ++e) o.set(e, x.get(e) + kf * h.get(e));
+        store16<T>(Y + (long)m * a.ldy + c0, o);
+    }
+}
+
+template <class T, int C, int TT>
+static int launch_mlp_lds(const MlpDev& d, hipStream_t s) {
+    typedef MlpLdsCfg<T, C, TT> CF;
+    if constexpr (!CF::FITS) {
+        return 1;   // caller falls back
+    } else {
+        allow_big_lds(gated_mlp_lds_kernel<T, C, TT>, CF::BYTES);
+        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_lds_kernel<T, C, TT>), dim3(d.M / CF::BM), dim3(256), CF::BYTES, s, d);
+        return MPHSIR_OK;
+    }
+}
+
 template <class T, int C>
 static int launch_mlp(const MlpDev& d, hipStream_t s) {
+    // preferred: LDS-staged weights; two token tiles per wave when there are enough tokens to fill the chip
+    int rc = 1;
+    if (d.M % 128 == 0 && (d.tpw == 2 || (d.tpw == 0 && d.M / 128 >= 512))) rc = launch_mlp_lds<T, C, 2>(d, s);
+    if (rc == 1) rc = launch_mlp_lds<T, C, 1>(d, s);
+    if (rc != 1) return rc;
     constexpr int PAD = 16 / sizeof(T);
     const size_t shmem = (64 * (C + PAD) + 4 * 16 * (32 + PAD)) * sizeof(T);
     allow_big_lds(gated_mlp_kernel<T, C>, shmem);
@@ -173,7 +347,7 @@ extern "C" int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* s
                        (a->ldx * esz) % 16 == 0 && (a->ldy * esz) % 16 == 0, "gated_mlp: 16-byte alignment required");
     if (a->keep) MPHSIR_REQUIRE(a->rows_per_batch > 0, "gated_mlp: keep needs rows_per_batch");
     MlpDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->W1, a->b1, a->W2, a->b2, a->keep,
-             (long)(a->rows_per_batch > 0 ? a->rows_per_batch : a->M), a->Y, (long)a->ldy, (int)a->M, a->HP};
+             (long)(a->rows_per_batch > 0 ? a->rows_per_batch : a->M), a->Y, (long)a->ldy, (int)a->M, a->HP, a->tiles_per_wave};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == MPHSIR_F32 ? dispatch_mlp<float>(d, a->C, s) : dispatch_mlp<bf16_t>(d, a->C, s);
 }

@@ -37,6 +37,8 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     float* sq = nk + HD;                              // [2*HD] raw sums of squares
     float* dn = sq + 2 * HD;                          // [2*HD] d nq, d nk
     float* red = dn + 2 * HD;                         // [HD] row reductions
+    float* Ws = red + HD;                             // [32][LDG] chunk of Wo[:, head]
+    float* Ms = Ws + 32 * LDG;                        // [32][LDG] chunk of dM[:, head]
     const int tid = threadIdx.x, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
     const float temp = a.temperature[h];
 
@@ -62,19 +64,45 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
         for (int j = 0; j < HD; ++j) A[tid * LDG + j] *= inv;
     }
     __syncthreads();
+    // dA[i][j] = sum_co Wo[co][hHD+i] dM[co][hHD+j]  and  dWo_b[co][hHD+i] = sum_j dM[co][hHD+j] A[i][j]:
+    // the head slices of Wo and dM are streamed through LDS in chunks of FB_CO rows (coalesced), each thread keeps
+    // its dA outputs in registers across chunks.
     const float* dM = a.dM + (long)b * C * C;
-    for (int o = tid; o < HD * HD; o += 256) {        // dA[i][j] = sum_co Wo[co][hHD+i] dM[co][hHD+j]
-        const int i = o / HD, j = o % HD;
-        float s = 0.f;
-        for (int co = 0; co < C; ++co) s += a.Wo[(long)co * C + h * HD + i] * dM[(long)co * C + h * HD + j];
-        D[i * LDG + j] = s;
-    }
     float* dWo = a.dWo + (long)b * C * C;
-    for (int o = tid; o < C * HD; o += 256) {         // dWo_b[co][hHD+i] = sum_j dM[co][hHD+j] A[i][j]
-        const int co = o / HD, i = o % HD;
-        float s = 0.f;
-        for (int j = 0; j < HD; ++j) s += dM[(long)co * C + h * HD + j] * A[i * LDG + j];
-        dWo[(long)co * C + h * HD + i] = s;
+    constexpr int FB_CO = 32, MAXO = 36;              // HD*HD/256 <= 36 for HD <= 96
+    const int nout = (HD * HD + 255) / 256;
+    float accA[MAXO];
+#pragma unroll
+    for (int k = 0; k < MAXO; ++k) accA[k] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += FB_CO) {
+        __syncthreads();
+        for (int idx = tid; idx < FB_CO * HD; idx += 256) {
+            const int rr = idx / HD, cc = idx % HD;
+            Ws[rr * LDG + cc] = a.Wo[(long)(c0 + rr) * C + h * HD + cc];
+            Ms[rr * LDG + cc] = dM[(long)(c0 + rr) * C + h * HD + cc];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MAXO; ++k) {
+            const int o = tid + 256 * k;
+            if (k < nout && o < HD * HD) {
+                const int i = o / HD, j = o % HD;
+                float s = accA[k];
+                for (int rr = 0; rr < FB_CO; ++rr) s += Ws[rr * LDG + i] * Ms[rr * LDG + j];
+                accA[k] = s;
+            }
+        }
+        for (int o = tid; o < FB_CO * HD; o += 256) {     // dWo rows of this chunk
+            const int rr = o / HD, i = o % HD;
+            float s = 0.f;
+            for (int j = 0; j < HD; ++j) s += Ms[rr * LDG + j] * A[i * LDG + j];
+            dWo[(long)(c0 + rr) * C + h * HD + i] = s;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXO; ++k) {
+        const int o = tid + 256 * k;
+        if (k < nout && o < HD * HD) D[(o / HD) * LDG + o % HD] = accA[k];
     }
     __syncthreads();
     if (tid < HD) {                                   // softmax backward per row; logits = Gtilde * temp
@@ -317,7 +345,7 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 96, "spectral_fold_bwd: head_dim %d > 96", HD);
     FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->W2, a->dWo, a->dtemp, a->B, a->C, HD};
-    const size_t shmem = (3 * (size_t)HD * (HD + 1) + 7 * HD) * sizeof(float);
+    const size_t shmem = (3 * (size_t)HD * (HD + 1) + 7 * HD + 64 * (size_t)(HD + 1)) * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32) {
         allow_big_lds(spectral_fold_bwd_kernel<float>, shmem);

@@ -102,7 +102,7 @@ def pack_gated_mlp(fc1_w, fc1_b, fc2_w, dtype):
     return W1, b1, W2
 
 
-def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, out=None):
+def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, out=None, tiles_per_wave=0):
     """x (M,C) row-major view -> x + keep * mlp(LN(x)); weights from pack_gated_mlp."""
     lib = _lib.load()
     _check(x, W1, W2, b1, b2, ln_w, ln_b, keep)
@@ -115,7 +115,7 @@ def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, ou
     a.X, a.ldx, a.ln_w, a.ln_b = _p(x), ldx, _p(ln_w), _p(ln_b)
     a.W1, a.b1, a.W2, a.b2 = _p(W1), _p(b1), _p(W2), _p(b2)
     a.keep, a.rows_per_batch = _p(keep), rows_per_batch
-    a.Y, a.ldy, a.M, a.C, a.HP = _p(y), _rows(y)[1], M, C, HP
+    a.Y, a.ldy, a.M, a.C, a.HP, a.tiles_per_wave = _p(y), _rows(y)[1], M, C, HP, tiles_per_wave
     _lib.check(lib.mphsir_gated_mlp_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gated_mlp_fwd")
     _acct("gated_mlp", 6.0 * M * C * HP, 2.0 * M * C * x.element_size() + 3.0 * C * HP * x.element_size())
     return y

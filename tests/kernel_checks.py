@@ -73,20 +73,19 @@ def check_gemm_tok_per_sample_combine(dev, dtype):
     assert rel_l2(y.reshape(B, H, W, C), ref) < TOL[dtype]
 
 
-def check_gated_mlp(dev, dtype, C, hid):
+def check_gated_mlp(dev, dtype, C, hid, tpw=0, M=128):
     _use(dev)
     from mp_hsir_amd import ops
-    M = 128
     x = rnd((M, C), 1, dtype)
     P = {"fc1.weight": rnd((2 * hid, C), 2, scale=C ** -0.5), "fc1.bias": 0.1 * rnd((2 * hid,), 3),
          "fc2.weight": rnd((C, hid), 4, scale=hid ** -0.5), "fc2.bias": 0.1 * rnd((C,), 5)}
     lnw, lnb = 1 + 0.1 * rnd((C,), 6), 0.1 * rnd((C,), 7)
     keep = torch.tensor([1.0, 1.5]).to(dev)
     W1, b1, W2 = ops.pack_gated_mlp(P["fc1.weight"], P["fc1.bias"], P["fc2.weight"], dtype)
-    y = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, P["fc2.bias"], keep=keep, rows_per_batch=64)
+    y = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, P["fc2.bias"], keep=keep, rows_per_batch=M // 2, tiles_per_wave=tpw)
     Pd = {k: (v.to(dtype) if k.endswith("weight") else v).double().cpu() for k, v in P.items()}
     xn = O.layer_norm_c(x.double().cpu(), lnw.double().cpu(), lnb.double().cpu())
-    ref = x.double().cpu() + keep.double().cpu().repeat_interleave(64)[:, None] * O.gated_mlp(Pd, "", xn)
+    ref = x.double().cpu() + keep.double().cpu().repeat_interleave(M // 2)[:, None] * O.gated_mlp(Pd, "", xn)
     assert rel_l2(y, ref) < TOL[dtype]
 
 

@@ -27,6 +27,7 @@ def test_gemm_tok_per_sample_combine(dtype):
 @pytest.mark.parametrize("C,hid", K.MLP_CASES)
 def test_gated_mlp(dtype, C, hid):
     K.check_gated_mlp("cpu", dtype, C, hid)
+    K.check_gated_mlp("cpu", dtype, C, hid, tpw=2, M=256)
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)

@@ -39,6 +39,11 @@ def test_gemm_tok_per_sample_combine(dtype):
 @pytest.mark.parametrize("C,hid", K.MLP_CASES + [(64, 170), (192, 510), (256, 680), (384, 1021)])
 def test_gated_mlp(dtype, C, hid):
     K.check_gated_mlp("cuda", dtype, C, hid)
+    K.check_gated_mlp("cuda", dtype, C, hid, tpw=2, M=256)
+
+
+def test_gated_mlp_large_auto_tiles():
+    K.check_gated_mlp("cuda", torch.bfloat16, 128, 340, M=65536)
 
 
 GPU_WIN_CASES = K.WIN_CASES + [
