@@ -35,8 +35,15 @@ PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 PEAK_MFMA_TF = {"bf16": 2500.0, "f32": 157.3}
 RIDGE = 312.0                  # FLOP/B, bf16 dense MFMA peak / HBM peak
 
-KERNEL_IDS = {"gemm_tok": 0, "win_attn": 1, "dwconv_gram": 2, "spectral_fold": 3, "gated_mlp": 4, "dwconv_gate": 5,
-              "flat_adamw": 6}
+def kernel_ids(lib):
+    """name -> id of every kernel the library can time (mphsir_kernel_name)."""
+    lib.mphsir_kernel_name.restype = ctypes.c_char_p
+    out = {}
+    for kid in range(32):
+        n = lib.mphsir_kernel_name(kid).decode()
+        if n != "?":
+            out[n] = kid
+    return out
 
 
 def parse():
@@ -136,17 +143,16 @@ def main():
         torch.cuda.synchronize()
         acct, ops.ACCOUNT = ops.ACCOUNT, None
         per = {}
-        for name, kid in KERNEL_IDS.items():
+        for name, kid in kernel_ids(lib).items():
             if name not in acct and name != "flat_adamw":
                 continue
             lib.mphsir_prof_enable(kid)
-            for _ in range(2):
-                step()
+            step()
             n, ms = ctypes.c_int(0), ctypes.c_float(0)
             lib.mphsir_prof_read(ctypes.byref(n), ctypes.byref(ms))
             lib.mphsir_prof_enable(-1)
             if n.value:
-                per[name] = (n.value / 2.0, ms.value / 2.0)        # launches / step, ms / step
+                per[name] = (float(n.value), ms.value)              # launches / step, ms / step
         dom = max((k for k in per if k in acct), key=lambda k: per[k][1])
         launches, ms = per[dom]
         _, flops, nbytes = acct[dom]

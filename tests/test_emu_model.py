@@ -16,6 +16,8 @@ def test_tiny_forward_b4_matches_reference():
     assert M.check_tiny_forward("cpu", "t32_b4") < 2e-6
 
 
+@pytest.mark.skipif(not __import__("os").environ.get("MPHSIR_SLOW_TESTS"), reason="3 minutes on the emulator; runs on the GPU in "
+                    "tests/test_gpu_model.py::test_tiny_net_gradients_fp32 (set MPHSIR_SLOW_TESTS=1 to run here)")
 def test_tiny_gradients_match_reference():
     assert M.check_tiny_gradients("cpu") < 1e-4
 
