@@ -233,6 +233,16 @@ typedef struct mphsir_pg_bwd_args {
 } mphsir_pg_bwd_args;
 int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream);
 
+/* ---- dense 3x3 convolution (implicit GEMM) -----------------------------------------------------------
+ * Y[p][n] = sum_tap sum_ci X[p+tap][ci] * W[n][tap*Cin + ci]   stride 1, zero padding, no bias, channels-last.
+ * Replaces OverlapPatchEmbed.proj (net/MP_HSIR.py:458), Downsample/Upsample convs (:436,:446), TVSP.conv_last
+ * (:566) and `output` (:807).  Cin % 32 == 0, N % 16 == 0 (the caller zero-pads 31 -> 32), B*H*W % 64 == 0.
+ * Input gradient = the same call with flipped/transposed weights; weight gradient = mphsir_gemm_tn(dY,
+ * Col) with Col [B*H*W][9*Cin] written by mphsir_im2col3x3.                                           */
+int mphsir_conv3x3_tok(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, int32_t B, int32_t H, int32_t Wd,
+                       int32_t Cin, int32_t N, int dtype, void* stream);
+int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B, int32_t H, int32_t Wd, int32_t Cin, int dtype, void* stream);
+
 /* ---- token-reduction GEMM (weight gradients) --------------------------------------------------------
  * Cpart[b][s][n1][n2] = sum over the s-th token range of A[b][m][n1] * B[b][m][n2]  (fp32 partials;
  * the caller sums the nsplit partials in order).  A: [batch][M][lda], B: [batch][M][ldb] token-major
@@ -284,6 +294,8 @@ int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, f
 #define MPHSIR_K_GDFN_GATE_BWD 14
 #define MPHSIR_K_FOLD_BWD 15
 #define MPHSIR_K_PG_GATE_BWD 16
+#define MPHSIR_K_CONV3X3 17
+#define MPHSIR_K_IM2COL 18
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -482,9 +482,37 @@ def conv1x1(x, w):
     return _Conv1x1.apply(x, w)
 
 
+class _Conv3x3(torch.autograd.Function):
+    """dense 3x3 conv as an implicit GEMM on the HIP kernel (forward, input gradient) + im2col/gemm_tn (weights)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        Cout, Cin = w.shape[0], w.shape[1]
+        Cp = ops.round_up(Cin, 32)
+        xp = x.contiguous() if Cp == Cin else F.pad(x, (0, Cp - Cin)).contiguous()
+        y = ops.conv3x3_tok(xp, ops.pack_conv3x3(w, x.dtype))
+        ctx.save_for_backward(xp, w)
+        return y if y.shape[-1] == Cout else y[..., :Cout].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, w = ctx.saved_tensors
+        Cout, Cin = w.shape[0], w.shape[1]
+        Cp, Co32 = xp.shape[-1], ops.round_up(Cout, 32)
+        dyp = dy.contiguous() if Co32 == Cout else F.pad(dy, (0, Co32 - Cout)).contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3x3_tok(dyp, ops.pack_conv3x3(w, dy.dtype, flip_transpose=True))
+            dx = dx if dx.shape[-1] == Cin else dx[..., :Cin].contiguous()
+        if ctx.needs_input_grad[1]:
+            g = ops.gemm_tn(dyp.reshape(-1, Co32), ops.im2col3x3(xp))[:Cout]
+            dw = g.reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
+        return dx, dw
+
+
 def conv3x3(x, w):
-    """dense 3x3, stride 1, zero padding, no bias on channels-last data (MIOpen through PyTorch-ROCm: glue)."""
-    return F.conv2d(x.permute(0, 3, 1, 2), w.to(x.dtype), None, 1, 1).permute(0, 2, 3, 1).contiguous()
+    """dense 3x3, stride 1, zero padding, no bias on channels-last data."""
+    return _Conv3x3.apply(x, w)
 
 
 def pixel_unshuffle2(x):

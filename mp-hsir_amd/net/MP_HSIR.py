@@ -17,8 +17,9 @@ of libmphsir (include/mphsir.h):
     gemm_tok      M_b v + shortcut + DropPath*(sa*gate + .)                (ref :110-113, :715-718)
     gated_mlp     LN2 + fc1 + GELU gate + fc2 + DropPath residual          (ref :719)
 
-Dense 3x3 convs, pixel (un)shuffle, concatenation and the two interpolations of TVSP are PyTorch-ROCm
-glue.  There is no CPU path: without libmphsir.so, forward raises.
+The dense 3x3 convs run on the implicit-GEMM kernel conv3x3_tok; pixel (un)shuffle, concatenation and the
+two interpolations of TVSP are PyTorch-ROCm glue.  There is no CPU path: without
+libmphsir.so, forward raises.
 
 `file:line` citations are relative to the reference repository's net/MP_HSIR.py.
 """

@@ -441,3 +441,40 @@ def pg_gate_bwd(mu, dgate, pg):
         "linear_down.weight": P[C + 4 * r + 256:C + 5 * r + 256, 5 * r + 1:5 * r + 1 + C],
     }
     return dmu, g
+
+
+def pack_conv3x3(w, dtype, flip_transpose=False):
+    """conv weight (Cout,Cin,3,3) -> [Np][9*Cp] tap-major, channels zero-padded (Cin -> mult of 32, Cout -> mult of 16).
+    flip_transpose=True packs the weights of the input-gradient convolution instead (in/out swapped, taps flipped)."""
+    if flip_transpose:
+        w = w.flip(2, 3).transpose(0, 1)
+    Co, Ci = w.shape[0], w.shape[1]
+    Np, Cp = round_up(Co, 16), round_up(Ci, 32)
+    out = torch.zeros((Np, 9, Cp), dtype=dtype, device=w.device)
+    out[:Co, :, :Ci] = w.permute(0, 2, 3, 1).reshape(Co, 9, Ci).to(dtype)
+    return out.reshape(Np, 9 * Cp)
+
+
+def conv3x3_tok(x, wp):
+    """x (B,H,W,Cp) channels-last with Cp % 32 == 0; wp from pack_conv3x3 -> (B,H,W,Np)."""
+    lib = _lib.load()
+    _check(x, wp)
+    B, H, W, Cp = x.shape
+    Np = wp.shape[0]
+    assert x.is_contiguous() and wp.shape[1] == 9 * Cp and wp.dtype == x.dtype
+    y = torch.empty((B, H, W, Np), dtype=x.dtype, device=x.device)
+    _lib.check(lib.mphsir_conv3x3_tok(_p(x), Cp, _p(wp), _p(y), Np, B, H, W, Cp, Np, _DT[x.dtype], _stream(x)), "conv3x3_tok")
+    _acct("conv3x3_tok", 18.0 * B * H * W * Cp * Np, (B * H * W * (Cp + Np) + wp.numel()) * x.element_size())
+    return y
+
+
+def im2col3x3(x):
+    """x (B,H,W,Cp) -> (B*H*W, 9*Cp) gathered neighbourhoods (zero padding)."""
+    lib = _lib.load()
+    _check(x)
+    B, H, W, Cp = x.shape
+    assert x.is_contiguous()
+    col = torch.empty((B * H * W, 9 * Cp), dtype=x.dtype, device=x.device)
+    _lib.check(lib.mphsir_im2col3x3(_p(x), Cp, _p(col), B, H, W, Cp, _DT[x.dtype], _stream(x)), "im2col3x3")
+    _acct("im2col3x3", 0.0, 10.0 * x.numel() * x.element_size())
+    return col

@@ -240,3 +240,28 @@ def check_gemm_tn(dev, dtype, M, N1, N2, nsplit, batch):
     if not batch:
         c2 = ops.gemm_tn(wide[:, 8:8 + N1], b, nsplit=nsplit)
         assert rel_l2(c2, wide[:, 8:8 + N1].double().cpu().t() @ b.double().cpu()) < (3e-6 if dtype == torch.float32 else 1e-2)
+
+
+def check_conv3x3(dev, dtype, B, H, W, Cin, Cout):
+    """implicit-GEMM dense conv: forward, input gradient (flipped/transposed weights) and weight gradient
+    (im2col + token-reduction GEMM) vs torch autograd in fp64."""
+    _use(dev)
+    import torch.nn.functional as F
+    from mp_hsir_amd import ops
+    x, dy = rnd((B, H, W, Cin), 61, dtype), rnd((B, H, W, Cout), 62, dtype)
+    w = rnd((Cout, Cin, 3, 3), 63, scale=(9 * Cin) ** -0.5)
+    Cp, Np = ops.round_up(Cin, 32), ops.round_up(Cout, 16)
+    xp = F.pad(x, (0, Cp - Cin)).contiguous()
+    y = ops.conv3x3_tok(xp, ops.pack_conv3x3(w, dtype))[..., :Cout]
+    Co32 = ops.round_up(Cout, 32)
+    dyp = F.pad(dy, (0, Co32 - Cout)).contiguous()
+    dx = ops.conv3x3_tok(dyp, ops.pack_conv3x3(w, dtype, flip_transpose=True))[..., :Cin]
+    dw = ops.gemm_tn(dy.reshape(-1, Cout).contiguous() if Cout % 8 == 0 else F.pad(dy, (0, Np - Cout)).reshape(-1, Np).contiguous(),
+                     ops.im2col3x3(xp))[:Cout].reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
+    xr = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.to(dtype).double().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    yr.backward(dy.double().cpu().permute(0, 3, 1, 2))
+    assert rel_l2(y, yr.detach().permute(0, 2, 3, 1)) < TOL[dtype]
+    assert rel_l2(dx, xr.grad.permute(0, 2, 3, 1)) < TOL[dtype]
+    assert rel_l2(dw, wr.grad) < TOL[dtype]

@@ -63,3 +63,9 @@ def test_gated_mlp_bwd(dtype, C, hid):
 @pytest.mark.parametrize("M,N1,N2,nsplit,batch", [(256, 64, 64, 2, 0), (200, 96, 32, 3, 0), (128, 32, 32, 1, 2)])
 def test_gemm_tn(dtype, M, N1, N2, nsplit, batch):
     K.check_gemm_tn("cpu", dtype, M, N1, N2, nsplit, batch)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 8, 31, 32), (2, 8, 4, 32, 31), (1, 8, 8, 64, 48)])
+def test_conv3x3(dtype, B, H, W, Cin, Cout):
+    K.check_conv3x3("cpu", dtype, B, H, W, Cin, Cout)

@@ -99,3 +99,10 @@ def test_gated_mlp_bwd_c384_bf16():
                                                    (131072, 704, 128, None, 0), (4096, 128, 128, None, 32), (32768, 384, 128, None, 0)])
 def test_gemm_tn(dtype, M, N1, N2, nsplit, batch):
     K.check_gemm_tn("cuda", dtype, M, N1, N2, nsplit, batch)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 8, 31, 32), (2, 8, 4, 32, 31), (1, 8, 8, 64, 48), (4, 64, 64, 31, 64),
+                                             (2, 16, 16, 256, 512), (2, 64, 64, 128, 31)])
+def test_conv3x3(dtype, B, H, W, Cin, Cout):
+    K.check_conv3x3("cuda", dtype, B, H, W, Cin, Cout)
