@@ -32,7 +32,9 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
 
-template <class T, int C>
+// STAGE = true: the fc1 rows of the hidden chunk ([64][C]) and the matching columns of W1^T ([C][64]) are loaded
+// once per workgroup into LDS (coalesced) instead of every wave streaming its own fragments through L1.
+template <class T, int C, bool STAGE>
 __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
@@ -48,6 +50,8 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
     T* Ds = Xs + 64 * LDX;                              // [64][LDX]  dm = keep*dy
     T* Hs = Ds + 64 * LDX;                              // [4][16][LDH]  per wave: [dval(32) | dgate(32)], also h staging
     float* stat = reinterpret_cast<float*>(Hs + 4 * 16 * LDH);   // mean[64], rstd[64]
+    T* W1s = reinterpret_cast<T*>(stat + 128);          // [64][LDX]   (STAGE) value rows 0..31, gate rows 32..63
+    T* W1Ts = W1s + 64 * LDX;                           // [C][LDH]    (STAGE) W1^T columns: value 0..31 | gate 32..63
     float* Fs = reinterpret_cast<float*>(smem_v);       // [64][LDF] fp32 dxn (aliases Xs|Ds after the main loop)
     static_assert(64 * LDF * 4 <= 2 * 64 * LDX * sizeof(T), "fp32 dxn stage must fit in the two token tiles");
 
@@ -104,16 +108,36 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
     for (int i = 0; i < NCT; ++i) out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int j = 0; j < HP; j += 32) {
+        if (STAGE) {
+            constexpr int VPR = C / VEC, VPH = 32 / VEC;
+            for (int v = tid; v < 64 * VPR; v += 256) {
+                const int r = v / VPR, c = (v % VPR) * VEC;
+                const long srow = r < 32 ? j + r : HP + j + (r - 32);
+                store16<T>(W1s + r * LDX + c, load16<T>(W1 + srow * C + c));
+            }
+            for (int v = tid; v < C * 2 * VPH; v += 256) {
+                const int r = v / (2 * VPH), seg = (v / VPH) & 1, c = (v % VPH) * VEC;
+                store16<T>(W1Ts + r * LDH + seg * 32 + c, load16<T>(W1T + (long)r * 2 * HP + seg * HP + j + c));
+            }
+            __syncthreads();
+        }
         f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0}, g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
         f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};          // dh tiles
 #pragma unroll 4
         for (int kk = 0; kk < C; kk += TR::KCHUNK) {
             const frag_t bx = load_frag<T>(Xs, LDX, wv * 16, kk);
             const frag_t bd = load_frag<T>(Ds, LDX, wv * 16, kk);
-            mma(v0, load_frag<T>(W1, C, j, kk), bx);
-            mma(v1, load_frag<T>(W1, C, j + 16, kk), bx);
-            mma(g0, load_frag<T>(W1, C, HP + j, kk), bx);
-            mma(g1, load_frag<T>(W1, C, HP + j + 16, kk), bx);
+            if (STAGE) {
+                mma(v0, load_frag<T>(W1s, LDX, 0, kk), bx);
+                mma(v1, load_frag<T>(W1s, LDX, 16, kk), bx);
+                mma(g0, load_frag<T>(W1s, LDX, 32, kk), bx);
+                mma(g1, load_frag<T>(W1s, LDX, 48, kk), bx);
+            } else {
+                mma(v0, load_frag<T>(W1, C, j, kk), bx);
+                mma(v1, load_frag<T>(W1, C, j + 16, kk), bx);
+                mma(g0, load_frag<T>(W1, C, HP + j, kk), bx);
+                mma(g1, load_frag<T>(W1, C, HP + j + 16, kk), bx);
+            }
             mma(e0, load_frag<T>(W2T, C, j, kk), bd);
             mma(e1, load_frag<T>(W2T, C, j + 16, kk), bd);
         }
@@ -159,8 +183,13 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
             const frag_t bg = load_frag<T>(Hw, LDH, 0, 32 + kk);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                mma(out[ct], load_frag<T>(W1T, 2 * HP, ct * 16, j + kk), bv);
-                mma(out[ct], load_frag<T>(W1T, 2 * HP, ct * 16, HP + j + kk), bg);
+                if (STAGE) {
+                    mma(out[ct], load_frag<T>(W1Ts, LDH, ct * 16, kk), bv);
+                    mma(out[ct], load_frag<T>(W1Ts, LDH, ct * 16, 32 + kk), bg);
+                } else {
+                    mma(out[ct], load_frag<T>(W1T, 2 * HP, ct * 16, j + kk), bv);
+                    mma(out[ct], load_frag<T>(W1T, 2 * HP, ct * 16, HP + j + kk), bg);
+                }
             }
         }
         __syncthreads();
@@ -226,9 +255,15 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
 template <class T, int C>
 static int launch_mlp_bwd(const MlpBwdDev& d, hipStream_t s) {
     constexpr int PAD = 16 / sizeof(T);
-    const size_t shmem = (2 * 64 * (C + PAD) + 4 * 16 * (64 + PAD)) * sizeof(T) + 128 * sizeof(float);
-    allow_big_lds(gated_mlp_bwd_kernel<T, C>, shmem);
-    MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd_kernel<T, C>), dim3(d.M / 64), dim3(256), shmem, s, d);
+    constexpr size_t base = (2 * 64 * (C + PAD) + 4 * 16 * (64 + PAD)) * sizeof(T) + 128 * sizeof(float);
+    constexpr size_t staged = base + (64 * (size_t)(C + PAD) + (size_t)C * (64 + PAD)) * sizeof(T);
+    if constexpr (staged <= 160 * 1024) {
+        allow_big_lds(gated_mlp_bwd_kernel<T, C, true>, staged);
+        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd_kernel<T, C, true>), dim3(d.M / 64), dim3(256), staged, s, d);
+    } else {
+        allow_big_lds(gated_mlp_bwd_kernel<T, C, false>, base);
+        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd_kernel<T, C, false>), dim3(d.M / 64), dim3(256), base, s, d);
+    }
     return MPHSIR_OK;
 }
 

@@ -43,8 +43,19 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     const float temp = a.temperature[h];
 
     for (int i = tid; i < HD * HD; i += 256) {
+        // ordered sum over the splits; 8 independent loads in flight per step (the loads, not the adds, are the latency)
+        const float* gp = a.Gpart + ((long)b * a.nsplit * HEADS + h) * HD * HD + i;
+        const long gstride = (long)HEADS * HD * HD;
         float s = 0.f;
-        for (int sp = 0; sp < a.nsplit; ++sp) s += a.Gpart[(((long)b * a.nsplit + sp) * HEADS + h) * HD * HD + i];
+        int sp = 0;
+        for (; sp + 8 <= a.nsplit; sp += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = gp[(sp + u) * gstride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; sp < a.nsplit; ++sp) s += gp[sp * gstride];
         G[(i / HD) * LDG + i % HD] = s;
     }
     if (tid < 2 * HD) {
