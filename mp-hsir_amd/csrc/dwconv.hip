@@ -58,7 +58,7 @@ template <class T>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwWgDev a) {
     constexpr int VEC = Vec16<T>::N;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    float* red = reinterpret_cast<float*>(smem_v);        // [4][64][9*VEC]
+    float* red = reinterpret_cast<float*>(smem_v);        // [64][9*VEC]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cvec = blockIdx.y * 64 + lane, c0 = cvec * VEC;
     const bool live = c0 < a.C;
@@ -88,18 +88,24 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwWgDev a) {
                 }
             }
         }
-    float* mine = red + ((wv * 64 + lane) * 9) * VEC;
-    for (int t = 0; t < 9; ++t)
-        for (int e = 0; e < VEC; ++e) mine[t * VEC + e] = acc[t][e];
-    __syncthreads();
+    // cross-wave reduction in wave order through one [64][9*VEC] buffer (18 KB: keeps 4+ workgroups per CU resident)
+    float* mine = red + (lane * 9) * VEC;
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+            if (w == 0) {
+                for (int t = 0; t < 9; ++t)
+                    for (int e = 0; e < VEC; ++e) mine[t * VEC + e] = acc[t][e];
+            } else {
+                for (int t = 0; t < 9; ++t)
+                    for (int e = 0; e < VEC; ++e) mine[t * VEC + e] += acc[t][e];
+            }
+        }
+        __syncthreads();
+    }
     if (wv == 0 && live) {
         float* out = a.part + (long)blockIdx.x * 9 * a.C;
         for (int t = 0; t < 9; ++t)
-            for (int e = 0; e < VEC; ++e) {
-                float s = 0.f;
-                for (int w = 0; w < 4; ++w) s += red[((w * 64 + lane) * 9 + t) * VEC + e];   // fixed order
-                out[t * a.C + c0 + e] = s;
-            }
+            for (int e = 0; e < VEC; ++e) out[t * a.C + c0 + e] = mine[t * VEC + e];
     }
 }
 
@@ -190,7 +196,7 @@ extern "C" int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY
     MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0 && nblk > 0, "dwconv3x3_wgrad: bad shape");
     MPHSIR_REQUIRE(aligned16(X) && aligned16(dY) && (ldx * esz) % 16 == 0 && (lddy * esz) % 16 == 0, "dwconv3x3_wgrad: 16-byte alignment required");
     DwWgDev d{X, (long)ldx, dY, (long)lddy, partial, B, H, W, C, nblk};
-    const size_t shmem = 4 * 64 * 9 * vec * sizeof(float);
+    const size_t shmem = 64 * 9 * vec * sizeof(float);
     dim3 grid(nblk, (C / vec + 63) / 64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32) {

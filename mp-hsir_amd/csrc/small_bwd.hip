@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     }
     if (tid < 2 * HD) {
         float s = 0.f;
+#pragma unroll 8
         for (int sp = 0; sp < a.nsplit; ++sp) s += a.Spart[((long)b * a.nsplit + sp) * 2 * C + (tid / HD) * C + h * HD + tid % HD];
         sq[tid] = s;
         nq[tid] = fmaxf(sqrtf(s), 1e-12f);
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     for (int k = 0; k < MAXO; ++k) accA[k] = 0.f;
     for (int c0 = 0; c0 < C; c0 += FB_CO) {
         __syncthreads();
+#pragma unroll 4
         for (int idx = tid; idx < FB_CO * HD; idx += 256) {
             const int rr = idx / HD, cc = idx % HD;
             Ws[rr * LDG + cc] = a.Wo[(long)(c0 + rr) * C + h * HD + cc];

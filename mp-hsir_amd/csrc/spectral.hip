@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void spectral_fold_kernel(FoldDev a) {
     }
     if (tid < 2 * HD) {
         float s = 0.f;
+#pragma unroll 8
         for (int sp = 0; sp < a.nsplit; ++sp) s += a.Spart[((long)b * a.nsplit + sp) * 2 * C + (tid / HD) * C + h * HD + tid % HD];
         nq[tid] = fmaxf(sqrtf(s), 1e-12f);            // F.normalize eps (nk follows nq in memory)
     }

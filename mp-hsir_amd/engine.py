@@ -71,7 +71,7 @@ class DataParallelEngine:
             self.flat_p[o:o + n].copy_(p.data.reshape(-1))
             self.flat_g[o:o + n].copy_(p.grad.reshape(-1))
             p.data = self.flat_p[o:o + n].view(p.shape)
-            p.grad = self.flat_g[o:o + n].view(p.shape)
+            p.grad = None
             count += 1
             end = o + (n + 3) // 4 * 4
             if end - start >= self.bucket_elems:
@@ -80,6 +80,18 @@ class DataParallelEngine:
         if count:
             self.buckets.append([start, total, count])
         self.arena = (used, offs, total)
+        self._gviews = [self.flat_g[o:o + p.numel()].view(p.shape) for p, o in zip(used, offs)]
+        self._bucket_members = []            # per bucket: (params, arena views)
+        bi = 0
+        cur_p, cur_v = [], []
+        for p, o, gv in zip(used, offs, self._gviews):
+            while o >= self.buckets[bi][1]:
+                self._bucket_members.append((cur_p, cur_v))
+                cur_p, cur_v = [], []
+                bi += 1
+            cur_p.append(p)
+            cur_v.append(gv)
+        self._bucket_members.append((cur_p, cur_v))
         if self.world > 1:
             bucket_of = {}
             bi = 0
@@ -91,10 +103,19 @@ class DataParallelEngine:
             for p in used:
                 p.register_post_accumulate_grad_hook(self._make_hook(bucket_of[p]))
 
+    def _gather_bucket(self, bi):
+        """autograd hands every gradient over as a fresh tensor (p.grad was None): move the bucket's gradients into
+        the arena with one multi-tensor copy instead of one accumulate kernel per parameter."""
+        ps, views = self._bucket_members[bi]
+        torch._foreach_copy_(views, [p.grad for p in ps])
+        for p in ps:
+            p.grad = None
+
     def _make_hook(self, bi):
         def hook(_p):
             self._remaining[bi] -= 1
             if self._remaining[bi] == 0:
+                self._gather_bucket(bi)
                 s, e, _ = self.buckets[bi]
                 self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
         return hook
@@ -102,13 +123,14 @@ class DataParallelEngine:
     # ---- one optimisation step ---------------------------------------------------------------------
     def train_step(self, degraded, clean, prompt, lr=None):
         first = self.arena is None
-        if not first:
-            self.flat_g.zero_()
-            if self.world > 1:
-                self._remaining = [b[2] for b in self.buckets]
+        if not first and self.world > 1:
+            self._remaining = [b[2] for b in self.buckets]
         restored = self.net(degraded, prompt)
         loss = self.loss_fn(restored, clean)
         loss.backward()
+        if not first and self.world == 1:
+            for bi in range(len(self.buckets)):
+                self._gather_bucket(bi)
         if first:
             self._build_arenas()
             if self.world > 1:
