@@ -81,11 +81,8 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     // its dA outputs in registers across chunks.
     const float* dM = a.dM + (long)b * C * C;
     float* dWo = a.dWo + (long)b * C * C;
-    constexpr int FB_CO = 32, MAXO = 36;              // HD*HD/256 <= 36 for HD <= 96
-    const int nout = (HD * HD + 255) / 256;
-    float accA[MAXO];
-#pragma unroll
-    for (int k = 0; k < MAXO; ++k) accA[k] = 0.f;
+    constexpr int FB_CO = 32;
+    for (int o = tid; o < HD * HD; o += 256) D[(o / HD) * LDG + o % HD] = 0.f;      // dA accumulates in LDS
     for (int c0 = 0; c0 < C; c0 += FB_CO) {
         __syncthreads();
 #pragma unroll 4
@@ -95,27 +92,22 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
             Ms[rr * LDG + cc] = dM[(long)(c0 + rr) * C + h * HD + cc];
         }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < MAXO; ++k) {
-            const int o = tid + 256 * k;
-            if (k < nout && o < HD * HD) {
-                const int i = o / HD, j = o % HD;
-                float s = accA[k];
-                for (int rr = 0; rr < FB_CO; ++rr) s += Ws[rr * LDG + i] * Ms[rr * LDG + j];
-                accA[k] = s;
-            }
+#pragma unroll 1
+        for (int o = tid; o < HD * HD; o += 256) {
+            const int i = o / HD, j = o % HD;
+            float s = D[i * LDG + j];
+#pragma unroll 8
+            for (int rr = 0; rr < FB_CO; ++rr) s += Ws[rr * LDG + i] * Ms[rr * LDG + j];
+            D[i * LDG + j] = s;
         }
+#pragma unroll 1
         for (int o = tid; o < FB_CO * HD; o += 256) {     // dWo rows of this chunk
             const int rr = o / HD, i = o % HD;
             float s = 0.f;
+#pragma unroll 8
             for (int j = 0; j < HD; ++j) s += Ms[rr * LDG + j] * A[i * LDG + j];
             dWo[(long)(c0 + rr) * C + h * HD + i] = s;
         }
-    }
-#pragma unroll
-    for (int k = 0; k < MAXO; ++k) {
-        const int o = tid + 256 * k;
-        if (k < nout && o < HD * HD) D[(o / HD) * LDG + o % HD] = accA[k];
     }
     __syncthreads();
     if (tid < HD) {                                   // softmax backward per row; logits = Gtilde * temp

