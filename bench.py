@@ -161,8 +161,19 @@ def main():
             ach, peak, unit, bound = flops / (ms * 1e-3) / 1e12, PEAK_MFMA_TF[args.dtype], "TFLOP/s", "mfma"
         else:
             ach, peak, unit, bound = nbytes / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        try:
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+            if pm and not args.forward_only:
+                e = json.load(open(pm[-1])).get(dom, {})
+                if "hbm_read_bytes_per_launch" in e:
+                    traffic = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": launches,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "algorithmic_per_launch": round((flops if bound == "mfma" else nbytes) / launches),
+                    "launches_per_step": launches,
                     "avg_launch_us": round(ms * 1e3 / launches, 2), "flops_per_step": flops, "bytes_per_step": nbytes,
                     "tflops_equiv": round(flops / (ms * 1e-3) / 1e12, 2),
                     "kernel_ms_per_step": {k: round(v[1], 3) for k, v in sorted(per.items())}}

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 outputs under gpurun_out/ into the committed summaries under profiles/.
+
+    python tools/summarize_profiles.py <tag> <trace_dir> [<pmc_fetch_dir> <pmc_write_dir>]
+
+* <trace_dir>: `rocprofv3 --kernel-trace --stats --output-format csv` of `bench.py` -> profiles/<tag>_kernel_stats.csv
+* PMC dirs: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the same command (MI355X_MICROARCH.md
+  §HBM: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts exactly half the bytes of wide coalesced
+  reads -> doubled here) -> profiles/<tag>_pmc_summary.json with per-kernel mean HBM bytes per launch.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    m = re.search(r"mphsir\d*(\w+?)_kernel", name) or re.search(r"mphsir::(\w+?)_kernel", name)
+    if m:
+        n = m.group(1)
+        return re.sub(r"^\d+", "", n)
+    return name[:60]
+
+
+def counter_per_kernel(d, counter):
+    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(d, "*_counter_collection.csv"))
+    agg = defaultdict(lambda: [0, 0.0])
+    for row in csv.DictReader(open(f[0])):
+        if row["Counter_Name"] != counter:
+            continue
+        k = short(row["Kernel_Name"])
+        agg[k][0] += 1
+        agg[k][1] += float(row["Counter_Value"])
+    return agg
+
+
+def main():
+    tag, trace = sys.argv[1], sys.argv[2]
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    stats = glob.glob(os.path.join(trace, "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats, os.path.join(out, tag + "_kernel_stats.csv"))
+    summ = {}
+    for r in csv.DictReader(open(stats)):
+        k = short(r["Name"])
+        e = summ.setdefault(k, {"calls": 0, "total_ms": 0.0})
+        e["calls"] += int(r["Calls"])
+        e["total_ms"] += float(r["TotalDurationNs"]) / 1e6
+    for e in summ.values():
+        e["avg_us"] = round(e["total_ms"] * 1e3 / e["calls"], 2)
+        e["total_ms"] = round(e["total_ms"], 3)
+    if len(sys.argv) >= 5:
+        fe, wr = counter_per_kernel(sys.argv[3], "FETCH_SIZE"), counter_per_kernel(sys.argv[4], "WRITE_SIZE")
+        for k in summ:
+            if k in fe and k in wr and fe[k][0] and wr[k][0]:
+                rd = fe[k][1] / fe[k][0] * 1024 * 2       # KiB -> bytes, gfx950 half-count correction
+                wb = wr[k][1] / wr[k][0] * 1024
+                summ[k]["hbm_read_bytes_per_launch"] = round(rd)
+                summ[k]["hbm_write_bytes_per_launch"] = round(wb)
+    top = dict(sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:40])
+    with open(os.path.join(out, tag + "_pmc_summary.json"), "w") as f:
+        json.dump(top, f, indent=1, sort_keys=True)
+    for k, e in list(top.items())[:22]:
+        print("%-28s calls %5d avg %9.2f us  rd %s wr %s" % (k, e["calls"], e["avg_us"], e.get("hbm_read_bytes_per_launch"),
+                                                              e.get("hbm_write_bytes_per_launch")))
+
+
+if __name__ == "__main__":
+    main()
