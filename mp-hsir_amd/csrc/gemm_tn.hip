@@ -40,20 +40,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
 
     f32x4 acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int VPR = 64 / VEC;                // vectors per 64-column row segment
+    // Staging: threads 0..127 transpose the A tile, 128..255 the B tile.  Each thread loads 4 consecutive token rows
+    // of one 16-byte column vector and writes, per column, the 4 tokens as ONE 8/16-byte LDS store (4x fewer LDS
+    // write instructions than element-wise transposition, which was the bottleneck of the first version).
+    constexpr int VPR = 64 / VEC;                // column vectors per 64-wide tile row
+    const int half = tid >> 7, ht = tid & 127;
+    const T* Src = half ? B : A;
+    const long lds = half ? a.ldb : a.lda;
+    const int ncol0 = half ? n2_0 : n1_0, nmax = half ? a.N2 : a.N1;
+    T* Dst = half ? Bt : At;
     for (long m0 = m_lo; m0 < m_hi; m0 += KT) {
-        for (int v = tid; v < KT * VPR; v += 256) {
-            const int r = v / VPR, c = (v % VPR) * VEC;
-            const long m = m0 + r;
-            Vec16<T> xa, xb;
-            const bool okm = m < m_hi;
-            if (okm && n1_0 + c < a.N1) xa = load16<T>(A + m * a.lda + n1_0 + c);
-            else for (int e = 0; e < VEC; ++e) xa.set(e, 0.f);
-            if (okm && n2_0 + c < a.N2) xb = load16<T>(B + m * a.ldb + n2_0 + c);
-            else for (int e = 0; e < VEC; ++e) xb.set(e, 0.f);
+        for (int v = ht; v < (KT / 4) * VPR; v += 128) {
+            const int rq = v / VPR, c = (v % VPR) * VEC;      // token quad, column vector
+            Vec16<T> x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long m = m0 + rq * 4 + i;
+                if (m < m_hi && ncol0 + c < nmax) x[i] = load16<T>(Src + m * lds + ncol0 + c);
+                else for (int e = 0; e < VEC; ++e) x[i].set(e, 0.f);
+            }
+#pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                At[(c + e) * LDT + r] = xa.v[e];
-                Bt[(c + e) * LDT + r] = xb.v[e];
+                f32x4 q = {x[0].get(e), x[1].get(e), x[2].get(e), x[3].get(e)};
+                store4<T>(Dst + (c + e) * LDT + rq * 4, q);
             }
         }
         __syncthreads();

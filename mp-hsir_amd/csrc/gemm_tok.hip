@@ -26,7 +26,9 @@ struct GemmDev {
     int H, Wimg, shift;
 };
 
-template <class T, int EPI, bool LN>
+// NW = 16-column tiles per wave: one workgroup covers 64 tokens x 64*NW output channels, so the token tile is
+// staged (and LayerNorm-ed) once for up to 256 outputs instead of once per 64.
+template <class T, int EPI, bool LN, int NW>
 __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
     typedef ElemTraits<T> TR;
     constexpr int PAD = 16 / sizeof(T);
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
     float* stat = reinterpret_cast<float*>(smem + 64 * LDC * sizeof(float));   // mean[64], rstd[64]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int m0 = blockIdx.x * GT_BM, n0 = blockIdx.y * GT_BN;
+    const int m0 = blockIdx.x * GT_BM, n0 = blockIdx.y * GT_BN * NW;
     const T* X = reinterpret_cast<const T*>(a.X);
     const T* W = reinterpret_cast<const T*>(a.W) + (a.wbs ? (long)(m0 / a.rpb) * a.wbs : 0);
     const int K = a.K;
@@ -58,10 +60,11 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
         __syncthreads();
     }
 
-    const int ntile = n0 + wv * 16;            // this wave's 16 output channels
-    const bool active = ntile < a.N;           // wave-uniform
-    f32x4 acc[4];
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntile = n0 + wv * 16;            // this wave's first 16 output channels (+64 per extra tile)
+    f32x4 acc[NW][4];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        for (int i = 0; i < 4; ++i) acc[w][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int VEC = Vec16<T>::N;
     for (int k0 = 0; k0 < K; k0 += GT_KC) {
@@ -78,27 +81,36 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
             store16<T>(As + r * LDA + c, x);
         }
         __syncthreads();
-        if (active) {
-            for (int kk = 0; kk < kc; kk += TR::KCHUNK) {
-                const typename TR::frag_t wf = load_frag<T>(W, K, ntile, k0 + kk);
-                for (int mt = 0; mt < 4; ++mt) mma(acc[mt], load_frag<T>(As, LDA, mt * 16, kk), wf);
+        for (int kk = 0; kk < kc; kk += TR::KCHUNK) {
+            typename TR::frag_t af[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt] = load_frag<T>(As, LDA, mt * 16, kk);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if (ntile + w * 64 < a.N) {            // wave-uniform
+                    const typename TR::frag_t wf = load_frag<T>(W, K, ntile + w * 64, k0 + kk);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) mma(acc[w][mt], af[mt], wf);
+                }
             }
         }
         __syncthreads();
     }
 
-    // accumulators -> LDS (fp32): lane holds rows (lane>>4)*4+r of tile mt, column lane&15
-    if (active)
-        for (int mt = 0; mt < 4; ++mt)
-            for (int r = 0; r < 4; ++r) Cs[(mt * 16 + (lane >> 4) * 4 + r) * LDC + wv * 16 + (lane & 15)] = acc[mt][r];
-    __syncthreads();
-
     T* Y = reinterpret_cast<T*>(a.Y);
     const T* R = reinterpret_cast<const T*>(a.R);
     const T* SA = reinterpret_cast<const T*>(a.SA);
     constexpr int G = GT_BN / VEC;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    // accumulators of column group w -> LDS (fp32): lane holds rows (lane>>4)*4+r of tile mt, column lane&15
+    if (w) __syncthreads();
+    if (ntile + w * 64 < a.N)
+        for (int mt = 0; mt < 4; ++mt)
+            for (int r = 0; r < 4; ++r) Cs[(mt * 16 + (lane >> 4) * 4 + r) * LDC + wv * 16 + (lane & 15)] = acc[w][mt][r];
+    __syncthreads();
     for (int idx = tid; idx < 64 * G; idx += 256) {
-        const int r = idx / G, c = (idx % G) * VEC, n = n0 + c, m = m0 + r;
+        const int r = idx / G, c = (idx % G) * VEC, n = n0 + w * 64 + c, m = m0 + r;
         if (n >= a.N) continue;
         Vec16<T> out, res, sa;
         if (EPI >= 1) res = load16<T>(R + (long)m * a.ldr + n);
@@ -120,14 +132,24 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
         }
         store16<T>(Y + (long)m * a.ldy + n, out);
     }
+  }
+}
+
+template <class T, int EPI, bool LN, int NW>
+static int launch_gemm_nw(const GemmDev& d, hipStream_t s) {
+    dim3 grid(d.M / GT_BM, (d.N + GT_BN * NW - 1) / (GT_BN * NW));
+    const size_t shmem = 64 * (GT_BN + 4) * sizeof(float) + 128 * sizeof(float);
+    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TOK, (gemm_tok_kernel<T, EPI, LN, NW>), grid, dim3(256), shmem, s, d);
+    return MPHSIR_OK;
 }
 
 template <class T, int EPI, bool LN>
 static int launch_gemm(const GemmDev& d, hipStream_t s) {
-    dim3 grid(d.M / GT_BM, (d.N + GT_BN - 1) / GT_BN);
-    const size_t shmem = 64 * (GT_BN + 4) * sizeof(float) + 128 * sizeof(float);
-    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TOK, (gemm_tok_kernel<T, EPI, LN>), grid, dim3(256), shmem, s, d);
-    return MPHSIR_OK;
+    // enough workgroups to fill the chip first, then as many output channels per staged token tile as possible
+    const long mt = d.M / GT_BM;
+    if (d.N > 128 && mt >= 1024) return launch_gemm_nw<T, EPI, LN, 4>(d, s);
+    if (d.N > 64 && mt >= 512) return launch_gemm_nw<T, EPI, LN, 2>(d, s);
+    return launch_gemm_nw<T, EPI, LN, 1>(d, s);
 }
 
 template <class T>

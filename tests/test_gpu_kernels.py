@@ -25,7 +25,8 @@ def _real_library():
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
-@pytest.mark.parametrize("M,N,K_,ln,epi", K.GEMM_CASES + [(4096, 192, 64, True, 0), (2048, 128, 352, False, 1)])
+@pytest.mark.parametrize("M,N,K_,ln,epi", K.GEMM_CASES + [(4096, 192, 64, True, 0), (2048, 128, 352, False, 1), (65536, 384, 128, True, 0), (32768, 128, 64, False, 1),
+                                              (65536, 208, 96, True, 1)])
 def test_gemm_tok(dtype, M, N, K_, ln, epi):
     K.check_gemm_tok("cuda", dtype, M, N, K_, ln, epi)
 
