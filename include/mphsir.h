@@ -247,9 +247,10 @@ int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B, int32_t H
  * Cpart[b][s][n1][n2] = sum over the s-th token range of A[b][m][n1] * B[b][m][n2]  (fp32 partials;
  * the caller sums the nsplit partials in order).  A: [batch][M][lda], B: [batch][M][ldb] token-major
  * views (batch strides in elements).  This is dW = dY^T X of every Linear / 1x1 conv on the path and the
- * per-sample dM = d_out^T v of the folded channel attention (autograd of net/MP_HSIR.py, train.py:58-67). */
+ * per-sample dM = d_out^T v of the folded channel attention (autograd of net/MP_HSIR.py, train.py:58-67).
+ * colsum_part (optional, [batch][nsplit][N1]): partial column sums of A = the matching bias gradient.     */
 int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
-                   float* Cpart, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int dtype, void* stream);
+                   float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int dtype, void* stream);
 
 /* ---- plain depthwise 3x3 (backward building blocks) ----------------------------------------------
  * mphsir_dwconv3x3: Y[p][c] = sum_taps X[p+tap][c] * w9[tap][c] (zero padding); flip=1 uses the spatially

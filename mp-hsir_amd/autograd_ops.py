@@ -84,13 +84,13 @@ class _GatedMlp(torch.autograd.Function):
                                                   pk["W1T"], pk["W2T"])
         hid = blk.mlp.fc2.weight.shape[1]
         HP = h.shape[1]
-        dW2 = ops.gemm_tn(dm, h)[:, :hid]
-        dW1p = ops.gemm_tn(dpre, xn)
-        db1p = torch.sum(dpre, dim=0, dtype=torch.float32)
+        dW2, db2 = ops.gemm_tn(dm, h, colsum=True)
+        dW2 = dW2[:, :hid]
+        dW1p, db1p = ops.gemm_tn(dpre, xn, colsum=True)
         dln = part.sum(0)
         return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1],
                 torch.cat([dW1p[:hid], dW1p[HP:HP + hid]], 0), torch.cat([db1p[:hid], db1p[HP:HP + hid]]),
-                dW2, torch.sum(dm, dim=0, dtype=torch.float32))
+                dW2, db2)
 
 
 def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, MbT, temperature, wo, heads, B, H, W):
@@ -194,11 +194,9 @@ class _PgsstbAttn(torch.autograd.Function):
         dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
                                                  pk["rpb"], pk["wprojT"], heads, shift)
         dxn = dqkv @ pk["wqkv"]
-        d_qkv_w = ops.gemm_tn(dqkv, xnw)
-        d_qkv_b = torch.sum(dqkv, dim=0, dtype=torch.float32)
+        d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xnw, colsum=True)
         dsat2 = dsat.reshape(M, Cc)
-        d_proj_w = ops.gemm_tn(dsat2, oattn.reshape(M, Cc))
-        d_proj_b = torch.sum(dsat2, dim=0, dtype=torch.float32)
+        d_proj_w, d_proj_b = ops.gemm_tn(dsat2, oattn.reshape(M, Cc), colsum=True)
         # (5) norm1 backward + the residual path
         dx, part = ops.ln_bwd_win(x, dxn, dy, pk["ln1"][0], shift)
         dln = part.sum(0)

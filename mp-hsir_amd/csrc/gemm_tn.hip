@@ -17,6 +17,7 @@ struct TnDev {
     const void* A; long lda; long abs;
     const void* B; long ldb; long bbs;
     float* Cp;
+    float* colsum;      // optional [batch][nsplit][N1]: partial column sums of A (bias gradients for free)
     long M; int N1, N2, nsplit;
 };
 
@@ -40,6 +41,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
 
     f32x4 acc[4];
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // column sums of A ride along as one extra MFMA per K-chunk against an all-ones fragment (first n2 tile only)
+    const bool do_cs = a.colsum != nullptr && (blockIdx.x % t2n) == 0;
+    f32x4 accs = {0.f, 0.f, 0.f, 0.f};
+    typename TR::frag_t ones;
+    for (int e = 0; e < TR::EPL; ++e) ones[e] = from_f32<T>(1.0f);
     // Staging: threads 0..127 transpose the A tile, 128..255 the B tile.  Each thread loads 4 consecutive token rows
     // of one 16-byte column vector and writes, per column, the 4 tokens as ONE 8/16-byte LDS store (4x fewer LDS
     // write instructions than element-wise transposition, which was the bottleneck of the first version).
@@ -71,6 +77,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
             const typename TR::frag_t af = load_frag<T>(At, LDT, wv * 16, kk);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) mma(acc[nt], af, load_frag<T>(Bt, LDT, nt * 16, kk));
+            if (do_cs) mma(accs, af, ones);
         }
         __syncthreads();
     }
@@ -80,12 +87,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
             const int n1 = n1_0 + wv * 16 + (lane >> 4) * 4 + r, n2 = n2_0 + nt * 16 + (lane & 15);
             if (n1 < a.N1 && n2 < a.N2) Cp[(long)n1 * a.N2 + n2] = acc[nt][r];
         }
+    if (do_cs && (lane & 15) == 0)
+        for (int r = 0; r < 4; ++r) {
+            const int n1 = n1_0 + wv * 16 + (lane >> 4) * 4 + r;
+            if (n1 < a.N1) a.colsum[((long)bz * a.nsplit + sp) * a.N1 + n1] = accs[r];
+        }
 }
 
 }  // namespace mphsir
 
 extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
-                              float* Cpart, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int dtype, void* stream) {
+                              float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(A && B && Cpart, "gemm_tn: null pointer");
@@ -95,7 +107,7 @@ extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride
                    "gemm_tn: bad shape (N1, N2 must be multiples of %d)", vec);
     MPHSIR_REQUIRE(aligned16(A) && aligned16(B) && (lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0 &&
                        (a_batch_stride * esz) % 16 == 0 && (b_batch_stride * esz) % 16 == 0, "gemm_tn: 16-byte alignment required");
-    TnDev d{A, (long)lda, (long)a_batch_stride, B, (long)ldb, (long)b_batch_stride, Cpart, (long)M, N1, N2, nsplit};
+    TnDev d{A, (long)lda, (long)a_batch_stride, B, (long)ldb, (long)b_batch_stride, Cpart, colsum_part, (long)M, N1, N2, nsplit};
     dim3 grid(((N1 + 63) / 64) * ((N2 + 63) / 64), nsplit, batch);
     const size_t shmem = 2 * 64 * (64 + vec) * esz;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

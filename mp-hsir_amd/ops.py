@@ -359,9 +359,9 @@ def ln_bwd_win(x, dxn_w, dres, ln_w, shift):
     return dx, part
 
 
-def gemm_tn(a, b, nsplit=None):
+def gemm_tn(a, b, nsplit=None, colsum=False):
     """sum over tokens of a[m,:]^T b[m,:].  a (M,N1), b (M,N2) row-major views -> fp32 (N1,N2);
-    batched: a (Bt,M,N1), b (Bt,M,N2) -> (Bt,N1,N2)."""
+    batched: a (Bt,M,N1), b (Bt,M,N2) -> (Bt,N1,N2).  colsum=True also returns sum_m a[m,:] (fp32, (N1,))."""
     lib = _lib.load()
     _check(a, b)
     batched = a.dim() == 3
@@ -372,12 +372,17 @@ def gemm_tn(a, b, nsplit=None):
         tiles = ((N1 + 63) // 64) * ((N2 + 63) // 64) * Bt
         nsplit = max(1, min(M // 512, max(1, 1536 // tiles)))
     part = torch.empty((Bt, nsplit, N1, N2), dtype=torch.float32, device=a.device)
+    cs = torch.empty((Bt, nsplit, N1), dtype=torch.float32, device=a.device) if colsum else None
     _lib.check(lib.mphsir_gemm_tn(_p(a), a.stride(-2), a.stride(0) if batched else 0, _p(b), b.stride(-2),
-                                  b.stride(0) if batched else 0, _p(part), M, N1, N2, nsplit, Bt, _DT[a.dtype], _stream(a)),
+                                  b.stride(0) if batched else 0, _p(part), _p(cs), M, N1, N2, nsplit, Bt, _DT[a.dtype], _stream(a)),
                "gemm_tn")
     _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size() + part.numel() * 4.0)
     out = part.sum(dim=1) if nsplit > 1 else part[:, 0]
-    return out if batched else out[0]
+    out = out if batched else out[0]
+    if colsum:
+        c = cs.sum(dim=1) if nsplit > 1 else cs[:, 0]
+        return out, (c if batched else c[0])
+    return out
 
 
 def gdfn_gate_bwd(t, du):

@@ -232,9 +232,10 @@ def check_gemm_tn(dev, dtype, M, N1, N2, nsplit, batch):
     shape_a = (batch, M, N1) if batch else (M, N1)
     shape_b = (batch, M, N2) if batch else (M, N2)
     a, b = rnd(shape_a, 51, dtype), rnd(shape_b, 52, dtype)
-    c = ops.gemm_tn(a, b, nsplit=nsplit)
+    c, cs = ops.gemm_tn(a, b, nsplit=nsplit, colsum=True)
     ref = a.double().cpu().transpose(-1, -2) @ b.double().cpu()
     assert rel_l2(c, ref) < (3e-6 if dtype == torch.float32 else 1e-2)
+    assert rel_l2(cs, a.double().cpu().sum(dim=-2)) < (3e-6 if dtype == torch.float32 else 1e-2)
     # strided views (column slices of a wider matrix), as the backward uses them
     wide = rnd((M, N1 + 24), 53, dtype)
     if not batch:
