@@ -435,6 +435,7 @@ def pg_gate_bwd(mu, dgate, pg):
     a.dmu, a.L, a.R = _p(dmu), _p(L), _p(R)
     a.nW, a.C, a.r, a.KL, a.KR = nW, C, r, KL, KR
     _lib.check(lib.mphsir_pg_gate_bwd(ctypes.byref(a), _stream(mu)), "pg_gate_bwd")
+    _acct("pg_gate_bwd", 4.0 * nW * C * (128 + 2 * r), 4.0 * nW * (2 * C + KL + KR))
     P = gemm_tn(L, R)
     g = {
         "linear_up.weight": P[0:C, 0:r],
