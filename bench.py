@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: time inference only (not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured step (hipGraph)")
     return ap.parse_args()
 
 
@@ -111,7 +112,7 @@ def main():
                 return net(x, p)
     else:
         net.train()
-        eng = DataParallelEngine(net, lr=2e-4)
+        eng = DataParallelEngine(net, lr=2e-4, use_graph=not args.no_graph)
         def step():
             _, x, c, p = src.next()
             return eng.train_step(x, c, p)
@@ -121,7 +122,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 0 if args.forward_only or args.no_graph else 3)):   # graph mode: 2 eager steps + capture
         step()
     fence()
     t0 = time.perf_counter()
@@ -137,7 +138,9 @@ def main():
 
     roofline = None
     if not args.no_roofline:
-        # algorithmic work per step and per kernel (one accounted step), then per-kernel HIP-event timing
+        # algorithmic work per step and per kernel (one accounted step), then per-kernel HIP-event timing (eager launches)
+        if not args.forward_only:
+            eng.use_graph = False
         ops.ACCOUNT = {}
         step()
         torch.cuda.synchronize()
@@ -191,7 +194,7 @@ def main():
             "config": {"workload": "natural-scene MP_HSIR_Net(31,31,64,T=6) %s, 64x64x31 patches, batch %d/GPU, %s"
                                    % ("forward" if args.forward_only else "training step fwd+bwd+allreduce+AdamW",
                                       args.batch, "dp%d" % world),
-                       "global_batch": world * args.batch, "patch": "64x64x31", "parallelism": "dp%d" % world,
+                       "global_batch": world * args.batch, "patch": "64x64x31", "parallelism": "dp%d" % world, "launch": "eager" if (args.no_graph or args.forward_only) else "hipGraph replay",
                        "backward": "HIP kernels + library GEMMs for the 22 PGSSTB blocks; torch-op composite for the prompt modules"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

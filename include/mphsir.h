@@ -270,9 +270,11 @@ int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void* dT, int64
 /* ---- fused AdamW over the flat parameter arena ---------------------------------------------------
  * One decoupled-weight-decay Adam step on n contiguous fp32 parameters (n % 4 == 0) with gradient g,
  * moments m, v; g is multiplied by grad_scale first (1/world_size after a sum all-reduce).
- * Semantics = torch.optim.AdamW as the reference configures it (train.py:69); step is 1-based.     */
+ * Semantics = torch.optim.AdamW as the reference configures it (train.py:69); step is 1-based.
+ * hyper (optional device pointer to [lr, 1-beta1^step, sqrt(1-beta2^step)]) overrides lr/step so that a captured
+ * launch can be replayed with per-step values.                                                      */
 int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                      float eps, float weight_decay, int32_t step, float grad_scale, void* stream);
+                      float eps, float weight_decay, int32_t step, float grad_scale, const float* hyper, void* stream);
 
 /* ---- optional per-kernel launch timer (bench.py roofline leg) ----------------------------------
  * When enabled for kernel id `kid`, every launch of that kernel is bracketed by hipEvents on its

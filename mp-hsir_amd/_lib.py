@@ -102,7 +102,7 @@ _SYMBOLS = {
     "mphsir_dwconv3x3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                        c_int32, c_int, c_void_p]),
     "mphsir_flat_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,
-                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int32, ctypes.c_float, c_void_p]),
+                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int32, ctypes.c_float, c_void_p, c_void_p]),
     "mphsir_combine_bwd": (c_int, [c_void_p] * 7 + [c_int32] * 5 + [c_int, c_void_p]),
     "mphsir_win_attn_bwd": (c_int, [ctypes.POINTER(WinAttnBwdArgs), c_int, c_void_p]),
     "mphsir_win_attn_bwd_fits": (c_int, [c_int32, c_int32, c_int]),

@@ -1,6 +1,8 @@
 // libmphsir: version / error text / launch timer.
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "mphsir_host.h"
@@ -16,6 +18,16 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 void clear_error() { g_err[0] = 0; }
+
+bool lds_attr_needed(const void* fn, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> done;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& cur = done[fn];
+    if (cur >= bytes) return false;
+    cur = bytes;
+    return true;
+}
 
 struct ProfLog {
     int kid = -1;

@@ -39,9 +39,12 @@ void prof_after(int kid, hipStream_t s);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// dynamic LDS above 64 KiB must be opted into per kernel function
+// dynamic LDS above 64 KiB must be opted into per kernel function; done once per (function, size) so that replays /
+// stream captures of a warmed-up step issue no runtime-attribute calls
+bool lds_attr_needed(const void* fn, size_t bytes);
 template <class K> inline void allow_big_lds(K kern, size_t bytes) {
-    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (bytes > 48 * 1024 && lds_attr_needed(reinterpret_cast<const void*>(kern), bytes))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 }  // namespace mphsir

@@ -14,9 +14,11 @@ struct AdamDev {
     float* p; const float* g; float* m; float* v;
     long n;
     float lr, beta1, beta2, eps, wd, grad_scale, bc1, bc2_sqrt;
+    const float* hyper;     // optional device [lr, bias_correction1, sqrt(bias_correction2)]: graph-replay friendly
 };
 
 __global__ __launch_bounds__(256) void flat_adamw_kernel(AdamDev a) {
+    if (a.hyper) { a.lr = a.hyper[0]; a.bc1 = a.hyper[1]; a.bc2_sqrt = a.hyper[2]; }
     const long nvec = a.n / 4;
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
@@ -41,15 +43,16 @@ __global__ __launch_bounds__(256) void flat_adamw_kernel(AdamDev a) {
 }  // namespace mphsir
 
 extern "C" int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                                 float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void* stream) {
+                                 float beta2, float eps, float weight_decay, int32_t step, float grad_scale, const float* hyper,
+                                 void* stream) {
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(p && g && m && v, "flat_adamw: null pointer");
     MPHSIR_REQUIRE(n > 0 && n % 4 == 0, "flat_adamw: arena length must be a positive multiple of 4 (pad the arena)");
     MPHSIR_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "flat_adamw: 16-byte alignment required");
-    MPHSIR_REQUIRE(step >= 1, "flat_adamw: step is 1-based");
+    MPHSIR_REQUIRE(step >= 1 || hyper, "flat_adamw: step is 1-based");
     AdamDev d{p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, grad_scale,
-              1.0f - powf(beta1, (float)step), sqrtf(1.0f - powf(beta2, (float)step))};
+              1.0f - powf(beta1, (float)(step > 0 ? step : 1)), sqrtf(1.0f - powf(beta2, (float)(step > 0 ? step : 1))), hyper};
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
     MPHSIR_LAUNCH(MPHSIR_K_FLAT_ADAMW, flat_adamw_kernel, dim3((unsigned)blocks), dim3(256), 0,

@@ -245,13 +245,14 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
-def flat_adamw(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
-    """In-place AdamW step on flat fp32 arenas (length a multiple of 4)."""
+def flat_adamw(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, grad_scale=1.0, hyper=None):
+    """In-place AdamW step on flat fp32 arenas (length a multiple of 4).  hyper: optional device fp32 tensor
+    [lr, 1-beta1^step, sqrt(1-beta2^step)] read by the kernel instead of lr/step (for captured launches)."""
     lib = _lib.load()
     _check(p, g, m, v)
     assert p.dtype == torch.float32 and p.is_contiguous() and p.numel() == g.numel() == m.numel() == v.numel()
     _lib.check(lib.mphsir_flat_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
-                                     grad_scale, _stream(p)), "flat_adamw")
+                                     grad_scale, _p(hyper), _stream(p)), "flat_adamw")
     bump_weight_epoch()
 
 

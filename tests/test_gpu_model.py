@@ -140,3 +140,27 @@ def test_512x512_172band_forward_bf16():
         y_crop = net(x[:, :, :64, :64].contiguous(), t)
     assert y.shape == x.shape and torch.isfinite(y).all()
     assert not torch.allclose(y[:, :, :32, :32], y_crop[:, :, :32, :32], atol=1e-3)
+
+
+def test_graph_replay_matches_eager_training():
+    """the captured-and-replayed step (hipGraph) follows the same parameter trajectory as eager launches."""
+    from mp_hsir_amd.data import SyntheticPatchSource
+    from mp_hsir_amd.engine import DataParallelEngine
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    from golden.cases import TINY_CFG
+    from golden.detfill import surrogate_clip_prompt
+    res = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        net = MP_HSIR_Net(**TINY_CFG, clip_prompt=surrogate_clip_prompt(6), compute_dtype=torch.float32).cuda().eval()
+        eng = DataParallelEngine(net, lr=1e-3, use_graph=use_graph, graph_warmup=2)     # eval(): no DropPath randomness
+        src = SyntheticPatchSource(8, 64, 2, 6, "cuda", 2024, 0)
+        losses = []
+        for _ in range(5):
+            _, x, c, p = src.next()
+            losses.append(float(eng.train_step(x, c, p)))
+        eng.finish()
+        res.append((losses, net.output.weight.detach().clone(), net.encoder_level1.blocks[1].mlp.fc1.weight.detach().clone()))
+    (l0, a0, b0), (l1, a1, b1) = res
+    assert torch.allclose(torch.tensor(l0), torch.tensor(l1), rtol=1e-5, atol=1e-7), (l0, l1)
+    assert torch.allclose(a0, a1, rtol=1e-4, atol=1e-6) and torch.allclose(b0, b1, rtol=1e-4, atol=1e-6)
