@@ -319,6 +319,7 @@ class Text_Prompt(nn.Module):                                                   
             clip_prompt = self._encode_with_clip()
         assert tuple(clip_prompt.shape) == (task_classes, 512), clip_prompt.shape
         self.clip_prompt = clip_prompt.detach().float()      # plain attribute, not in state_dict
+        self._on_device = {}                                  # device copies (no host->device copy inside a captured step)
 
     def _encode_with_clip(self):
         try:
@@ -335,7 +336,9 @@ class Text_Prompt(nn.Module):                                                   
 
     def forward(self, x, de_class=None):
         T = self.task_classes
-        table = self.clip_prompt.to(x.device)
+        table = self._on_device.get(x.device)
+        if table is None:
+            table = self._on_device[x.device] = self.clip_prompt.to(x.device)
         if de_class.dim() > 1:
             w = F.one_hot(de_class, T).float().mean(dim=1)      # training path: mean of one-hots (:519-523)
         else:
