@@ -194,7 +194,9 @@ int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream);
  *   dWproj = dSAt^T Oattn, dbproj = colsum dSAt.  WprojT = proj.weight^T [C][C].
  *   mphsir_win_attn_bwd_fits(C, heads, dtype) tells whether the tile fits LDS (fp32: small widths only).
  * mphsir_ln_bwd_win: dX = dRes + LayerNorm_backward(dXNw) where dXNw [B*nW*64][C] is in window-token order
- *   (norm1 :667 + roll/partition :672-678 in reverse); part [B*nW][2][C] = partials of d(weight), d(bias). */
+ *   (norm1 :667 + roll/partition :672-678 in reverse); part [B*nW][2][C] = partials of d(weight), d(bias).
+ *   linear != 0: rows are plain token order (the pre-norms of TransformerBlock / CrossTransformer, :282,:286,:476,:477);
+ *   XN (optional, needs ln_b): also writes LN(X) in the row order of dXNw.                                    */
 int mphsir_combine_bwd(const void* dY, const void* SA, const float* gate, const float* keep, void* dOut, void* dSA,
                        float* dgate, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
 typedef struct mphsir_win_attn_bwd_args {
@@ -207,7 +209,8 @@ typedef struct mphsir_win_attn_bwd_args {
 int mphsir_win_attn_bwd(const mphsir_win_attn_bwd_args* a, int dtype, void* stream);
 int mphsir_win_attn_bwd_fits(int32_t C, int32_t heads, int dtype);
 int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const float* ln_w, void* dX, float* part,
-                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
+                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, const float* ln_b, void* XN, int32_t linear,
+                      int dtype, void* stream);
 
 /* ---- backward of the two small per-sample / per-window stages -----------------------------------------
  * mphsir_spectral_fold_bwd: backward of mphsir_spectral_fold.  dM [B][C][C] fp32 = gradient w.r.t. M_b.  Outputs:
@@ -248,9 +251,11 @@ int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B, int32_t H
  * the caller sums the nsplit partials in order).  A: [batch][M][lda], B: [batch][M][ldb] token-major
  * views (batch strides in elements).  This is dW = dY^T X of every Linear / 1x1 conv on the path and the
  * per-sample dM = d_out^T v of the folded channel attention (autograd of net/MP_HSIR.py, train.py:58-67).
- * colsum_part (optional, [batch][nsplit][N1]): partial column sums of A = the matching bias gradient.     */
+ * colsum_part (optional, [batch][nsplit][N1]): partial column sums of A = the matching bias gradient.
+ * tile128 != 0 selects 128x128 output tiles per workgroup (fewer operand re-reads; for N1, N2 >= 128).     */
 int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
-                   float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int dtype, void* stream);
+                   float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch,
+                   int32_t tile128, int dtype, void* stream);
 
 /* ---- plain depthwise 3x3 (backward building blocks) ----------------------------------------------
  * mphsir_dwconv3x3: Y[p][c] = sum_taps X[p+tap][c] * w9[tap][c] (zero padding); flip=1 uses the spatially

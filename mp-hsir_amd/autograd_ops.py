@@ -321,11 +321,10 @@ class _GdfnRes(torch.autograd.Function):
         dtdw4 = dtdw.reshape(B, H, W, 2 * HP)
         dt_ = ops.dwconv3x3(dtdw4, pf["w9"], flip=True).reshape(-1, 2 * HP)
         d_dw = _unpad_halves(ops.dwconv3x3_wgrad(t4, dtdw4).t(), hid, HP).reshape(2 * hid, 1, 3, 3)
-        lw, lb = ln.body.weight, ln.body.bias
-        xn = _ln_fwd(a2, lw, lb)
+        lw, lb = ln.pair()
+        da, dlw, dlb, xn = ops.ln_bwd_tok(a2, dt_ @ pf["w_in"], dy, lw, lb)
         d_in_w = _unpad_halves(ops.gemm_tn(dt_, xn), hid, HP).reshape(2 * hid, D, 1, 1)
-        da, dlw, dlb = _ln_vjp(a2, lw, lb, dt_ @ pf["w_in"])
-        return None, None, None, dy + da, dlw, dlb, d_in_w, d_dw, d_out_w
+        return None, None, None, da, dlw, dlb, d_in_w, d_dw, d_out_w
 
 
 def _gdfn_res_ag(ffn, ln, a2, B, H, W):
@@ -369,12 +368,11 @@ class _SelfChannelAttnRes(torch.autograd.Function):
             dt3 = torch.as_strided(dtq, (M, 3 * D), (3 * D, 1))
         else:
             dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * D)
-        lw, lb = ln.body.weight, ln.body.bias
-        xn = _ln_fwd(t2, lw, lb)
+        lw, lb = ln.pair()
+        dt_in, dlw, dlb, xn = ops.ln_bwd_tok(t2, dt3 @ pa["wqkv"], da, lw, lb)
         d_qkv = ops.gemm_tn(dt3, xn).reshape(3 * D, D, 1, 1)
-        dt_in, dlw, dlb = _ln_vjp(t2, lw, lb, dt3 @ pa["wqkv"])
         d_dw = torch.cat([dwq, dwk, dwv], dim=1).t().reshape(3 * D, 1, 3, 3)
-        return None, None, None, da + dt_in, dlw, dlb, d_qkv, d_dw, dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1)
+        return None, None, None, dt_in, dlw, dlb, d_qkv, d_dw, dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1)
 
 
 class _CrossChannelAttnRes(torch.autograd.Function):
@@ -413,13 +411,13 @@ class _CrossChannelAttnRes(torch.autograd.Function):
             attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
         dtq2 = dtq.reshape(M, D)
         dkv = torch.cat([dtk, dtv], dim=-1).reshape(M, 2 * D)
-        xq = _ln_fwd(text2, ct.norm11.body.weight, ct.norm11.body.bias)
-        xv = _ln_fwd(vis2, ct.norm12.body.weight, ct.norm12.body.bias)
+        n11w, n11b = ct.norm11.pair()
+        n12w, n12b = ct.norm12.pair()
+        dtext, d11w, d11b, xq = ops.ln_bwd_tok(text2, dtq2.contiguous() @ pa["wq"], da, n11w, n11b)
+        dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis2, dkv @ pa["wkv"], torch.zeros_like(vis2), n12w, n12b)
         d_wq = ops.gemm_tn(dtq2, xq).reshape(D, D, 1, 1)
         d_wkv = ops.gemm_tn(dkv, xv).reshape(2 * D, D, 1, 1)
-        dtext, d11w, d11b = _ln_vjp(text2, ct.norm11.body.weight, ct.norm11.body.bias, dtq2 @ pa["wq"])
-        dvis, d12w, d12b = _ln_vjp(vis2, ct.norm12.body.weight, ct.norm12.body.bias, dkv @ pa["wkv"])
-        return (None, None, da + dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.t().reshape(D, 1, 3, 3),
+        return (None, None, dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.t().reshape(D, 1, 3, 3),
                 torch.cat([dwk, dwv], dim=1).t().reshape(2 * D, 1, 3, 3), dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1))
 
 

@@ -315,6 +315,8 @@ struct LnBwdDev {
     const void* X; const void* dXNw; const void* dRes; const float* ln_w;
     void* dX; float* part;      // part [B*nW][2][C]
     WinGeom g; int C;
+    const float* ln_b; void* XN;   // optional: also emit LN(x) (rows in the order of dXNw)
+    int linear;                    // 1: dXNw rows are plain token order (no window gather)
 };
 
 template <class T>
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256) void ln_bwd_win_kernel(LnBwdDev a) {
     T* dX = reinterpret_cast<T*>(a.dX);
     const int nv = C / VEC;
     const int t = tid >> 2, q = tid & 3;
-    const long pix = win_pixel(a.g, blockIdx.x, t);
+    const long pix = a.linear ? (long)blockIdx.x * 64 + t : win_pixel(a.g, blockIdx.x, t);
     // pass 1: statistics of x, and the two LN-backward row sums
     float s = 0.f;
     for (int i = q; i < nv; i += 4) {
@@ -355,6 +357,11 @@ __global__ __launch_bounds__(256) void ln_bwd_win_kernel(LnBwdDev a) {
             const float gw = g.get(e) * a.ln_w[c], xh = (xv.get(e) - mean) * rstd;
             s1 += gw; s2 += gw * xh;
             Fs[t * LDF + c] = g.get(e);
+        }
+        if (a.XN) {
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) o.set(e, (xv.get(e) - mean) * rstd * a.ln_w[i * VEC + e] + a.ln_b[i * VEC + e]);
+            store16<T>(reinterpret_cast<T*>(a.XN) + ((long)blockIdx.x * 64 + t) * C + i * VEC, o);
         }
     }
     s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
@@ -461,14 +468,16 @@ extern "C" int mphsir_win_attn_bwd_fits(int32_t C, int32_t heads, int dtype) {
 }
 
 extern "C" int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const float* ln_w, void* dX, float* part,
-                                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream) {
+                                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, const float* ln_b, void* XN, int32_t linear,
+                                 int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(X && dXNw && dRes && ln_w && dX && part, "ln_bwd_win: null pointer");
     MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "ln_bwd_win: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(geom_ok(B, H, W, shift) && C > 0 && C % 32 == 0 && C <= 512, "ln_bwd_win: bad geometry");
     MPHSIR_REQUIRE(aligned16(X) && aligned16(dXNw) && aligned16(dRes) && aligned16(dX), "ln_bwd_win: 16-byte alignment required");
-    LnBwdDev d{X, dXNw, dRes, ln_w, dX, part, WinGeom{B, H, W, shift}, C};
+    MPHSIR_REQUIRE(!XN || ln_b, "ln_bwd_win: XN output needs ln_b");
+    LnBwdDev d{X, dXNw, dRes, ln_w, dX, part, WinGeom{B, H, W, shift}, C, ln_b, XN, linear};
     const size_t shmem = (64 * (size_t)(C + 4) + 256) * sizeof(float);
     const int nblk = B * (H / 8) * (W / 8);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -21,83 +21,113 @@ struct TnDev {
     long M; int N1, N2, nsplit;
 };
 
-template <class T>
+// R1, R2 in {1,2}: the workgroup's output tile is (64*R1) x (64*R2); wave w owns rows [16*R1*w, 16*R1*(w+1)).
+template <class T, int R1, int R2>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
     typedef ElemTraits<T> TR;
     constexpr int PAD = 16 / sizeof(T);
     constexpr int VEC = Vec16<T>::N;
-    constexpr int KT = 64, LDT = KT + PAD;
+    constexpr int KT = 64, LDT = KT + PAD, TN1 = 64 * R1, TN2 = 64 * R2;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    T* At = reinterpret_cast<T*>(smem_v);        // [64 n1][LDT]
-    T* Bt = At + 64 * LDT;                       // [64 n2][LDT]
+    T* At = reinterpret_cast<T*>(smem_v);        // [TN1][LDT]
+    T* Bt = At + TN1 * LDT;                      // [TN2][LDT]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int t2n = (a.N2 + 63) / 64;
-    const int n1_0 = (blockIdx.x / t2n) * 64, n2_0 = (blockIdx.x % t2n) * 64;
+    const int t2n = (a.N2 + TN2 - 1) / TN2;
+    const int n1_0 = (blockIdx.x / t2n) * TN1, n2_0 = (blockIdx.x % t2n) * TN2;
     const int sp = blockIdx.y, bz = blockIdx.z;
     const long per = ((a.M + a.nsplit - 1) / a.nsplit + KT - 1) / KT * KT;
     const long m_lo = (long)sp * per, m_hi = (m_lo + per < a.M) ? m_lo + per : a.M;
     const T* A = reinterpret_cast<const T*>(a.A) + (long)bz * a.abs;
     const T* B = reinterpret_cast<const T*>(a.B) + (long)bz * a.bbs;
 
-    f32x4 acc[4];
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[R1][4 * R2];
+#pragma unroll
+    for (int i = 0; i < R1; ++i)
+#pragma unroll
+        for (int j = 0; j < 4 * R2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // column sums of A ride along as one extra MFMA per K-chunk against an all-ones fragment (first n2 tile only)
     const bool do_cs = a.colsum != nullptr && (blockIdx.x % t2n) == 0;
-    f32x4 accs = {0.f, 0.f, 0.f, 0.f};
+    f32x4 accs[R1];
+#pragma unroll
+    for (int i = 0; i < R1; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     typename TR::frag_t ones;
     for (int e = 0; e < TR::EPL; ++e) ones[e] = from_f32<T>(1.0f);
-    // Staging: threads 0..127 transpose the A tile, 128..255 the B tile.  Each thread loads 4 consecutive token rows
-    // of one 16-byte column vector and writes, per column, the 4 tokens as ONE 8/16-byte LDS store (4x fewer LDS
-    // write instructions than element-wise transposition, which was the bottleneck of the first version).
-    constexpr int VPR = 64 / VEC;                // column vectors per 64-wide tile row
-    const int half = tid >> 7, ht = tid & 127;
-    const T* Src = half ? B : A;
-    const long lds = half ? a.ldb : a.lda;
-    const int ncol0 = half ? n2_0 : n1_0, nmax = half ? a.N2 : a.N1;
-    T* Dst = half ? Bt : At;
+    // Staging: each item = 4 consecutive token rows of one 16-byte column vector, written per column as ONE 8/16-byte
+    // LDS store (the MFMA K axis = tokens must be lane-contiguous, so both operand tiles are transposed on the way in).
+    constexpr int VPA = TN1 / VEC, VPB = TN2 / VEC, ITEMS_A = (KT / 4) * VPA, ITEMS_B = (KT / 4) * VPB;
     for (long m0 = m_lo; m0 < m_hi; m0 += KT) {
-        for (int v = ht; v < (KT / 4) * VPR; v += 128) {
-            const int rq = v / VPR, c = (v % VPR) * VEC;      // token quad, column vector
+        for (int v = tid; v < ITEMS_A + ITEMS_B; v += 256) {
+            const bool isb = v >= ITEMS_A;
+            const int u = isb ? v - ITEMS_A : v, vp = isb ? VPB : VPA;
+            const int rq = u / vp, c = (u % vp) * VEC;
+            const T* Src = isb ? B : A;
+            const long lds = isb ? a.ldb : a.lda;
+            const int col = (isb ? n2_0 : n1_0) + c, nmax = isb ? a.N2 : a.N1;
             Vec16<T> x[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const long m = m0 + rq * 4 + i;
-                if (m < m_hi && ncol0 + c < nmax) x[i] = load16<T>(Src + m * lds + ncol0 + c);
+                if (m < m_hi && col < nmax) x[i] = load16<T>(Src + m * lds + col);
                 else for (int e = 0; e < VEC; ++e) x[i].set(e, 0.f);
             }
+            T* Dst = (isb ? Bt : At) + c * LDT + rq * 4;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 f32x4 q = {x[0].get(e), x[1].get(e), x[2].get(e), x[3].get(e)};
-                store4<T>(Dst + (c + e) * LDT + rq * 4, q);
+                store4<T>(Dst + e * LDT, q);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < KT; kk += TR::KCHUNK) {
-            const typename TR::frag_t af = load_frag<T>(At, LDT, wv * 16, kk);
+            typename TR::frag_t af[R1];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) mma(acc[nt], af, load_frag<T>(Bt, LDT, nt * 16, kk));
-            if (do_cs) mma(accs, af, ones);
+            for (int i = 0; i < R1; ++i) af[i] = load_frag<T>(At, LDT, (wv * R1 + i) * 16, kk);
+#pragma unroll
+            for (int nt = 0; nt < 4 * R2; ++nt) {
+                const typename TR::frag_t bf = load_frag<T>(Bt, LDT, nt * 16, kk);
+#pragma unroll
+                for (int i = 0; i < R1; ++i) mma(acc[i][nt], af[i], bf);
+            }
+            if (do_cs)
+#pragma unroll
+                for (int i = 0; i < R1; ++i) mma(accs[i], af[i], ones);
         }
         __syncthreads();
     }
     float* Cp = a.Cp + (((long)bz * a.nsplit + sp) * a.N1) * a.N2;
-    for (int nt = 0; nt < 4; ++nt)
-        for (int r = 0; r < 4; ++r) {
-            const int n1 = n1_0 + wv * 16 + (lane >> 4) * 4 + r, n2 = n2_0 + nt * 16 + (lane & 15);
-            if (n1 < a.N1 && n2 < a.N2) Cp[(long)n1 * a.N2 + n2] = acc[nt][r];
-        }
+#pragma unroll
+    for (int i = 0; i < R1; ++i)
+#pragma unroll
+        for (int nt = 0; nt < 4 * R2; ++nt)
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = n1_0 + (wv * R1 + i) * 16 + (lane >> 4) * 4 + r, n2 = n2_0 + nt * 16 + (lane & 15);
+                if (n1 < a.N1 && n2 < a.N2) Cp[(long)n1 * a.N2 + n2] = acc[i][nt][r];
+            }
     if (do_cs && (lane & 15) == 0)
-        for (int r = 0; r < 4; ++r) {
-            const int n1 = n1_0 + wv * 16 + (lane >> 4) * 4 + r;
-            if (n1 < a.N1) a.colsum[((long)bz * a.nsplit + sp) * a.N1 + n1] = accs[r];
-        }
+#pragma unroll
+        for (int i = 0; i < R1; ++i)
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = n1_0 + (wv * R1 + i) * 16 + (lane >> 4) * 4 + r;
+                if (n1 < a.N1) a.colsum[((long)bz * a.nsplit + sp) * a.N1 + n1] = accs[i][r];
+            }
+}
+
+template <class T, int R1, int R2>
+static int launch_tn(const TnDev& d, int batch, hipStream_t s) {
+    constexpr int esz = sizeof(T), vec = 16 / esz;
+    dim3 grid(((d.N1 + 64 * R1 - 1) / (64 * R1)) * ((d.N2 + 64 * R2 - 1) / (64 * R2)), d.nsplit, batch);
+    const size_t shmem = (size_t)(64 * R1 + 64 * R2) * (64 + vec) * esz;
+    allow_big_lds(gemm_tn_kernel<T, R1, R2>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_kernel<T, R1, R2>), grid, dim3(256), shmem, s, d);
+    return MPHSIR_OK;
 }
 
 }  // namespace mphsir
 
 extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
-                              float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int dtype, void* stream) {
+                              float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int32_t tile128,
+                              int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(A && B && Cpart, "gemm_tn: null pointer");
@@ -108,12 +138,9 @@ extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride
     MPHSIR_REQUIRE(aligned16(A) && aligned16(B) && (lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0 &&
                        (a_batch_stride * esz) % 16 == 0 && (b_batch_stride * esz) % 16 == 0, "gemm_tn: 16-byte alignment required");
     TnDev d{A, (long)lda, (long)a_batch_stride, B, (long)ldb, (long)b_batch_stride, Cpart, colsum_part, (long)M, N1, N2, nsplit};
-    dim3 grid(((N1 + 63) / 64) * ((N2 + 63) / 64), nsplit, batch);
-    const size_t shmem = 2 * 64 * (64 + vec) * esz;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MPHSIR_F32)
-        MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_kernel<float>), grid, dim3(256), shmem, s, d);
-    else
-        MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_kernel<bf16_t>), grid, dim3(256), shmem, s, d);
+    const bool big = tile128 > 0;
+    if (dtype == MPHSIR_F32) return big ? launch_tn<float, 2, 2>(d, batch, s) : launch_tn<float, 1, 1>(d, batch, s);
+    return big ? launch_tn<bf16_t, 2, 2>(d, batch, s) : launch_tn<bf16_t, 1, 1>(d, batch, s);
     return MPHSIR_OK;
 }

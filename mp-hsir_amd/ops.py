@@ -354,13 +354,28 @@ def ln_bwd_win(x, dxn_w, dres, ln_w, shift):
     assert x.is_contiguous() and dxn_w.is_contiguous() and dres.is_contiguous()
     dx = torch.empty_like(x)
     part = torch.empty((B * H * W // 64, 2, C), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mphsir_ln_bwd_win(_p(x), _p(dxn_w), _p(dres), _p(ln_w), _p(dx), _p(part), B, H, W, C, shift,
+    _lib.check(lib.mphsir_ln_bwd_win(_p(x), _p(dxn_w), _p(dres), _p(ln_w), _p(dx), _p(part), B, H, W, C, shift, None, None, 0,
                                      _DT[x.dtype], _stream(x)), "ln_bwd_win")
     _acct("ln_bwd_win", 10.0 * x.numel(), 4.0 * x.numel() * x.element_size())
     return dx, part
 
 
-def gemm_tn(a, b, nsplit=None, colsum=False):
+def ln_bwd_tok(x2, dxn, dres, ln_w, ln_b):
+    """plain token order: (dx = dres + LN_backward(dxn), d ln weight, d ln bias, LN(x)) for x2 (M,C), M % 64 == 0."""
+    lib = _lib.load()
+    _check(x2, dxn, dres, ln_w, ln_b)
+    M, C = x2.shape
+    assert x2.is_contiguous() and dxn.is_contiguous() and dres.is_contiguous() and M % 64 == 0
+    dx, xn = torch.empty_like(x2), torch.empty_like(x2)
+    part = torch.empty((M // 64, 2, C), dtype=torch.float32, device=x2.device)
+    _lib.check(lib.mphsir_ln_bwd_win(_p(x2), _p(dxn), _p(dres), _p(ln_w), _p(dx), _p(part), M // 64, 8, 8, C, 0, _p(ln_b), _p(xn), 1,
+                                     _DT[x2.dtype], _stream(x2)), "ln_bwd_win")
+    _acct("ln_bwd_win", 12.0 * x2.numel(), 5.0 * x2.numel() * x2.element_size())
+    g = part.sum(dim=0)
+    return dx, g[0], g[1], xn
+
+
+def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None):
     """sum over tokens of a[m,:]^T b[m,:].  a (M,N1), b (M,N2) row-major views -> fp32 (N1,N2);
     batched: a (Bt,M,N1), b (Bt,M,N2) -> (Bt,N1,N2).  colsum=True also returns sum_m a[m,:] (fp32, (N1,))."""
     lib = _lib.load()
@@ -369,13 +384,17 @@ def gemm_tn(a, b, nsplit=None, colsum=False):
     Bt = a.shape[0] if batched else 1
     M, N1, N2 = a.shape[-2], a.shape[-1], b.shape[-1]
     assert a.stride(-1) == 1 and b.stride(-1) == 1 and b.shape[-2] == M and a.dtype == b.dtype
+    if tile128 is None:
+        tile128 = N1 >= 128 and N2 >= 128 and M * Bt >= 32768
     if nsplit is None:
-        tiles = ((N1 + 63) // 64) * ((N2 + 63) // 64) * Bt
-        nsplit = max(1, min(M // 512, max(1, 1536 // tiles)))
+        ts = 128 if tile128 else 64
+        tiles = ((N1 + ts - 1) // ts) * ((N2 + ts - 1) // ts) * Bt
+        nsplit = max(1, min(M // 512, 64, max(1, 1536 // tiles)))
     part = torch.empty((Bt, nsplit, N1, N2), dtype=torch.float32, device=a.device)
     cs = torch.empty((Bt, nsplit, N1), dtype=torch.float32, device=a.device) if colsum else None
     _lib.check(lib.mphsir_gemm_tn(_p(a), a.stride(-2), a.stride(0) if batched else 0, _p(b), b.stride(-2),
-                                  b.stride(0) if batched else 0, _p(part), _p(cs), M, N1, N2, nsplit, Bt, _DT[a.dtype], _stream(a)),
+                                  b.stride(0) if batched else 0, _p(part), _p(cs), M, N1, N2, nsplit, Bt, int(bool(tile128)),
+                                  _DT[a.dtype], _stream(a)),
                "gemm_tn")
     _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size() + part.numel() * 4.0)
     out = part.sum(dim=1) if nsplit > 1 else part[:, 0]

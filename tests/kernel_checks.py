@@ -226,13 +226,13 @@ def check_gated_mlp_bwd(dev, dtype, C, hid):
     assert rel_l2(dln[0], lw.grad) < tol and rel_l2(dln[1], lb.grad) < tol
 
 
-def check_gemm_tn(dev, dtype, M, N1, N2, nsplit, batch):
+def check_gemm_tn(dev, dtype, M, N1, N2, nsplit, batch, tile128=None):
     _use(dev)
     from mp_hsir_amd import ops
     shape_a = (batch, M, N1) if batch else (M, N1)
     shape_b = (batch, M, N2) if batch else (M, N2)
     a, b = rnd(shape_a, 51, dtype), rnd(shape_b, 52, dtype)
-    c, cs = ops.gemm_tn(a, b, nsplit=nsplit, colsum=True)
+    c, cs = ops.gemm_tn(a, b, nsplit=nsplit, colsum=True, tile128=tile128)
     ref = a.double().cpu().transpose(-1, -2) @ b.double().cpu()
     assert rel_l2(c, ref) < (3e-6 if dtype == torch.float32 else 1e-2)
     assert rel_l2(cs, a.double().cpu().sum(dim=-2)) < (3e-6 if dtype == torch.float32 else 1e-2)

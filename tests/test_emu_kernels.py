@@ -66,6 +66,11 @@ def test_gemm_tn(dtype, M, N1, N2, nsplit, batch):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
+def test_gemm_tn_tile128(dtype):
+    K.check_gemm_tn("cpu", dtype, 192, 160, 136, 2, 0, tile128=True)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 8, 31, 32), (2, 8, 4, 32, 31), (1, 8, 8, 64, 48)])
 def test_conv3x3(dtype, B, H, W, Cin, Cout):
     K.check_conv3x3("cpu", dtype, B, H, W, Cin, Cout)
