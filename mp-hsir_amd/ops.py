@@ -385,7 +385,7 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None):
     M, N1, N2 = a.shape[-2], a.shape[-1], b.shape[-1]
     assert a.stride(-1) == 1 and b.stride(-1) == 1 and b.shape[-2] == M and a.dtype == b.dtype
     if tile128 is None:
-        tile128 = N1 >= 128 and N2 >= 128 and M * Bt >= 32768
+        tile128 = False      # measured on MI355X: 128x128 tiles are slower here (fewer workgroups, lower occupancy)
     if nsplit is None:
         ts = 128 if tile128 else 64
         tiles = ((N1 + ts - 1) // ts) * ((N2 + ts - 1) // ts) * Bt
