@@ -70,24 +70,35 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwWgDev a) {
     float acc[9][VEC];
     for (int t = 0; t < 9; ++t)
         for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
-    if (live)
+    // software pipeline: the 10 vectors of the next pixel are in flight while the current pixel is accumulated
+    // (out-of-image taps load as zeros, so the accumulate step has no branches)
+    Vec16<T> cg, cx[9], ng, nx[9];
+    auto fetch = [&](long pix, Vec16<T>& g, Vec16<T> (&xs)[9]) {
+        const int b = (int)(pix / HW), p = (int)(pix % HW), y = p / a.W, x = p % a.W;
+        g = load16<T>(dY + pix * a.lddy + c0);
+        const T* base = X + (long)b * HW * a.ldx;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) xs[t] = load16<T>(base + ((long)yy * a.W + xx) * a.ldx + c0);
+            else for (int e = 0; e < VEC; ++e) xs[t].set(e, 0.f);
+        }
+    };
+    if (live && p_lo + wv < p_hi) {
+        fetch(p_lo + wv, cg, cx);
         for (long pix = p_lo + wv; pix < p_hi; pix += 4) {
-            const int b = (int)(pix / HW), p = (int)(pix % HW), y = p / a.W, x = p % a.W;
-            const Vec16<T> g = load16<T>(dY + pix * a.lddy + c0);
-            const T* base = X + (long)b * HW * a.ldx;
+            const bool more = pix + 4 < p_hi;
+            if (more) fetch(pix + 4, ng, nx);
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int yy = y + dy;
-                if (yy < 0 || yy >= a.H) continue;
+            for (int t = 0; t < 9; ++t)
+                for (int e = 0; e < VEC; ++e) acc[t][e] += cx[t].get(e) * cg.get(e);
+            if (more) {
+                cg = ng;
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int xx = x + dx;
-                    if (xx < 0 || xx >= a.W) continue;
-                    const Vec16<T> t = load16<T>(base + ((long)yy * a.W + xx) * a.ldx + c0);
-                    for (int e = 0; e < VEC; ++e) acc[(dy + 1) * 3 + (dx + 1)][e] += t.get(e) * g.get(e);
-                }
+                for (int t = 0; t < 9; ++t) cx[t] = nx[t];
             }
         }
+    }
     // cross-wave reduction in wave order through one [64][9*VEC] buffer (18 KB: keeps 4+ workgroups per CU resident)
     float* mine = red + (lane * 9) * VEC;
     for (int w = 0; w < 4; ++w) {

@@ -32,9 +32,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
     T* At = reinterpret_cast<T*>(smem_v);        // [TN1][LDT]
     T* Bt = At + TN1 * LDT;                      // [TN2][LDT]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int t2n = (a.N2 + TN2 - 1) / TN2;
-    const int n1_0 = (blockIdx.x / t2n) * TN1, n2_0 = (blockIdx.x % t2n) * TN2;
-    const int sp = blockIdx.y, bz = blockIdx.z;
+    const int t2n = (a.N2 + TN2 - 1) / TN2, ntiles = ((a.N1 + TN1 - 1) / TN1) * t2n;
+    // XCD-aware block -> (token split, output tile) map: workgroups are dealt round-robin over the 8 XCDs (blocks L and
+    // L+8 share an L2), so tile = (L/8) % ntiles, split = L%8 + 8*(L/(8*ntiles)) puts all tiles of one token range on
+    // one XCD: the operand rows they share are fetched from HBM once and re-read from that L2.  (Speed only.)
+    const int L = blockIdx.x;
+    const int tile = (L >> 3) % ntiles, sp = (L & 7) + 8 * (L / (8 * ntiles)), bz = blockIdx.z;
+    if (sp >= a.nsplit) return;
+    const int n1_0 = (tile / t2n) * TN1, n2_0 = (tile % t2n) * TN2;
     const long per = ((a.M + a.nsplit - 1) / a.nsplit + KT - 1) / KT * KT;
     const long m_lo = (long)sp * per, m_hi = (m_lo + per < a.M) ? m_lo + per : a.M;
     const T* A = reinterpret_cast<const T*>(a.A) + (long)bz * a.abs;
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
 #pragma unroll
         for (int j = 0; j < 4 * R2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // column sums of A ride along as one extra MFMA per K-chunk against an all-ones fragment (first n2 tile only)
-    const bool do_cs = a.colsum != nullptr && (blockIdx.x % t2n) == 0;
+    const bool do_cs = a.colsum != nullptr && (tile % t2n) == 0;
     f32x4 accs[R1];
 #pragma unroll
     for (int i = 0; i < R1; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -55,29 +60,41 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
     // Staging: each item = 4 consecutive token rows of one 16-byte column vector, written per column as ONE 8/16-byte
     // LDS store (the MFMA K axis = tokens must be lane-contiguous, so both operand tiles are transposed on the way in).
     constexpr int VPA = TN1 / VEC, VPB = TN2 / VEC, ITEMS_A = (KT / 4) * VPA, ITEMS_B = (KT / 4) * VPB;
-    for (long m0 = m_lo; m0 < m_hi; m0 += KT) {
-        for (int v = tid; v < ITEMS_A + ITEMS_B; v += 256) {
+    constexpr int NI = (ITEMS_A + ITEMS_B) / 256;          // items per thread (1 for bf16 64x64 tiles)
+    static_assert((ITEMS_A + ITEMS_B) % 256 == 0, "tile staging must divide evenly over the workgroup");
+    Vec16<T> x[NI][4];                                     // register stage: next K-step's rows are in flight during the MFMAs
+    auto gload = [&](long m0) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int v = tid + 256 * it;
             const bool isb = v >= ITEMS_A;
-            const int u = isb ? v - ITEMS_A : v, vp = isb ? VPB : VPA;
-            const int rq = u / vp, c = (u % vp) * VEC;
+            const int u = isb ? v - ITEMS_A : v;
+            const int rq = u & 15, c = (u >> 4) * VEC;        // token quad fastest: conflict-free transposed LDS stores
             const T* Src = isb ? B : A;
             const long lds = isb ? a.ldb : a.lda;
             const int col = (isb ? n2_0 : n1_0) + c, nmax = isb ? a.N2 : a.N1;
-            Vec16<T> x[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const long m = m0 + rq * 4 + i;
-                if (m < m_hi && col < nmax) x[i] = load16<T>(Src + m * lds + col);
-                else for (int e = 0; e < VEC; ++e) x[i].set(e, 0.f);
-            }
-            T* Dst = (isb ? Bt : At) + c * LDT + rq * 4;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                f32x4 q = {x[0].get(e), x[1].get(e), x[2].get(e), x[3].get(e)};
-                store4<T>(Dst + e * LDT, q);
+                if (m < m_hi && col < nmax) x[it][i] = load16<T>(Src + m * lds + col);
+                else x[it][i] = Vec16<T>{};
             }
         }
+    };
+    gload(m_lo);
+    for (long m0 = m_lo; m0 < m_hi; m0 += KT) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int v = tid + 256 * it;
+            const bool isb = v >= ITEMS_A;
+            const int u = isb ? v - ITEMS_A : v;
+            const int rq = u & 15, c = (u >> 4) * VEC;
+            T* Dst = (isb ? Bt : At) + c * LDT + rq * 4;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) store_quad(Dst + e * LDT, x[it][0], x[it][1], x[it][2], x[it][3], e);
+        }
         __syncthreads();
+        if (m0 + KT < m_hi) gload(m0 + KT);
 #pragma unroll
         for (int kk = 0; kk < KT; kk += TR::KCHUNK) {
             typename TR::frag_t af[R1];
@@ -116,7 +133,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
 template <class T, int R1, int R2>
 static int launch_tn(const TnDev& d, int batch, hipStream_t s) {
     constexpr int esz = sizeof(T), vec = 16 / esz;
-    dim3 grid(((d.N1 + 64 * R1 - 1) / (64 * R1)) * ((d.N2 + 64 * R2 - 1) / (64 * R2)), d.nsplit, batch);
+    const int ntiles = ((d.N1 + 64 * R1 - 1) / (64 * R1)) * ((d.N2 + 64 * R2 - 1) / (64 * R2));
+    dim3 grid(ntiles * ((d.nsplit + 7) / 8 * 8), 1, batch);
     const size_t shmem = (size_t)(64 * R1 + 64 * R2) * (64 + vec) * esz;
     allow_big_lds(gemm_tn_kernel<T, R1, R2>, shmem);
     MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_kernel<T, R1, R2>), grid, dim3(256), shmem, s, d);

@@ -91,6 +91,17 @@ template <> struct Vec16<bf16_t> {
     __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
     __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
 };
+// gather element e of four 16-byte vectors into 4 consecutive elements at p (a 4-row transpose step) without a
+// float round trip: pure register shuffles
+__device__ __forceinline__ void store_quad(float* p, const Vec16<float>& a, const Vec16<float>& b, const Vec16<float>& c,
+                                           const Vec16<float>& d, int e) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{a.v[e], b.v[e], c.v[e], d.v[e]};
+}
+__device__ __forceinline__ void store_quad(bf16_t* p, const Vec16<bf16_t>& a, const Vec16<bf16_t>& b, const Vec16<bf16_t>& c,
+                                           const Vec16<bf16_t>& d, int e) {
+    *reinterpret_cast<bf16x4*>(p) = bf16x4{a.v[e], b.v[e], c.v[e], d.v[e]};
+}
+
 template <class T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
     Vec16<T> r;
     r.v = *reinterpret_cast<const decltype(r.v)*>(p);

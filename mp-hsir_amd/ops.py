@@ -389,7 +389,7 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None):
     if nsplit is None:
         ts = 128 if tile128 else 64
         tiles = ((N1 + ts - 1) // ts) * ((N2 + ts - 1) // ts) * Bt
-        nsplit = max(1, min(M // 512, 64, max(1, 1536 // tiles)))
+        nsplit = max(1, min(M // 512, 64, max(1, 768 // tiles)))      # ~3 workgroups per CU (measured optimum)
     part = torch.empty((Bt, nsplit, N1, N2), dtype=torch.float32, device=a.device)
     cs = torch.empty((Bt, nsplit, N1), dtype=torch.float32, device=a.device) if colsum else None
     _lib.check(lib.mphsir_gemm_tn(_p(a), a.stride(-2), a.stride(0) if batched else 0, _p(b), b.stride(-2),
