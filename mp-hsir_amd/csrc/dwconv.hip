@@ -15,36 +15,53 @@ struct DwDev {
     int B, H, W, C, flip;
 };
 
+// One thread = one 16-byte channel vector x one strip of DW_S pixels along x.  The 9 taps (fp32) live in registers and
+// the 3x3 neighbourhood slides: 3 new vector loads per output pixel instead of 9 + 18 (taps) -- the first version was
+// bound by L1/TA bandwidth (432 B of vector-memory traffic per 16-byte output), not by HBM.
+constexpr int DW_S = 8;
+
 template <class T>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwDev a) {
     constexpr int VEC = Vec16<T>::N;
-    const int cv = a.C / VEC, HW = a.H * a.W;
-    const long total = (long)a.B * HW * cv;
-    const T* X = reinterpret_cast<const T*>(a.X);
-    T* Y = reinterpret_cast<T*>(a.Y);
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long pix = idx / cv;
-        const int c0 = (int)(idx % cv) * VEC, b = (int)(pix / HW), p = (int)(pix % HW), y = p / a.W, x = p % a.W;
-        const T* base = X + (long)b * HW * a.ldx;
+    const int cv = a.C / VEC, nsx = a.W / DW_S;
+    const long total = (long)a.B * a.H * nsx * cv;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c0 = (int)(idx % cv) * VEC;
+    long q = idx / cv;
+    const int x0 = (int)(q % nsx) * DW_S;  q /= nsx;
+    const int y = (int)(q % a.H), b = (int)(q / a.H);
+    const T* X = reinterpret_cast<const T*>(a.X) + (long)b * a.H * a.W * a.ldx + c0;
+    T* Y = reinterpret_cast<T*>(a.Y) + (long)b * a.H * a.W * a.ldy + c0;
+    float w[9][VEC];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        for (int e = 0; e < VEC; ++e) w[t][e] = a.w9[(a.flip ? 8 - t : t) * a.ldw + c0 + e];
+    auto column = [&](int x, Vec16<T> (&col)[3]) {      // rows y-1, y, y+1 of column x (zeros outside the image)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            if (x >= 0 && x < a.W && yy >= 0 && yy < a.H) col[r] = load16<T>(X + ((long)yy * a.W + x) * a.ldx);
+            else col[r] = Vec16<T>{};
+        }
+    };
+    Vec16<T> cl[3], cm[3], cr[3];
+    column(x0 - 1, cl);
+    column(x0, cm);
+#pragma unroll
+    for (int i = 0; i < DW_S; ++i) {
+        column(x0 + i + 1, cr);
         float acc[VEC];
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= a.H) continue;
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = x + dx;
-                if (xx < 0 || xx >= a.W) continue;
-                const int tap = a.flip ? (1 - dy) * 3 + (1 - dx) : (dy + 1) * 3 + (dx + 1);
-                const Vec16<T> t = load16<T>(base + ((long)yy * a.W + xx) * a.ldx + c0);
-                const float* w = a.w9 + tap * a.ldw + c0;
-                for (int e = 0; e < VEC; ++e) acc[e] += t.get(e) * w[e];
-            }
-        }
+        for (int r = 0; r < 3; ++r)
+            for (int e = 0; e < VEC; ++e)
+                acc[e] += cl[r].get(e) * w[r * 3][e] + cm[r].get(e) * w[r * 3 + 1][e] + cr[r].get(e) * w[r * 3 + 2][e];
         Vec16<T> o;
         for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
-        store16<T>(Y + pix * a.ldy + c0, o);
+        store16<T>(Y + ((long)y * a.W + x0 + i) * a.ldy, o);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
     }
 }
 
@@ -63,42 +80,47 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwWgDev a) {
     const int cvec = blockIdx.y * 64 + lane, c0 = cvec * VEC;
     const bool live = c0 < a.C;
     const int HW = a.H * a.W;
-    const long P = (long)a.B * HW, per = (P + a.nblk - 1) / a.nblk;
+    const long P = (long)a.B * HW, per = ((P + a.nblk - 1) / a.nblk + DW_S - 1) / DW_S * DW_S;   // whole strips per block
     const long p_lo = (long)blockIdx.x * per, p_hi = (p_lo + per < P) ? p_lo + per : P;
     const T* X = reinterpret_cast<const T*>(a.X);
     const T* dY = reinterpret_cast<const T*>(a.dY);
     float acc[9][VEC];
     for (int t = 0; t < 9; ++t)
         for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
-    // software pipeline: the 10 vectors of the next pixel are in flight while the current pixel is accumulated
-    // (out-of-image taps load as zeros, so the accumulate step has no branches)
-    Vec16<T> cg, cx[9], ng, nx[9];
-    auto fetch = [&](long pix, Vec16<T>& g, Vec16<T> (&xs)[9]) {
-        const int b = (int)(pix / HW), p = (int)(pix % HW), y = p / a.W, x = p % a.W;
-        g = load16<T>(dY + pix * a.lddy + c0);
-        const T* base = X + (long)b * HW * a.ldx;
+    // each wave walks strips of DW_S pixels along x with a sliding 3x3 window: 3 new x vectors + 1 dy vector per pixel
+    const long s_lo = p_lo / DW_S, s_hi = p_hi / DW_S;
+    if (live)
+        for (long sidx = s_lo + wv; sidx < s_hi; sidx += 4) {
+            const long pix0 = sidx * DW_S;
+            const int b = (int)(pix0 / HW), p = (int)(pix0 % HW), y = p / a.W, x0 = p % a.W;
+            const T* base = X + (long)b * HW * a.ldx + c0;
+            auto column = [&](int x, Vec16<T> (&col)[3]) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) xs[t] = load16<T>(base + ((long)yy * a.W + xx) * a.ldx + c0);
-            else for (int e = 0; e < VEC; ++e) xs[t].set(e, 0.f);
-        }
-    };
-    if (live && p_lo + wv < p_hi) {
-        fetch(p_lo + wv, cg, cx);
-        for (long pix = p_lo + wv; pix < p_hi; pix += 4) {
-            const bool more = pix + 4 < p_hi;
-            if (more) fetch(pix + 4, ng, nx);
+                for (int r = 0; r < 3; ++r) {
+                    const int yy = y + r - 1;
+                    if (x >= 0 && x < a.W && yy >= 0 && yy < a.H) col[r] = load16<T>(base + ((long)yy * a.W + x) * a.ldx);
+                    else col[r] = Vec16<T>{};
+                }
+            };
+            Vec16<T> cl[3], cm[3], cr[3];
+            column(x0 - 1, cl);
+            column(x0, cm);
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-                for (int e = 0; e < VEC; ++e) acc[t][e] += cx[t].get(e) * cg.get(e);
-            if (more) {
-                cg = ng;
+            for (int i = 0; i < DW_S; ++i) {
+                column(x0 + i + 1, cr);
+                const Vec16<T> g = load16<T>(dY + (pix0 + i) * a.lddy + c0);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) cx[t] = nx[t];
+                for (int r = 0; r < 3; ++r)
+                    for (int e = 0; e < VEC; ++e) {
+                        const float ge = g.get(e);
+                        acc[r * 3][e] += cl[r].get(e) * ge;
+                        acc[r * 3 + 1][e] += cm[r].get(e) * ge;
+                        acc[r * 3 + 2][e] += cr[r].get(e) * ge;
+                    }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
             }
         }
-    }
     // cross-wave reduction in wave order through one [64][9*VEC] buffer (18 KB: keeps 4+ workgroups per CU resident)
     float* mine = red + (lane * 9) * VEC;
     for (int w = 0; w < 4; ++w) {
@@ -187,8 +209,8 @@ extern "C" int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int
     MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0, "dwconv3x3: C must be a multiple of %d", vec);
     MPHSIR_REQUIRE(aligned16(X) && aligned16(Y) && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0, "dwconv3x3: 16-byte alignment required");
     DwDev d{X, (long)ldx, w9, (long)ldw, Y, (long)ldy, B, H, W, C, flip};
-    long blocks = ((long)B * H * W * (C / vec) + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    MPHSIR_REQUIRE(W % DW_S == 0, "dwconv3x3: W must be a multiple of %d", DW_S);
+    const long blocks = ((long)B * H * (W / DW_S) * (C / vec) + 255) / 256;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV, (dwconv3x3_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
@@ -204,7 +226,7 @@ extern "C" int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY
     MPHSIR_REQUIRE(X && dY && partial, "dwconv3x3_wgrad: null pointer");
     MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "dwconv3x3_wgrad: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2, vec = 16 / esz;
-    MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0 && nblk > 0, "dwconv3x3_wgrad: bad shape");
+    MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0 && nblk > 0 && W % DW_S == 0, "dwconv3x3_wgrad: bad shape");
     MPHSIR_REQUIRE(aligned16(X) && aligned16(dY) && (ldx * esz) % 16 == 0 && (lddy * esz) % 16 == 0, "dwconv3x3_wgrad: 16-byte alignment required");
     DwWgDev d{X, (long)ldx, dY, (long)lddy, partial, B, H, W, C, nblk};
     const size_t shmem = 64 * 9 * vec * sizeof(float);

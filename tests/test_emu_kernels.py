@@ -48,7 +48,7 @@ def test_gdfn_chain(dtype):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
-@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 5, 7, 96)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 5, 8, 96)])
 def test_dwconv_plain(dtype, shape):
     K.check_dwconv_plain("cpu", dtype, shape)
 
