@@ -136,6 +136,147 @@ __global__ __launch_bounds__(256) void dwconv_gram_kernel(GramDev a) {
     }
 }
 
+// ---- dwconv_gram, second form: the depthwise pass of ALL heads of a 64-pixel tile runs first with a sliding 3x3
+// window (one thread = one channel vector x one strip of 8 pixels x one of q/k/v: 3 loads per output instead of 27,
+// the first form was L1/TA-bandwidth bound), q and k land transposed in LDS as whole 16-byte rows of 8 pixels, then
+// the per-head Gram / sum-of-squares reductions run from LDS exactly as before.
+template <class T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    Vec16<bf16_t> o;
+    for (int i = 0; i < 8; ++i) o.set(i, v[i]);
+    store16<bf16_t>(p, o);
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+template <class T, int C, int HD>
+__global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
+    typedef ElemTraits<T> TR;
+    constexpr int PAD = 16 / sizeof(T);
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int HEADS = C / HD;
+    constexpr int LDT = 64 + PAD;
+    constexpr int NT = HD / 16;
+    constexpr int SLOTS = (NT * NT + 3) / 4;
+    constexpr int CV = C / VEC;
+    constexpr int NSQ = (2 * C + 255) / 256;             // rows of [q;k] per thread for the sums of squares
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    T* qT = reinterpret_cast<T*>(smem_v);                // [C][LDT]
+    T* kT = qT + C * LDT;                                // [C][LDT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
+    const int HW = a.H * a.W, tiles = HW / 64, tpw = tiles / a.nsplit;
+    const long img = (long)b * HW;
+    T* V = reinterpret_cast<T*>(a.V) + img * a.ldvo;
+
+    f32x4 g[HEADS][SLOTS];
+    float ssq[NSQ];
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h)
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) g[h][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NSQ; ++i) ssq[i] = 0.f;
+
+    for (int tile = sp * tpw; tile < (sp + 1) * tpw; ++tile) {
+        for (int it = tid; it < 3 * CV * 8; it += 256) {
+            const int which = it / (CV * 8), rem = it % (CV * 8), cvec = rem % CV, st = rem / CV;
+            const int c0 = cvec * VEC;
+            const int p0 = tile * 64 + st * 8, y = p0 / a.W, x0 = p0 % a.W;
+            const T* src = (which == 0 ? reinterpret_cast<const T*>(a.Tq) + img * a.ldq
+                            : which == 1 ? reinterpret_cast<const T*>(a.Tk) + img * a.ldk
+                                         : reinterpret_cast<const T*>(a.Tv) + img * a.ldv) + c0;
+            const long ld = which == 0 ? a.ldq : which == 1 ? a.ldk : a.ldv;
+            const float* wsrc = (which == 0 ? a.wq : which == 1 ? a.wk : a.wv) + c0;
+            float w[9][VEC];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                for (int e = 0; e < VEC; ++e) w[t][e] = wsrc[t * a.ldw + e];
+            auto column = [&](int x, Vec16<T> (&col)[3]) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int yy = y + r - 1;
+                    if (x >= 0 && x < a.W && yy >= 0 && yy < a.H) col[r] = load16<T>(src + ((long)yy * a.W + x) * ld);
+                    else col[r] = Vec16<T>{};
+                }
+            };
+            Vec16<T> cl[3], cm[3], cr[3];
+            float out[VEC][8];
+            column(x0 - 1, cl);
+            column(x0, cm);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                column(x0 + i + 1, cr);
+                for (int e = 0; e < VEC; ++e) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        s += cl[r].get(e) * w[r * 3][e] + cm[r].get(e) * w[r * 3 + 1][e] + cr[r].get(e) * w[r * 3 + 2][e];
+                    out[e][i] = s;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
+            }
+            if (which < 2) {
+                T* dst = (which == 0 ? qT : kT) + c0 * LDT + st * 8;
+                for (int e = 0; e < VEC; ++e) store8<T>(dst + e * LDT, out[e]);
+            } else {
+                for (int i = 0; i < 8; ++i) {
+                    Vec16<T> o;
+                    for (int e = 0; e < VEC; ++e) o.set(e, out[e][i]);
+                    store16<T>(V + (long)(p0 + i) * a.ldvo + c0, o);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NSQ; ++i) {
+            const int row = tid + 256 * i;
+            if (row < 2 * C) {
+                const T* rp = qT + row * LDT;                // rows C..2C-1 are kT (contiguous)
+                float s = 0.f;
+                for (int j = 0; j < 64; ++j) { const float v = to_f32(rp[j]); s += v * v; }
+                ssq[i] += s;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h)
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int t = wv + 4 * s;
+                if (t < NT * NT) {
+                    const int ti = t / NT, tj = t % NT;
+#pragma unroll
+                    for (int kk = 0; kk < 64; kk += TR::KCHUNK)
+                        mma(g[h][s], load_frag<T>(qT + h * HD * LDT, LDT, ti * 16, kk), load_frag<T>(kT + h * HD * LDT, LDT, tj * 16, kk));
+                }
+            }
+        __syncthreads();
+    }
+
+    float* Gp = a.Gpart + (long)blockIdx.x * HEADS * HD * HD;
+    float* Sp = a.Spart + (long)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h)
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int t = wv + 4 * s;
+            if (t < NT * NT) {
+                const int ti = t / NT, tj = t % NT;
+                for (int r = 0; r < 4; ++r)
+                    Gp[(h * HD + ti * 16 + (lane >> 4) * 4 + r) * HD + tj * 16 + (lane & 15)] = g[h][s][r];
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < NSQ; ++i) {
+        const int row = tid + 256 * i;
+        if (row < 2 * C) Sp[row] = ssq[i];                   // [2][C]: q rows then k rows
+    }
+}
+
 struct FoldDev {
     const float* Gpart; const float* Spart; int nsplit;
     const float* temperature;   // [HEADS]
@@ -213,29 +354,66 @@ struct GateDev {
 };
 
 // GDFN middle (FFN/FeedForward.forward net/MP_HSIR.py:261-263, :387-389): u = gelu(dw(t)[:HP]) * dw(t)[HP:]
+// One thread = one channel vector x one strip of 8 pixels; both halves slide a 3x3 window (3 loads per output).
 template <class T>
 __global__ __launch_bounds__(256) void dwconv_gate_kernel(GateDev a) {
-    constexpr int VEC = Vec16<T>::N;
-    const int vpp = a.HP / VEC, HW = a.H * a.W;
-    const long total = (long)a.B * HW * vpp;
-    const T* Tin = reinterpret_cast<const T*>(a.Tin);
-    T* U = reinterpret_cast<T*>(a.U);
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long pix = idx / vpp;
-        const int c0 = (int)(idx % vpp) * VEC, b = (int)(pix / HW), p = (int)(pix % HW), y = p / a.W, x = p % a.W;
-        const T* base = Tin + (long)b * HW * a.ldt;
-        float v1[VEC], v2[VEC];
-        dw3x3_vec<T>(base, a.ldt, a.w9, a.ldw, c0, y, x, a.H, a.W, v1);
-        dw3x3_vec<T>(base, a.ldt, a.w9, a.ldw, a.HP + c0, y, x, a.H, a.W, v2);
+    constexpr int VEC = Vec16<T>::N, S = 8;
+    const int vpp = a.HP / VEC, nsx = a.W / S;
+    const long total = (long)a.B * a.H * nsx * vpp;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c0 = (int)(idx % vpp) * VEC;
+    long q = idx / vpp;
+    const int x0 = (int)(q % nsx) * S;  q /= nsx;
+    const int y = (int)(q % a.H), b = (int)(q / a.H);
+    const T* Tin = reinterpret_cast<const T*>(a.Tin) + (long)b * a.H * a.W * a.ldt;
+    T* U = reinterpret_cast<T*>(a.U) + (long)b * a.H * a.W * a.ldu + c0;
+    float w1[9][VEC], w2[9][VEC];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        for (int e = 0; e < VEC; ++e) { w1[t][e] = a.w9[t * a.ldw + c0 + e]; w2[t][e] = a.w9[t * a.ldw + a.HP + c0 + e]; }
+    auto column = [&](int x, int ch, Vec16<T> (&col)[3]) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = y + r - 1;
+            if (x >= 0 && x < a.W && yy >= 0 && yy < a.H) col[r] = load16<T>(Tin + ((long)yy * a.W + x) * a.ldt + ch);
+            else col[r] = Vec16<T>{};
+        }
+    };
+    Vec16<T> al[3], am[3], ar[3], bl[3], bm[3], br[3];
+    column(x0 - 1, c0, al); column(x0, c0, am);
+    column(x0 - 1, a.HP + c0, bl); column(x0, a.HP + c0, bm);
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        column(x0 + i + 1, c0, ar);
+        column(x0 + i + 1, a.HP + c0, br);
         Vec16<T> o;
-        for (int e = 0; e < VEC; ++e) o.set(e, gelu_erf(v1[e]) * v2[e]);
-        store16<T>(U + pix * a.ldu + c0, o);
+        for (int e = 0; e < VEC; ++e) {
+            float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                v1 += al[r].get(e) * w1[r * 3][e] + am[r].get(e) * w1[r * 3 + 1][e] + ar[r].get(e) * w1[r * 3 + 2][e];
+                v2 += bl[r].get(e) * w2[r * 3][e] + bm[r].get(e) * w2[r * 3 + 1][e] + br[r].get(e) * w2[r * 3 + 2][e];
+            }
+            o.set(e, gelu_erf(v1) * v2);
+        }
+        store16<T>(U + ((long)y * a.W + x0 + i) * a.ldu, o);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { al[r] = am[r]; am[r] = ar[r]; bl[r] = bm[r]; bm[r] = br[r]; }
     }
 }
 
 template <class T, int C, int HD>
 static int launch_gram(const GramDev& d, hipStream_t s) {
     constexpr int PAD = 16 / sizeof(T);
+    constexpr size_t shmem2 = 2 * (size_t)C * (64 + PAD) * sizeof(T);
+    if constexpr (shmem2 <= 160 * 1024) {
+        if (d.W % 8 == 0) {
+            allow_big_lds(dwconv_gram2_kernel<T, C, HD>, shmem2);
+            MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GRAM, (dwconv_gram2_kernel<T, C, HD>), dim3(d.B * d.nsplit), dim3(256), shmem2, s, d);
+            return MPHSIR_OK;
+        }
+    }
     const size_t shmem = 2 * HD * (64 + PAD) * sizeof(T);
     allow_big_lds(dwconv_gram_kernel<T, C, HD>, shmem);
     MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GRAM, (dwconv_gram_kernel<T, C, HD>), dim3(d.B * d.nsplit), dim3(256), shmem, s, d);
@@ -307,9 +485,9 @@ extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* st
     MPHSIR_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->HP > 0 && a->HP % 8 == 0, "dwconv_gate: bad shape");
     MPHSIR_REQUIRE(aligned16(a->T) && aligned16(a->U) && (a->ldt * esz) % 16 == 0 && (a->ldu * esz) % 16 == 0, "dwconv_gate: 16-byte alignment required");
     GateDev d{a->T, (long)a->ldt, a->w9, (long)a->ldw, a->U, (long)a->ldu, a->B, a->H, a->W, a->HP};
-    const long total = (long)a->B * a->H * a->W * (a->HP / (16 / esz));
-    long blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    MPHSIR_REQUIRE(a->W % 8 == 0, "dwconv_gate: W must be a multiple of 8");
+    const long total = (long)a->B * a->H * (a->W / 8) * (a->HP / (16 / esz));
+    const long blocks = (total + 255) / 256;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
