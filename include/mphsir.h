@@ -281,6 +281,24 @@ int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void* dT, int64
 int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int32_t step, float grad_scale, const float* hyper, void* stream);
 
+/* ---- flat-arena utilities -------------------------------------------------------------------------
+ * reduce_parts: dst[b][i] = sum_{s < nsplit} src[b*src_batch_stride + s*stride + i], i < n, b < nbatch, summed in a
+ * fixed order (a function of nsplit and n only: deterministic), for up to MPHSIR_REDUCE_MAX_SEGS independent segments in ONE launch.  Replaces the
+ * at::sum the reference's autograd runs per parameter gradient (train.py:58-67) for every split-M partial buffer
+ * the backward kernels of this library write.  All pointers fp32 device memory.                        */
+#define MPHSIR_REDUCE_MAX_SEGS 32
+typedef struct mphsir_reduce_seg {
+    const float* src; float* dst;
+    int64_t n, stride, src_batch_stride, dst_batch_stride;
+    int32_t nsplit, nbatch;
+} mphsir_reduce_seg;
+int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, void* stream);
+
+/* pack_gather: dst[i] = index[i] >= 0 ? (T)arena[index[i]] : 0 for i < n (n % (16/sizeof(T)) == 0).  One launch
+ * rebuilds every kernel-layout weight tensor (cast, zero padding, transposes, value|gate splits) from the flat fp32
+ * parameter arena after an optimizer step; `index` is static (built once from the packers on the host side).   */
+int mphsir_pack_gather(const float* arena, const int32_t* index, void* dst, int64_t n, int dtype, void* stream);
+
 /* ---- optional per-kernel launch timer (bench.py roofline leg) ----------------------------------
  * When enabled for kernel id `kid`, every launch of that kernel is bracketed by hipEvents on its
  * own stream.  read(): synchronises the recorded events, returns the number of launches and their
@@ -304,6 +322,8 @@ int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, f
 #define MPHSIR_K_PG_GATE_BWD 16
 #define MPHSIR_K_CONV3X3 17
 #define MPHSIR_K_IM2COL 18
+#define MPHSIR_K_REDUCE_PARTS 19
+#define MPHSIR_K_PACK_GATHER 20
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -83,6 +83,15 @@ class PgBwdArgs(ctypes.Structure):
                                          "dmu", "L", "R")] + [(n, c_int32) for n in ("nW", "C", "r", "KL", "KR")]
 
 
+class ReduceSeg(ctypes.Structure):
+    """mirror of struct mphsir_reduce_seg"""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("n", c_int64), ("stride", c_int64), ("src_batch_stride", c_int64),
+                ("dst_batch_stride", c_int64), ("nsplit", c_int32), ("nbatch", c_int32)]
+
+
+REDUCE_MAX_SEGS = 32
+
+
 _SYMBOLS = {
     # name: (restype, argtypes)
     "mphsir_version": (ctypes.c_char_p, []),
@@ -117,6 +126,8 @@ _SYMBOLS = {
     "mphsir_gdfn_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "mphsir_gated_mlp_bwd": (c_int, [ctypes.POINTER(MlpBwdArgs), c_int, c_void_p]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
+    "mphsir_reduce_parts": (c_int, [ctypes.POINTER(ReduceSeg), c_int32, c_void_p]),
+    "mphsir_pack_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }
 
 

@@ -84,10 +84,11 @@ class _GatedMlp(torch.autograd.Function):
                                                   pk["W1T"], pk["W2T"])
         hid = blk.mlp.fc2.weight.shape[1]
         HP = h.shape[1]
-        dW2, db2 = ops.gemm_tn(dm, h, colsum=True)
-        dW2 = dW2[:, :hid]
-        dW1p, db1p = ops.gemm_tn(dpre, xn, colsum=True)
-        dln = part.sum(0)
+        with ops.reduce_scope():                                   # one ordered-sum launch for all five partial buffers
+            dW2, db2 = ops.gemm_tn(dm, h, colsum=True)
+            dW2 = dW2[:, :hid]
+            dW1p, db1p = ops.gemm_tn(dpre, xn, colsum=True)
+            dln = ops.reduce_parts(part)
         return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1],
                 torch.cat([dW1p[:hid], dW1p[HP:HP + hid]], 0), torch.cat([db1p[:hid], db1p[HP:HP + hid]]),
                 dW2, db2)
@@ -105,7 +106,7 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     N = H * W
     M = B * N
     dt = v.dtype
-    dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C))                      # (B,C,C) fp32
+    dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), immediate=True)      # (B,C,C) fp32, read right below
     W2, dwo, dtemp = ops.spectral_fold_bwd(gp, sp, temperature.detach().reshape(heads).float().contiguous(),
                                            wo.detach().reshape(C, C).float().contiguous(), dM, dt)
     # q, k of the forward (never stored) are recomputed by the depthwise kernel; when q|k|v are adjacent channel
@@ -171,37 +172,52 @@ class _PgsstbAttn(torch.autograd.Function):
         pk = blk.packed(dt)
         sp = blk.gobal_spectral_attn.packed(dt)
         dy = dy.contiguous()
-        # (1) branch sum  y = x + keep*(sa*gate + out)
-        d_out, d_sa, dgate = ops.combine_bwd(dy, sa, gate, k1, shift)
-        # (2) global spectral attention
-        t4 = t.reshape(B, H, W, 3 * Cc)
-        w9 = sp["w9"]
-        tq, tk, tv = t4[..., :Cc], t4[..., Cc:2 * Cc], t4[..., 2 * Cc:]
-        dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
-            d_out.reshape(M, Cc), tq, tk, tv, w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:], v, gp, spart, Mb, MbT,
-            blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W)
-        if dtq.data_ptr() + Cc * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * Cc:
-            dt3 = torch.as_strided(dtq, (M, 3 * Cc), (3 * Cc, 1))
-        else:
-            dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
-        d_sa = d_sa.reshape(M, Cc).addmm_(dt3, sp["wqkv"])                       # + dt Wqkv  (1x1 conv backward)
-        d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
-        d_sdw = torch.cat([dwq, dwk, dwv], dim=1).t().reshape(3 * Cc, 1, 3, 3)
-        # (3) local spectral-prompt gate: one launch per block + one token-reduction GEMM over the windows
-        dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"])
-        dpg = tuple(gpg[k].reshape(getattr_path(blk.local_spectral_attn, k).shape) for k in _PG_KEYS)
-        # (4) window attention core
-        dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
-                                                 pk["rpb"], pk["wprojT"], heads, shift)
-        dxn = dqkv @ pk["wqkv"]
-        d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xnw, colsum=True)
-        dsat2 = dsat.reshape(M, Cc)
-        d_proj_w, d_proj_b = ops.gemm_tn(dsat2, oattn.reshape(M, Cc), colsum=True)
-        # (5) norm1 backward + the residual path
-        dx, part = ops.ln_bwd_win(x, dxn, dy, pk["ln1"][0], shift)
-        dln = part.sum(0)
-        return (None, None, dx, dln[0], dln[1], d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, drpb.sum(0),
+        with ops.reduce_scope():      # every split partial of this backward is summed by ONE launch when the scope exits
+            # (1) branch sum  y = x + keep*(sa*gate + out)
+            d_out, d_sa, dgate = ops.combine_bwd(dy, sa, gate, k1, shift)
+            # (2) global spectral attention
+            t4 = t.reshape(B, H, W, 3 * Cc)
+            w9 = sp["w9"]
+            tq, tk, tv = t4[..., :Cc], t4[..., Cc:2 * Cc], t4[..., 2 * Cc:]
+            dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
+                d_out.reshape(M, Cc), tq, tk, tv, w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:], v, gp, spart, Mb, MbT,
+                blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W)
+            if dtq.data_ptr() + Cc * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * Cc:
+                dt3 = torch.as_strided(dtq, (M, 3 * Cc), (3 * Cc, 1))
+            else:
+                dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
+            d_sa = d_sa.reshape(M, Cc).addmm_(dt3, sp["wqkv"])                       # + dt Wqkv  (1x1 conv backward)
+            d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
+            # (3) local spectral-prompt gate: one launch per block + one token-reduction GEMM over the windows
+            dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"])
+            dpg = tuple(gpg[k].reshape(getattr_path(blk.local_spectral_attn, k).shape) for k in _PG_KEYS)
+            # (4) window attention core
+            dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
+                                                     pk["rpb"], pk["wprojT"], heads, shift)
+            dxn = dqkv @ pk["wqkv"]
+            d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xnw, colsum=True)
+            dsat2 = dsat.reshape(M, Cc)
+            d_proj_w, d_proj_b = ops.gemm_tn(dsat2, oattn.reshape(M, Cc), colsum=True)
+            # (5) norm1 backward + the residual path
+            dx, part = ops.ln_bwd_win(x, dxn, dy, pk["ln1"][0], shift)
+            dln = ops.reduce_parts(part)
+            drpb = ops.reduce_parts(drpb)
+        d_sdw = _join_taps(dwq, dwk, dwv).t().reshape(3 * Cc, 1, 3, 3)
+        return (None, None, dx, dln[0], dln[1], d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, drpb,
                 dtemp.reshape(heads, 1, 1), d_sqkv, d_sdw, dwo.reshape(Cc, Cc, 1, 1)) + tuple(dpg)
+
+
+def _join_taps(*dw):
+    """[9][C] tap gradients of adjacent channel ranges -> [9][sum C]; a view when they already are slices of one buffer."""
+    w0 = dw[0]
+    ok, off = True, w0.data_ptr()
+    for w in dw:
+        ok = ok and w.data_ptr() == off and w.stride() == w0.stride() and w.stride(1) == 1
+        off += w.shape[1] * w.element_size()
+    n = sum(w.shape[1] for w in dw)
+    if ok and w0.stride(0) >= n:
+        return torch.as_strided(w0, (9, n), w0.stride())
+    return torch.cat(dw, dim=1)
 
 
 def getattr_path(mod, dotted):
@@ -314,16 +330,19 @@ class _GdfnRes(torch.autograd.Function):
         D = a2.shape[1]
         dy = dy.contiguous()
         t4 = t.reshape(B, H, W, 2 * HP)
-        tdw = ops.dwconv3x3(t4, pf["w9"]).reshape(-1, 2 * HP)
-        du = dy @ pf["w_out"]                                              # (M,HP)
-        u, dtdw = ops.gdfn_gate_bwd(tdw, du)
-        d_out_w = ops.gemm_tn(dy, u)[:, :hid].reshape(D, hid, 1, 1)
-        dtdw4 = dtdw.reshape(B, H, W, 2 * HP)
-        dt_ = ops.dwconv3x3(dtdw4, pf["w9"], flip=True).reshape(-1, 2 * HP)
-        d_dw = _unpad_halves(ops.dwconv3x3_wgrad(t4, dtdw4).t(), hid, HP).reshape(2 * hid, 1, 3, 3)
-        lw, lb = ln.pair()
-        da, dlw, dlb, xn = ops.ln_bwd_tok(a2, dt_ @ pf["w_in"], dy, lw, lb)
-        d_in_w = _unpad_halves(ops.gemm_tn(dt_, xn), hid, HP).reshape(2 * hid, D, 1, 1)
+        with ops.reduce_scope():
+            tdw = ops.dwconv3x3(t4, pf["w9"]).reshape(-1, 2 * HP)
+            du = dy @ pf["w_out"]                                              # (M,HP)
+            u, dtdw = ops.gdfn_gate_bwd(tdw, du)
+            d_out_w = ops.gemm_tn(dy, u)[:, :hid].reshape(D, hid, 1, 1)
+            dtdw4 = dtdw.reshape(B, H, W, 2 * HP)
+            dt_ = ops.dwconv3x3(dtdw4, pf["w9"], flip=True).reshape(-1, 2 * HP)
+            d_dw = ops.dwconv3x3_wgrad(t4, dtdw4)
+            lw, lb = ln.pair()
+            da, dlw, dlb, xn = ops.ln_bwd_tok(a2, dt_ @ pf["w_in"], dy, lw, lb)
+            d_in_w = ops.gemm_tn(dt_, xn)
+        d_dw = _unpad_halves(d_dw.t(), hid, HP).reshape(2 * hid, 1, 3, 3)
+        d_in_w = _unpad_halves(d_in_w, hid, HP).reshape(2 * hid, D, 1, 1)
         return None, None, None, da, dlw, dlb, d_in_w, d_dw, d_out_w
 
 
@@ -361,17 +380,18 @@ class _SelfChannelAttnRes(torch.autograd.Function):
         w9 = pa["w9"]
         da = da.contiguous()
         q4 = q.reshape(B, H, W, 3 * D)
-        dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
-            da, q4[..., :D], q4[..., D:2 * D], q4[..., 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
-            attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
-        if dtq.data_ptr() + D * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * D:
-            dt3 = torch.as_strided(dtq, (M, 3 * D), (3 * D, 1))
-        else:
-            dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * D)
-        lw, lb = ln.pair()
-        dt_in, dlw, dlb, xn = ops.ln_bwd_tok(t2, dt3 @ pa["wqkv"], da, lw, lb)
-        d_qkv = ops.gemm_tn(dt3, xn).reshape(3 * D, D, 1, 1)
-        d_dw = torch.cat([dwq, dwk, dwv], dim=1).t().reshape(3 * D, 1, 3, 3)
+        with ops.reduce_scope():      # every split partial of this backward is summed by ONE launch when the scope exits
+            dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
+                da, q4[..., :D], q4[..., D:2 * D], q4[..., 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
+                attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
+            if dtq.data_ptr() + D * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * D:
+                dt3 = torch.as_strided(dtq, (M, 3 * D), (3 * D, 1))
+            else:
+                dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * D)
+            lw, lb = ln.pair()
+            dt_in, dlw, dlb, xn = ops.ln_bwd_tok(t2, dt3 @ pa["wqkv"], da, lw, lb)
+            d_qkv = ops.gemm_tn(dt3, xn).reshape(3 * D, D, 1, 1)
+        d_dw = _join_taps(dwq, dwk, dwv).t().reshape(3 * D, 1, 3, 3)
         return None, None, None, dt_in, dlw, dlb, d_qkv, d_dw, dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1)
 
 
@@ -406,17 +426,18 @@ class _CrossChannelAttnRes(torch.autograd.Function):
         w9 = pa["w9"]
         da = da.contiguous()
         tq4, tkv4 = tq.reshape(B, H, W, D), tkv.reshape(B, H, W, 2 * D)
-        dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
-            da, tq4, tkv4[..., :D], tkv4[..., D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
-            attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
-        dtq2 = dtq.reshape(M, D)
-        dkv = torch.cat([dtk, dtv], dim=-1).reshape(M, 2 * D)
-        n11w, n11b = ct.norm11.pair()
-        n12w, n12b = ct.norm12.pair()
-        dtext, d11w, d11b, xq = ops.ln_bwd_tok(text2, dtq2.contiguous() @ pa["wq"], da, n11w, n11b)
-        dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis2, dkv @ pa["wkv"], torch.zeros_like(vis2), n12w, n12b)
-        d_wq = ops.gemm_tn(dtq2, xq).reshape(D, D, 1, 1)
-        d_wkv = ops.gemm_tn(dkv, xv).reshape(2 * D, D, 1, 1)
+        with ops.reduce_scope():      # every split partial of this backward is summed by ONE launch when the scope exits
+            dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
+                da, tq4, tkv4[..., :D], tkv4[..., D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
+                attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
+            dtq2 = dtq.reshape(M, D)
+            dkv = torch.cat([dtk, dtv], dim=-1).reshape(M, 2 * D)
+            n11w, n11b = ct.norm11.pair()
+            n12w, n12b = ct.norm12.pair()
+            dtext, d11w, d11b, xq = ops.ln_bwd_tok(text2, dtq2.contiguous() @ pa["wq"], da, n11w, n11b)
+            dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis2, dkv @ pa["wkv"], torch.zeros_like(vis2), n12w, n12b)
+            d_wq = ops.gemm_tn(dtq2, xq).reshape(D, D, 1, 1)
+            d_wkv = ops.gemm_tn(dkv, xv).reshape(2 * D, D, 1, 1)
         return (None, None, dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.t().reshape(D, 1, 3, 3),
                 torch.cat([dwk, dwv], dim=1).t().reshape(2 * D, 1, 3, 3), dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1))
 
@@ -440,7 +461,7 @@ def tvsp(mod, x, clip_prompt, prompt_weights):
     y = _gdfn_res_ag(ct.ffn, ct.norm2, a, B, ps, ps).reshape(B, ps, ps, D)
     if (H, W) != (ps, ps):                                                             # ref :580
         y = F.interpolate(y.permute(0, 3, 1, 2), (H, W), mode="bilinear").permute(0, 2, 3, 1).contiguous()
-    return conv3x3(y, mod.conv_last.weight)
+    return conv3x3(y, mod.conv_last)
 
 
 def prompt_fusion(mod, x, prompt):
@@ -451,16 +472,36 @@ def prompt_fusion(mod, x, prompt):
     a = _SelfChannelAttnRes.apply(at, tb.norm1, (B, H, W), t.reshape(-1, D), tb.norm1.body.weight, tb.norm1.body.bias,
                                   at.qkv.weight, at.qkv_dwconv.weight, at.project_out.weight, at.temperature)
     y = _gdfn_res_ag(tb.ffn, tb.norm2, a, B, H, W).reshape(B, H, W, D)
-    return conv1x1(y, mod.conv.weight)
+    return conv1x1(y, mod.conv)
 
 
 # ---- plain convs / resamplers ----------------------------------------------------------------------
+def _conv_cache(conv):
+    c = conv.__dict__.get("_mphsir_cache")
+    if c is None:
+        c = conv.__dict__["_mphsir_cache"] = ops.WeightCache()
+    return c
+
+
+def _packed_conv1x1(conv, w, dtype):
+    N, K = w.shape[0], w.shape[1]
+    return _conv_cache(conv).get([w], dtype, lambda: dict(w=w.reshape(N, K).to(ops.cdt(dtype)).contiguous(),
+                                                           wT=w.reshape(N, K).t().to(ops.cdt(dtype)).contiguous()))
+
+
+def _packed_conv3x3(conv, w, dtype):
+    return _conv_cache(conv).get([w], dtype, lambda: dict(fwd=ops.pack_conv3x3(w, dtype),
+                                                           bwd=ops.pack_conv3x3(w, dtype, flip_transpose=True)))
+
+
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
+    def forward(ctx, x, w, conv):
         N, K = w.shape[0], w.shape[1]
-        y = ops.gemm_tok(x.reshape(-1, K), w.reshape(N, K).to(x.dtype).contiguous())
+        pk = _packed_conv1x1(conv, w, x.dtype)
+        ctx.save_for_backward(x, w)
+        ctx.conv = conv
+        y = ops.gemm_tok(x.reshape(-1, K), pk["w"])
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -468,26 +509,31 @@ class _Conv1x1(torch.autograd.Function):
         x, w = ctx.saved_tensors
         N, K = w.shape[0], w.shape[1]
         dy2, x2 = dy.reshape(-1, N), x.reshape(-1, K)
-        dx = ops.gemm_tok(dy2.contiguous(), w.reshape(N, K).t().to(x.dtype).contiguous()).reshape(x.shape) \
-            if ctx.needs_input_grad[0] and N % 32 == 0 and K % 16 == 0 else (dy2 @ w.reshape(N, K).to(dy.dtype)).reshape(x.shape)
+        pk = _packed_conv1x1(ctx.conv, w, x.dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (ops.gemm_tok(dy2.contiguous(), pk["wT"]) if N % 32 == 0 and K % 16 == 0 else dy2 @ pk["w"]).reshape(x.shape)
         dw = ops.gemm_tn(dy2.contiguous(), x2).reshape(w.shape) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        return dx, dw, None
 
 
-def conv1x1(x, w):
-    return _Conv1x1.apply(x, w)
+def conv1x1(x, conv):
+    """bias-free 1x1 conv / Linear on channels-last data; `conv` is the nn.Conv2d holder (its packed weights are cached on it)."""
+    return _Conv1x1.apply(x, conv.weight, conv)
 
 
 class _Conv3x3(torch.autograd.Function):
     """dense 3x3 conv as an implicit GEMM on the HIP kernel (forward, input gradient) + im2col/gemm_tn (weights)."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, conv):
         Cout, Cin = w.shape[0], w.shape[1]
         Cp = ops.round_up(Cin, 32)
         xp = x.contiguous() if Cp == Cin else F.pad(x, (0, Cp - Cin)).contiguous()
-        y = ops.conv3x3_tok(xp, ops.pack_conv3x3(w, x.dtype))
+        pk = _packed_conv3x3(conv, w, x.dtype)
+        y = ops.conv3x3_tok(xp, pk["fwd"])
         ctx.save_for_backward(xp, w)
+        ctx.conv = conv
         return y if y.shape[-1] == Cout else y[..., :Cout].contiguous()
 
     @staticmethod
@@ -498,17 +544,18 @@ class _Conv3x3(torch.autograd.Function):
         dyp = dy.contiguous() if Co32 == Cout else F.pad(dy, (0, Co32 - Cout)).contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = ops.conv3x3_tok(dyp, ops.pack_conv3x3(w, dy.dtype, flip_transpose=True))
+            pk = _packed_conv3x3(ctx.conv, w, dy.dtype)
+            dx = ops.conv3x3_tok(dyp, pk["bwd"])
             dx = dx if dx.shape[-1] == Cin else dx[..., :Cin].contiguous()
         if ctx.needs_input_grad[1]:
             g = ops.gemm_tn(dyp.reshape(-1, Co32), ops.im2col3x3(xp))[:Cout]
             dw = g.reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
-        return dx, dw
+        return dx, dw, None
 
 
-def conv3x3(x, w):
-    """dense 3x3, stride 1, zero padding, no bias on channels-last data."""
-    return _Conv3x3.apply(x, w)
+def conv3x3(x, conv):
+    """dense 3x3, stride 1, zero padding, no bias on channels-last data; `conv` is the nn.Conv2d holder."""
+    return _Conv3x3.apply(x, conv.weight, conv)
 
 
 def pixel_unshuffle2(x):

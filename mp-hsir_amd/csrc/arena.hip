@@ -1,0 +1,123 @@
+// arena utilities: the two places where hundreds of tiny framework kernels per step are replaced by one launch each.
+//
+//  * reduce_parts: every split-M / per-workgroup partial buffer a backward function produced (gemm_tn tiles and
+//    column sums, LayerNorm / rel-pos-bias / depthwise-tap / fold partials) is summed in a fixed order by ONE launch
+//    over up to MPHSIR_REDUCE_MAX_SEGS segments (the reference: one at::sum per parameter gradient).  Fixed summation
+//    order, no atomics: bitwise reproducible.
+//  * pack_gather: all kernel-layout weights (cast to the compute dtype, padded, transposed, split, gathered) are one
+//    gather from the flat fp32 parameter arena through a static int32 index map built once from the packers
+//    (host: engine.PackPlan); index < 0 = zero padding.  Runs right after flat_adamw inside the captured step.
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+struct RedSegDev {
+    const float* src; float* dst;
+    long n, stride, sbs, dbs, t0, nitems; // t0: first thread of this segment (a multiple of 64: waves never straddle segments)
+    int nsplit, vec, lg;                  // 2^lg adjacent lanes share one work item (4 consecutive outputs) and split the split axis
+};
+struct RedDev {
+    RedSegDev s[MPHSIR_REDUCE_MAX_SEGS];
+    int nseg; long threads;
+};
+
+__global__ __launch_bounds__(256) void reduce_parts_kernel(RedDev a) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.threads) return;            // whole waves only (threads is a multiple of 64)
+    // constant indices only: a dynamically indexed by-value kernel argument would be copied to scratch by every lane
+    RedSegDev s = a.s[0];
+#pragma unroll
+    for (int k = 1; k < MPHSIR_REDUCE_MAX_SEGS; ++k)
+        if (k < a.nseg && t >= a.s[k].t0) s = a.s[k];
+    const int G = 1 << s.lg;
+    const long local = t - s.t0, item = local >> s.lg, ipb = (s.n + 3) / 4;
+    const int g = (int)(local & (G - 1));
+    const bool live = item < s.nitems;
+    const long b = live ? item / ipb : 0, i4 = live ? (item % ipb) * 4 : 0;
+    const float* src = s.src + b * s.sbs + i4;
+    const int ne = (s.n - i4) < 4 ? (int)(s.n - i4) : 4;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        if (s.vec) {
+#pragma unroll 4
+            for (int sp = g; sp < s.nsplit; sp += G) acc += *reinterpret_cast<const f32x4*>(src + (long)sp * s.stride);
+        } else {
+            for (int sp = g; sp < s.nsplit; sp += G)
+                for (int e = 0; e < ne; ++e) acc[e] += src[(long)sp * s.stride + e];
+        }
+    }
+    // fixed xor tree over the lanes of the group: the summation order depends on (nsplit, G) only -> deterministic
+    for (int m = 1; m < G; m <<= 1)
+        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], m);
+    if (live && g == 0) {
+        float* dst = s.dst + b * s.dbs + i4;
+        if (s.vec) *reinterpret_cast<f32x4*>(dst) = acc;
+        else
+            for (int e = 0; e < ne; ++e) dst[e] = acc[e];
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void pack_gather_kernel(const float* arena, const int* idx, T* dst, long n) {
+    constexpr int VEC = Vec16<T>::N;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n / VEC; i += stride) {
+        Vec16<T> o;
+        for (int h = 0; h < VEC / 4; ++h) {
+            const int* ip = idx + i * VEC + 4 * h;
+            const int i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3];
+            o.set(4 * h + 0, i0 >= 0 ? arena[i0] : 0.f);
+            o.set(4 * h + 1, i1 >= 0 ? arena[i1] : 0.f);
+            o.set(4 * h + 2, i2 >= 0 ? arena[i2] : 0.f);
+            o.set(4 * h + 3, i3 >= 0 ? arena[i3] : 0.f);
+        }
+        store16<T>(dst + i * VEC, o);
+    }
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(segs && nseg > 0 && nseg <= MPHSIR_REDUCE_MAX_SEGS, "reduce_parts: 1..%d segments per call", MPHSIR_REDUCE_MAX_SEGS);
+    RedDev d;
+    d.nseg = nseg;
+    long threads = 0;
+    for (int k = 0; k < nseg; ++k) {
+        const mphsir_reduce_seg& g = segs[k];
+        MPHSIR_REQUIRE(g.src && g.dst && g.n > 0 && g.nsplit > 0 && g.nbatch > 0, "reduce_parts: bad segment %d", k);
+        const bool vec = aligned16(g.src) && aligned16(g.dst) && g.n % 4 == 0 && g.stride % 4 == 0 &&
+                         g.src_batch_stride % 4 == 0 && g.dst_batch_stride % 4 == 0;
+        const long nitems = (long)g.nbatch * ((g.n + 3) / 4);
+        int lg = 0;                        // lanes per item: keep <= 32 splits per lane, and small segments still fill waves
+        while (lg < 6 && (g.nsplit >> lg) > 32) ++lg;
+        while (lg < 6 && (nitems << lg) < 8192 && (g.nsplit >> lg) > 4) ++lg;
+        d.s[k] = RedSegDev{g.src, g.dst, (long)g.n, (long)g.stride, (long)g.src_batch_stride, (long)g.dst_batch_stride, threads, nitems,
+                           g.nsplit, vec ? 1 : 0, lg};
+        threads += ((nitems << lg) + 63) / 64 * 64;
+    }
+    d.threads = threads;
+    MPHSIR_LAUNCH(MPHSIR_K_REDUCE_PARTS, reduce_parts_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                  reinterpret_cast<hipStream_t>(stream), d);
+    return MPHSIR_OK;
+}
+
+extern "C" int mphsir_pack_gather(const float* arena, const int32_t* index, void* dst, int64_t n, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(arena && index && dst, "pack_gather: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "pack_gather: dtype %d unsupported", dtype);
+    const int vec = dtype == MPHSIR_F32 ? 4 : 8;
+    MPHSIR_REQUIRE(n > 0 && n % vec == 0 && aligned16(index) && aligned16(dst), "pack_gather: n must be a multiple of %d, 16-byte alignment", vec);
+    long blocks = (n / vec + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MPHSIR_F32) {
+        MPHSIR_LAUNCH(MPHSIR_K_PACK_GATHER, pack_gather_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, arena, index, reinterpret_cast<float*>(dst), (long)n);
+    } else {
+        MPHSIR_LAUNCH(MPHSIR_K_PACK_GATHER, pack_gather_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, arena, index, reinterpret_cast<bf16_t*>(dst), (long)n);
+    }
+    return MPHSIR_OK;
+}

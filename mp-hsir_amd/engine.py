@@ -29,9 +29,110 @@ def l1_after_clamp(restored, clean):
     return (restored.clamp(0, 1) - clean).abs().mean()
 
 
+class PackPlan:
+    """All kernel-layout weights of the model as ONE gather from the flat fp32 parameter arena.
+
+    The per-module packers (net/MP_HSIR.py `packed()`, ops.pack_*) are pure data movement: cast, zero padding,
+    transposes, value|gate row splits.  Run once with the arena holding its own indices (two fp32 passes: low 12 bits
+    + 1, high bits) they yield, for every element of every packed tensor, the arena element it copies (or "padding").
+    After that a step's ~500 cast/copy/fill launches are one `mphsir_pack_gather` launch per dtype into persistent
+    buffers the module caches are pinned to.  Every map is verified bitwise against the packer's real output when the
+    plan is built; a cache whose packer does anything else (or reads parameters outside the arena) is left unpinned."""
+
+    def __init__(self, flat_p):
+        self.flat = flat_p
+        self.epoch = -1
+        self.groups = {}            # dtype -> (index int32, persistent buffer)
+        self.pinned = self.skipped = 0
+        self.why = []               # (parameter shapes, reason) of every cache left unpinned
+
+    def build(self):
+        from torch.utils._pytree import tree_flatten, tree_map, tree_unflatten
+        flat = self.flat
+        lo_ptr, hi_ptr = flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()
+
+        def inside(t):
+            return lo_ptr <= t.data_ptr() < hi_ptr
+        caches = [c for c in ops.WeightCache.live() if c.last is not None and all(inside(p) for p in c.last[0])]
+        with torch.no_grad():
+            real = [c.last[2]() for c in caches]
+            saved = flat.clone()
+            ar = torch.arange(flat.numel(), device=flat.device)
+            traces = []
+            ops._TRACE[0] = True
+            try:
+                for code in ((ar & 0xFFF) + 1, ar >> 12):
+                    flat.copy_(code.float())
+                    # a no-op cast leaves a VIEW of the arena in the trace: detach it from the next overwrite
+                    traces.append([tree_map(lambda t: t.clone() if isinstance(t, torch.Tensor) and inside(t) else t, c.last[2]())
+                                   for c in caches])
+            finally:
+                ops._TRACE[0] = False
+                flat.copy_(saved)
+            todo = []                   # (cache, spec, leaves with placeholders, [(leaf slot, dtype, idx, shape)])
+            for c, r, tlo, thi in zip(caches, real, traces[0], traces[1]):
+                lr_, spec = tree_flatten(r)
+                llo, lhi = tree_flatten(tlo)[0], tree_flatten(thi)[0]
+                leaves, maps = list(lr_), []
+                bad = None if len(llo) == len(lr_) == len(lhi) else "leaf count"
+                for j, t in enumerate(lr_):
+                    if bad:
+                        break
+                    if not isinstance(t, torch.Tensor) or inside(t):
+                        continue                                    # parameter views need no copy at all
+                    a, b = llo[j], lhi[j]
+                    if not (t.is_contiguous() and a.shape == t.shape and b.shape == t.shape and t.dtype in ops._DT):
+                        bad = "leaf %d: layout %s %s %s" % (j, tuple(t.shape), t.dtype, t.is_contiguous())
+                        break
+                    a, b = a.reshape(-1).double(), b.reshape(-1).double()
+                    idx = torch.where(a > 0, b * 4096 + a - 1, -torch.ones_like(a)).long()
+                    got = torch.where(idx >= 0, saved[idx.clamp(min=0)], torch.zeros((), device=flat.device)).to(t.dtype)
+                    if not torch.equal(got, t.reshape(-1)):
+                        bad = "leaf %d %s: not a gather of the arena (%d of %d elements differ)" % (
+                            j, tuple(t.shape), int((got != t.reshape(-1)).sum()), got.numel())
+                        break
+                    maps.append((j, t.dtype, idx.int(), t.shape))
+                if bad is None:
+                    todo.append((c, spec, leaves, maps))
+                    self.pinned += 1
+                else:
+                    self.skipped += 1
+                    self.why.append(([tuple(p.shape) for p in c.last[0]][:3], bad))
+            per = {}
+            for _, _, _, maps in todo:
+                for j, dt, idx, shape in maps:
+                    lst, off = per.setdefault(dt, ([], [0]))
+                    n = idx.numel()
+                    pad = (-n) % 8
+                    lst.append(idx if pad == 0 else torch.cat([idx, torch.full((pad,), -1, dtype=torch.int32, device=idx.device)]))
+                    off.append(off[-1] + n + pad)
+            self.groups = {dt: (torch.cat(lst), torch.empty(off[-1], dtype=dt, device=flat.device)) for dt, (lst, off) in per.items()}
+            cursor = {dt: 0 for dt in per}
+            for c, spec, leaves, maps in todo:
+                for j, dt, idx, shape in maps:
+                    n = idx.numel()
+                    o = cursor[dt]
+                    leaves[j] = self.groups[dt][1][o:o + n].view(shape)
+                    cursor[dt] = o + n + (-n) % 8
+                c.pinned = (c.last[1], self, tuple(p._version for p in c.last[0]), tree_unflatten(leaves, spec))
+        self.refresh()
+        return self
+
+    def refresh(self):
+        """one gather launch per dtype; call after every optimizer update of the arena (capturable)."""
+        for dt, (idx, buf) in self.groups.items():
+            ops.pack_gather(self.flat, idx, dt, out=buf)
+        self.epoch = ops.weight_epoch()
+
+    def release(self):
+        for c in ops.WeightCache.live():
+            if c.pinned is not None and c.pinned[1] is self:
+                c.pinned = None
+
+
 class DataParallelEngine:
     def __init__(self, net, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, bucket_mb=32, process_group=None,
-                 loss_fn=l1_after_clamp, use_graph=False, graph_warmup=2):
+                 loss_fn=l1_after_clamp, use_graph=False, graph_warmup=2, use_pack_plan=True):
         self.net, self.lr, self.betas, self.eps, self.wd = net, lr, betas, eps, weight_decay
         self.loss_fn = loss_fn
         self.pg = process_group
@@ -45,6 +146,7 @@ class DataParallelEngine:
         # step make the eager loop host-bound.  With world > 1 the all-reduce stays outside the graph (one
         # arena-wide reduction after the replay: 58 MB over xGMI is <1 ms next to a ~45 ms step).
         self.use_graph, self.graph_warmup, self._graph = use_graph, graph_warmup, None
+        self.use_pack_plan, self.plan = use_pack_plan, None
         if self.world > 1:      # DDP's initial parameter broadcast (rank 0 -> all), one flat message
             ps = [p for p in net.parameters()]
             flat = torch.cat([p.data.reshape(-1).float() for p in ps])
@@ -147,6 +249,8 @@ class DataParallelEngine:
                 if self.world == 1:
                     ops.flat_adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 0.0, 0, self.betas[0], self.betas[1],
                                    self.eps, self.wd, 1.0, hyper=self._hyper)
+                    if self.plan is not None:
+                        self.plan.refresh()
                 self._sloss = loss.detach()
             self._graph = g
         self._sx.copy_(degraded)
@@ -160,6 +264,8 @@ class DataParallelEngine:
                 dist.all_reduce(self.flat_g[s:e], group=self.pg)
             ops.flat_adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 0.0, 0, self.betas[0], self.betas[1], self.eps,
                            self.wd, 1.0 / self.world, hyper=self._hyper)
+            if self.plan is not None:
+                self.plan.refresh()
         return self._sloss
 
     def finish(self):
@@ -168,6 +274,8 @@ class DataParallelEngine:
         ops.bump_weight_epoch()
 
     def train_step(self, degraded, clean, prompt, lr=None):
+        if self.use_pack_plan and self.plan is None and self.arena is not None:
+            self.plan = PackPlan(self.flat_p).build()      # caches were populated by the step(s) before
         if self.use_graph and self.arena is not None and self.step_count >= self.graph_warmup and degraded.is_cuda:
             return self._train_step_graph(degraded, clean, prompt, lr)
         first = self.arena is None
@@ -193,6 +301,8 @@ class DataParallelEngine:
         self.step_count += 1
         ops.flat_adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr if lr is None else lr, self.step_count,
                        self.betas[0], self.betas[1], self.eps, self.wd, 1.0 / self.world)
+        if self.plan is not None:
+            self.plan.refresh()
         return loss.detach()
 
 

@@ -56,22 +56,7 @@ def _hidden(dim, factor):
     return int(dim * factor)
 
 
-class _Cache:
-    """Per-module cache of weights converted/padded for the kernels, keyed on the compute dtype and
-    on the version counters of the source parameters (in-place updates, load_state_dict) plus the
-    package-wide epoch that raw-pointer optimizers bump (ops.bump_weight_epoch)."""
-
-    def __init__(self):
-        self.key = None
-        self.val = None
-
-    def get(self, params, dtype, build):
-        key = (dtype, ops.weight_epoch(), tuple(p._version for p in params), params[0].device)
-        if key != self.key:
-            with torch.no_grad():
-                self.val = build()
-            self.key = key
-        return self.val
+_Cache = ops.WeightCache     # per-module cache of kernel-layout weights (see ops.WeightCache / engine.PackPlan)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -99,7 +84,7 @@ class Spectral_Attention(nn.Module):                                            
         C = self.project_out.weight.shape[0]
 
         def build():
-            return dict(wqkv=self.qkv.weight.reshape(3 * C, C).to(dtype).contiguous(),
+            return dict(wqkv=self.qkv.weight.reshape(3 * C, C).to(ops.cdt(dtype)).contiguous(),
                         w9=ops.pack_dw(self.qkv_dwconv.weight),
                         wo=self.project_out.weight.reshape(C, C).float().contiguous(),
                         temp=self.temperature.reshape(-1).float().contiguous())
@@ -177,9 +162,9 @@ class PGSSTB(nn.Module):                                                        
             W1, b1, W2 = ops.pack_gated_mlp(m.fc1.weight, m.fc1.bias, m.fc2.weight, dtype)
             f = lambda t: t.detach().float().contiguous()
             return dict(
-                wqkv=a.qkv.weight.to(dtype).contiguous(), bqkv=f(a.qkv.bias),
+                wqkv=a.qkv.weight.to(ops.cdt(dtype)).contiguous(), bqkv=f(a.qkv.bias),
                 wproj=ops.pack_win_proj(a.proj.weight, self.num_heads, dtype), bproj=f(a.proj.bias),
-                wprojT=a.proj.weight.t().to(dtype).contiguous(),
+                wprojT=a.proj.weight.t().to(ops.cdt(dtype)).contiguous(),
                 rpb=f(a.relative_position_bias_table), W1=W1, b1=b1, W2=W2, b2=f(m.fc2.bias),
                 W1T=W1.t().contiguous(), W2T=W2.t().contiguous(),
                 ln1=(f(self.norm1.weight), f(self.norm1.bias)), ln2=(f(self.norm2.weight), f(self.norm2.bias)),
@@ -248,14 +233,14 @@ class FeedForward(nn.Module):                                                   
             hid = two_hid // 2
             HP = ops.round_up(hid, 32)
             dev = self.project_in.weight.device
-            w_in = torch.zeros((2 * HP, D), dtype=dtype, device=dev)
+            w_in = torch.zeros((2 * HP, D), dtype=ops.cdt(dtype), device=dev)
             wi = self.project_in.weight.reshape(two_hid, D)
-            w_in[:hid], w_in[HP:HP + hid] = wi[:hid].to(dtype), wi[hid:].to(dtype)
+            w_in[:hid], w_in[HP:HP + hid] = wi[:hid].to(ops.cdt(dtype)), wi[hid:].to(ops.cdt(dtype))
             w9 = torch.zeros((9, 2 * HP), dtype=torch.float32, device=dev)
             w9s = ops.pack_dw(self.dwconv.weight)
             w9[:, :hid], w9[:, HP:HP + hid] = w9s[:, :hid], w9s[:, hid:]
-            w_out = torch.zeros((D, HP), dtype=dtype, device=dev)
-            w_out[:, :hid] = self.project_out.weight.reshape(D, hid).to(dtype)
+            w_out = torch.zeros((D, HP), dtype=ops.cdt(dtype), device=dev)
+            w_out[:, :hid] = self.project_out.weight.reshape(D, hid).to(ops.cdt(dtype))
             return dict(w_in=w_in, w9=w9, w_out=w_out)
         return self._cache.get(ps, dtype, build)
 
@@ -280,8 +265,8 @@ class CrossAttention(nn.Module):                                                
         D = self.q.weight.shape[0]
 
         def build():
-            return dict(wq=self.q.weight.reshape(D, D).to(dtype).contiguous(),
-                        wkv=self.kv.weight.reshape(2 * D, D).to(dtype).contiguous(),
+            return dict(wq=self.q.weight.reshape(D, D).to(ops.cdt(dtype)).contiguous(),
+                        wkv=self.kv.weight.reshape(2 * D, D).to(ops.cdt(dtype)).contiguous(),
                         w9=torch.cat([ops.pack_dw(self.q_dwconv.weight), ops.pack_dw(self.kv_dwconv.weight)], 1).contiguous(),
                         wo=self.project_out.weight.reshape(D, D).float().contiguous(),
                         temp=self.temperature.reshape(-1).float().contiguous())
@@ -444,14 +429,14 @@ class MP_HSIR_Net(nn.Module):                                                   
         dt = self._dtype()
         clip, w = self.text_prompt(inp_img, task_id)
         x_in = inp_img.to(dt).permute(0, 2, 3, 1).contiguous()                     # channels-last from here on
-        e1 = self.encoder_level1(AG.conv3x3(x_in, self.patch_embed.proj.weight))
-        e2 = self.encoder_level2(AG.pixel_unshuffle2(AG.conv3x3(e1, self.down1_2.body[0].weight)))
-        lat = self.latent(AG.pixel_unshuffle2(AG.conv3x3(e2, self.down2_3.body[0].weight)))
-        d2_in = AG.pixel_shuffle2(AG.conv3x3(lat, self.up3_2.body[0].weight))
+        e1 = self.encoder_level1(AG.conv3x3(x_in, self.patch_embed.proj))
+        e2 = self.encoder_level2(AG.pixel_unshuffle2(AG.conv3x3(e1, self.down1_2.body[0])))
+        lat = self.latent(AG.pixel_unshuffle2(AG.conv3x3(e2, self.down2_3.body[0])))
+        d2_in = AG.pixel_shuffle2(AG.conv3x3(lat, self.up3_2.body[0]))
         f2 = self.fusion2(e2, self.prompt2(e2, clip, w))
-        d2 = self.decoder_level2(AG.conv1x1(torch.cat([d2_in, f2], -1), self.reduce_chan_level2.weight))
-        d1_in = AG.pixel_shuffle2(AG.conv3x3(d2, self.up2_1.body[0].weight))
+        d2 = self.decoder_level2(AG.conv1x1(torch.cat([d2_in, f2], -1), self.reduce_chan_level2))
+        d1_in = AG.pixel_shuffle2(AG.conv3x3(d2, self.up2_1.body[0]))
         f1 = self.fusion1(e1, self.prompt1(e1, clip, w))
         r = self.refinement(self.decoder_level1(torch.cat([d1_in, f1], -1)))
-        out = AG.conv3x3(r, self.output.weight).permute(0, 3, 1, 2).to(inp_img.dtype) + inp_img
+        out = AG.conv3x3(r, self.output).permute(0, 3, 1, 2).to(inp_img.dtype) + inp_img
         return out

@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/mphsir.h): shape checks, output allocation,
 pointer/stream plumbing.  No arithmetic happens here."""
 import ctypes
+import weakref
 
 import torch
 
@@ -39,6 +40,82 @@ def _check(*tensors):
             raise RuntimeError("mp-hsir_amd: emulated test library bound but got a GPU tensor")
         if not emu and not t.is_cuda:
             raise RuntimeError("mp-hsir_amd: ops run on the GPU only (got a CPU tensor; there is no CPU fallback)")
+
+
+# ---- deferred ordered reduction of split partials (mphsir_reduce_parts) -----------------------------------------
+_SCOPE = None
+
+
+class reduce_scope:
+    """Inside the scope every `reduce_parts` call only records its segment and returns the (not yet written) output
+    tensor; one mphsir_reduce_parts launch per <= 32 segments fills them when the scope exits.  Callers may slice /
+    reshape the outputs inside the scope but must not READ them (no kernels on them) before it exits."""
+
+    def __enter__(self):
+        global _SCOPE
+        self.prev, self.segs = _SCOPE, []
+        _SCOPE = self
+        return self
+
+    def __exit__(self, *exc):
+        global _SCOPE
+        _SCOPE = self.prev
+        if exc[0] is None:
+            _flush(self.segs)
+        self.segs = []
+        return False
+
+
+def _flush(segs):
+    lib = _lib.load()
+    for i in range(0, len(segs), _lib.REDUCE_MAX_SEGS):
+        chunk = segs[i:i + _lib.REDUCE_MAX_SEGS]
+        arr = (_lib.ReduceSeg * len(chunk))()
+        nbytes = 0.0
+        for k, (part, out, n, nsplit, nbatch) in enumerate(chunk):
+            arr[k].src, arr[k].dst = part.data_ptr(), out.data_ptr()
+            arr[k].n, arr[k].stride, arr[k].src_batch_stride, arr[k].dst_batch_stride = n, n, nsplit * n, n
+            arr[k].nsplit, arr[k].nbatch = nsplit, nbatch
+            nbytes += 4.0 * nbatch * n * (nsplit + 1)
+        _lib.check(lib.mphsir_reduce_parts(arr, len(chunk), _stream(chunk[0][0])), "reduce_parts")
+        _acct("reduce_parts", nbytes / 4.0, nbytes)
+
+
+def reduce_parts(part, batched=False, immediate=False):
+    """part fp32 contiguous (nsplit, *shape) [batched: (Bt, nsplit, *shape)] -> sum over the split axis in split order
+    (deterministic), shape (*shape) [(Bt, *shape)].  Deferred to the end of the enclosing `reduce_scope`, if any."""
+    _check(part)
+    assert part.dtype == torch.float32 and part.is_contiguous()
+    if batched:
+        Bt, nsplit, shape = part.shape[0], part.shape[1], tuple(part.shape[2:])
+    else:
+        Bt, nsplit, shape = 1, part.shape[0], tuple(part.shape[1:])
+    if nsplit == 1:
+        return part[:, 0] if batched else part[0]
+    out = torch.empty(((Bt,) + shape) if batched else shape, dtype=torch.float32, device=part.device)
+    n = 1
+    for d in shape:
+        n *= d
+    seg = (part, out, n, nsplit, Bt)
+    if _SCOPE is None or immediate:
+        _flush([seg])
+    else:
+        _SCOPE.segs.append(seg)
+    return out
+
+
+def pack_gather(arena, index, dtype, out=None):
+    """out[i] = arena[index[i]] cast to dtype, 0 where index[i] < 0 (index int32, len % 8 == 0)."""
+    lib = _lib.load()
+    _check(arena, index, out)
+    assert arena.dtype == torch.float32 and index.dtype == torch.int32 and arena.is_contiguous() and index.is_contiguous()
+    n = index.numel()
+    if out is None:
+        out = torch.empty((n,), dtype=dtype, device=arena.device)
+    assert out.numel() == n and out.dtype == dtype and out.is_contiguous()
+    _lib.check(lib.mphsir_pack_gather(_p(arena), _p(index), _p(out), n, _DT[dtype], _stream(arena)), "pack_gather")
+    _acct("pack_gather", 0.0, n * (8.0 + out.element_size()))
+    return out
 
 
 def _rows(t):
@@ -91,14 +168,14 @@ def pack_gated_mlp(fc1_w, fc1_b, fc2_w, dtype):
     two_hid, C = fc1_w.shape
     hid = two_hid // 2
     HP = round_up(hid, 32)
-    W1 = torch.zeros((2 * HP, C), dtype=dtype, device=fc1_w.device)
-    W1[:hid] = fc1_w[:hid].to(dtype)
-    W1[HP:HP + hid] = fc1_w[hid:].to(dtype)
+    W1 = torch.zeros((2 * HP, C), dtype=cdt(dtype), device=fc1_w.device)
+    W1[:hid] = fc1_w[:hid].to(cdt(dtype))
+    W1[HP:HP + hid] = fc1_w[hid:].to(cdt(dtype))
     b1 = torch.zeros((2 * HP,), dtype=torch.float32, device=fc1_w.device)
     b1[:hid] = fc1_b[:hid]
     b1[HP:HP + hid] = fc1_b[hid:]
-    W2 = torch.zeros((C, HP), dtype=dtype, device=fc1_w.device)
-    W2[:, :hid] = fc2_w.to(dtype)
+    W2 = torch.zeros((C, HP), dtype=cdt(dtype), device=fc1_w.device)
+    W2[:, :hid] = fc2_w.to(cdt(dtype))
     return W1, b1, W2
 
 
@@ -127,9 +204,9 @@ def pack_win_proj(proj_w, heads, dtype):
     hd = C // heads
     hdp = _lib.load().mphsir_win_attn_hdp(hd, _DT[dtype])
     if hdp == hd:
-        return proj_w.to(dtype).contiguous()
-    out = torch.zeros((C, heads, hdp), dtype=dtype, device=proj_w.device)
-    out[:, :, :hd] = proj_w.reshape(C, heads, hd).to(dtype)
+        return proj_w.to(cdt(dtype)).contiguous()
+    out = torch.zeros((C, heads, hdp), dtype=cdt(dtype), device=proj_w.device)
+    out[:, :, :hd] = proj_w.reshape(C, heads, hd).to(cdt(dtype))
     return out.reshape(C, heads * hdp)
 
 
@@ -245,6 +322,47 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+# ---- kernel-layout weights: per-module caches and the one-launch pack plan ------------------------------------------
+_TRACE = [False]
+
+
+def cdt(dtype):
+    """dtype the packers materialise a kernel-layout weight in: `dtype`, except while a PackPlan traces the packers with
+    index-valued parameters (fp32 keeps the indices exact; the LAYOUT still follows `dtype`)."""
+    return torch.float32 if _TRACE[0] else dtype
+
+
+class WeightCache:
+    """Cache of one module's weights converted / padded / transposed for the kernels, keyed on the compute dtype, the
+    version counters of the source parameters (in-place updates, load_state_dict) and the package-wide epoch that
+    raw-pointer optimizers bump (bump_weight_epoch).  A PackPlan may `pin` persistent buffers it refreshes itself with
+    one pack_gather launch per optimizer step; the pinned value is served while the plan is in sync with the epoch."""
+    _all = []
+
+    def __init__(self):
+        self.key = self.val = self.last = self.pinned = None
+        WeightCache._all.append(weakref.ref(self))
+
+    @classmethod
+    def live(cls):
+        out = [r() for r in cls._all]
+        cls._all = [r for r, c in zip(cls._all, out) if c is not None]
+        return [c for c in out if c is not None]
+
+    def get(self, params, dtype, build):
+        pin = self.pinned
+        versions = tuple(p._version for p in params)
+        if pin is not None and pin[0] == dtype and pin[1].epoch == weight_epoch() and pin[2] == versions:
+            return pin[3]
+        key = (dtype, weight_epoch(), versions, params[0].device)
+        if key != self.key:
+            with torch.no_grad():
+                self.val = build()
+            self.key = key
+            self.last = (list(params), dtype, build)
+        return self.val
+
+
 def flat_adamw(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, grad_scale=1.0, hyper=None):
     """In-place AdamW step on flat fp32 arenas (length a multiple of 4).  hyper: optional device fp32 tensor
     [lr, 1-beta1^step, sqrt(1-beta2^step)] read by the kernel instead of lr/step (for captured launches)."""
@@ -280,7 +398,7 @@ def dwconv3x3_wgrad(x, dy, nblk=None):
     _lib.check(lib.mphsir_dwconv3x3_wgrad(_p(x), x.stride(2), _p(dy), dy.stride(2), _p(part), nblk, B, H, W, C,
                                           _DT[x.dtype], _stream(x)), "dwconv3x3_wgrad")
     _acct("dwconv3x3_wgrad", 18.0 * B * H * W * C, 2.0 * B * H * W * C * x.element_size())
-    return part.sum(dim=0)
+    return reduce_parts(part)
 
 
 def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T):
@@ -371,11 +489,11 @@ def ln_bwd_tok(x2, dxn, dres, ln_w, ln_b):
     _lib.check(lib.mphsir_ln_bwd_win(_p(x2), _p(dxn), _p(dres), _p(ln_w), _p(dx), _p(part), M // 64, 8, 8, C, 0, _p(ln_b), _p(xn), 1,
                                      _DT[x2.dtype], _stream(x2)), "ln_bwd_win")
     _acct("ln_bwd_win", 12.0 * x2.numel(), 5.0 * x2.numel() * x2.element_size())
-    g = part.sum(dim=0)
+    g = reduce_parts(part)
     return dx, g[0], g[1], xn
 
 
-def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None):
+def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False):
     """sum over tokens of a[m,:]^T b[m,:].  a (M,N1), b (M,N2) row-major views -> fp32 (N1,N2);
     batched: a (Bt,M,N1), b (Bt,M,N2) -> (Bt,N1,N2).  colsum=True also returns sum_m a[m,:] (fp32, (N1,))."""
     lib = _lib.load()
@@ -397,10 +515,10 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None):
                                   _DT[a.dtype], _stream(a)),
                "gemm_tn")
     _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size() + part.numel() * 4.0)
-    out = part.sum(dim=1) if nsplit > 1 else part[:, 0]
+    out = reduce_parts(part, batched=True, immediate=immediate)
     out = out if batched else out[0]
     if colsum:
-        c = cs.sum(dim=1) if nsplit > 1 else cs[:, 0]
+        c = reduce_parts(cs, batched=True, immediate=immediate)
         return out, (c if batched else c[0])
     return out
 
@@ -433,7 +551,7 @@ def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype):
     a.B, a.C, a.heads, a.nsplit = B, C, heads, nsplit
     _lib.check(lib.mphsir_spectral_fold_bwd(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold_bwd")
     _acct("spectral_fold_bwd", 4.0 * B * C * C * hd, 3.0 * B * C * C * 4)
-    return W2, dWo.sum(dim=0), dtemp.sum(dim=0)
+    return W2, reduce_parts(dWo), reduce_parts(dtemp)
 
 
 def pg_gate_bwd(mu, dgate, pg):
@@ -477,8 +595,8 @@ def pack_conv3x3(w, dtype, flip_transpose=False):
         w = w.flip(2, 3).transpose(0, 1)
     Co, Ci = w.shape[0], w.shape[1]
     Np, Cp = round_up(Co, 16), round_up(Ci, 32)
-    out = torch.zeros((Np, 9, Cp), dtype=dtype, device=w.device)
-    out[:Co, :, :Ci] = w.permute(0, 2, 3, 1).reshape(Co, 9, Ci).to(dtype)
+    out = torch.zeros((Np, 9, Cp), dtype=cdt(dtype), device=w.device)
+    out[:Co, :, :Ci] = w.permute(0, 2, 3, 1).reshape(Co, 9, Ci).to(cdt(dtype))
     return out.reshape(Np, 9 * Cp)
 
 

@@ -266,3 +266,37 @@ def check_conv3x3(dev, dtype, B, H, W, Cin, Cout):
     assert rel_l2(y, yr.detach().permute(0, 2, 3, 1)) < TOL[dtype]
     assert rel_l2(dx, xr.grad.permute(0, 2, 3, 1)) < TOL[dtype]
     assert rel_l2(dw, wr.grad) < TOL[dtype]
+
+
+def check_reduce_parts(dev):
+    """mphsir_reduce_parts: deferred scope (several segments, one launch), odd lengths (scalar path), batched layout,
+    > 32 segments (two launches), and bitwise equality with an ordered fp32 sum."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    shapes = [((5, 7, 12), False), ((3, 225, 2), False), ((4, 6, 16, 8), True), ((1, 9, 4), False), ((17, 33), False),
+              ((300, 18), False), ((130, 2, 32), False), ((2, 70, 5), True)]
+    parts = [rnd(s, 70 + i) for i, (s, _) in enumerate(shapes)]
+    with ops.reduce_scope():
+        outs = [ops.reduce_parts(p, batched=b) for p, (_, b) in zip(parts, shapes)]
+    for p, o, (_, b) in zip(parts, outs, shapes):
+        ref = p.double().sum(1 if b else 0)
+        assert rel_l2(o, ref) < 3e-7, (p.shape, rel_l2(o, ref))
+    many = [rnd((3, 8 + i), 90 + i) for i in range(40)]
+    with ops.reduce_scope():
+        outs = [ops.reduce_parts(p) for p in many]
+    for p, o in zip(many, outs):
+        assert torch.equal(o.cpu(), ((p[0] + p[1]) + p[2]).cpu())
+    assert torch.equal(ops.reduce_parts(many[0]).cpu(), outs[0].cpu())          # immediate mode outside a scope
+    big = rnd((300, 18), 99)
+    assert torch.equal(ops.reduce_parts(big).cpu(), ops.reduce_parts(big.clone()).cpu())   # fixed order: bitwise reproducible
+
+
+def check_pack_gather(dev, dtype):
+    _use(dev)
+    from mp_hsir_amd import ops
+    arena = rnd((1000,), 95)
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(-1, 1000, (256,), generator=g, dtype=torch.int32).to(arena.device)
+    out = ops.pack_gather(arena, idx, dtype)
+    ref = torch.where(idx >= 0, arena[idx.clamp(min=0).long()], torch.zeros(())).to(dtype)
+    assert torch.equal(out.cpu(), ref.cpu())

@@ -119,3 +119,50 @@ def check_block_gradients(dev, name="nat_enc1", dtype=torch.float32, tol=2e-4):
         assert err < tol, (k, err)
     assert worst < tol, worst
     return worst
+
+
+def check_pack_plan(dev, dtype=torch.float32, steps=3):
+    """engine.PackPlan (all kernel-layout weights = one gather from the flat arena) against the per-module packers:
+    every module cache gets pinned, and the parameter trajectory of a few AdamW steps is bitwise the same."""
+    from torch import nn
+    from mp_hsir_amd import autograd_ops as AG
+    from mp_hsir_amd import ops
+    from mp_hsir_amd.engine import DataParallelEngine
+    from mp_hsir_amd.net.MP_HSIR import PGSSTB, PromptFusion
+
+    class Small(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inp = nn.Conv2d(8, 32, 3, padding=1, bias=False)
+            self.blk = PGSSTB(32, 1, [8, 8], 8, 4, 0.0, 2.66, 8, 128)
+            self.fuse = PromptFusion(64, 32, 2, 2.66, False)          # TransformerBlock(64) + 1x1 conv 64 -> 32
+            self.out = nn.Conv2d(32, 8, 3, padding=1, bias=False)
+
+        def forward(self, x, prompt):
+            h = AG.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(dtype), self.inp)
+            h = self.fuse(h, self.blk(h))
+            return AG.conv3x3(h, self.out).permute(0, 3, 1, 2).float() + x
+
+    res = []
+    for use_plan in (False, True):
+        torch.manual_seed(3)
+        net = Small().to(dev).eval()
+        eng = DataParallelEngine(net, lr=1e-2, use_pack_plan=use_plan)
+        g = torch.Generator().manual_seed(11)
+        losses = []
+        for _ in range(steps):
+            x, c = torch.rand(2, 8, 16, 8, generator=g).to(dev), torch.rand(2, 8, 16, 8, generator=g).to(dev)
+            losses.append(float(eng.train_step(x, c, None)))
+        if use_plan:
+            assert eng.plan is not None and eng.plan.pinned >= 5 and eng.plan.skipped == 0, (eng.plan.pinned, eng.plan.skipped)
+            ops.ACCOUNT = {}
+            eng.train_step(x, c, None)
+            acct, ops.ACCOUNT = ops.ACCOUNT, None
+            assert acct["pack_gather"][0] == len(eng.plan.groups) >= 1
+            eng.plan.release()
+        else:
+            eng.train_step(x, c, None)
+        res.append((losses, {k: v.detach().clone().cpu() for k, v in net.state_dict().items()}))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k

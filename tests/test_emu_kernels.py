@@ -74,3 +74,12 @@ def test_gemm_tn_tile128(dtype):
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 8, 31, 32), (2, 8, 4, 32, 31), (1, 8, 8, 64, 48)])
 def test_conv3x3(dtype, B, H, W, Cin, Cout):
     K.check_conv3x3("cpu", dtype, B, H, W, Cin, Cout)
+
+
+def test_reduce_parts():
+    K.check_reduce_parts("cpu")
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+def test_pack_gather(dtype):
+    K.check_pack_gather("cpu", dtype)

@@ -25,3 +25,9 @@ def test_tiny_gradients_match_reference():
 def test_block_gradients_match_reference():
     """stand-alone PGSSTB (C=64, 2 heads, shifted): HIP backward kernels vs the reference's dx / dparams."""
     assert M.check_block_gradients("cpu") < 2e-5
+
+
+def test_pack_plan_matches_per_module_packers():
+    import torch
+    M.check_pack_plan("cpu")
+    M.check_pack_plan("cpu", torch.bfloat16, steps=2)

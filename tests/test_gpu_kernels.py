@@ -107,3 +107,12 @@ def test_gemm_tn(dtype, M, N1, N2, nsplit, batch):
                                              (2, 16, 16, 256, 512), (2, 64, 64, 128, 31)])
 def test_conv3x3(dtype, B, H, W, Cin, Cout):
     K.check_conv3x3("cuda", dtype, B, H, W, Cin, Cout)
+
+
+def test_reduce_parts():
+    K.check_reduce_parts("cuda")
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+def test_pack_gather(dtype):
+    K.check_pack_gather("cuda", dtype)

@@ -168,3 +168,8 @@ def test_graph_replay_matches_eager_training():
     for u, v in ((a0, a1), (b0, b1)):
         d = (u - v).abs()
         assert float(d.max()) < 5 * 2e-3 and float(d.mean()) < 2e-5, (float(d.max()), float(d.mean()))
+
+
+def test_pack_plan_matches_per_module_packers():
+    M.check_pack_plan("cuda")
+    M.check_pack_plan("cuda", torch.bfloat16)
