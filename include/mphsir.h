@@ -252,7 +252,8 @@ int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B, int32_t H
  * views (batch strides in elements).  This is dW = dY^T X of every Linear / 1x1 conv on the path and the
  * per-sample dM = d_out^T v of the folded channel attention (autograd of net/MP_HSIR.py, train.py:58-67).
  * colsum_part (optional, [batch][nsplit][N1]): partial column sums of A = the matching bias gradient.
- * tile128 != 0 selects 128x128 output tiles per workgroup (fewer operand re-reads; for N1, N2 >= 128).     */
+ * tile128 != 0 selects the large-tile variant: fp32 128x128 tiles; bf16 the transposed-LDS-read kernel
+ * (ds_read_b64_tr_b16, no transposing stores, two LDS stages) with a 64- or 128-wide tile per operand.       */
 int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
                    float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch,
                    int32_t tile128, int dtype, void* stream);

@@ -130,6 +130,137 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
             }
 }
 
+// ---- bf16 fast path: no transposing stores --------------------------------------------------------------------
+// Both operands are token-major (K-strided), so the 64x64 kernel above transposes them on the way into LDS with
+// 8-byte stores.  gfx950 can transpose on the way OUT instead (ds_read_b64_tr_b16): the tiles are stored exactly as
+// they are loaded (16-byte chunks of token rows, XOR-swizzled so that both the stores and the transposed reads are
+// bank-conflict free), two LDS stages with ONE barrier per 64-token step, register-staged global loads in flight
+// during the MFMAs, and a (W1 x W2) in {64,128}^2 output tile per workgroup so the L1 fill rate (64 B/clk/CU) no
+// longer bounds the kernel: at 128x128 a step moves 32 KB for 2.1 MFLOP.
+template <int W> __device__ __forceinline__ int tr_off(int row, int ch);      // byte offset of 16-byte chunk ch of token row `row`
+template <> __device__ __forceinline__ int tr_off<128>(int row, int ch) {       // 256-byte rows (cdna_hip_programming.md T10, image (b))
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+template <> __device__ __forceinline__ int tr_off<64>(int row, int ch) {        // 128-byte rows: two rows per bank sweep
+    return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)));
+}
+
+// fragment (16 columns starting at col0, tokens kk..kk+31) of a swizzled [64][W] image
+template <int W> __device__ __forceinline__ bf16x8 tr_frag(const char* img, int col0, int kk) {
+    const int l = lane_id(), g4 = l >> 4, q = (l & 15) >> 2, p = l & 3;
+    const int row = kk + 8 * g4 + q, ch = (col0 >> 3) + (p >> 1);
+    const bf16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(img + tr_off<W>(row, ch) + 8 * (p & 1)));
+    const bf16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(img + tr_off<W>(row + 4, ch) + 8 * (p & 1)));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int W1, int W2>
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnDev a) {      // 2 waves/SIMD = 2 workgroups/CU (2 x 64 KB LDS)
+    typedef bf16_t T;
+    constexpr int KT = 64, RW = W1 / 64, NT = W2 / 16;
+    constexpr int IMG_A = KT * W1 * 2, IMG_B = KT * W2 * 2, STAGE = IMG_A + IMG_B;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    char* smem = reinterpret_cast<char*>(smem_v);                  // [2 stages][A image | B image]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t2n = (a.N2 + W2 - 1) / W2, ntiles = ((a.N1 + W1 - 1) / W1) * t2n;
+    const int L = blockIdx.x;                                       // XCD-aware map, as in gemm_tn_kernel
+    const int tile = (L >> 3) % ntiles, sp = (L & 7) + 8 * (L / (8 * ntiles)), bz = blockIdx.z;
+    if (sp >= a.nsplit) return;
+    const int n1_0 = (tile / t2n) * W1, n2_0 = (tile % t2n) * W2;
+    const long per = ((a.M + a.nsplit - 1) / a.nsplit + KT - 1) / KT * KT;
+    const long m_lo = (long)sp * per, m_hi = (m_lo + per < a.M) ? m_lo + per : a.M;
+    const T* A = reinterpret_cast<const T*>(a.A) + (long)bz * a.abs;
+    const T* B = reinterpret_cast<const T*>(a.B) + (long)bz * a.bbs;
+
+    f32x4 acc[RW][NT];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = a.colsum != nullptr && (tile % t2n) == 0;
+    f32x4 accs[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+
+    constexpr int CA = W1 / 8, CB = W2 / 8, ITEMS_A = KT * CA, ITEMS_B = KT * CB, NI = (ITEMS_A + ITEMS_B) / 256;
+    Vec16<T> x[NI];
+    auto gload = [&](long m0) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int v = tid + 256 * it;
+            const bool isb = v >= ITEMS_A;                          // ITEMS_A is a multiple of 256: uniform per `it`
+            const int u = isb ? v - ITEMS_A : v, cpr = isb ? CB : CA;
+            const int row = u / cpr, ch = u % cpr;                  // chunk fastest: a wave reads whole 128/256-byte row pieces
+            const long m = m0 + row;
+            const int col = (isb ? n2_0 : n1_0) + ch * 8, nmax = isb ? a.N2 : a.N1;
+            if (m < m_hi && col < nmax) x[it] = load16<T>((isb ? B : A) + m * (isb ? a.ldb : a.lda) + col);
+            else x[it] = Vec16<T>{};
+        }
+    };
+    auto sstore = [&](char* stage) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int v = tid + 256 * it;
+            const bool isb = v >= ITEMS_A;
+            const int u = isb ? v - ITEMS_A : v, cpr = isb ? CB : CA;
+            const int row = u / cpr, ch = u % cpr;
+            char* dst = isb ? stage + IMG_A + tr_off<W2>(row, ch) : stage + tr_off<W1>(row, ch);
+            store16<T>(reinterpret_cast<T*>(dst), x[it]);
+        }
+    };
+    gload(m_lo);
+    int buf = 0;
+    for (long m0 = m_lo; m0 < m_hi; m0 += KT, buf ^= 1) {
+        char* stage = smem + buf * STAGE;
+        sstore(stage);
+        __syncthreads();         // the only barrier per step: the other stage was last read before the previous barrier
+        if (m0 + KT < m_hi) gload(m0 + KT);
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 32) {
+            bf16x8 af[RW];
+#pragma unroll
+            for (int i = 0; i < RW; ++i) af[i] = tr_frag<W1>(stage, (wv * RW + i) * 16, kk);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8 bf = tr_frag<W2>(stage + IMG_A, nt * 16, kk);
+#pragma unroll
+                for (int i = 0; i < RW; ++i) mma(acc[i][nt], af[i], bf);
+            }
+            if (do_cs)
+#pragma unroll
+                for (int i = 0; i < RW; ++i) mma(accs[i], af[i], ones);
+        }
+    }
+    float* Cp = a.Cp + (((long)bz * a.nsplit + sp) * a.N1) * a.N2;
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = n1_0 + (wv * RW + i) * 16 + (lane >> 4) * 4 + r, n2 = n2_0 + nt * 16 + (lane & 15);
+                if (n1 < a.N1 && n2 < a.N2) Cp[(long)n1 * a.N2 + n2] = acc[i][nt][r];
+            }
+    if (do_cs && (lane & 15) == 0)
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+            for (int r = 0; r < 4; ++r) {
+                const int n1 = n1_0 + (wv * RW + i) * 16 + (lane >> 4) * 4 + r;
+                if (n1 < a.N1) a.colsum[((long)bz * a.nsplit + sp) * a.N1 + n1] = accs[i][r];
+            }
+}
+
+template <int W1, int W2>
+static int launch_tn_tr(const TnDev& d, int batch, hipStream_t s) {
+    const int ntiles = ((d.N1 + W1 - 1) / W1) * ((d.N2 + W2 - 1) / W2);
+    dim3 grid(ntiles * ((d.nsplit + 7) / 8 * 8), 1, batch);
+    const size_t shmem = 2 * (size_t)(W1 + W2) * 64 * 2;
+    allow_big_lds(gemm_tn_tr_kernel<W1, W2>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_tr_kernel<W1, W2>), grid, dim3(256), shmem, s, d);
+    return MPHSIR_OK;
+}
+
 template <class T, int R1, int R2>
 static int launch_tn(const TnDev& d, int batch, hipStream_t s) {
     constexpr int esz = sizeof(T), vec = 16 / esz;
@@ -159,6 +290,8 @@ extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool big = tile128 > 0;
     if (dtype == MPHSIR_F32) return big ? launch_tn<float, 2, 2>(d, batch, s) : launch_tn<float, 1, 1>(d, batch, s);
-    return big ? launch_tn<bf16_t, 2, 2>(d, batch, s) : launch_tn<bf16_t, 1, 1>(d, batch, s);
-    return MPHSIR_OK;
+    if (!big) return launch_tn<bf16_t, 1, 1>(d, batch, s);
+    // bf16 "big": the transposed-read kernel; each operand's tile width follows its matrix width
+    if (N1 > 64) return N2 > 64 ? launch_tn_tr<128, 128>(d, batch, s) : launch_tn_tr<128, 64>(d, batch, s);
+    return N2 > 64 ? launch_tn_tr<64, 128>(d, batch, s) : launch_tn_tr<64, 64>(d, batch, s);
 }

@@ -63,6 +63,14 @@ __device__ __forceinline__ void mma(f32x4& acc, f32x4 a, f32x4 b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
 }
 
+// Hardware-transposed LDS read (gfx950 ds_read_b64_tr_b16): per group of 16 lanes, lane 4q+p passes the address of
+// row q, columns 4p..4p+3 of a 4x16 block of bf16; lane i gets column i of the 4 rows.  Two of them (rows k..k+3 and
+// k+4..k+7) make the 16-byte fragment of a K-STRIDED (token-major) operand without a transposing store.
+// EXEC must be all ones; every lane's address must be 8-byte aligned.
+__device__ __forceinline__ bf16x4 lds_read_tr16(const bf16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+
 template <class T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }

@@ -493,6 +493,10 @@ def ln_bwd_tok(x2, dxn, dres, ln_w, ln_b):
     return dx, g[0], g[1], xn
 
 
+TN_BIG_TILES = True        # bf16 token-reduction GEMMs use the transposed-LDS-read kernel (ds_read_b64_tr_b16)
+TN_BIG_ROUNDS = 2.0        # ... and aim for this many full rounds of resident workgroups
+
+
 def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False):
     """sum over tokens of a[m,:]^T b[m,:].  a (M,N1), b (M,N2) row-major views -> fp32 (N1,N2);
     batched: a (Bt,M,N1), b (Bt,M,N2) -> (Bt,N1,N2).  colsum=True also returns sum_m a[m,:] (fp32, (N1,))."""
@@ -503,11 +507,16 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False):
     M, N1, N2 = a.shape[-2], a.shape[-1], b.shape[-1]
     assert a.stride(-1) == 1 and b.stride(-1) == 1 and b.shape[-2] == M and a.dtype == b.dtype
     if tile128 is None:
-        tile128 = False      # measured on MI355X: 128x128 tiles are slower here (fewer workgroups, lower occupancy)
+        tile128 = TN_BIG_TILES and a.dtype == torch.bfloat16
     if nsplit is None:
-        ts = 128 if tile128 else 64
-        tiles = ((N1 + ts - 1) // ts) * ((N2 + ts - 1) // ts) * Bt
-        nsplit = max(1, min(M // 512, 64, max(1, 768 // tiles)))      # ~3 workgroups per CU (measured optimum)
+        if tile128 and a.dtype == torch.bfloat16:     # transposed-read kernel: 64/128-wide tile per operand, 2 workgroups per CU
+            tiles = ((N1 + 127) // 128 if N1 > 64 else 1) * ((N2 + 127) // 128 if N2 > 64 else 1) * Bt
+            resident = 2 if (N1 > 64 and N2 > 64) else (4 if (N1 <= 64 and N2 <= 64) else 3)    # workgroups per CU (LDS, VGPRs)
+            nsplit = max(1, min(M // 256, 128, max(1, int(256 * resident * TN_BIG_ROUNDS) // tiles)))
+        else:
+            ts = 128 if tile128 else 64
+            tiles = ((N1 + ts - 1) // ts) * ((N2 + ts - 1) // ts) * Bt
+            nsplit = max(1, min(M // 512, 64, max(1, 768 // tiles)))      # ~3 workgroups per CU (measured optimum)
     part = torch.empty((Bt, nsplit, N1, N2), dtype=torch.float32, device=a.device)
     cs = torch.empty((Bt, nsplit, N1), dtype=torch.float32, device=a.device) if colsum else None
     _lib.check(lib.mphsir_gemm_tn(_p(a), a.stride(-2), a.stride(0) if batched else 0, _p(b), b.stride(-2),

@@ -278,7 +278,28 @@ inline f32x4_t mfma_16x16x4_f32(float a, float b, f32x4_t c) {
     wave_sync();
     return c;
 }
+// ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per group of 16 lanes, lane 4q+p supplies the address of row q,
+// columns 4p..4p+3 of a 4x16 block of 16-bit elements; lane i receives column i, row q in element q.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+inline bf16x4_t ds_read_tr16_b64(const void* p) {
+    WaveState& w = my_wave();
+    int l = lane_id();
+    memcpy(w.xa[l], &p, sizeof(p));
+    wave_sync();
+    int g = l & ~15, i = l & 15;
+    bf16x4_t r;
+    for (int q = 0; q < 4; ++q) {
+        const char* src;
+        memcpy(&src, w.xa[g + 4 * q + (i >> 2)], sizeof(src));
+        __bf16 v;
+        memcpy(&v, src + 2 * (i & 3), 2);
+        r[q] = v;
+    }
+    wave_sync();
+    return r;
+}
 }  // namespace hipemu
+#define __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p) hipemu::ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu::mfma_16x16x32<hipemu::bf16x8_t>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipemu::mfma_16x16x32<hipemu::f16x8_t>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4_f32(a, b, c)

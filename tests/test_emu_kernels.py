@@ -70,6 +70,12 @@ def test_gemm_tn_tile128(dtype):
     K.check_gemm_tn("cpu", dtype, 192, 160, 136, 2, 0, tile128=True)
 
 
+@pytest.mark.parametrize("M,N1,N2,nsplit,batch", [(200, 64, 128, 2, 0), (130, 136, 48, 1, 0), (96, 40, 56, 3, 2)])
+def test_gemm_tn_transposed_read_widths(M, N1, N2, nsplit, batch):
+    import torch
+    K.check_gemm_tn("cpu", torch.bfloat16, M, N1, N2, nsplit, batch, tile128=True)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 8, 31, 32), (2, 8, 4, 32, 31), (1, 8, 8, 64, 48)])
 def test_conv3x3(dtype, B, H, W, Cin, Cout):

@@ -116,3 +116,9 @@ def test_reduce_parts():
 @pytest.mark.parametrize("dtype", K.DTYPES)
 def test_pack_gather(dtype):
     K.check_pack_gather("cuda", dtype)
+
+
+@pytest.mark.parametrize("M,N1,N2,nsplit,batch", [(200, 64, 128, 2, 0), (130, 136, 48, 1, 0), (96, 40, 56, 3, 2), (8192, 704, 128, 8, 0),
+                                                  (4096, 128, 352, 5, 0), (4096, 64, 64, 4, 3), (4096, 384, 64, 7, 0)])
+def test_gemm_tn_transposed_read_widths(M, N1, N2, nsplit, batch):
+    K.check_gemm_tn("cuda", torch.bfloat16, M, N1, N2, nsplit, batch, tile128=True)
