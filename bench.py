@@ -179,7 +179,10 @@ def main():
                     "launches_per_step": launches,
                     "avg_launch_us": round(ms * 1e3 / launches, 2), "flops_per_step": flops, "bytes_per_step": nbytes,
                     "tflops_equiv": round(flops / (ms * 1e-3) / 1e12, 2),
-                    "kernel_ms_per_step": {k: round(v[1], 3) for k, v in sorted(per.items())}}
+                    "kernel_ms_per_step": {k: round(v[1], 3) for k, v in sorted(per.items())},
+                    # per kernel: [launches, ms, algorithmic GB, achieved TB/s, achieved TFLOP/s] per step
+                    "kernel_table": {k: [int(v[0]), round(v[1], 3), round(acct[k][2] / 1e9, 3), round(acct[k][2] / v[1] / 1e9, 2),
+                                         round(acct[k][1] / v[1] / 1e9, 1)] for k, v in sorted(per.items()) if k in acct}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -195,7 +198,7 @@ def main():
                                    % ("forward" if args.forward_only else "training step fwd+bwd+allreduce+AdamW",
                                       args.batch, "dp%d" % world),
                        "global_batch": world * args.batch, "patch": "64x64x31", "parallelism": "dp%d" % world, "launch": "eager" if (args.no_graph or args.forward_only) else "hipGraph replay",
-                       "backward": "HIP kernels + library GEMMs for the 22 PGSSTB blocks; torch-op composite for the prompt modules"},
+                       "backward": "HIP kernels for every module (token-reduction GEMMs, fused block/prompt-module backward); hipBLASLt only for two plain dX GEMMs per block"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -179,6 +179,7 @@ typedef struct mphsir_mlp_bwd_args {
     const void* W1; const float* b1; const void* W1T; const void* W2T;
     void* dX; void* XN; void* H; void* DPRE; float* part;
     int64_t M; int32_t C, HP;
+    int32_t variant;                  /* 0 = library's choice; 1..3 pin a kernel form (tests / tuning), see gated_mlp_bwd.hip */
 } mphsir_mlp_bwd_args;
 int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream);
 

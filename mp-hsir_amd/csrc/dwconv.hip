@@ -146,10 +146,6 @@ struct GateBwdDev {
     const void* T; const void* dU; void* U; void* dT; long M; int HP;
 };
 
-__device__ __forceinline__ float gelu_grad_erf(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-}
-
 // backward of u = gelu(x1) * x2 with [x1|x2] = T[:, :HP], T[:, HP:]  (FFN/FeedForward :263, :389); also re-emits u
 template <class T>
 __global__ __launch_bounds__(256) void gdfn_gate_bwd_kernel(GateBwdDev a) {
@@ -167,9 +163,10 @@ __global__ __launch_bounds__(256) void gdfn_gate_bwd_kernel(GateBwdDev a) {
         const Vec16<T> du = load16<T>(dU + m * a.HP + c0);
         Vec16<T> u, d1, d2;
         for (int e = 0; e < VEC; ++e) {
-            const float g = gelu_erf(x1.get(e));
+            float g, dgl;
+            Math<T>::gelu_pair(x1.get(e), g, dgl);
             u.set(e, g * x2.get(e));
-            d1.set(e, du.get(e) * x2.get(e) * gelu_grad_erf(x1.get(e)));
+            d1.set(e, du.get(e) * x2.get(e) * dgl);
             d2.set(e, du.get(e) * g);
         }
         store16<T>(U + m * a.HP + c0, u);

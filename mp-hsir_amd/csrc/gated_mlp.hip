@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void gated_mlp_kernel(MlpDev a) {
         const int hr = (lane >> 4) * 4;
         f32x4 h0, h1;
         for (int r = 0; r < 4; ++r) {
-            h0[r] = (v0[r] + a.b1[j + hr + r]) * gelu_erf(g0[r] + a.b1[HP + j + hr + r]);
-            h1[r] = (v1[r] + a.b1[j + 16 + hr + r]) * gelu_erf(g1[r] + a.b1[HP + j + 16 + hr + r]);
+            h0[r] = (v0[r] + a.b1[j + hr + r]) * Math<T>::gelu(g0[r] + a.b1[HP + j + hr + r]);
+            h1[r] = (v1[r] + a.b1[j + 16 + hr + r]) * Math<T>::gelu(g1[r] + a.b1[HP + j + 16 + hr + r]);
         }
         store4<T>(Hw + (lane & 15) * LDH + hr, h0);
         store4<T>(Hw + (lane & 15) * LDH + 16 + hr, h1);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
             for (int u = 0; u < 2; ++u) {
                 f32x4 h;
                 for (int r = 0; r < 4; ++r)
-                    h[r] = (vv[t][u][r] + a.b1[j + u * 16 + hr + r]) * gelu_erf(gg[t][u][r] + a.b1[HP + j + u * 16 + hr + r]);
+                    h[r] = (vv[t][u][r] + a.b1[j + u * 16 + hr + r]) * Math<T>::gelu(gg[t][u][r] + a.b1[HP + j + u * 16 + hr + r]);
                 store4<T>(Hw + (t * 16 + (lane & 15)) * LDH + u * 16 + hr, h);
             }
         __syncthreads();

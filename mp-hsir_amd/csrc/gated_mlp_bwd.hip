@@ -28,10 +28,6 @@ struct MlpBwdDev {
     int M, HP;
 };
 
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-}
-
 // STAGE = true: the fc1 rows of the hidden chunk ([64][C]) and the matching columns of W1^T ([C][64]) are loaded
 // once per workgroup into LDS (coalesced) instead of every wave streaming its own fragments through L1.
 template <class T, int C, bool STAGE>
@@ -146,11 +142,13 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
         for (int r = 0; r < 4; ++r) {
             const float va = v0[r] + a.b1[j + hr + r], ga = g0[r] + a.b1[HP + j + hr + r];
             const float vb = v1[r] + a.b1[j + 16 + hr + r], gb = g1[r] + a.b1[HP + j + 16 + hr + r];
-            const float ea = gelu_erf(ga), eb = gelu_erf(gb);
+            float ea, eb, da, db;
+            Math<T>::gelu_pair(ga, ea, da);
+            Math<T>::gelu_pair(gb, eb, db);
             h0[r] = va * ea;            h1[r] = vb * eb;
             dv0[r] = e0[r] * ea;        dv1[r] = e1[r] * eb;
-            dg0[r] = e0[r] * va * gelu_erf_grad(ga);
-            dg1[r] = e1[r] * vb * gelu_erf_grad(gb);
+            dg0[r] = e0[r] * va * da;
+            dg1[r] = e1[r] * vb * db;
         }
         // h chunk -> HBM through the per-wave LDS buffer (whole 64-byte row segments per token)
         store4<T>(Hw + tk * LDH + hr, h0);
@@ -252,8 +250,316 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
     }
 }
 
+// ---- second form ------------------------------------------------------------------------------------------------
+// The first form is bound by LDS traffic and barriers (measured 140-170 TFLOP/s): one 16-token tile per wave means
+// every weight fragment read from LDS feeds exactly one MFMA, the token fragments are re-read from LDS for each of
+// the HP/32 chunks, the next chunk's weights are fetched only after the previous chunk is done, and the wave-private
+// h / dpre staging goes through five workgroup barriers per chunk.  Here
+//   * the wave's LN(x) and dm fragments live in REGISTERS for the whole chunk loop (the token tiles leave LDS),
+//   * a wave owns TT 16-token tiles, so one weight fragment feeds TT MFMAs,
+//   * all three weight slices of a chunk (fc1 rows, W2^T rows, W1^T columns) are staged in LDS once per workgroup
+//     and the NEXT chunk's slices are already in flight in registers during the MFMAs,
+//   * wave-private staging uses wave barriers: two workgroup barriers per chunk remain.
+template <class T, int C, int TT>
+__global__ __launch_bounds__(256) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
+    typedef ElemTraits<T> TR;
+    typedef typename TR::frag_t frag_t;
+    constexpr int PAD = 16 / sizeof(T), LDX = C + PAD, LDH = 64 + PAD, LDF = C + 4, VEC = Vec16<T>::N;
+    constexpr int NCT = C / 16, NV = C / VEC, VPT = NV / 4;
+    constexpr int TOK = 64 * TT, WT = 16 * TT;
+    constexpr int NKC = C / TR::KCHUNK, NKH = 32 / TR::KCHUNK;
+    constexpr size_t P0 = 2 * (size_t)TOK * LDX * sizeof(T);
+    constexpr size_t P1 = ((size_t)96 * LDX + (size_t)C * LDH + 4 * WT * LDH) * sizeof(T);
+    constexpr size_t P2 = (size_t)TOK * LDF * 4;
+    constexpr size_t REG = ((P0 > P1 ? (P0 > P2 ? P0 : P2) : (P1 > P2 ? P1 : P2)) + 15) / 16 * 16;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    char* smem = reinterpret_cast<char*>(smem_v);
+    T* Xs = reinterpret_cast<T*>(smem);                  // phase 0: [TOK][LDX] LN(x)
+    T* Ds = Xs + TOK * LDX;                              //          [TOK][LDX] dm
+    T* W1s = reinterpret_cast<T*>(smem);                 // loop: [64][LDX] fc1 rows: value 0..31 | gate 32..63
+    T* W2Ts = W1s + 64 * LDX;                            //       [32][LDX] W2^T rows of the chunk
+    T* W1Ts = W2Ts + 32 * LDX;                           //       [C][LDH]  W1^T columns: value 0..31 | gate 32..63
+    T* Hs = W1Ts + C * LDH;                              //       [4][WT][LDH] per wave: h, then [dval | dgate]
+    float* Fs = reinterpret_cast<float*>(smem);          // end:  [TOK][LDF] fp32 dxn
+    float* stat = reinterpret_cast<float*>(smem + REG);  // mean[TOK], rstd[TOK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long m0 = (long)blockIdx.x * TOK;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* DM = reinterpret_cast<const T*>(a.DM);
+    const T* dY = reinterpret_cast<const T*>(a.dY);
+    const int HP = a.HP;
+
+    // ---- phase 0: LN(x) (also written to XN) and dm into LDS, 4 adjacent lanes per token; then into fragments ----
+#pragma unroll
+    for (int pass = 0; pass < TT; ++pass) {
+        const int r = pass * 64 + (tid >> 2), q = tid & 3;
+        const T* row = X + (m0 + r) * C;
+        Vec16<T> xv[VPT];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            xv[i] = load16<T>(row + (q + 4 * i) * VEC);
+            for (int e = 0; e < VEC; ++e) s += xv[i].get(e);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            for (int e = 0; e < VEC; ++e) { float d = xv[i].get(e) - mean; d2 += d * d; }
+        d2 += __shfl_xor(d2, 1);
+        d2 += __shfl_xor(d2, 2);
+        const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+        if (q == 0) { stat[r] = mean; stat[TOK + r] = rstd; }
+        T* XN = reinterpret_cast<T*>(a.XN) + (m0 + r) * C;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
+            store16<T>(Xs + r * LDX + c0, o);
+            store16<T>(XN + c0, o);
+            store16<T>(Ds + r * LDX + c0, load16<T>(DM + (m0 + r) * C + c0));
+        }
+    }
+    __syncthreads();
+    frag_t bx[TT][NKC], bd[TT][NKC];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            bx[t][kc] = load_frag<T>(Xs, LDX, wv * WT + 16 * t, kc * TR::KCHUNK);
+            bd[t][kc] = load_frag<T>(Ds, LDX, wv * WT + 16 * t, kc * TR::KCHUNK);
+        }
+
+    // ---- weight slices of one chunk: global -> registers (prefetch) -> LDS ----------------------------------------
+    const T* W1 = reinterpret_cast<const T*>(a.W1);
+    const T* W1T = reinterpret_cast<const T*>(a.W1T);
+    const T* W2T = reinterpret_cast<const T*>(a.W2T);
+    constexpr int VPR = C / VEC, VPH = 32 / VEC;
+    constexpr int NW1 = 64 * VPR, NW2 = 32 * VPR, NWT = C * 2 * VPH, NVW = NW1 + NW2 + NWT, NPT = (NVW + 255) / 256;
+    Vec16<T> wreg[NPT];
+    auto wload = [&](int j) {
+#pragma unroll
+        for (int it = 0; it < NPT; ++it) {
+            const int v = tid + 256 * it;
+            if (v < NW1) {
+                const int r = v / VPR, c = (v % VPR) * VEC;
+                wreg[it] = load16<T>(W1 + (long)(r < 32 ? j + r : HP + j + (r - 32)) * C + c);
+            } else if (v < NW1 + NW2) {
+                const int u = v - NW1, r = u / VPR, c = (u % VPR) * VEC;
+                wreg[it] = load16<T>(W2T + (long)(j + r) * C + c);
+            } else if (v < NVW) {
+                const int u = v - NW1 - NW2, r = u / (2 * VPH), seg = (u / VPH) & 1, c = (u % VPH) * VEC;
+                wreg[it] = load16<T>(W1T + (long)r * 2 * HP + seg * HP + j + c);
+            }
+        }
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int it = 0; it < NPT; ++it) {
+            const int v = tid + 256 * it;
+            if (v < NW1) {
+                const int r = v / VPR, c = (v % VPR) * VEC;
+                store16<T>(W1s + r * LDX + c, wreg[it]);
+            } else if (v < NW1 + NW2) {
+                const int u = v - NW1, r = u / VPR, c = (u % VPR) * VEC;
+                store16<T>(W2Ts + r * LDX + c, wreg[it]);
+            } else if (v < NVW) {
+                const int u = v - NW1 - NW2, r = u / (2 * VPH), seg = (u / VPH) & 1, c = (u % VPH) * VEC;
+                store16<T>(W1Ts + r * LDH + seg * 32 + c, wreg[it]);
+            }
+        }
+    };
+    wload(0);
+
+    T* Hw = Hs + wv * WT * LDH;
+    T* Hout = reinterpret_cast<T*>(a.H);
+    T* Pout = reinterpret_cast<T*>(a.DPRE);
+    f32x4 out[TT][NCT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) out[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int hr = (lane >> 4) * 4, tk = lane & 15;
+
+    for (int j = 0; j < HP; j += 32) {
+        __syncthreads();                 // every wave is done with the previous chunk's slices (and, first time, with Xs/Ds)
+        wstore();
+        __syncthreads();
+        if (j + 32 < HP) wload(j + 32);  // in flight during the MFMAs below
+        f32x4 pv[2][TT], pg[2][TT], pe[2][TT];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) pv[f][t] = pg[f][t] = pe[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int kk = kc * TR::KCHUNK;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const frag_t wv_ = load_frag<T>(W1s, LDX, 16 * f, kk), wg_ = load_frag<T>(W1s, LDX, 32 + 16 * f, kk);
+                const frag_t w2_ = load_frag<T>(W2Ts, LDX, 16 * f, kk);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    mma(pv[f][t], wv_, bx[t][kc]);
+                    mma(pg[f][t], wg_, bx[t][kc]);
+                    mma(pe[f][t], w2_, bd[t][kc]);
+                }
+            }
+        }
+        f32x4 hh[2][TT], dv[2][TT], dg[2][TT];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float bv[4], bg[4];
+            for (int r = 0; r < 4; ++r) { bv[r] = a.b1[j + 16 * f + hr + r]; bg[r] = a.b1[HP + j + 16 * f + hr + r]; }
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+                for (int r = 0; r < 4; ++r) {
+                    const float va = pv[f][t][r] + bv[r], ga = pg[f][t][r] + bg[r];
+                    float ea, da;
+                    Math<T>::gelu_pair(ga, ea, da);
+                    hh[f][t][r] = va * ea;
+                    dv[f][t][r] = pe[f][t][r] * ea;
+                    dg[f][t][r] = pe[f][t][r] * va * da;
+                }
+        }
+        // h chunk -> HBM through the wave's staging rows (whole 64-byte row segments per token)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            store4<T>(Hw + (16 * t + tk) * LDH + hr, hh[0][t]);
+            store4<T>(Hw + (16 * t + tk) * LDH + 16 + hr, hh[1][t]);
+        }
+        wave_barrier();
+        for (int i = lane; i < WT * VPH; i += 64) {
+            const int t = i / VPH, c = (i % VPH) * VEC;
+            store16<T>(Hout + (m0 + wv * WT + t) * HP + j + c, load16<T>(Hw + t * LDH + c));
+        }
+        wave_barrier();
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            store4<T>(Hw + (16 * t + tk) * LDH + hr, dv[0][t]);
+            store4<T>(Hw + (16 * t + tk) * LDH + 16 + hr, dv[1][t]);
+            store4<T>(Hw + (16 * t + tk) * LDH + 32 + hr, dg[0][t]);
+            store4<T>(Hw + (16 * t + tk) * LDH + 48 + hr, dg[1][t]);
+        }
+        wave_barrier();
+        for (int i = lane; i < WT * 2 * VPH; i += 64) {
+            const int t = i / (2 * VPH), seg = (i / VPH) & 1, c = (i % VPH) * VEC;
+            store16<T>(Pout + (m0 + wv * WT + t) * 2 * HP + seg * HP + j + c, load16<T>(Hw + t * LDH + seg * 32 + c));
+        }
+        // dxn[c][tok] += W1T[c][j..j+31] * dval + W1T[c][HP+j..] * dgate
+#pragma unroll
+        for (int kh = 0; kh < 2 * NKH; ++kh) {
+            frag_t bh[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) bh[t] = load_frag<T>(Hw, LDH, 16 * t, kh * TR::KCHUNK);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const frag_t wt_ = load_frag<T>(W1Ts, LDH, ct * 16, kh * TR::KCHUNK);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) mma(out[t][ct], wt_, bh[t]);
+            }
+        }
+        wave_barrier();
+    }
+    __syncthreads();
+
+    // ---- dxn -> fp32 LDS stage; LayerNorm backward; dx = dy + ...; parameter-gradient partials per 64 tokens -----
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const int tok = wv * WT + 16 * t + (lane & 15), cr = (lane >> 4) * 4;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(Fs + tok * LDF + ct * 16 + cr) = out[t][ct];
+    }
+    __syncthreads();
+    float* part = a.part + (long)blockIdx.x * TT * 2 * C;
+    for (int i = tid; i < TT * C; i += 256) {                 // d(ln bias)[c] = sum_tok dxn, per group of 64 tokens
+        const int g = i / C, c = i % C;
+        float s = 0.f;
+        for (int t = 0; t < 64; ++t) s += Fs[(g * 64 + t) * LDF + c];
+        part[(g * 2 + 1) * C + c] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < TT; ++pass) {
+        const int r = pass * 64 + (tid >> 2), q = tid & 3;
+        const float mean = stat[r], rstd = stat[TOK + r];
+        const T* xrow = X + (m0 + r) * C;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            const Vec16<T> xv = load16<T>(xrow + c0);
+            for (int e = 0; e < VEC; ++e) {
+                const float gw = Fs[r * LDF + c0 + e] * a.ln_w[c0 + e], xh = (xv.get(e) - mean) * rstd;
+                s1 += gw;
+                s2 += gw * xh;
+            }
+        }
+        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+        s1 *= 1.0f / (float)C;
+        s2 *= 1.0f / (float)C;
+        T* dxrow = reinterpret_cast<T*>(a.dX) + (m0 + r) * C;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            const Vec16<T> xv = load16<T>(xrow + c0);
+            const Vec16<T> dy = load16<T>(dY + (m0 + r) * C + c0);
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) {
+                const float dxn = Fs[r * LDF + c0 + e], xh = (xv.get(e) - mean) * rstd;
+                o.set(e, dy.get(e) + rstd * (dxn * a.ln_w[c0 + e] - s1 - xh * s2));
+                Fs[r * LDF + c0 + e] = dxn * xh;          // for d(ln weight)
+            }
+            store16<T>(dxrow + c0, o);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < TT * C; i += 256) {                 // d(ln weight)[c] = sum_tok dxn * xhat
+        const int g = i / C, c = i % C;
+        float s = 0.f;
+        for (int t = 0; t < 64; ++t) s += Fs[(g * 64 + t) * LDF + c];
+        part[(g * 2) * C + c] = s;
+    }
+}
+
+template <class T, int C, int TT>
+constexpr size_t mlp_bwd2_lds() {
+    constexpr size_t PAD = 16 / sizeof(T), LDX = C + PAD, LDH = 64 + PAD, LDF = C + 4, TOK = 64 * TT, WT = 16 * TT;
+    constexpr size_t P0 = 2 * TOK * LDX * sizeof(T), P1 = (96 * LDX + C * LDH + 4 * WT * LDH) * sizeof(T), P2 = TOK * LDF * 4;
+    constexpr size_t REG = ((P0 > P1 ? (P0 > P2 ? P0 : P2) : (P1 > P2 ? P1 : P2)) + 15) / 16 * 16;
+    return REG + 2 * TOK * sizeof(float);
+}
+
+template <class T, int C, int TT>
+constexpr bool mlp_bwd2_fits() { return mlp_bwd2_lds<T, C, TT>() <= 160 * 1024 && (C / Vec16<T>::N) % 4 == 0; }
+
+template <class T, int C, int TT>
+static int launch_mlp_bwd2(const MlpBwdDev& d, hipStream_t s) {
+    if constexpr (mlp_bwd2_fits<T, C, TT>()) {
+        constexpr size_t lds = mlp_bwd2_lds<T, C, TT>();
+        allow_big_lds(gated_mlp_bwd2_kernel<T, C, TT>, lds);
+        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd2_kernel<T, C, TT>), dim3(d.M / (64 * TT)), dim3(256), lds, s, d);
+    }
+    return MPHSIR_OK;
+}
+
+// variant: 0 = choose (second form when it fits LDS; two tiles per wave for C <= 128 once that still leaves >= 2
+// workgroups per CU), 1 = first form, 2 / 3 = second form with one / two 16-token tiles per wave.
 template <class T, int C>
-static int launch_mlp_bwd(const MlpBwdDev& d, hipStream_t s) {
+static int launch_mlp_bwd(const MlpBwdDev& d, int variant, hipStream_t s) {
+    if (variant != 1) {
+        if constexpr (mlp_bwd2_fits<T, C, 2>()) {
+            if (d.M % 128 == 0 && (variant == 3 || (variant == 0 && C <= 128 && d.M / 128 >= 512))) return launch_mlp_bwd2<T, C, 2>(d, s);
+        }
+        if constexpr (mlp_bwd2_fits<T, C, 1>()) {
+            if (variant == 0 || variant == 2) return launch_mlp_bwd2<T, C, 1>(d, s);
+        }
+    }
     constexpr int PAD = 16 / sizeof(T);
     constexpr size_t base = (2 * 64 * (C + PAD) + 4 * 16 * (64 + PAD)) * sizeof(T) + 128 * sizeof(float);
     constexpr size_t staged = base + (64 * (size_t)(C + PAD) + (size_t)C * (64 + PAD)) * sizeof(T);
@@ -268,15 +574,15 @@ static int launch_mlp_bwd(const MlpBwdDev& d, hipStream_t s) {
 }
 
 template <class T>
-static int dispatch_mlp_bwd(const MlpBwdDev& d, int C, hipStream_t s) {
+static int dispatch_mlp_bwd(const MlpBwdDev& d, int C, int variant, hipStream_t s) {
     switch (C) {
-        case 32: return launch_mlp_bwd<T, 32>(d, s);
-        case 64: return launch_mlp_bwd<T, 64>(d, s);
-        case 96: return launch_mlp_bwd<T, 96>(d, s);
-        case 128: return launch_mlp_bwd<T, 128>(d, s);
-        case 192: return launch_mlp_bwd<T, 192>(d, s);
-        case 256: return launch_mlp_bwd<T, 256>(d, s);
-        case 384: return launch_mlp_bwd<T, 384>(d, s);
+        case 32: return launch_mlp_bwd<T, 32>(d, variant, s);
+        case 64: return launch_mlp_bwd<T, 64>(d, variant, s);
+        case 96: return launch_mlp_bwd<T, 96>(d, variant, s);
+        case 128: return launch_mlp_bwd<T, 128>(d, variant, s);
+        case 192: return launch_mlp_bwd<T, 192>(d, variant, s);
+        case 256: return launch_mlp_bwd<T, 256>(d, variant, s);
+        case 384: return launch_mlp_bwd<T, 384>(d, variant, s);
     }
     set_error("gated_mlp_bwd: C=%d not instantiated", C);
     return MPHSIR_EINVAL;
@@ -297,5 +603,6 @@ extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, voi
     MlpBwdDev d{a->X, a->dY, a->DM, a->ln_w, a->ln_b, a->W1, a->b1, a->W1T, a->W2T, a->dX, a->XN, a->H, a->DPRE, a->part,
                 (int)a->M, a->HP};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return dtype == MPHSIR_F32 ? dispatch_mlp_bwd<float>(d, a->C, s) : dispatch_mlp_bwd<bf16_t>(d, a->C, s);
+    MPHSIR_REQUIRE(a->variant >= 0 && a->variant <= 3, "gated_mlp_bwd: variant must be 0..3");
+    return dtype == MPHSIR_F32 ? dispatch_mlp_bwd<float>(d, a->C, a->variant, s) : dispatch_mlp_bwd<bf16_t>(d, a->C, a->variant, s);
 }

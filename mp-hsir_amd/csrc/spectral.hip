@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(GateDev a) {
                 v1 += al[r].get(e) * w1[r * 3][e] + am[r].get(e) * w1[r * 3 + 1][e] + ar[r].get(e) * w1[r * 3 + 2][e];
                 v2 += bl[r].get(e) * w2[r * 3][e] + bm[r].get(e) * w2[r * 3 + 1][e] + br[r].get(e) * w2[r * 3 + 2][e];
             }
-            o.set(e, gelu_erf(v1) * v2);
+            o.set(e, Math<T>::gelu(v1) * v2);
         }
         store16<T>(U + ((long)y * a.W + x0 + i) * a.ldu, o);
 #pragma unroll

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
-            for (int r = 0; r < 4; ++r) { const float e = expf(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+            for (int r = 0; r < 4; ++r) { const float e = Math<T>::exp(s[kt][r] - mx); s[kt][r] = e; sum += e; }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;

@@ -401,7 +401,7 @@ def dwconv3x3_wgrad(x, dy, nblk=None):
     return reduce_parts(part)
 
 
-def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T):
+def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0):
     """-> dx, xn, h, dpre, part (see include/mphsir.h).  x, dy, dm: contiguous (M,C)."""
     lib = _lib.load()
     _check(x, dy, dm, W1, W1T, W2T)
@@ -418,7 +418,7 @@ def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T):
     a.X, a.dY, a.DM, a.ln_w, a.ln_b = _p(x), _p(dy), _p(dm), _p(ln_w), _p(ln_b)
     a.W1, a.b1, a.W1T, a.W2T = _p(W1), _p(b1), _p(W1T), _p(W2T)
     a.dX, a.XN, a.H, a.DPRE, a.part = _p(dx), _p(xn), _p(h), _p(dpre), _p(part)
-    a.M, a.C, a.HP = M, C, HP
+    a.M, a.C, a.HP, a.variant = M, C, HP, variant
     _lib.check(lib.mphsir_gated_mlp_bwd(ctypes.byref(a), _DT[dt], _stream(x)), "gated_mlp_bwd")
     _acct("gated_mlp_bwd", 12.0 * M * C * HP, (3.0 * M * C + 3.0 * M * HP + M * C) * x.element_size())
     return dx, xn, h, dpre, part

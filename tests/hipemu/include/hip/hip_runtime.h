@@ -226,6 +226,7 @@ inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __expf(float x) { return expf(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }
 inline float __fdividef(float a, float b) { return a / b; }
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 
 // ---- matrix-core emulation: fragment maps per cdna_hip_programming.md §3 -----------------------
 namespace hipemu {
@@ -299,6 +300,8 @@ inline bf16x4_t ds_read_tr16_b64(const void* p) {
     return r;
 }
 }  // namespace hipemu
+#define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
+#define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p) hipemu::ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu::mfma_16x16x32<hipemu::bf16x8_t>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipemu::mfma_16x16x32<hipemu::f16x8_t>(a, b, c)

@@ -192,7 +192,7 @@ def check_dwconv_plain(dev, dtype, shape):
     assert rel_l2(dw, wr.grad.reshape(C, 9).t()) < TOL[dtype]
 
 
-def check_gated_mlp_bwd(dev, dtype, C, hid):
+def check_gated_mlp_bwd(dev, dtype, C, hid, variant=0):
     """HIP data-gradient kernel + token-reduction GEMMs vs autograd of the fp64 oracle."""
     _use(dev)
     from mp_hsir_amd import ops
@@ -205,7 +205,7 @@ def check_gated_mlp_bwd(dev, dtype, C, hid):
     W1, b1, W2 = ops.pack_gated_mlp(P["fc1.weight"], P["fc1.bias"], P["fc2.weight"], dtype)
     HP = W2.shape[1]
     dm = (dy.float() * keep.repeat_interleave(64)[:, None]).to(dtype)
-    dx, xn, h, dpre, part = ops.gated_mlp_bwd(x, dy, dm, lnw, lnb, W1, b1, W1.t().contiguous(), W2.t().contiguous())
+    dx, xn, h, dpre, part = ops.gated_mlp_bwd(x, dy, dm, lnw, lnb, W1, b1, W1.t().contiguous(), W2.t().contiguous(), variant=variant)
     dW2 = (dm.float().t() @ h.float())[:, :hid]
     dW1p = dpre.float().t() @ xn.float()
     dW1 = torch.cat([dW1p[:hid], dW1p[HP:HP + hid]], 0)

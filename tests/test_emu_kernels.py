@@ -60,6 +60,12 @@ def test_gated_mlp_bwd(dtype, C, hid):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,hid,variant", [(32, 85, 1), (32, 85, 3), (96, 255, 3)])
+def test_gated_mlp_bwd_kernel_forms(dtype, C, hid, variant):
+    K.check_gated_mlp_bwd("cpu", dtype, C, hid, variant=variant)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("M,N1,N2,nsplit,batch", [(256, 64, 64, 2, 0), (200, 96, 32, 3, 0), (128, 32, 32, 1, 2)])
 def test_gemm_tn(dtype, M, N1, N2, nsplit, batch):
     K.check_gemm_tn("cpu", dtype, M, N1, N2, nsplit, batch)

@@ -91,6 +91,13 @@ def test_gated_mlp_bwd(dtype, C, hid):
     K.check_gated_mlp_bwd("cuda", dtype, C, hid)
 
 
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,hid,variant", [(32, 85, 1), (32, 85, 3), (96, 255, 3), (128, 340, 1), (128, 340, 2), (128, 340, 3), (64, 170, 3),
+                                           (256, 680, 1), (256, 680, 2)])
+def test_gated_mlp_bwd_kernel_forms(dtype, C, hid, variant):
+    K.check_gated_mlp_bwd("cuda", dtype, C, hid, variant=variant)
+
+
 def test_gated_mlp_bwd_c384_bf16():
     K.check_gated_mlp_bwd("cuda", torch.bfloat16, 384, 1021)
 

@@ -7,7 +7,7 @@ for r in csv.DictReader(open(f[0])):
     e = agg[k][r["Counter_Name"]]
     e[0] += 1; e[1] += float(r["Counter_Value"])
 for k, cs in agg.items():
-    if "gemm_tn" not in k and len(sys.argv) < 3: continue
+    if len(sys.argv) > 2 and sys.argv[2] not in k: continue
     print(k)
     for c, (n, v) in sorted(cs.items()):
         print("   %-28s %14.0f per launch (%d launches)" % (c, v / n, n))
