@@ -84,7 +84,7 @@ struct WinBwdDev {
 };
 
 template <class T, int C, int HD> struct WinBwdCfg {
-    static constexpr int PAD = 16 / sizeof(T);
+    static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     static constexpr int HEADS = C / HD;
     static constexpr int KC = ElemTraits<T>::KCHUNK;
     static constexpr int HDP = (HD + KC - 1) / KC * KC;
@@ -460,7 +460,7 @@ extern "C" int mphsir_win_attn_bwd(const mphsir_win_attn_bwd_args* a, int dtype,
 
 extern "C" int mphsir_win_attn_bwd_fits(int32_t C, int32_t heads, int dtype) {
     using namespace mphsir;
-    const int hd = C / heads, kc = dtype == MPHSIR_F32 ? 16 : 32, esz = dtype == MPHSIR_F32 ? 4 : 2, pad = 16 / esz;
+    const int hd = C / heads, kc = dtype == MPHSIR_F32 ? 16 : 32, esz = dtype == MPHSIR_F32 ? 4 : 2, pad = LDS_PAD_BYTES / esz;
     const int hdp = (hd + kc - 1) / kc * kc;
     const size_t elems = 2 * 64 * (size_t)(C + pad) + 4 * 64 * (size_t)(hdp + pad) + 3 * (size_t)hd * (64 + pad) +
                          (hdp >= 64 ? 0 : 3 * 64 * (size_t)(64 + pad));

@@ -24,7 +24,7 @@ struct ConvDev {
 template <class T>
 __global__ __launch_bounds__(256) void conv3x3_tok_kernel(ConvDev a) {
     typedef ElemTraits<T> TR;
-    constexpr int PAD = 16 / sizeof(T), KC = 32, LDA = KC + PAD, LDC = 64 + 4;
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T), KC = 32, LDA = KC + PAD, LDC = 64 + 4;
     constexpr int VEC = Vec16<T>::N;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     T* As = reinterpret_cast<T*>(smem_v);          // [64][LDA]

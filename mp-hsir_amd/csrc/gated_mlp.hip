@@ -27,7 +27,7 @@ template <class T, int C>
 __global__ __launch_bounds__(256) void gated_mlp_kernel(MlpDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
-    constexpr int PAD = 16 / sizeof(T);
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     constexpr int LDX = C + PAD;
     constexpr int LDH = 32 + PAD;
     constexpr int VEC = Vec16<T>::N;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void gated_mlp_kernel(MlpDev a) {
 // is loaded once per workgroup with coalesced 16-byte loads, and each wave owns TT token tiles (BM = 64*TT)
 // so every weight fragment read from LDS feeds TT MFMAs.
 template <class T, int C, int TT> struct MlpLdsCfg {
-    static constexpr int PAD = 16 / sizeof(T);
+    static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     static constexpr int BM = 64 * TT;
     static constexpr int LDX = C + PAD, LDH = 32 + PAD;
     static constexpr size_t ELEMS = (size_t)BM * LDX + 64 * LDX + (size_t)C * LDH + 4 * 16 * TT * LDH;
@@ -311,7 +311,7 @@ static int launch_mlp(const MlpDev& d, hipStream_t s) {
     if (d.M % 128 == 0 && (d.tpw == 2 || (d.tpw == 0 && d.M / 128 >= 512))) rc = launch_mlp_lds<T, C, 2>(d, s);
     if (rc == 1) rc = launch_mlp_lds<T, C, 1>(d, s);
     if (rc != 1) return rc;
-    constexpr int PAD = 16 / sizeof(T);
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     const size_t shmem = (64 * (C + PAD) + 4 * 16 * (32 + PAD)) * sizeof(T);
     allow_big_lds(gated_mlp_kernel<T, C>, shmem);
     MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_kernel<T, C>), dim3(d.M / 64), dim3(256), shmem, s, d);

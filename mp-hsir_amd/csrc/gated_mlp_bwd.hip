@@ -34,7 +34,7 @@ template <class T, int C, bool STAGE>
 __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
-    constexpr int PAD = 16 / sizeof(T);
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     constexpr int LDX = C + PAD;
     constexpr int LDH = 64 + PAD;
     constexpr int LDF = C + 4;                          // fp32 staging of dxn
@@ -264,7 +264,7 @@ template <class T, int C, int TT>
 __global__ __launch_bounds__(256) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
-    constexpr int PAD = 16 / sizeof(T), LDX = C + PAD, LDH = 64 + PAD, LDF = C + 4, VEC = Vec16<T>::N;
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T), LDX = C + PAD, LDH = 64 + PAD, LDF = C + 4, VEC = Vec16<T>::N;
     constexpr int NCT = C / 16, NV = C / VEC, VPT = NV / 4;
     constexpr int TOK = 64 * TT, WT = 16 * TT;
     constexpr int NKC = C / TR::KCHUNK, NKH = 32 / TR::KCHUNK;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
 
 template <class T, int C, int TT>
 constexpr size_t mlp_bwd2_lds() {
-    constexpr size_t PAD = 16 / sizeof(T), LDX = C + PAD, LDH = 64 + PAD, LDF = C + 4, TOK = 64 * TT, WT = 16 * TT;
+    constexpr size_t PAD = LDS_PAD_BYTES / sizeof(T), LDX = C + PAD, LDH = 64 + PAD, LDF = C + 4, TOK = 64 * TT, WT = 16 * TT;
     constexpr size_t P0 = 2 * TOK * LDX * sizeof(T), P1 = (96 * LDX + C * LDH + 4 * WT * LDH) * sizeof(T), P2 = TOK * LDF * 4;
     constexpr size_t REG = ((P0 > P1 ? (P0 > P2 ? P0 : P2) : (P1 > P2 ? P1 : P2)) + 15) / 16 * 16;
     return REG + 2 * TOK * sizeof(float);
@@ -560,7 +560,7 @@ static int launch_mlp_bwd(const MlpBwdDev& d, int variant, hipStream_t s) {
             if (variant == 0 || variant == 2) return launch_mlp_bwd2<T, C, 1>(d, s);
         }
     }
-    constexpr int PAD = 16 / sizeof(T);
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     constexpr size_t base = (2 * 64 * (C + PAD) + 4 * 16 * (64 + PAD)) * sizeof(T) + 128 * sizeof(float);
     constexpr size_t staged = base + (64 * (size_t)(C + PAD) + (size_t)C * (64 + PAD)) * sizeof(T);
     if constexpr (staged <= 160 * 1024) {

@@ -25,7 +25,7 @@ struct TnDev {
 template <class T, int R1, int R2>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
     typedef ElemTraits<T> TR;
-    constexpr int PAD = 16 / sizeof(T);
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     constexpr int VEC = Vec16<T>::N;
     constexpr int KT = 64, LDT = KT + PAD, TN1 = 64 * R1, TN2 = 64 * R2;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
@@ -263,10 +263,10 @@ static int launch_tn_tr(const TnDev& d, int batch, hipStream_t s) {
 
 template <class T, int R1, int R2>
 static int launch_tn(const TnDev& d, int batch, hipStream_t s) {
-    constexpr int esz = sizeof(T), vec = 16 / esz;
+    constexpr int esz = sizeof(T), pad = LDS_PAD_BYTES / esz;
     const int ntiles = ((d.N1 + 64 * R1 - 1) / (64 * R1)) * ((d.N2 + 64 * R2 - 1) / (64 * R2));
     dim3 grid(ntiles * ((d.nsplit + 7) / 8 * 8), 1, batch);
-    const size_t shmem = (size_t)(64 * R1 + 64 * R2) * (64 + vec) * esz;
+    const size_t shmem = (size_t)(64 * R1 + 64 * R2) * (64 + pad) * esz;
     allow_big_lds(gemm_tn_kernel<T, R1, R2>, shmem);
     MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_kernel<T, R1, R2>), grid, dim3(256), shmem, s, d);
     return MPHSIR_OK;

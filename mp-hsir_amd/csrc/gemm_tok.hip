@@ -31,14 +31,15 @@ struct GemmDev {
 template <class T, int EPI, bool LN, int NW>
 __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
     typedef ElemTraits<T> TR;
-    constexpr int PAD = 16 / sizeof(T);
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     constexpr int LDA = GT_KC + PAD;
     constexpr int LDC = GT_BN + 4;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)                                     // 16-byte aligned base
     unsigned char* smem = reinterpret_cast<unsigned char*>(smem_v);
     T* As = reinterpret_cast<T*>(smem);                                   // [64][LDA]
     float* Cs = reinterpret_cast<float*>(smem);                           // [64][LDC] (aliases As)
-    float* stat = reinterpret_cast<float*>(smem + 64 * LDC * sizeof(float));   // mean[64], rstd[64]
+    constexpr size_t TILE_B = 64 * LDC * sizeof(float) > 64 * LDA * sizeof(T) ? 64 * LDC * sizeof(float) : 64 * LDA * sizeof(T);
+    float* stat = reinterpret_cast<float*>(smem + TILE_B);               // mean[64], rstd[64]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m0 = blockIdx.x * GT_BM, n0 = blockIdx.y * GT_BN * NW;
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
 template <class T, int EPI, bool LN, int NW>
 static int launch_gemm_nw(const GemmDev& d, hipStream_t s) {
     dim3 grid(d.M / GT_BM, (d.N + GT_BN * NW - 1) / (GT_BN * NW));
-    const size_t shmem = 64 * (GT_BN + 4) * sizeof(float) + 128 * sizeof(float);
+    constexpr size_t a_b = 64 * (size_t)(GT_KC + LDS_PAD_BYTES / sizeof(T)) * sizeof(T), c_b = 64 * (size_t)(GT_BN + 4) * sizeof(float);
+    const size_t shmem = (a_b > c_b ? a_b : c_b) + 128 * sizeof(float);
     MPHSIR_LAUNCH(MPHSIR_K_GEMM_TOK, (gemm_tok_kernel<T, EPI, LN, NW>), grid, dim3(256), shmem, s, d);
     return MPHSIR_OK;
 }

@@ -52,7 +52,7 @@ __device__ __forceinline__ void dw3x3_vec(const T* base, long ld, const float* w
 template <class T, int C, int HD>
 __global__ __launch_bounds__(256) void dwconv_gram_kernel(GramDev a) {
     typedef ElemTraits<T> TR;
-    constexpr int PAD = 16 / sizeof(T);
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     constexpr int VEC = Vec16<T>::N;
     constexpr int HEADS = C / HD;
     constexpr int LDT = 64 + PAD;
@@ -154,7 +154,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
 template <class T, int C, int HD>
 __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
     typedef ElemTraits<T> TR;
-    constexpr int PAD = 16 / sizeof(T);
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     constexpr int VEC = Vec16<T>::N;
     constexpr int HEADS = C / HD;
     constexpr int LDT = 64 + PAD;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(GateDev a) {
 
 template <class T, int C, int HD>
 static int launch_gram(const GramDev& d, hipStream_t s) {
-    constexpr int PAD = 16 / sizeof(T);
+    constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     constexpr size_t shmem2 = 2 * (size_t)C * (64 + PAD) * sizeof(T);
     if constexpr (shmem2 <= 160 * 1024) {
         if (d.W % 8 == 0) {

@@ -34,7 +34,7 @@ struct WinAttnDev {
 };
 
 template <class T, int C, int HD> struct WinAttnCfg {
-    static constexpr int PAD = 16 / sizeof(T);
+    static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     static constexpr int HEADS = C / HD;
     static constexpr int HDP = (HD + ElemTraits<T>::KCHUNK - 1) / ElemTraits<T>::KCHUNK * ElemTraits<T>::KCHUNK;
     static constexpr int LDX = C + (64 * (C + PAD) * sizeof(T) > 98304 ? 0 : PAD);   // drop the pad when LDS is tight
