@@ -130,6 +130,9 @@ typedef struct mphsir_fold_args {
     void* M;                    /* [B][C][C] compute dtype */
     void* MT;                   /* optional [B][C][C]: M transposed (saved for backward) */
     int32_t B, C, heads, nsplit;
+    float* Gsum; float* Ssum;   /* optional [B][heads][hd][hd], [B][2][C]: the reduced Gram / sums of squares, i.e.
+                                   the same data with nsplit = 1 -- what mphsir_spectral_fold_bwd needs (saved for
+                                   backward instead of the partials)                                           */
 } mphsir_fold_args;
 int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* stream);
 

@@ -50,7 +50,7 @@ class FoldArgs(ctypes.Structure):
     """mirror of struct mphsir_fold_args"""
     _fields_ = [("Gpart", c_void_p), ("Spart", c_void_p), ("temperature", c_void_p), ("Wo", c_void_p), ("M", c_void_p),
                 ("MT", c_void_p)] + \
-               [(n, c_int32) for n in ("B", "C", "heads", "nsplit")]
+               [(n, c_int32) for n in ("B", "C", "heads", "nsplit")] + [("Gsum", c_void_p), ("Ssum", c_void_p)]
 
 
 class GateArgs(ctypes.Structure):

@@ -155,7 +155,7 @@ class _PgsstbAttn(torch.autograd.Function):
         w9 = sp["w9"]
         v, gp, spart, _ = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
                                           3 * Cc, B, H, W, Cc, heads)
-        Mb, MbT = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt, transposed=True)
+        Mb, MbT, gp, spart = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt, transposed=True)   # keep the sums, drop the partials
         y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
         ctx.blk, ctx.k1 = blk, k1
         ctx.save_for_backward(x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT)
@@ -364,7 +364,7 @@ class _SelfChannelAttnRes(torch.autograd.Function):
         w9 = pa["w9"]
         v, gp, sp, _ = ops.dwconv_gram(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
                                        B, H, W, D, attn.num_heads)
-        Mb, MbT = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
+        Mb, MbT, gp, sp = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
         a = ops.gemm_tok(v, Mb, epi=1, res=t2)
         ctx.attn, ctx.ln, ctx.geom = attn, ln, geom
         ctx.save_for_backward(t2, q, v, gp, sp, Mb, MbT)
@@ -409,7 +409,7 @@ class _CrossChannelAttnRes(torch.autograd.Function):
         w9 = pa["w9"]
         v, gp, sp, _ = ops.dwconv_gram(tq, tkv[:, :D], tkv[:, D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
                                        B, H, W, D, ct.attn.num_heads)
-        Mb, MbT = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
+        Mb, MbT, gp, sp = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
         a = ops.gemm_tok(v, Mb, epi=1, res=text2)
         ctx.ct, ctx.geom = ct, geom
         ctx.save_for_backward(text2, vis2, tq, tkv, v, gp, sp, Mb, MbT)

@@ -25,25 +25,33 @@ struct FoldBwdDev {
     int B, C, HD;
 };
 
+// One workgroup per (sample, head).  The two products with the head slices of project_out and dM,
+//     dA[i][j]   = sum_co Wo[co][hHD+i] dM[co][hHD+j]          (K = output channels, streamed in chunks of FB_CO rows)
+//     dWo[co][i] = sum_j  dM[co][hHD+j] A[i][j]                (K = head dim)
+// run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32; the first one gathers its K-strided fragments with scalar
+// LDS reads, no transposed copy); the softmax forward / backward rows are shared by 4 lanes each.  Everything is
+// fp32 and every sum has a fixed order: bitwise reproducible.
+constexpr int FB_CO_MAX = 64;
+__host__ __device__ constexpr int fb_co(int hd) { return hd > 64 ? 32 : 64; }     // LDS budget at head_dim 96
+
 template <class T>
 __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    const int HD = a.HD, C = a.C, HEADS = C / HD, LDG = HD + 1;
-    float* G = reinterpret_cast<float*>(smem_v);      // raw Gram           [HD][LDG]
-    float* A = G + HD * LDG;                          // probabilities      [HD][LDG]
-    float* D = A + HD * LDG;                          // dA -> dGtilde      [HD][LDG]
-    float* nq = D + HD * LDG;                         // [HD] (clamped norms)   nk follows
-    float* nk = nq + HD;
-    float* sq = nk + HD;                              // [2*HD] raw sums of squares
-    float* dn = sq + 2 * HD;                          // [2*HD] d nq, d nk
-    float* red = dn + 2 * HD;                         // [HD] row reductions
-    float* Ws = red + HD;                             // [32][LDG] chunk of Wo[:, head]
-    float* Ms = Ws + 32 * LDG;                        // [32][LDG] chunk of dM[:, head]
-    const int tid = threadIdx.x, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
+    const int HD = a.HD, C = a.C, HEADS = C / HD, LD = HD + 8, NT = HD / 16, FB_CO = fb_co(HD);
+    float* G = reinterpret_cast<float*>(smem_v);      // raw Gram                  [HD][LD]
+    float* A = G + HD * LD;                           // probabilities             [HD][LD]
+    float* D = A + HD * LD;                           // dA -> dGtilde -> dG       [HD][LD]
+    float* Ws = D + HD * LD;                          // [FB_CO][LD] rows of Wo[:, head]
+    float* Ms = Ws + FB_CO * LD;                      // [FB_CO][LD] rows of dM[:, head]
+    float* nq = Ms + FB_CO * LD;                      // [2*HD] clamped norms (nq | nk)
+    float* rn = nq + 2 * HD;                          // [2*HD] their reciprocals
+    float* sq = rn + 2 * HD;                          // [2*HD] raw sums of squares
+    float* dn = sq + 2 * HD;                          // [2*HD] d nq | d nk
+    float* red = dn + 2 * HD;                         // [HD] per-row d temperature terms
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
     const float temp = a.temperature[h];
 
-    for (int i = tid; i < HD * HD; i += 256) {
-        // ordered sum over the splits; 8 independent loads in flight per step (the loads, not the adds, are the latency)
+    for (int i = tid; i < HD * HD; i += 256) {        // ordered sum over the splits (1 when the forward saved the sums)
         const float* gp = a.Gpart + ((long)b * a.nsplit * HEADS + h) * HD * HD + i;
         const long gstride = (long)HEADS * HD * HD;
         float s = 0.f;
@@ -56,87 +64,124 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
             for (int u = 0; u < 8; ++u) s += t[u];
         }
         for (; sp < a.nsplit; ++sp) s += gp[sp * gstride];
-        G[(i / HD) * LDG + i % HD] = s;
+        G[(i / HD) * LD + i % HD] = s;
     }
     if (tid < 2 * HD) {
         float s = 0.f;
 #pragma unroll 8
         for (int sp = 0; sp < a.nsplit; ++sp) s += a.Spart[((long)b * a.nsplit + sp) * 2 * C + (tid / HD) * C + h * HD + tid % HD];
         sq[tid] = s;
-        nq[tid] = fmaxf(sqrtf(s), 1e-12f);
+        const float n = fmaxf(sqrtf(s), 1e-12f);      // F.normalize eps
+        nq[tid] = n;
+        rn[tid] = 1.0f / n;
     }
     __syncthreads();
-    if (tid < HD) {                                   // A = softmax_rows(G / (nq nk^T) * temp)
-        const float tq = temp / nq[tid];
+    const float* rq = rn;
+    const float* rk = rn + HD;
+    const int qd = tid & 3;                           // 4 adjacent lanes per row (rows >= HD idle but take part in the shuffles)
+    for (int row = tid >> 2; row < (HD + 63) / 64 * 64; row += 64) {      // A = softmax_rows(G / (nq nk^T) * temp)
+        const bool on = row < HD;
+        const float tq = on ? temp * rq[row] : 0.f;
         float m = -3.0e38f;
-        for (int j = 0; j < HD; ++j) m = fmaxf(m, G[tid * LDG + j] * tq / nk[j]);
+        if (on) for (int j = qd; j < HD; j += 4) m = fmaxf(m, G[row * LD + j] * tq * rk[j]);
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
         float den = 0.f;
-        for (int j = 0; j < HD; ++j) { const float e = expf(G[tid * LDG + j] * tq / nk[j] - m); A[tid * LDG + j] = e; den += e; }
+        if (on) for (int j = qd; j < HD; j += 4) { const float e = expf(G[row * LD + j] * tq * rk[j] - m); A[row * LD + j] = e; den += e; }
+        den += __shfl_xor(den, 1);
+        den += __shfl_xor(den, 2);
         const float inv = 1.0f / den;
-        for (int j = 0; j < HD; ++j) A[tid * LDG + j] *= inv;
+        if (on) for (int j = qd; j < HD; j += 4) A[row * LD + j] *= inv;
     }
-    __syncthreads();
-    // dA[i][j] = sum_co Wo[co][hHD+i] dM[co][hHD+j]  and  dWo_b[co][hHD+i] = sum_j dM[co][hHD+j] A[i][j]:
-    // the head slices of Wo and dM are streamed through LDS in chunks of FB_CO rows (coalesced), each thread keeps
-    // its dA outputs in registers across chunks.
     const float* dM = a.dM + (long)b * C * C;
     float* dWo = a.dWo + (long)b * C * C;
-    constexpr int FB_CO = 32;
-    for (int o = tid; o < HD * HD; o += 256) D[(o / HD) * LDG + o % HD] = 0.f;      // dA accumulates in LDS
+    constexpr int NS = 9;                             // dA tiles per wave: t = wv + 4*s < NT*NT <= 36 (head_dim <= 96)
+    f32x4 accA[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) accA[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int lr = lane & 15, lk = 4 * (lane >> 4);
     for (int c0 = 0; c0 < C; c0 += FB_CO) {
-        __syncthreads();
-#pragma unroll 4
+        __syncthreads();                              // previous chunk consumed (first time: A complete)
         for (int idx = tid; idx < FB_CO * HD; idx += 256) {
             const int rr = idx / HD, cc = idx % HD;
-            Ws[rr * LDG + cc] = a.Wo[(long)(c0 + rr) * C + h * HD + cc];
-            Ms[rr * LDG + cc] = dM[(long)(c0 + rr) * C + h * HD + cc];
+            const bool in = c0 + rr < C;
+            Ws[rr * LD + cc] = in ? a.Wo[(long)(c0 + rr) * C + h * HD + cc] : 0.f;
+            Ms[rr * LD + cc] = in ? dM[(long)(c0 + rr) * C + h * HD + cc] : 0.f;
         }
         __syncthreads();
-#pragma unroll 1
-        for (int o = tid; o < HD * HD; o += 256) {
-            const int i = o / HD, j = o % HD;
-            float s = D[i * LDG + j];
-#pragma unroll 8
-            for (int rr = 0; rr < FB_CO; ++rr) s += Ws[rr * LDG + i] * Ms[rr * LDG + j];
-            D[i * LDG + j] = s;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int t = wv + 4 * s;
+            if (t < NT * NT) {                        // wave-uniform
+                const int ti = t / NT, tj = t % NT;
+                for (int k0 = 0; k0 < FB_CO; k0 += 16) {
+                    f32x4 fa, fb;
+                    for (int e = 0; e < 4; ++e) {
+                        fa[e] = Ws[(k0 + lk + e) * LD + ti * 16 + lr];
+                        fb[e] = Ms[(k0 + lk + e) * LD + tj * 16 + lr];
+                    }
+                    mma(accA[s], fa, fb);
+                }
+            }
         }
-#pragma unroll 1
-        for (int o = tid; o < FB_CO * HD; o += 256) {     // dWo rows of this chunk
-            const int rr = o / HD, i = o % HD;
-            float s = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < HD; ++j) s += Ms[rr * LDG + j] * A[i * LDG + j];
-            dWo[(long)(c0 + rr) * C + h * HD + i] = s;
+        if (wv * 16 < FB_CO && c0 + wv * 16 < C)       // dWo rows c0 + 16*wv .. +15 of this head's columns
+            for (int ti = 0; ti < NT; ++ti) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int k0 = 0; k0 < HD; k0 += 16)
+                    mma(acc, *reinterpret_cast<const f32x4*>(Ms + (wv * 16 + lr) * LD + k0 + lk),
+                        *reinterpret_cast<const f32x4*>(A + (ti * 16 + lr) * LD + k0 + lk));
+                for (int r = 0; r < 4; ++r) {
+                    const int co = c0 + wv * 16 + (lane >> 4) * 4 + r;
+                    if (co < C) dWo[(long)co * C + h * HD + ti * 16 + lr] = acc[r];
+                }
+            }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int t = wv + 4 * s;
+        if (t < NT * NT) {
+            const int ti = t / NT, tj = t % NT;
+            for (int r = 0; r < 4; ++r) D[(ti * 16 + (lane >> 4) * 4 + r) * LD + tj * 16 + lr] = accA[s][r];
         }
     }
     __syncthreads();
-    if (tid < HD) {                                   // softmax backward per row; logits = Gtilde * temp
-        const int i = tid;
+    for (int row = tid >> 2; row < (HD + 63) / 64 * 64; row += 64) {      // softmax backward per row; logits = Gtilde * temp
+        const bool on = row < HD;
         float rs = 0.f;
-        for (int j = 0; j < HD; ++j) rs += A[i * LDG + j] * D[i * LDG + j];
+        if (on) for (int j = qd; j < HD; j += 4) rs += A[row * LD + j] * D[row * LD + j];
+        rs += __shfl_xor(rs, 1);
+        rs += __shfl_xor(rs, 2);
         float dt = 0.f, dnq = 0.f;
-        for (int j = 0; j < HD; ++j) {
-            const float dl = A[i * LDG + j] * (D[i * LDG + j] - rs);
-            const float gt = G[i * LDG + j] / (nq[i] * nk[j]);
-            dt += dl * gt;
-            const float dgt = dl * temp;
-            dnq -= dgt * gt / nq[i];
-            D[i * LDG + j] = dgt;                     // keep dGtilde
-        }
-        red[i] = dt;
-        dn[i] = dnq;
+        if (on)
+            for (int j = qd; j < HD; j += 4) {
+                const float dl = A[row * LD + j] * (D[row * LD + j] - rs);
+                const float gt = G[row * LD + j] * rq[row] * rk[j];
+                dt += dl * gt;
+                const float dgt = dl * temp;
+                dnq -= dgt * gt * rq[row];
+                D[row * LD + j] = dgt;                // keep dGtilde
+            }
+        dt += __shfl_xor(dt, 1);  dt += __shfl_xor(dt, 2);
+        dnq += __shfl_xor(dnq, 1);  dnq += __shfl_xor(dnq, 2);
+        if (on && qd == 0) { red[row] = dt; dn[row] = dnq; }
     }
     __syncthreads();
-    if (tid < HD) {                                   // d nk[j] = -sum_i dGtilde[i][j] * Gtilde[i][j] / nk[j]
-        const int j = tid;
+    for (int row = tid >> 2; row < (HD + 63) / 64 * 64; row += 64) {      // d nk[j] = -sum_i dGtilde[i][j] * Gtilde[i][j] / nk[j]
+        const bool on = row < HD;                     // "row" = column j here
         float s = 0.f;
-        for (int i = 0; i < HD; ++i) s -= D[i * LDG + j] * G[i * LDG + j] / (nq[i] * nk[j]) / nk[j];
-        dn[HD + j] = s;
+        if (on) for (int i = qd; i < HD; i += 4) s -= D[i * LD + row] * G[i * LD + row] * rq[i] * rk[row] * rk[row];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (on && qd == 0) dn[HD + row] = s;
     }
-    if (tid == 0) {
-        float s = 0.f;
-        for (int i = 0; i < HD; ++i) s += red[i];
-        a.dtemp[b * HEADS + h] = s;
+    if (wv == 0) {
+        const float v = wave_sum((lane < HD ? red[lane] : 0.f) + (lane + 64 < HD ? red[lane + 64] : 0.f));
+        if (lane == 0) a.dtemp[b * HEADS + h] = v;
+    }
+    __syncthreads();
+    for (int o = tid; o < HD * HD; o += 256) {        // dG[i][j] = dGtilde[i][j] / (nq[i] nk[j])
+        const int i = o / HD, j = o % HD;
+        D[i * LD + j] *= rq[i] * rk[j];
     }
     __syncthreads();
     // W2_b rows of this head: q rows hHD+i and k rows C+hHD+j, all 2C columns
@@ -146,10 +191,10 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
         const int i = o / C2, col = o % C2;           // q-gradient row
         float v = 0.f;
         if (col < C) {
-            if (col == h * HD + i) v = sq[i] > 1e-24f ? dn[i] / nq[i] : 0.f;         // 2 * dsq = dnq / nq
+            if (col == h * HD + i) v = sq[i] > 1e-24f ? dn[i] * rq[i] : 0.f;          // 2 * dsq = dnq / nq
         } else {
             const int cp = col - C - h * HD;
-            if (cp >= 0 && cp < HD) v = D[i * LDG + cp] / (nq[i] * nk[cp]);           // dG[i][j]
+            if (cp >= 0 && cp < HD) v = D[i * LD + cp];                               // dG[i][j]
         }
         W2[(long)(h * HD + i) * C2 + col] = from_f32<T>(v);
     }
@@ -158,9 +203,9 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
         float v = 0.f;
         if (col < C) {
             const int ci = col - h * HD;
-            if (ci >= 0 && ci < HD) v = D[ci * LDG + j] / (nq[ci] * nk[j]);           // Nq^T
+            if (ci >= 0 && ci < HD) v = D[ci * LD + j];                               // Nq^T
         } else if (col == C + h * HD + j) {
-            v = sq[HD + j] > 1e-24f ? dn[HD + j] / nk[j] : 0.f;
+            v = sq[HD + j] > 1e-24f ? dn[HD + j] * rk[j] : 0.f;
         }
         W2[(long)(C + h * HD + j) * C2 + col] = from_f32<T>(v);
     }
@@ -350,7 +395,8 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 96, "spectral_fold_bwd: head_dim %d > 96", HD);
     FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->W2, a->dWo, a->dtemp, a->B, a->C, HD};
-    const size_t shmem = (3 * (size_t)HD * (HD + 1) + 7 * HD + 64 * (size_t)(HD + 1)) * sizeof(float);
+    MPHSIR_REQUIRE(HD % 16 == 0, "spectral_fold_bwd: head_dim %d must be a multiple of 16", HD);
+    const size_t shmem = ((3 * (size_t)HD + 2 * fb_co(HD)) * (HD + 8) + 9 * (size_t)HD) * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32) {
         allow_big_lds(spectral_fold_bwd_kernel<float>, shmem);

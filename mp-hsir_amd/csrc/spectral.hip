@@ -284,6 +284,7 @@ struct FoldDev {
     void* Mout;                 // [B][C][C] compute dtype
     void* MTout;                // optional [B][C][C]: M^T (training: dv = d_out M is a token GEMM with weight M^T)
     int B, C, HD;
+    float* Gsum; float* Ssum;   // optional: reduced Gram [B][HEADS][HD][HD] and sums of squares [B][2][C]
 };
 
 // grid = (B*HEADS, C/FOLD_CO): every workgroup redoes the (tiny) reduction + softmax of its head and
@@ -316,12 +317,14 @@ __global__ __launch_bounds__(256) void spectral_fold_kernel(FoldDev a) {
         }
         for (; sp < a.nsplit; ++sp) s += gp[sp * gstride];
         G[(i / HD) * LDG + i % HD] = s;
+        if (a.Gsum && blockIdx.y == 0) a.Gsum[((long)b * HEADS + h) * HD * HD + i] = s;
     }
     if (tid < 2 * HD) {
         float s = 0.f;
 #pragma unroll 8
         for (int sp = 0; sp < a.nsplit; ++sp) s += a.Spart[((long)b * a.nsplit + sp) * 2 * C + (tid / HD) * C + h * HD + tid % HD];
         nq[tid] = fmaxf(sqrtf(s), 1e-12f);            // F.normalize eps (nk follows nq in memory)
+        if (a.Ssum && blockIdx.y == 0) a.Ssum[(long)b * 2 * C + (tid / HD) * C + h * HD + tid % HD] = s;
     }
     for (int i = tid; i < FOLD_CO * HD; i += 256)
         Ws[(i / HD) * LDG + i % HD] = a.Wo[(long)(co0 + i / HD) * C + h * HD + i % HD];
@@ -462,7 +465,8 @@ extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* 
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold: bad shape");
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 128, "spectral_fold: head_dim %d > 128", HD);
-    FoldDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->M, a->MT, a->B, a->C, HD};
+    MPHSIR_REQUIRE((a->Gsum == nullptr) == (a->Ssum == nullptr), "spectral_fold: Gsum and Ssum go together");
+    FoldDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->M, a->MT, a->B, a->C, HD, a->Gsum, a->Ssum};
     MPHSIR_REQUIRE(a->C % FOLD_CO == 0, "spectral_fold: C must be a multiple of %d", FOLD_CO);
     const size_t shmem = ((size_t)HD * (HD + 1) + 2 * HD + (size_t)FOLD_CO * (HD + 1)) * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

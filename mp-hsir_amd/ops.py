@@ -277,7 +277,8 @@ def dwconv_gram(tq, tk, tv, wq, wk, wv, ldw, B, H, W, C, heads, nsplit=None):
 
 
 def spectral_fold(gp, sp, temperature, Wo, dtype, transposed=False):
-    """-> per-sample folded matrix M (B, C, C) in `dtype` (and M^T when transposed=True)."""
+    """-> per-sample folded matrix M (B, C, C) in `dtype`; with transposed=True (training) -> (M, M^T, gsum, ssum):
+    gsum (B,1,heads,hd,hd) / ssum (B,1,2,C) are the reduced partials, the form spectral_fold_bwd wants."""
     lib = _lib.load()
     _check(gp, sp, temperature, Wo)
     B, nsplit, heads, hd, _ = gp.shape
@@ -288,10 +289,15 @@ def spectral_fold(gp, sp, temperature, Wo, dtype, transposed=False):
     a.Gpart, a.Spart, a.temperature, a.Wo, a.M = _p(gp), _p(sp), _p(temperature), _p(Wo), _p(Mo)
     MT = torch.empty_like(Mo) if transposed else None
     a.MT = _p(MT)
+    gsum = ssum = None
+    if transposed:
+        gsum = torch.empty((B, 1, heads, hd, hd), dtype=torch.float32, device=gp.device)
+        ssum = torch.empty((B, 1, 2, C), dtype=torch.float32, device=gp.device)
+        a.Gsum, a.Ssum = _p(gsum), _p(ssum)
     a.B, a.C, a.heads, a.nsplit = B, C, heads, nsplit
     _lib.check(lib.mphsir_spectral_fold(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold")
     _acct("spectral_fold", 2.0 * B * C * C * hd, gp.numel() * 4 + sp.numel() * 4 + C * C * 4 + Mo.numel() * Mo.element_size())
-    return (Mo, MT) if transposed else Mo
+    return (Mo, MT, gsum, ssum) if transposed else Mo
 
 
 def dwconv_gate(t, w9, B, H, W):

@@ -138,6 +138,11 @@ def check_spectral_attention_chain(dev, dtype, C, heads, shape, nsplit):
     Mb = ops.spectral_fold(gp, sp, P["temperature"].reshape(heads).contiguous(),
                            P["project_out.weight"].reshape(C, C).contiguous(), dtype)
     y = ops.gemm_tok(v, Mb)
+    # training form: also M^T and the reduced partials (what the backward kernel reads)
+    Mb2, MbT, gsum, ssum = ops.spectral_fold(gp, sp, P["temperature"].reshape(heads).contiguous(),
+                                             P["project_out.weight"].reshape(C, C).contiguous(), dtype, transposed=True)
+    assert torch.equal(Mb2.cpu(), Mb.cpu()) and torch.equal(MbT.cpu(), Mb.transpose(1, 2).cpu())
+    assert rel_l2(gsum[:, 0], gp.double().sum(1)) < 3e-7 and rel_l2(ssum[:, 0], sp.double().sum(1)) < 3e-7
     Pd = {k: v_.double().cpu() for k, v_ in P.items()}
     Pd["qkv.weight"] = wqkv.double().cpu().reshape(3 * C, C, 1, 1)
     ref = O.spectral_attention(Pd, "", x.double().cpu(), heads)

@@ -44,7 +44,7 @@ for (B, H, C, heads, cr) in [(32, 64, 128, 2, 8), (32, 32, 128, 4, 16), (32, 16,
     v, gp, spart, _ = f()
     f = lambda: ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt, transposed=True)
     rep("spectral_fold", t_us(f))
-    Mb, MbT = f()
+    Mb, MbT, gp, spart = f()
     f = lambda: ops.gemm_tok(v, Mb, epi=2, res=x2, sa=sa2, gate=gate, geom=(H, W, 4))
     rep("gemm_tok apply+combine", t_us(f), 2.0 * M * C * C, 4.0 * M * C * es)
     f = lambda: ops.gated_mlp_fwd(x2, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"], pk["W2"], pk["b2"])
