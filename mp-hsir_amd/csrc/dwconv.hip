@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwDev a) {
     constexpr int VEC = Vec16<T>::N;
     const int cv = a.C / VEC, nsx = a.W / DW_S;
     const long total = (long)a.B * a.H * nsx * cv;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = xcd_contiguous_block() * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c0 = (int)(idx % cv) * VEC;
     long q = idx / cv;
@@ -207,7 +207,7 @@ extern "C" int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int
     MPHSIR_REQUIRE(aligned16(X) && aligned16(Y) && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0, "dwconv3x3: 16-byte alignment required");
     DwDev d{X, (long)ldx, w9, (long)ldw, Y, (long)ldy, B, H, W, C, flip};
     MPHSIR_REQUIRE(W % DW_S == 0, "dwconv3x3: W must be a multiple of %d", DW_S);
-    const long blocks = ((long)B * H * (W / DW_S) * (C / vec) + 255) / 256;
+    const long blocks = (((long)B * H * (W / DW_S) * (C / vec) + 255) / 256 + 7) / 8 * 8;      // multiple of 8: XCD-contiguous order
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV, (dwconv3x3_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);

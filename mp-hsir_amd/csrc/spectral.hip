@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(GateDev a) {
     constexpr int VEC = Vec16<T>::N, S = 8;
     const int vpp = a.HP / VEC, nsx = a.W / S;
     const long total = (long)a.B * a.H * nsx * vpp;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = xcd_contiguous_block() * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c0 = (int)(idx % vpp) * VEC;
     long q = idx / vpp;
@@ -491,7 +491,7 @@ extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* st
     GateDev d{a->T, (long)a->ldt, a->w9, (long)a->ldw, a->U, (long)a->ldu, a->B, a->H, a->W, a->HP};
     MPHSIR_REQUIRE(a->W % 8 == 0, "dwconv_gate: W must be a multiple of 8");
     const long total = (long)a->B * a->H * (a->W / 8) * (a->HP / (16 / esz));
-    const long blocks = (total + 255) / 256;
+    const long blocks = ((total + 255) / 256 + 7) / 8 * 8;            // multiple of 8: XCD-contiguous order
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);

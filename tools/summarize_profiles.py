@@ -23,8 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def short(name):
     m = re.search(r"mphsir\d*(\w+?)_kernel", name) or re.search(r"mphsir::(\w+?)_kernel", name)
     if m:
-        n = m.group(1)
-        return re.sub(r"^\d+", "", n)
+        n = re.sub(r"^\d+", "", m.group(1))
+        # kernel forms that share one C-ABI entry point / library kernel id
+        return {"gemm_tn_tr": "gemm_tn", "gated_mlp_bwd2": "gated_mlp_bwd", "gated_mlp_lds": "gated_mlp", "dwconv_gram2": "dwconv_gram"}.get(n, n)
     return name[:60]
 
 
