@@ -91,10 +91,16 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL over xGMI.  MPHSIR_DIST_BACKEND=gloo is a TEST hook: it lets the whole N>1 path (broadcast, gradient
+        # all-reduce outside the captured step, AdamW + repack after it) run with several ranks sharing one GPU box.
+        backend = os.environ.get("MPHSIR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from mp_hsir_amd import _lib, ops
     from mp_hsir_amd.data import SyntheticPatchSource
     from mp_hsir_amd.engine import DataParallelEngine

@@ -81,7 +81,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwWgDev a) {
     const bool live = c0 < a.C;
     const int HW = a.H * a.W;
     const long P = (long)a.B * HW, per = ((P + a.nblk - 1) / a.nblk + DW_S - 1) / DW_S * DW_S;   // whole strips per block
-    const long p_lo = (long)blockIdx.x * per, p_hi = (p_lo + per < P) ? p_lo + per : P;
+    // neighbouring pixel ranges share their boundary rows: keep them on one XCD (one L2) when the grid allows it
+    const long blk = (gridDim.x & 7) == 0 ? xcd_contiguous_block() : (long)blockIdx.x;
+    const long p_lo = blk * per, p_hi = (p_lo + per < P) ? p_lo + per : P;
     const T* X = reinterpret_cast<const T*>(a.X);
     const T* dY = reinterpret_cast<const T*>(a.dY);
     float acc[9][VEC];

@@ -2,11 +2,12 @@
 //
 // Every 1x1 conv / Linear of the MP-HSIR path that is not inside a larger fused kernel goes through
 // here (reference call sites listed in include/mphsir.h).  One 256-thread workgroup computes a
-// 64-token x 64-channel tile: the token rows are staged through LDS in K-chunks (optionally
-// LayerNorm-ed on the way in), each wave owns one 16-channel column tile and streams its weight
-// rows straight from L2 as MFMA fragments (weights are tiny and shared by every workgroup), the
-// fp32 accumulators are staged through LDS so the epilogue and the global stores run on whole
-// 16-byte vectors along the channel axis.
+// 64-token x (64*NW)-channel tile: the token rows go through two LDS stages in K-chunks (optionally
+// LayerNorm-ed on the way in; the next chunk is already in flight in registers during the MFMAs, one
+// barrier per chunk), each wave owns 16-channel column tiles and streams its weight rows straight
+// from L2 as MFMA fragments (weights are tiny and shared by every workgroup).  The accumulators hold
+// the transposed tile (channels x tokens), so a lane owns 4 consecutive channels of a token and the
+// epilogue (bias / residual / branch sum) is a direct 8- or 16-byte load-modify-store.
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
 
@@ -33,12 +34,10 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
     typedef ElemTraits<T> TR;
     constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     constexpr int LDA = GT_KC + PAD;
-    constexpr int LDC = GT_BN + 4;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)                                     // 16-byte aligned base
     unsigned char* smem = reinterpret_cast<unsigned char*>(smem_v);
-    T* As = reinterpret_cast<T*>(smem);                                   // [64][LDA]
-    float* Cs = reinterpret_cast<float*>(smem);                           // [64][LDC] (aliases As)
-    constexpr size_t TILE_B = 64 * LDC * sizeof(float) > 64 * LDA * sizeof(T) ? 64 * LDC * sizeof(float) : 64 * LDA * sizeof(T);
+    T* As = reinterpret_cast<T*>(smem);                                   // [2 stages][64][LDA]
+    constexpr size_t TILE_B = 2 * 64 * LDA * sizeof(T);
     float* stat = reinterpret_cast<float*>(smem + TILE_B);               // mean[64], rstd[64]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -62,85 +61,95 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
     }
 
     const int ntile = n0 + wv * 16;            // this wave's first 16 output channels (+64 per extra tile)
+    // accumulators hold the TRANSPOSED tile (rows = output channels, columns = tokens): a lane then owns 4 consecutive
+    // channels of one token and the epilogue is a plain 8/16-byte load-modify-store per tile, no LDS round trip
     f32x4 acc[NW][4];
 #pragma unroll
     for (int w = 0; w < NW; ++w)
         for (int i = 0; i < 4; ++i) acc[w][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int VEC = Vec16<T>::N;
-    for (int k0 = 0; k0 < K; k0 += GT_KC) {
-        const int kc = (K - k0) < GT_KC ? (K - k0) : GT_KC;    // 32 or 64
-        const int vpr = kc / VEC;                              // vectors per row
-        for (int v = tid; v < 64 * vpr; v += 256) {
-            const int r = v / vpr, c = (v % vpr) * VEC;
-            Vec16<T> x = load16<T>(X + (long)(m0 + r) * a.ldx + k0 + c);
-            if (LN) {
-                const float mean = stat[r], rstd = stat[64 + r];
-                for (int i = 0; i < VEC; ++i)
-                    x.set(i, (x.get(i) - mean) * rstd * a.ln_w[k0 + c + i] + a.ln_b[k0 + c + i]);
-            }
-            store16<T>(As + r * LDA + c, x);
+    constexpr int NX = 64 * (GT_KC / VEC) / 256;              // 16-byte vectors per thread and K-chunk
+    Vec16<T> xr[NX];
+    auto gload = [&](int k0) {                                // next chunk of the token tile -> registers
+        const int kc = (K - k0) < GT_KC ? (K - k0) : GT_KC, vpr = kc / VEC;
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int v = tid + 256 * it;
+            if (v < 64 * vpr) xr[it] = load16<T>(X + (long)(m0 + v / vpr) * a.ldx + k0 + (v % vpr) * VEC);
         }
-        __syncthreads();
+    };
+    auto sstore = [&](T* dst, int k0) {                       // registers (-> LayerNorm) -> LDS stage
+        const int kc = (K - k0) < GT_KC ? (K - k0) : GT_KC, vpr = kc / VEC;
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int v = tid + 256 * it;
+            if (v < 64 * vpr) {
+                const int r = v / vpr, c = (v % vpr) * VEC;
+                Vec16<T> x = xr[it];
+                if (LN) {
+                    const float mean = stat[r], rstd = stat[64 + r];
+                    for (int i = 0; i < VEC; ++i)
+                        x.set(i, (x.get(i) - mean) * rstd * a.ln_w[k0 + c + i] + a.ln_b[k0 + c + i]);
+                }
+                store16<T>(dst + r * LDA + c, x);
+            }
+        }
+    };
+    gload(0);
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += GT_KC, buf ^= 1) {
+        const int kc = (K - k0) < GT_KC ? (K - k0) : GT_KC;    // 32 or 64
+        T* Ab = As + buf * 64 * LDA;
+        sstore(Ab, k0);
+        __syncthreads();           // one barrier per chunk: the other stage was last read before the previous barrier
+        if (k0 + GT_KC < K) gload(k0 + GT_KC);
         for (int kk = 0; kk < kc; kk += TR::KCHUNK) {
             typename TR::frag_t af[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt] = load_frag<T>(As, LDA, mt * 16, kk);
+            for (int mt = 0; mt < 4; ++mt) af[mt] = load_frag<T>(Ab, LDA, mt * 16, kk);
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 if (ntile + w * 64 < a.N) {            // wave-uniform
                     const typename TR::frag_t wf = load_frag<T>(W, K, ntile + w * 64, k0 + kk);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) mma(acc[w][mt], af[mt], wf);
+                    for (int mt = 0; mt < 4; ++mt) mma(acc[w][mt], wf, af[mt]);
                 }
             }
         }
-        __syncthreads();
     }
 
     T* Y = reinterpret_cast<T*>(a.Y);
     const T* R = reinterpret_cast<const T*>(a.R);
     const T* SA = reinterpret_cast<const T*>(a.SA);
-    constexpr int G = GT_BN / VEC;
+    const int hw = EPI == 2 ? a.H * a.Wimg : 1;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    // accumulators of column group w -> LDS (fp32): lane holds rows (lane>>4)*4+r of tile mt, column lane&15
-    if (w) __syncthreads();
-    if (ntile + w * 64 < a.N)
-        for (int mt = 0; mt < 4; ++mt)
-            for (int r = 0; r < 4; ++r) Cs[(mt * 16 + (lane >> 4) * 4 + r) * LDC + wv * 16 + (lane & 15)] = acc[w][mt][r];
-    __syncthreads();
-    for (int idx = tid; idx < 64 * G; idx += 256) {
-        const int r = idx / G, c = (idx % G) * VEC, n = n0 + w * 64 + c, m = m0 + r;
-        if (n >= a.N) continue;
-        Vec16<T> out, res, sa;
-        if (EPI >= 1) res = load16<T>(R + (long)m * a.ldr + n);
-        float kf = 1.f;
-        const float* g = nullptr;
-        if (EPI == 2) {
-            sa = load16<T>(SA + (long)m * a.ldsa + n);
-            const int hw = a.H * a.Wimg, b = m / hw, p = m % hw, y = p / a.Wimg, x = p % a.Wimg;
-            const int ys = (y - a.shift + a.H) % a.H, xs = (x - a.shift + a.Wimg) % a.Wimg;   // shifted-frame coords
-            g = a.gate + ((long)b * (hw / 64) + (ys >> 3) * (a.Wimg >> 3) + (xs >> 3)) * a.N + n;
-            if (a.keep) kf = a.keep[b];
+    for (int w = 0; w < NW; ++w) {
+        const int n = ntile + w * 64 + (lane >> 4) * 4;        // 4 consecutive output channels of this lane
+        if (ntile + w * 64 >= a.N) continue;
+        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const long m = m0 + mt * 16 + (lane & 15);
+            f32x4 v = acc[w][mt] + bias4;
+            if (EPI == 1) v += load4<T>(R + m * a.ldr + n);
+            if (EPI == 2) {
+                const int b = (int)(m / hw), p = (int)(m % hw), y = p / a.Wimg, x = p % a.Wimg;
+                const int ys = (y - a.shift + a.H) % a.H, xs = (x - a.shift + a.Wimg) % a.Wimg;   // shifted-frame coords
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.gate + ((long)b * (hw / 64) + (ys >> 3) * (a.Wimg >> 3) + (xs >> 3)) * a.N + n);
+                const float kf = a.keep ? a.keep[b] : 1.f;
+                v = load4<T>(R + m * a.ldr + n) + kf * (load4<T>(SA + m * a.ldsa + n) * g + v);
+            }
+            store4<T>(Y + m * a.ldy + n, v);
         }
-        for (int i = 0; i < VEC; ++i) {
-            float v = Cs[r * LDC + c + i];
-            if (a.bias) v += a.bias[n + i];
-            if (EPI == 1) v += res.get(i);
-            if (EPI == 2) v = res.get(i) + kf * (sa.get(i) * g[i] + v);
-            out.set(i, v);
-        }
-        store16<T>(Y + (long)m * a.ldy + n, out);
     }
-  }
 }
 
 template <class T, int EPI, bool LN, int NW>
 static int launch_gemm_nw(const GemmDev& d, hipStream_t s) {
     dim3 grid(d.M / GT_BM, (d.N + GT_BN * NW - 1) / (GT_BN * NW));
-    constexpr size_t a_b = 64 * (size_t)(GT_KC + LDS_PAD_BYTES / sizeof(T)) * sizeof(T), c_b = 64 * (size_t)(GT_BN + 4) * sizeof(float);
-    const size_t shmem = (a_b > c_b ? a_b : c_b) + 128 * sizeof(float);
+    const size_t shmem = 2 * 64 * (size_t)(GT_KC + LDS_PAD_BYTES / sizeof(T)) * sizeof(T) + 128 * sizeof(float);
     MPHSIR_LAUNCH(MPHSIR_K_GEMM_TOK, (gemm_tok_kernel<T, EPI, LN, NW>), grid, dim3(256), shmem, s, d);
     return MPHSIR_OK;
 }

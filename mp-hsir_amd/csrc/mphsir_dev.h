@@ -92,6 +92,14 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// 4 consecutive elements -> fp32 (the counterpart of store4)
+template <class T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
 // 16-byte vector of T (8 bf16 / 4 f32) <-> fp32 registers, for coalesced global/LDS traffic.
 template <class T> struct Vec16;
 template <> struct Vec16<float> {
