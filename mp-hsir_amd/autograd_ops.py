@@ -107,8 +107,11 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     M = B * N
     dt = v.dtype
     dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), immediate=True)      # (B,C,C) fp32, read right below
-    W2, dwo, dtemp = ops.spectral_fold_bwd(gp, sp, temperature.detach().reshape(heads).float().contiguous(),
-                                           wo.detach().reshape(C, C).float().contiguous(), dM, dt)
+    # the fold backward is a latency-bound 64..256-workgroup kernel: it runs on the side stream while this one
+    # recomputes q,k (depthwise) and does the dv GEMM, which do not need its result
+    with ops.side_stream(dM) as fork:
+        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temperature.detach().reshape(heads).float().contiguous(),
+                                                   wo.detach().reshape(C, C).float().contiguous(), dM, dt, reduce=False)
     # q, k of the forward (never stored) are recomputed by the depthwise kernel; when q|k|v are adjacent channel
     # slices of one tensor (self-attention) every depthwise pass runs once over the joint channel range.
     joint = (t_q.data_ptr() + C * t_q.element_size() == t_k.data_ptr() and t_k.data_ptr() + C * t_k.element_size() == t_v.data_ptr()
@@ -119,8 +122,10 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
         qk = ops.dwconv3x3(torch.as_strided(t_q, (B, H, W, 2 * C), t_q.stride()), torch.as_strided(w9q, (9, 2 * C), w9q.stride()))
     else:
         qk = torch.cat([ops.dwconv3x3(t_q, w9q), ops.dwconv3x3(t_k, w9k)], dim=-1)
-    ops.gemm_tok(qk.reshape(M, 2 * C), W2, out=dall[:, :2 * C])                       # [dq | dk]
     ops.gemm_tok(d_out, MbT, out=dall[:, 2 * C:])                                     # dv = d_out M_b
+    fork.join(W2, dwo_p, dtemp_p)
+    dwo, dtemp = ops.reduce_parts(dwo_p), ops.reduce_parts(dtemp_p)
+    ops.gemm_tok(qk.reshape(M, 2 * C), W2, out=dall[:, :2 * C])                       # [dq | dk]
     dall4 = dall.reshape(B, H, W, 3 * C)
     if joint:
         t_all = torch.as_strided(t_q, (B, H, W, 3 * C), t_q.stride())

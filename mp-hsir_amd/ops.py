@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/mphsir.h): shape checks, output allocation,
 pointer/stream plumbing.  No arithmetic happens here."""
 import ctypes
+import os
 import weakref
 
 import torch
@@ -40,6 +41,50 @@ def _check(*tensors):
             raise RuntimeError("mp-hsir_amd: emulated test library bound but got a GPU tensor")
         if not emu and not t.is_cuda:
             raise RuntimeError("mp-hsir_amd: ops run on the GPU only (got a CPU tensor; there is no CPU fallback)")
+
+
+# ---- side stream: small latency-bound kernels (64-256 workgroups) run beside the big streaming ones ------------------
+_SIDE = {}
+# Off by default: measured on MI355X (tools/bench_fork.py, graph-replay trace) the fold backward does overlap the
+# depthwise recompute (71 % of its time), but the cross-queue edges of the forked graph cost as much as that saves
+# (whole step 34.12 ms either way).  MPHSIR_SIDE_STREAM=1 enables it.
+USE_SIDE_STREAM = os.environ.get("MPHSIR_SIDE_STREAM", "0") == "1"
+
+
+class side_stream:
+    """`with ops.side_stream() as s:` launches onto a second HIP stream that first waits for everything already queued
+    on the current one (fork); `s.join(*tensors)` makes the current stream wait for it and hands the tensors over
+    (record_stream).  Works under hipGraph capture (fork/join from the capturing stream = parallel graph branches).
+    No-op on CPU tensors (emulator) or when disabled."""
+
+    def __init__(self, like):
+        self.on = USE_SIDE_STREAM and like.is_cuda
+        self.ctx = None
+        if self.on:
+            dev = like.device
+            self.main = torch.cuda.current_stream(dev)
+            self.side = _SIDE.get(dev)
+            if self.side is None:
+                self.side = _SIDE[dev] = torch.cuda.Stream(dev)
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.on:
+            self.main.wait_stream(self.side)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
 
 
 # ---- deferred ordered reduction of split partials (mphsir_reduce_parts) -----------------------------------------
@@ -550,8 +595,9 @@ def gdfn_gate_bwd(t, du):
     return u, dt_
 
 
-def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype):
-    """-> W2 (B,2C,2C) in `dtype`, dWo (C,C) fp32, dtemp (heads,) fp32."""
+def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True):
+    """-> W2 (B,2C,2C) in `dtype`, dWo (C,C) fp32, dtemp (heads,) fp32 (reduce=False: the per-sample partials
+    (B,C,C) / (B,heads) instead, for the caller to pass to reduce_parts)."""
     lib = _lib.load()
     _check(gp, sp, temperature, Wo, dM)
     B, nsplit, heads, hd, _ = gp.shape
@@ -566,6 +612,8 @@ def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype):
     a.B, a.C, a.heads, a.nsplit = B, C, heads, nsplit
     _lib.check(lib.mphsir_spectral_fold_bwd(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold_bwd")
     _acct("spectral_fold_bwd", 4.0 * B * C * C * hd, 3.0 * B * C * C * 4)
+    if not reduce:
+        return W2, dWo, dtemp
     return W2, reduce_parts(dWo), reduce_parts(dtemp)
 
 
