@@ -296,6 +296,13 @@ typedef struct mphsir_reduce_seg {
     const float* src; float* dst;
     int64_t n, stride, src_batch_stride, dst_batch_stride;
     int32_t nsplit, nbatch;
+    /* optional 2-D form (rows > 1): the segment is a rows x n sub-block of a wider partial matrix and lands in dst as a
+     * (possibly transposed) dense block: element (r, i) is read at src + r*src_ld + i (+ s*stride) and written to
+     * dst + r*dst_ld + i*dst_col_stride.  Un-padding (hidden 170 -> 192), sub-block extraction and the [9][C] -> [C][9]
+     * tap transposes of the parameter gradients happen here instead of in separate copy / cat launches.
+     * rows <= 1: plain vector of n elements (src_ld, dst_ld ignored, dst_col_stride 0 or 1).                         */
+    int32_t rows, dst_col_stride;
+    int64_t src_ld, dst_ld;
 } mphsir_reduce_seg;
 int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, void* stream);
 

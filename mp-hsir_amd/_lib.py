@@ -86,7 +86,8 @@ class PgBwdArgs(ctypes.Structure):
 class ReduceSeg(ctypes.Structure):
     """mirror of struct mphsir_reduce_seg"""
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("n", c_int64), ("stride", c_int64), ("src_batch_stride", c_int64),
-                ("dst_batch_stride", c_int64), ("nsplit", c_int32), ("nbatch", c_int32)]
+                ("dst_batch_stride", c_int64), ("nsplit", c_int32), ("nbatch", c_int32), ("rows", c_int32),
+                ("dst_col_stride", c_int32), ("src_ld", c_int64), ("dst_ld", c_int64)]
 
 
 REDUCE_MAX_SEGS = 32

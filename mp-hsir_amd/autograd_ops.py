@@ -85,13 +85,10 @@ class _GatedMlp(torch.autograd.Function):
         hid = blk.mlp.fc2.weight.shape[1]
         HP = h.shape[1]
         with ops.reduce_scope():                                   # one ordered-sum launch for all five partial buffers
-            dW2, db2 = ops.gemm_tn(dm, h, colsum=True)
-            dW2 = dW2[:, :hid]
-            dW1p, db1p = ops.gemm_tn(dpre, xn, colsum=True)
+            dW2, db2 = ops.gemm_tn_blocks(dm, h, [(0, Cc)], ncols=hid, colsum=True)             # drops the padded hidden columns
+            dW1, db1 = ops.gemm_tn_blocks(dpre, xn, [(0, hid), (HP, hid)], colsum=True)            # value rows | gate rows
             dln = ops.reduce_parts(part)
-        return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1],
-                torch.cat([dW1p[:hid], dW1p[HP:HP + hid]], 0), torch.cat([db1p[:hid], db1p[HP:HP + hid]]),
-                dW2, db2)
+        return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1], dW1, db1, dW2, db2)
 
 
 def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, MbT, temperature, wo, heads, B, H, W):
@@ -99,7 +96,7 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
 
     d_out (M,C); t_q/t_k/t_v: (B,H,W,*) views of the 1x1-conv outputs that fed dwconv_gram (channels-last,
     C channels each); w9*: fp32 tap-major dw weights [9][C] views; v, gp, sp, Mb, MbT as saved by the forward.
-    Returns d(t_q), d(t_k), d(t_v) (B,H,W,C each), d(dw taps) [9][C] x3, d temperature (heads,), d Wo (C,C).
+    Returns d(t_q), d(t_k), d(t_v) (B,H,W,C each), d(dw taps) (C,9) x3, d temperature (heads,), d Wo (C,C).
     All HIP: dM = d_out^T v (gemm_tn), fold backward (one launch), [dq|dk] and dv as per-sample token GEMMs,
     depthwise backward (data + taps)."""
     C = v.shape[1]
@@ -131,12 +128,13 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
         t_all = torch.as_strided(t_q, (B, H, W, 3 * C), t_q.stride())
         w9_all = torch.as_strided(w9q, (9, 3 * C), w9q.stride())
         dt_all = ops.dwconv3x3(dall4, w9_all, flip=True)
-        dw_all = ops.dwconv3x3_wgrad(t_all, dall4)
-        return (dt_all[..., :C], dt_all[..., C:2 * C], dt_all[..., 2 * C:], dw_all[:, :C], dw_all[:, C:2 * C], dw_all[:, 2 * C:],
+        dw_all = ops.dwconv3x3_wgrad(t_all, dall4, col_ranges=[(0, 3 * C)])             # (3C, 9): the parameter's layout
+        return (dt_all[..., :C], dt_all[..., C:2 * C], dt_all[..., 2 * C:], dw_all[:C], dw_all[C:2 * C], dw_all[2 * C:],
                 dtemp, dwo)
     dq4, dk4, dv4 = dall4[..., :C], dall4[..., C:2 * C], dall4[..., 2 * C:]
     return (ops.dwconv3x3(dq4, w9q, flip=True), ops.dwconv3x3(dk4, w9k, flip=True), ops.dwconv3x3(dv4, w9v, flip=True),
-            ops.dwconv3x3_wgrad(t_q, dq4), ops.dwconv3x3_wgrad(t_k, dk4), ops.dwconv3x3_wgrad(t_v, dv4), dtemp, dwo)
+            ops.dwconv3x3_wgrad(t_q, dq4, col_ranges=[(0, C)]), ops.dwconv3x3_wgrad(t_k, dk4, col_ranges=[(0, C)]),
+            ops.dwconv3x3_wgrad(t_v, dv4, col_ranges=[(0, C)]), dtemp, dwo)
 
 
 _PG_KEYS = ("linear_down.weight", "linear_up.weight", "linear_prompt.weight", "prompt_param", "q.weight", "kv.weight",
@@ -207,22 +205,22 @@ class _PgsstbAttn(torch.autograd.Function):
             dx, part = ops.ln_bwd_win(x, dxn, dy, pk["ln1"][0], shift)
             dln = ops.reduce_parts(part)
             drpb = ops.reduce_parts(drpb)
-        d_sdw = _join_taps(dwq, dwk, dwv).t().reshape(3 * Cc, 1, 3, 3)
+        d_sdw = _join_taps(dwq, dwk, dwv).reshape(3 * Cc, 1, 3, 3)
         return (None, None, dx, dln[0], dln[1], d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, drpb,
                 dtemp.reshape(heads, 1, 1), d_sqkv, d_sdw, dwo.reshape(Cc, Cc, 1, 1)) + tuple(dpg)
 
 
 def _join_taps(*dw):
-    """[9][C] tap gradients of adjacent channel ranges -> [9][sum C]; a view when they already are slices of one buffer."""
+    """(C,9) tap gradients of adjacent channel ranges -> (sum C, 9); a view when they already are row slices of one buffer."""
     w0 = dw[0]
     ok, off = True, w0.data_ptr()
     for w in dw:
-        ok = ok and w.data_ptr() == off and w.stride() == w0.stride() and w.stride(1) == 1
-        off += w.shape[1] * w.element_size()
-    n = sum(w.shape[1] for w in dw)
-    if ok and w0.stride(0) >= n:
-        return torch.as_strided(w0, (9, n), w0.stride())
-    return torch.cat(dw, dim=1)
+        ok = (ok and w.data_ptr() == off and w.is_contiguous()
+              and w.untyped_storage().data_ptr() == w0.untyped_storage().data_ptr())
+        off += w.numel() * w.element_size()
+    if ok:
+        return torch.as_strided(w0, (sum(w.shape[0] for w in dw), 9), (9, 1))
+    return torch.cat(dw, dim=0)
 
 
 def getattr_path(mod, dotted):
@@ -305,10 +303,6 @@ def _ln_fwd(x2, w, b):
     return F.layer_norm(x2.float(), (x2.shape[-1],), w.float(), b.float(), 1e-5).to(x2.dtype)
 
 
-def _unpad_halves(w, hid, HP):
-    return torch.cat([w[:hid], w[HP:HP + hid]], 0)
-
-
 class _GdfnRes(torch.autograd.Function):
     """y = a + project_out(gelu(x1) * x2), [x1|x2] = dwconv(project_in(LN(a)))   (ref FFN :251-265 / FeedForward
     :374-391 inside the pre-norm residual of :286 / :477).  HIP forward; backward = HIP depthwise / gate /
@@ -339,15 +333,13 @@ class _GdfnRes(torch.autograd.Function):
             tdw = ops.dwconv3x3(t4, pf["w9"]).reshape(-1, 2 * HP)
             du = dy @ pf["w_out"]                                              # (M,HP)
             u, dtdw = ops.gdfn_gate_bwd(tdw, du)
-            d_out_w = ops.gemm_tn(dy, u)[:, :hid].reshape(D, hid, 1, 1)
+            d_out_w = ops.gemm_tn_blocks(dy, u, [(0, D)], ncols=hid).reshape(D, hid, 1, 1)
             dtdw4 = dtdw.reshape(B, H, W, 2 * HP)
             dt_ = ops.dwconv3x3(dtdw4, pf["w9"], flip=True).reshape(-1, 2 * HP)
-            d_dw = ops.dwconv3x3_wgrad(t4, dtdw4)
+            d_dw = ops.dwconv3x3_wgrad(t4, dtdw4, col_ranges=[(0, hid), (HP, hid)]).reshape(2 * hid, 1, 3, 3)
             lw, lb = ln.pair()
             da, dlw, dlb, xn = ops.ln_bwd_tok(a2, dt_ @ pf["w_in"], dy, lw, lb)
-            d_in_w = ops.gemm_tn(dt_, xn)
-        d_dw = _unpad_halves(d_dw.t(), hid, HP).reshape(2 * hid, 1, 3, 3)
-        d_in_w = _unpad_halves(d_in_w, hid, HP).reshape(2 * hid, D, 1, 1)
+            d_in_w = ops.gemm_tn_blocks(dt_, xn, [(0, hid), (HP, hid)]).reshape(2 * hid, D, 1, 1)
         return None, None, None, da, dlw, dlb, d_in_w, d_dw, d_out_w
 
 
@@ -396,7 +388,7 @@ class _SelfChannelAttnRes(torch.autograd.Function):
             lw, lb = ln.pair()
             dt_in, dlw, dlb, xn = ops.ln_bwd_tok(t2, dt3 @ pa["wqkv"], da, lw, lb)
             d_qkv = ops.gemm_tn(dt3, xn).reshape(3 * D, D, 1, 1)
-        d_dw = _join_taps(dwq, dwk, dwv).t().reshape(3 * D, 1, 3, 3)
+        d_dw = _join_taps(dwq, dwk, dwv).reshape(3 * D, 1, 3, 3)
         return None, None, None, dt_in, dlw, dlb, d_qkv, d_dw, dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1)
 
 
@@ -443,8 +435,8 @@ class _CrossChannelAttnRes(torch.autograd.Function):
             dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis2, dkv @ pa["wkv"], torch.zeros_like(vis2), n12w, n12b)
             d_wq = ops.gemm_tn(dtq2, xq).reshape(D, D, 1, 1)
             d_wkv = ops.gemm_tn(dkv, xv).reshape(2 * D, D, 1, 1)
-        return (None, None, dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.t().reshape(D, 1, 3, 3),
-                torch.cat([dwk, dwv], dim=1).t().reshape(2 * D, 1, 3, 3), dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1))
+        return (None, None, dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.reshape(D, 1, 3, 3),
+                _join_taps(dwk, dwv).reshape(2 * D, 1, 3, 3), dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1))
 
 
 def tvsp(mod, x, clip_prompt, prompt_weights):

@@ -15,7 +15,8 @@ namespace mphsir {
 struct RedSegDev {
     const float* src; float* dst;
     long n, stride, sbs, dbs, t0, nitems; // t0: first thread of this segment (a multiple of 64: waves never straddle segments)
-    int nsplit, vec, lg;                  // 2^lg adjacent lanes share one work item (4 consecutive outputs) and split the split axis
+    long src_ld, dst_ld;                  // 2-D form: row pitches (rows x n block of a wider matrix)
+    int nsplit, vec, lg, rows, dcs;       // 2^lg adjacent lanes share one work item (4 consecutive outputs) and split the split axis
 };
 struct RedDev {
     RedSegDev s[MPHSIR_REDUCE_MAX_SEGS];
@@ -31,11 +32,11 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(RedDev a) {
     for (int k = 1; k < MPHSIR_REDUCE_MAX_SEGS; ++k)
         if (k < a.nseg && t >= a.s[k].t0) s = a.s[k];
     const int G = 1 << s.lg;
-    const long local = t - s.t0, item = local >> s.lg, ipb = (s.n + 3) / 4;
+    const long local = t - s.t0, item = local >> s.lg, ipr = (s.n + 3) / 4, ipb = ipr * s.rows;
     const int g = (int)(local & (G - 1));
     const bool live = item < s.nitems;
-    const long b = live ? item / ipb : 0, i4 = live ? (item % ipb) * 4 : 0;
-    const float* src = s.src + b * s.sbs + i4;
+    const long b = live ? item / ipb : 0, rem = live ? item % ipb : 0, r = rem / ipr, i4 = (rem % ipr) * 4;
+    const float* src = s.src + b * s.sbs + r * s.src_ld + i4;
     const int ne = (s.n - i4) < 4 ? (int)(s.n - i4) : 4;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (live) {
@@ -51,10 +52,10 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(RedDev a) {
     for (int m = 1; m < G; m <<= 1)
         for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], m);
     if (live && g == 0) {
-        float* dst = s.dst + b * s.dbs + i4;
+        float* dst = s.dst + b * s.dbs + r * s.dst_ld + i4 * s.dcs;
         if (s.vec) *reinterpret_cast<f32x4*>(dst) = acc;
         else
-            for (int e = 0; e < ne; ++e) dst[e] = acc[e];
+            for (int e = 0; e < ne; ++e) dst[(long)e * s.dcs] = acc[e];
     }
 }
 
@@ -88,14 +89,16 @@ extern "C" int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, 
     for (int k = 0; k < nseg; ++k) {
         const mphsir_reduce_seg& g = segs[k];
         MPHSIR_REQUIRE(g.src && g.dst && g.n > 0 && g.nsplit > 0 && g.nbatch > 0, "reduce_parts: bad segment %d", k);
-        const bool vec = aligned16(g.src) && aligned16(g.dst) && g.n % 4 == 0 && g.stride % 4 == 0 &&
-                         g.src_batch_stride % 4 == 0 && g.dst_batch_stride % 4 == 0;
-        const long nitems = (long)g.nbatch * ((g.n + 3) / 4);
+        const int rows = g.rows > 1 ? g.rows : 1, dcs = g.dst_col_stride > 0 ? g.dst_col_stride : 1;
+        const long src_ld = rows > 1 ? (long)g.src_ld : 0, dst_ld = rows > 1 ? (long)g.dst_ld : 0;
+        const bool vec = aligned16(g.src) && aligned16(g.dst) && g.n % 4 == 0 && g.stride % 4 == 0 && dcs == 1 &&
+                         g.src_batch_stride % 4 == 0 && g.dst_batch_stride % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0;
+        const long nitems = (long)g.nbatch * rows * ((g.n + 3) / 4);
         int lg = 0;                        // lanes per item: keep <= 32 splits per lane, and small segments still fill waves
         while (lg < 6 && (g.nsplit >> lg) > 32) ++lg;
         while (lg < 6 && (nitems << lg) < 8192 && (g.nsplit >> lg) > 4) ++lg;
         d.s[k] = RedSegDev{g.src, g.dst, (long)g.n, (long)g.stride, (long)g.src_batch_stride, (long)g.dst_batch_stride, threads, nitems,
-                           g.nsplit, vec ? 1 : 0, lg};
+                           src_ld, dst_ld, g.nsplit, vec ? 1 : 0, lg, rows, dcs};
         threads += ((nitems << lg) + 63) / 64 * 64;
     }
     d.threads = threads;

@@ -112,22 +112,32 @@ class reduce_scope:
 
 
 def _flush(segs):
+    """segs: dicts with the fields of mphsir_reduce_seg + the tensors that keep the memory alive until the launch."""
     lib = _lib.load()
     for i in range(0, len(segs), _lib.REDUCE_MAX_SEGS):
         chunk = segs[i:i + _lib.REDUCE_MAX_SEGS]
         arr = (_lib.ReduceSeg * len(chunk))()
         nbytes = 0.0
-        for k, (part, out, n, nsplit, nbatch) in enumerate(chunk):
-            arr[k].src, arr[k].dst = part.data_ptr(), out.data_ptr()
-            arr[k].n, arr[k].stride, arr[k].src_batch_stride, arr[k].dst_batch_stride = n, n, nsplit * n, n
-            arr[k].nsplit, arr[k].nbatch = nsplit, nbatch
-            nbytes += 4.0 * nbatch * n * (nsplit + 1)
-        _lib.check(lib.mphsir_reduce_parts(arr, len(chunk), _stream(chunk[0][0])), "reduce_parts")
+        for k, g in enumerate(chunk):
+            a = arr[k]
+            a.src, a.dst = g["src"], g["dst"]
+            a.n, a.stride, a.src_batch_stride, a.dst_batch_stride = g["n"], g["stride"], g["sbs"], g["dbs"]
+            a.nsplit, a.nbatch, a.rows, a.dst_col_stride = g["nsplit"], g["nbatch"], g["rows"], g["dcs"]
+            a.src_ld, a.dst_ld = g["src_ld"], g["dst_ld"]
+            nbytes += 4.0 * g["nbatch"] * max(1, g["rows"]) * g["n"] * (g["nsplit"] + 1)
+        _lib.check(lib.mphsir_reduce_parts(arr, len(chunk), _stream(chunk[0]["keep"][0])), "reduce_parts")
         _acct("reduce_parts", nbytes / 4.0, nbytes)
 
 
+def _submit(seg, immediate):
+    if _SCOPE is None or immediate:
+        _flush([seg])
+    else:
+        _SCOPE.segs.append(seg)
+
+
 def reduce_parts(part, batched=False, immediate=False):
-    """part fp32 contiguous (nsplit, *shape) [batched: (Bt, nsplit, *shape)] -> sum over the split axis in split order
+    """part fp32 contiguous (nsplit, *shape) [batched: (Bt, nsplit, *shape)] -> sum over the split axis in a fixed order
     (deterministic), shape (*shape) [(Bt, *shape)].  Deferred to the end of the enclosing `reduce_scope`, if any."""
     _check(part)
     assert part.dtype == torch.float32 and part.is_contiguous()
@@ -141,11 +151,30 @@ def reduce_parts(part, batched=False, immediate=False):
     n = 1
     for d in shape:
         n *= d
-    seg = (part, out, n, nsplit, Bt)
-    if _SCOPE is None or immediate:
-        _flush([seg])
+    _submit(dict(src=part.data_ptr(), dst=out.data_ptr(), n=n, stride=n, sbs=nsplit * n, dbs=n, nsplit=nsplit, nbatch=Bt,
+                 rows=1, dcs=1, src_ld=0, dst_ld=0, keep=(part, out)), immediate)
+    return out
+
+
+def reduce_block(part, r0, nr, c0, nc, out, transpose=False, immediate=False):
+    """Sum the (r0:r0+nr, c0:c0+nc) sub-block of the partial matrices part (nsplit, R, Cc) over the split axis straight
+    into the 2-D fp32 view `out`: shape (nr, nc) with unit column stride, or -- transpose=True -- shape (nc, nr).  This is
+    where padded hidden rows are dropped, sub-blocks of a factor product are cut out and tap gradients are transposed,
+    instead of in separate copy / cat launches.  Deferred like reduce_parts."""
+    _check(part, out)
+    assert part.dtype == torch.float32 and part.is_contiguous() and part.dim() == 3 and out.dtype == torch.float32
+    nsplit, R, Cc = part.shape
+    assert 0 <= r0 and r0 + nr <= R and 0 <= c0 and c0 + nc <= Cc and out.dim() == 2
+    if transpose:
+        assert tuple(out.shape) == (nc, nr) and out.stride(1) == 1
+        dst_ld, dcs = 1, out.stride(0)
     else:
-        _SCOPE.segs.append(seg)
+        assert tuple(out.shape) == (nr, nc) and out.stride(1) == 1
+        dst_ld, dcs = out.stride(0), 1
+    _submit(dict(src=part.data_ptr() + 4 * (r0 * Cc + c0), dst=out.data_ptr(), n=nc, stride=R * Cc, sbs=0, dbs=0, nsplit=nsplit,
+                 nbatch=1, rows=max(nr, 1), dcs=dcs, src_ld=Cc, dst_ld=dst_ld, keep=(part, out)), immediate)
+    if nr == 1:      # the C side treats rows <= 1 as the 1-D form: identical addressing for a single row
+        pass
     return out
 
 
@@ -438,8 +467,10 @@ def dwconv3x3(x, w9, flip=False):
     return y
 
 
-def dwconv3x3_wgrad(x, dy, nblk=None):
-    """-> fp32 [9][C] = sum_p x[p+tap] * dy[p]."""
+def dwconv3x3_wgrad(x, dy, nblk=None, col_ranges=None):
+    """-> fp32 [9][C] = sum_p x[p+tap] * dy[p].  With col_ranges=[(c0, nc), ...] the result is returned in the
+    parameter's own layout instead: (sum nc, 9), channel-major, only those channel ranges (transposed + un-padded inside
+    the partial reduction)."""
     lib = _lib.load()
     _check(x, dy)
     B, H, W, C = x.shape
@@ -449,7 +480,14 @@ def dwconv3x3_wgrad(x, dy, nblk=None):
     _lib.check(lib.mphsir_dwconv3x3_wgrad(_p(x), x.stride(2), _p(dy), dy.stride(2), _p(part), nblk, B, H, W, C,
                                           _DT[x.dtype], _stream(x)), "dwconv3x3_wgrad")
     _acct("dwconv3x3_wgrad", 18.0 * B * H * W * C, 2.0 * B * H * W * C * x.element_size())
-    return reduce_parts(part)
+    if col_ranges is None:
+        return reduce_parts(part)
+    out = torch.empty((sum(nc for _, nc in col_ranges), 9), dtype=torch.float32, device=x.device)
+    o = 0
+    for c0, nc in col_ranges:
+        reduce_block(part, 0, 9, c0, nc, out[o:o + nc], transpose=True)
+        o += nc
+    return out
 
 
 def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0):
@@ -548,9 +586,10 @@ TN_BIG_TILES = True        # bf16 token-reduction GEMMs use the transposed-LDS-r
 TN_BIG_ROUNDS = 2.0        # ... and aim for this many full rounds of resident workgroups
 
 
-def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False):
+def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, reduce=True):
     """sum over tokens of a[m,:]^T b[m,:].  a (M,N1), b (M,N2) row-major views -> fp32 (N1,N2);
-    batched: a (Bt,M,N1), b (Bt,M,N2) -> (Bt,N1,N2).  colsum=True also returns sum_m a[m,:] (fp32, (N1,))."""
+    batched: a (Bt,M,N1), b (Bt,M,N2) -> (Bt,N1,N2).  colsum=True also returns sum_m a[m,:] (fp32, (N1,)).
+    reduce=False returns the raw split partials (Bt,nsplit,N1,N2) [and (Bt,nsplit,N1)] for reduce_block."""
     lib = _lib.load()
     _check(a, b)
     batched = a.dim() == 3
@@ -575,12 +614,34 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False):
                                   _DT[a.dtype], _stream(a)),
                "gemm_tn")
     _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size() + part.numel() * 4.0)
+    if not reduce:
+        return (part, cs) if colsum else part
     out = reduce_parts(part, batched=True, immediate=immediate)
     out = out if batched else out[0]
     if colsum:
         c = reduce_parts(cs, batched=True, immediate=immediate)
         return out, (c if batched else c[0])
     return out
+
+
+def gemm_tn_blocks(a, b, row_ranges, ncols=None, colsum=False):
+    """gemm_tn that keeps only the row ranges [(r0, nr), ...] (stacked in that order) and the first `ncols` columns of
+    the (N1, N2) product: the un-padding of the hidden dimension happens in the partial reduction itself.
+    -> fp32 (sum nr, ncols) [and the matching entries of the column sums of a, (sum nr,)]."""
+    N2 = b.shape[-1]
+    ncols = N2 if ncols is None else ncols
+    res = gemm_tn(a, b, colsum=colsum, reduce=False)
+    part, cs = (res if colsum else (res, None))
+    rows = sum(nr for _, nr in row_ranges)
+    out = torch.empty((rows, ncols), dtype=torch.float32, device=a.device)
+    outc = torch.empty((1, rows), dtype=torch.float32, device=a.device) if colsum else None
+    o = 0
+    for r0, nr in row_ranges:
+        reduce_block(part[0], r0, nr, 0, ncols, out[o:o + nr])
+        if colsum:
+            reduce_block(cs[0].unsqueeze(1), 0, 1, r0, nr, outc[:, o:o + nr])
+        o += nr
+    return (out, outc[0]) if colsum else out
 
 
 def gdfn_gate_bwd(t, du):
@@ -637,17 +698,20 @@ def pg_gate_bwd(mu, dgate, pg):
     a.nW, a.C, a.r, a.KL, a.KR = nW, C, r, KL, KR
     _lib.check(lib.mphsir_pg_gate_bwd(ctypes.byref(a), _stream(mu)), "pg_gate_bwd")
     _acct("pg_gate_bwd", 4.0 * nW * C * (128 + 2 * r), 4.0 * nW * (2 * C + KL + KR))
-    P = gemm_tn(L, R)
-    g = {
-        "linear_up.weight": P[0:C, 0:r],
-        "proj.weight": P[C:C + r, r:2 * r],
-        "proj.bias": P[C:C + r, 2 * r],
-        "kv.weight": P[C + r:C + 3 * r, 2 * r + 1:3 * r + 1],
-        "q.weight": P[C + 3 * r:C + 4 * r, 3 * r + 1:4 * r + 1],
-        "prompt_param": P[C + 4 * r:C + 4 * r + 128, 4 * r + 1:5 * r + 1],
-        "linear_prompt.weight": P[C + 4 * r + 128:C + 4 * r + 256, 5 * r + 1:5 * r + 1 + C],
-        "linear_down.weight": P[C + 4 * r + 256:C + 5 * r + 256, 5 * r + 1:5 * r + 1 + C],
+    part = gemm_tn(L, R, reduce=False)[0]                      # (nsplit, KL, KR): every parameter gradient is a sub-block
+    blocks = {
+        "linear_up.weight": (0, C, 0, r),
+        "proj.weight": (C, r, r, r),
+        "proj.bias": (C, r, 2 * r, 1),
+        "kv.weight": (C + r, 2 * r, 2 * r + 1, r),
+        "q.weight": (C + 3 * r, r, 3 * r + 1, r),
+        "prompt_param": (C + 4 * r, 128, 4 * r + 1, r),
+        "linear_prompt.weight": (C + 4 * r + 128, 128, 5 * r + 1, C),
+        "linear_down.weight": (C + 4 * r + 256, r, 5 * r + 1, C),
     }
+    g = {k: reduce_block(part, r0, nr, c0, nc, torch.empty((nr, nc), dtype=torch.float32, device=mu.device))
+         for k, (r0, nr, c0, nc) in blocks.items()}
+    g["proj.bias"] = g["proj.bias"].reshape(r)
     return dmu, g
 
 

@@ -305,3 +305,26 @@ def check_pack_gather(dev, dtype):
     out = ops.pack_gather(arena, idx, dtype)
     ref = torch.where(idx >= 0, arena[idx.clamp(min=0).long()], torch.zeros(())).to(dtype)
     assert torch.equal(out.cpu(), ref.cpu())
+
+
+def check_reduce_block(dev):
+    """2-D segments of mphsir_reduce_parts: sub-block extraction with un-padding, stacking two row ranges into one
+    output, a transposed destination, a single-row block and an unaligned sub-block (scalar path)."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    part = rnd((5, 24, 40), 120)
+    full = part.double().sum(0)
+    with ops.reduce_scope():
+        a = torch.empty((12, 40), dtype=torch.float32, device=part.device)
+        ops.reduce_block(part, 0, 6, 0, 40, a[:6])
+        ops.reduce_block(part, 16, 6, 0, 40, a[6:])
+        b = ops.reduce_block(part, 4, 8, 8, 16, torch.empty((8, 16), dtype=torch.float32, device=part.device))
+        c = ops.reduce_block(part, 0, 9, 0, 24, torch.empty((24, 9), dtype=torch.float32, device=part.device), transpose=True)
+        d = ops.reduce_block(part, 3, 1, 5, 7, torch.empty((1, 7), dtype=torch.float32, device=part.device))
+        e = ops.reduce_block(part, 2, 5, 3, 10, torch.empty((5, 10), dtype=torch.float32, device=part.device))
+        wide = torch.zeros((8, 32), dtype=torch.float32, device=part.device)
+        ops.reduce_block(part, 1, 8, 4, 12, wide[:, 8:20])
+    assert rel_l2(a, torch.cat([full[:6], full[16:22]])) < 3e-7
+    assert rel_l2(b, full[4:12, 8:24]) < 3e-7 and rel_l2(c, full[:9, :24].t()) < 3e-7
+    assert rel_l2(d, full[3:4, 5:12]) < 3e-7 and rel_l2(e, full[2:7, 3:13]) < 3e-7
+    assert rel_l2(wide[:, 8:20], full[1:9, 4:16]) < 3e-7 and float(wide[:, :8].abs().sum()) == 0 and float(wide[:, 20:].abs().sum()) == 0

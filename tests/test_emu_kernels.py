@@ -95,3 +95,7 @@ def test_reduce_parts():
 @pytest.mark.parametrize("dtype", K.DTYPES)
 def test_pack_gather(dtype):
     K.check_pack_gather("cpu", dtype)
+
+
+def test_reduce_block():
+    K.check_reduce_block("cpu")

@@ -129,3 +129,7 @@ def test_pack_gather(dtype):
                                                   (4096, 128, 352, 5, 0), (4096, 64, 64, 4, 3), (4096, 384, 64, 7, 0)])
 def test_gemm_tn_transposed_read_widths(M, N1, N2, nsplit, batch):
     K.check_gemm_tn("cuda", torch.bfloat16, M, N1, N2, nsplit, batch, tile128=True)
+
+
+def test_reduce_block():
+    K.check_reduce_block("cuda")
