@@ -199,10 +199,50 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
         }
     }
 
+    __syncthreads();
+    // the wave's LN(x) fragments stay in registers for the whole hidden-chunk loop (Xs is only reused by the epilogue)
+    constexpr int NKC = C / TR::KCHUNK;
+    frag_t bx[TT][NKC];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) bx[t][kc] = load_frag<T>(Xs, LDX, (wv * TT + t) * 16, kc * TR::KCHUNK);
+
     const T* W1 = reinterpret_cast<const T*>(a.W1);
     const T* W2 = reinterpret_cast<const T*>(a.W2);
     T* Hw = Hs + wv * 16 * TT * LDH;
     const int HP = a.HP;
+    // weight slices of one 32-wide hidden chunk: global -> registers (prefetched one chunk ahead) -> LDS
+    constexpr int VPR = C / VEC, VPH = 32 / VEC;
+    constexpr int NW1 = 64 * VPR, NW2 = C * VPH, NVW = NW1 + NW2, NPT = (NVW + 255) / 256;
+    Vec16<T> wreg[NPT];
+    auto wload = [&](int j) {
+#pragma unroll
+        for (int it = 0; it < NPT; ++it) {
+            const int v = tid + 256 * it;
+            if (v < NW1) {
+                const int r = v / VPR, c = (v % VPR) * VEC;
+                wreg[it] = load16<T>(W1 + (long)(r < 32 ? j + r : HP + j + (r - 32)) * C + c);
+            } else if (v < NVW) {
+                const int u = v - NW1, r = u / VPH, c = (u % VPH) * VEC;
+                wreg[it] = load16<T>(W2 + (long)r * HP + j + c);
+            }
+        }
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int it = 0; it < NPT; ++it) {
+            const int v = tid + 256 * it;
+            if (v < NW1) {
+                const int r = v / VPR, c = (v % VPR) * VEC;
+                store16<T>(W1s + r * LDX + c, wreg[it]);
+            } else if (v < NVW) {
+                const int u = v - NW1, r = u / VPH, c = (u % VPH) * VEC;
+                store16<T>(W2s + r * LDH + c, wreg[it]);
+            }
+        }
+    };
+    wload(0);
     f32x4 out[TT][NCT];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
@@ -210,36 +250,25 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
         for (int i = 0; i < NCT; ++i) out[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int j = 0; j < HP; j += 32) {
-        __syncthreads();                                   // previous chunk's weight tiles fully consumed (and Xs staged)
-        {
-            constexpr int VPR = C / VEC;
-            for (int v = tid; v < 64 * VPR; v += 256) {
-                const int r = v / VPR, c = (v % VPR) * VEC;
-                const long srow = r < 32 ? j + r : HP + j + (r - 32);
-                store16<T>(W1s + r * LDX + c, load16<T>(W1 + srow * C + c));
-            }
-            constexpr int VPH = 32 / VEC;
-            for (int v = tid; v < C * VPH; v += 256) {
-                const int r = v / VPH, c = (v % VPH) * VEC;
-                store16<T>(W2s + r * LDH + c, load16<T>(W2 + (long)r * HP + j + c));
-            }
-        }
+        __syncthreads();                                   // previous chunk's weight tiles fully consumed
+        wstore();
         __syncthreads();
+        if (j + 32 < HP) wload(j + 32);                    // in flight during the MFMAs below
         f32x4 vv[TT][2], gg[TT][2];
 #pragma unroll
         for (int t = 0; t < TT; ++t)
             for (int u = 0; u < 2; ++u) { vv[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; gg[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll 2
-        for (int kk = 0; kk < C; kk += TR::KCHUNK) {
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int kk = kc * TR::KCHUNK;
             const frag_t wv0 = load_frag<T>(W1s, LDX, 0, kk), wv1 = load_frag<T>(W1s, LDX, 16, kk);
             const frag_t wg0 = load_frag<T>(W1s, LDX, 32, kk), wg1 = load_frag<T>(W1s, LDX, 48, kk);
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
-                const frag_t bx = load_frag<T>(Xs, LDX, (wv * TT + t) * 16, kk);
-                mma(vv[t][0], wv0, bx);
-                mma(vv[t][1], wv1, bx);
-                mma(gg[t][0], wg0, bx);
-                mma(gg[t][1], wg1, bx);
+                mma(vv[t][0], wv0, bx[t][kc]);
+                mma(vv[t][1], wv1, bx[t][kc]);
+                mma(gg[t][0], wg0, bx[t][kc]);
+                mma(gg[t][1], wg1, bx[t][kc]);
             }
         }
         const int hr = (lane >> 4) * 4;
@@ -251,7 +280,7 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
                     h[r] = (vv[t][u][r] + a.b1[j + u * 16 + hr + r]) * Math<T>::gelu(gg[t][u][r] + a.b1[HP + j + u * 16 + hr + r]);
                 store4<T>(Hw + (t * 16 + (lane & 15)) * LDH + u * 16 + hr, h);
             }
-        __syncthreads();
+        wave_barrier();                                    // Hw is wave-private
 #pragma unroll
         for (int kk = 0; kk < 32; kk += TR::KCHUNK) {
             frag_t bh[TT];
@@ -264,6 +293,7 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
                 for (int t = 0; t < TT; ++t) mma(out[t][ct], w2, bh[t]);
             }
         }
+        wave_barrier();
     }
     __syncthreads();
 
