@@ -130,17 +130,28 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         __syncthreads();   // Xs ready (h=0) / previous head's K, V^T, bias column no longer read
         if (tid < 225) rpbs[tid] = a.rpb[tid * CF::HEADS + h];
         // ---- (a) q, k, v^T for head h ---------------------------------------------------------
+        // unit u = (16-channel tile of q|k|v, half of the 64 tokens); a wave walks units u = wv, wv+4, ...  The weight
+        // fragments come straight from L2 and each feeds only two MFMAs, so their latency is the cost of this phase:
+        // the next unit's fragments are loaded (second register set) while the current unit runs.
         constexpr int TPW = HD / 16;                 // channel tiles per q/k/v
-        for (int u = wv; u < 3 * TPW * 2; u += 4) {
+        constexpr int NUNITS = 3 * TPW * 2, NKC = C / TR::KCHUNK;
+        auto loadw = [&](frag_t (&w)[NKC], int u) {
+            if (u < NUNITS) {
+                const int ct = u >> 1, wrow = (ct / TPW) * C + h * HD + (ct % TPW) * 16;
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) w[kc] = load_frag<T>(Wqkv, C, wrow, kc * TR::KCHUNK);
+            }
+        };
+        auto unit = [&](const frag_t (&w)[NKC], int u) {
+            if (u >= NUNITS) return;
             const int ct = u >> 1, th = u & 1, which = ct / TPW, cti = ct % TPW;
             const int wrow = which * C + h * HD + cti * 16;
             f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
             if (which < 2) {
-#pragma unroll 4
-                for (int kk = 0; kk < C; kk += TR::KCHUNK) {
-                    const frag_t wf = load_frag<T>(Wqkv, C, wrow, kk);
-                    mma(c0, wf, load_frag<T>(Xs, CF::LDX, th * 32, kk));
-                    mma(c1, wf, load_frag<T>(Xs, CF::LDX, th * 32 + 16, kk));
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) {
+                    mma(c0, w[kc], load_frag<T>(Xs, CF::LDX, th * 32, kc * TR::KCHUNK));
+                    mma(c1, w[kc], load_frag<T>(Xs, CF::LDX, th * 32 + 16, kc * TR::KCHUNK));
                 }
                 const int cr = cti * 16 + (lane >> 4) * 4;        // 4 consecutive channels of the head
                 const float sc = which == 0 ? scale : 1.f;
@@ -153,11 +164,10 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
                 store4<T>(dst + (th * 32 + (lane & 15)) * CF::LDQ + cr, c0);
                 store4<T>(dst + (th * 32 + 16 + (lane & 15)) * CF::LDQ + cr, c1);
             } else {
-#pragma unroll 4
-                for (int kk = 0; kk < C; kk += TR::KCHUNK) {
-                    const frag_t wf = load_frag<T>(Wqkv, C, wrow, kk);
-                    mma(c0, load_frag<T>(Xs, CF::LDX, th * 32, kk), wf);
-                    mma(c1, load_frag<T>(Xs, CF::LDX, th * 32 + 16, kk), wf);
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) {
+                    mma(c0, load_frag<T>(Xs, CF::LDX, th * 32, kc * TR::KCHUNK), w[kc]);
+                    mma(c1, load_frag<T>(Xs, CF::LDX, th * 32 + 16, kc * TR::KCHUNK), w[kc]);
                 }
                 const float bb = a.bqkv[wrow + (lane & 15)];
                 for (int r = 0; r < 4; ++r) { c0[r] += bb; c1[r] += bb; }
@@ -165,10 +175,29 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
                 store4<T>(vrow + th * 32, c0);
                 store4<T>(vrow + th * 32 + 16, c1);
             }
+        };
+        {
+            frag_t wa[NKC], wb[NKC];
+            loadw(wa, wv);
+            for (int u = wv; u < NUNITS; u += 8) {
+                loadw(wb, u + 4);
+                unit(wa, u);
+                loadw(wa, u + 8);
+                unit(wb, u + 4);
+            }
         }
         __syncthreads();
 
         // ---- (b) S^T = K Q^T for this wave's 16 queries, + bias + mask, softmax over keys --------
+        // the proj fragments of phase (d) (straight from L2, one MFMA each) are requested now: their latency hides
+        // behind the softmax and P V of this head
+        constexpr int NKD = CF::HDP / TR::KCHUNK;
+        frag_t wpf[NKD][NCT];
+#pragma unroll
+        for (int kd = 0; kd < NKD; ++kd)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                wpf[kd][ct] = load_frag<T>(Wp, CF::HEADS * CF::HDP, ct * 16, h * CF::HDP + kd * TR::KCHUNK);
         f32x4 s[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -227,11 +256,10 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
 
         // ---- (d) out[co][tok] += Wproj[co][h*hd + :] * O[tok][:] -------------------------------
 #pragma unroll
-        for (int kk = 0; kk < CF::HDP; kk += TR::KCHUNK) {
-            const frag_t of = load_frag<T>(Qs, CF::LDQ, wv * 16, kk);
+        for (int kd = 0; kd < NKD; ++kd) {
+            const frag_t of = load_frag<T>(Qs, CF::LDQ, wv * 16, kd * TR::KCHUNK);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-                mma(out[ct], load_frag<T>(Wp, CF::HEADS * CF::HDP, ct * 16, h * CF::HDP + kk), of);
+            for (int ct = 0; ct < NCT; ++ct) mma(out[ct], wpf[kd][ct], of);
         }
     }
     __syncthreads();
