@@ -191,35 +191,55 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
             }
         if (tid < 225) rpbs[tid] = a.rpb[tid * CF::HEADS + h];
         // ---- (a) recompute q,k,v (row-major, q/k also transposed) and dO_h = d_sa W_proj[:, head] ------
-        for (int u = wv; u < 4 * TPW * 2; u += 4) {
-            const int ct = u >> 1, th = u & 1, which = ct / TPW, cti = ct % TPW;
-            f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-            const int wrow = (which < 3 ? which * C : 0) + h * HD + cti * 16;
-            const T* Wsrc = which < 3 ? Wqkv : WpT;
-            const T* Bsrc = which < 3 ? Xs : Ds;
-#pragma unroll 4
-            for (int kk = 0; kk < C; kk += TR::KCHUNK) {
-                const frag_t wf = load_frag<T>(Wsrc, C, wrow, kk);
-                mma(c0, wf, load_frag<T>(Bsrc, CF::LDX, th * 32, kk));
-                mma(c1, wf, load_frag<T>(Bsrc, CF::LDX, th * 32 + 16, kk));
+        // unit u = (16-channel tile of q|k|v|dO, half of the 64 tokens).  The weight fragments come straight from L2 and
+        // feed two MFMAs each: the next unit's fragments are loaded into a second register set during the current unit.
+        constexpr int NUNITS = 4 * TPW * 2, NKC = C / TR::KCHUNK, UPW = NUNITS / 4;      // units per wave (NUNITS % 4 == 0)
+        {
+            frag_t wq[2][NKC];
+            {
+                const int ct = wv >> 1, which = ct / TPW, cti = ct % TPW;
+                const int wrow = (which < 3 ? which * C : 0) + h * HD + cti * 16;
+                const T* Wsrc = which < 3 ? Wqkv : WpT;
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) wq[0][kc] = load_frag<T>(Wsrc, C, wrow, kc * TR::KCHUNK);
             }
-            const int cr = cti * 16 + (lane >> 4) * 4;
-            if (which < 3) {
-                const float sc = which == 0 ? scale : 1.f;
-                for (int r = 0; r < 4; ++r) {
-                    const float bb = a.bqkv[wrow + (lane >> 4) * 4 + r];
-                    c0[r] = (c0[r] + bb) * sc;
-                    c1[r] = (c1[r] + bb) * sc;
+#pragma unroll
+            for (int i = 0; i < UPW; ++i) {              // fully unrolled: the register set index i & 1 is static
+                const int u = wv + 4 * i;
+                if (i + 1 < UPW) {
+                    const int ct = (u + 4) >> 1, which = ct / TPW, cti = ct % TPW;
+                    const int wrow = (which < 3 ? which * C : 0) + h * HD + cti * 16;
+                    const T* Wsrc = which < 3 ? Wqkv : WpT;
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) wq[(i + 1) & 1][kc] = load_frag<T>(Wsrc, C, wrow, kc * TR::KCHUNK);
                 }
-            }
-            T* rowm = which == 0 ? Qr : which == 1 ? Kr : which == 2 ? Vr : Or;
-            store4<T>(rowm + (th * 32 + (lane & 15)) * CF::LDQ + cr, c0);
-            store4<T>(rowm + (th * 32 + 16 + (lane & 15)) * CF::LDQ + cr, c1);
-            if (which != 2) {
-                T* tr = which == 0 ? Qt : which == 1 ? Kt : Ot;
-                for (int r = 0; r < 4; ++r) {
-                    tr[(cr + r) * CF::LDT + th * 32 + (lane & 15)] = from_f32<T>(c0[r]);
-                    tr[(cr + r) * CF::LDT + th * 32 + 16 + (lane & 15)] = from_f32<T>(c1[r]);
+                const int ct = u >> 1, th = u & 1, which = ct / TPW, cti = ct % TPW;
+                f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+                const int wrow = (which < 3 ? which * C : 0) + h * HD + cti * 16;
+                const T* Bsrc = which < 3 ? Xs : Ds;
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc) {
+                    mma(c0, wq[i & 1][kc], load_frag<T>(Bsrc, CF::LDX, th * 32, kc * TR::KCHUNK));
+                    mma(c1, wq[i & 1][kc], load_frag<T>(Bsrc, CF::LDX, th * 32 + 16, kc * TR::KCHUNK));
+                }
+                const int cr = cti * 16 + (lane >> 4) * 4;
+                if (which < 3) {
+                    const float sc = which == 0 ? scale : 1.f;
+                    for (int r = 0; r < 4; ++r) {
+                        const float bb = a.bqkv[wrow + (lane >> 4) * 4 + r];
+                        c0[r] = (c0[r] + bb) * sc;
+                        c1[r] = (c1[r] + bb) * sc;
+                    }
+                }
+                T* rowm = which == 0 ? Qr : which == 1 ? Kr : which == 2 ? Vr : Or;
+                store4<T>(rowm + (th * 32 + (lane & 15)) * CF::LDQ + cr, c0);
+                store4<T>(rowm + (th * 32 + 16 + (lane & 15)) * CF::LDQ + cr, c1);
+                if (which != 2) {
+                    T* tr = which == 0 ? Qt : which == 1 ? Kt : Ot;
+                    for (int r = 0; r < 4; ++r) {
+                        tr[(cr + r) * CF::LDT + th * 32 + (lane & 15)] = from_f32<T>(c0[r]);
+                        tr[(cr + r) * CF::LDT + th * 32 + 16 + (lane & 15)] = from_f32<T>(c1[r]);
+                    }
                 }
             }
         }

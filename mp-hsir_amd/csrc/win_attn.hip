@@ -135,14 +135,14 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         // the next unit's fragments are loaded (second register set) while the current unit runs.
         constexpr int TPW = HD / 16;                 // channel tiles per q/k/v
         constexpr int NUNITS = 3 * TPW * 2, NKC = C / TR::KCHUNK;
-        auto loadw = [&](frag_t (&w)[NKC], int u) {
+        auto loadw = [&](frag_t (&w)[NKC], int u) __attribute__((always_inline)) {
             if (u < NUNITS) {
                 const int ct = u >> 1, wrow = (ct / TPW) * C + h * HD + (ct % TPW) * 16;
 #pragma unroll
                 for (int kc = 0; kc < NKC; ++kc) w[kc] = load_frag<T>(Wqkv, C, wrow, kc * TR::KCHUNK);
             }
         };
-        auto unit = [&](const frag_t (&w)[NKC], int u) {
+        auto unit = [&](const frag_t (&w)[NKC], int u) __attribute__((always_inline)) {
             if (u >= NUNITS) return;
             const int ct = u >> 1, th = u & 1, which = ct / TPW, cti = ct % TPW;
             const int wrow = which * C + h * HD + cti * 16;
