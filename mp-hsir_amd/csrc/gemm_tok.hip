@@ -101,19 +101,29 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
     for (int k0 = 0; k0 < K; k0 += GT_KC, buf ^= 1) {
         const int kc = (K - k0) < GT_KC ? (K - k0) : GT_KC;    // 32 or 64
         T* Ab = As + buf * 64 * LDA;
+        // this chunk's weight fragments (straight from L2) are requested before the barrier: their latency overlaps the
+        // LDS stage of the token tile instead of stalling the first MFMA of every K-step
+        constexpr int NKK = GT_KC / TR::KCHUNK;
+        typename TR::frag_t wfr[NKK][NW];
+#pragma unroll
+        for (int q = 0; q < NKK; ++q)
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if (q * TR::KCHUNK < kc && ntile + w * 64 < a.N) wfr[q][w] = load_frag<T>(W, K, ntile + w * 64, k0 + q * TR::KCHUNK);
         sstore(Ab, k0);
         __syncthreads();           // one barrier per chunk: the other stage was last read before the previous barrier
         if (k0 + GT_KC < K) gload(k0 + GT_KC);
-        for (int kk = 0; kk < kc; kk += TR::KCHUNK) {
+#pragma unroll
+        for (int q = 0; q < NKK; ++q) {
+            if (q * TR::KCHUNK >= kc) break;
             typename TR::frag_t af[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt] = load_frag<T>(Ab, LDA, mt * 16, kk);
+            for (int mt = 0; mt < 4; ++mt) af[mt] = load_frag<T>(Ab, LDA, mt * 16, q * TR::KCHUNK);
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 if (ntile + w * 64 < a.N) {            // wave-uniform
-                    const typename TR::frag_t wf = load_frag<T>(W, K, ntile + w * 64, k0 + kk);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) mma(acc[w][mt], wf, af[mt]);
+                    for (int mt = 0; mt < 4; ++mt) mma(acc[w][mt], wfr[q][w], af[mt]);
                 }
             }
         }
