@@ -70,8 +70,12 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
 
     constexpr int VEC = Vec16<T>::N;
     constexpr int NX = 64 * (GT_KC / VEC) / 256;              // 16-byte vectors per thread and K-chunk
-    Vec16<T> xr[NX];
-    auto gload = [&](int k0) {                                // next chunk of the token tile -> registers
+    // The token tile goes global -> registers -> LDS in 64-wide K-chunks.  Two register sets keep the NEXT TWO chunks in
+    // flight while the current one is multiplied (the kernel is HBM/latency bound: bytes in flight per workgroup are
+    // what matters), two LDS stages leave one barrier per chunk.
+    Vec16<T> xa[NX], xb[NX];
+    auto gload = [&](Vec16<T> (&xr)[NX], int k0) __attribute__((always_inline)) {
+        if (k0 >= K) return;
         const int kc = (K - k0) < GT_KC ? (K - k0) : GT_KC, vpr = kc / VEC;
 #pragma unroll
         for (int it = 0; it < NX; ++it) {
@@ -79,28 +83,8 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
             if (v < 64 * vpr) xr[it] = load16<T>(X + (long)(m0 + v / vpr) * a.ldx + k0 + (v % vpr) * VEC);
         }
     };
-    auto sstore = [&](T* dst, int k0) {                       // registers (-> LayerNorm) -> LDS stage
-        const int kc = (K - k0) < GT_KC ? (K - k0) : GT_KC, vpr = kc / VEC;
-#pragma unroll
-        for (int it = 0; it < NX; ++it) {
-            const int v = tid + 256 * it;
-            if (v < 64 * vpr) {
-                const int r = v / vpr, c = (v % vpr) * VEC;
-                Vec16<T> x = xr[it];
-                if (LN) {
-                    const float mean = stat[r], rstd = stat[64 + r];
-                    for (int i = 0; i < VEC; ++i)
-                        x.set(i, (x.get(i) - mean) * rstd * a.ln_w[k0 + c + i] + a.ln_b[k0 + c + i]);
-                }
-                store16<T>(dst + r * LDA + c, x);
-            }
-        }
-    };
-    gload(0);
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += GT_KC, buf ^= 1) {
-        const int kc = (K - k0) < GT_KC ? (K - k0) : GT_KC;    // 32 or 64
-        T* Ab = As + buf * 64 * LDA;
+    auto step = [&](Vec16<T> (&xr)[NX], int k0, T* Ab) __attribute__((always_inline)) {
+        const int kc = (K - k0) < GT_KC ? (K - k0) : GT_KC, vpr = kc / VEC;    // 32 or 64
         // this chunk's weight fragments (straight from L2) are requested before the barrier: their latency overlaps the
         // LDS stage of the token tile instead of stalling the first MFMA of every K-step
         constexpr int NKK = GT_KC / TR::KCHUNK;
@@ -110,9 +94,22 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
 #pragma unroll
             for (int w = 0; w < NW; ++w)
                 if (q * TR::KCHUNK < kc && ntile + w * 64 < a.N) wfr[q][w] = load_frag<T>(W, K, ntile + w * 64, k0 + q * TR::KCHUNK);
-        sstore(Ab, k0);
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {                      // registers (-> LayerNorm) -> LDS stage
+            const int v = tid + 256 * it;
+            if (v < 64 * vpr) {
+                const int r = v / vpr, c = (v % vpr) * VEC;
+                Vec16<T> x = xr[it];
+                if (LN) {
+                    const float mean = stat[r], rstd = stat[64 + r];
+                    for (int i = 0; i < VEC; ++i)
+                        x.set(i, (x.get(i) - mean) * rstd * a.ln_w[k0 + c + i] + a.ln_b[k0 + c + i]);
+                }
+                store16<T>(Ab + r * LDA + c, x);
+            }
+        }
         __syncthreads();           // one barrier per chunk: the other stage was last read before the previous barrier
-        if (k0 + GT_KC < K) gload(k0 + GT_KC);
+        gload(xr, k0 + 2 * GT_KC);
 #pragma unroll
         for (int q = 0; q < NKK; ++q) {
             if (q * TR::KCHUNK >= kc) break;
@@ -127,6 +124,12 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
                 }
             }
         }
+    };
+    gload(xa, 0);
+    gload(xb, GT_KC);
+    for (int k0 = 0; k0 < K; k0 += 2 * GT_KC) {
+        step(xa, k0, As);
+        if (k0 + GT_KC < K) step(xb, k0 + GT_KC, As + 64 * LDA);
     }
 
     T* Y = reinterpret_cast<T*>(a.Y);
