@@ -554,7 +554,7 @@ template <class T, int C>
 static int launch_mlp_bwd(const MlpBwdDev& d, int variant, hipStream_t s) {
     if (variant != 1) {
         if constexpr (mlp_bwd2_fits<T, C, 2>()) {
-            if (d.M % 128 == 0 && (variant == 3 || (variant == 0 && C <= 128 && d.M / 128 >= 512))) return launch_mlp_bwd2<T, C, 2>(d, s);
+            if (d.M % 128 == 0 && (variant == 3 || (variant == 0 && C <= 128 && d.M / 128 >= 256))) return launch_mlp_bwd2<T, C, 2>(d, s);
         }
         if constexpr (mlp_bwd2_fits<T, C, 1>()) {
             if (variant == 0 || variant == 2) return launch_mlp_bwd2<T, C, 1>(d, s);
