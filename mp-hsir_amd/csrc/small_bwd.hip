@@ -12,6 +12,7 @@
 //       windows) contains every parameter gradient of the branch as a sub-block.
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
+#include "pg_gate_dev.h"
 
 namespace mphsir {
 
@@ -232,6 +233,8 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
     float* s_ = sm, *d_ = sm + 32, *kv = sm + 64, *q_ = sm + 128, *o_ = sm + 160, *o2 = sm + 192;
     float* do2 = sm + 224, *do_ = sm + 256, *dq = sm + 288, *dkv = sm + 320, *dd = sm + 384, *ds = sm + 416;
     float* At = sm + 448;                             // [r][r] attention probabilities (r*r <= 1024)
+    float* red = At + 1024;                           // [256] partial sums of pg_matvec_cols
+    float* tmp = red + 256;                           // [C] Wprompt^T dlogit
     const long win = blockIdx.x;
     for (int c = tid; c < C; c += 256) { mu[c] = a.mu[win * C + c]; dg[c] = a.dgate[win * C + c]; }
     __syncthreads();
@@ -257,16 +260,13 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
         w[lane + 64] = e1 / tot;
     }
     __syncthreads();
-    if (tid < r) {
-        float acc = 0.f;
-        for (int p = 0; p < 128; ++p) acc += w[p] * a.Pp[p * r + tid];
-        s_[tid] = acc;
-    } else if (tid >= 64 && tid < 64 + 2 * r) {
+    if (tid >= 64 && tid < 64 + 2 * r) {
         const int i = tid - 64;
         float acc = 0.f;
         for (int j = 0; j < r; ++j) acc += a.Wkv[i * r + j] * d_[j];
         kv[i] = acc;
     }
+    pg_matvec_cols(a.Pp, 128, r, w, s_, red);
     __syncthreads();
     if (tid < r) {
         float acc = 0.f;
@@ -291,12 +291,8 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
         o2[tid] = acc;
     }
     // ---- backward --------------------------------------------------------------------------------------
-    if (tid >= 64 && tid < 64 + r) {                  // do2 = Wup^T dg
-        const int i = tid - 64;
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc += a.Wup[c * r + i] * dg[c];
-        do2[i] = acc;
-    }
+    __syncthreads();                                  // red is free again (its last readers were before two barriers)
+    pg_matvec_cols(a.Wup, C, r, dg, do2, red);        // do2 = Wup^T dg
     __syncthreads();
     if (tid < r) {                                    // do = Wpproj^T do2
         float acc = 0.f;
@@ -348,9 +344,10 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
         dl[lane + 64] = a1;
     }
     __syncthreads();
+    pg_matvec_cols(a.Wprompt, 128, C, dl, tmp, red);  // Wprompt^T dlogit
+    __syncthreads();
     for (int c = tid; c < C; c += 256) {              // dmu = Wprompt^T dlogit + Wdown^T dd
-        float acc = 0.f;
-        for (int p = 0; p < 128; ++p) acc += a.Wprompt[p * C + c] * dl[p];
+        float acc = tmp[c];
         for (int i = 0; i < r; ++i) acc += a.Wdown[i * C + c] * dd[i];
         a.dmu[win * C + c] = acc;
     }
@@ -417,7 +414,7 @@ extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
     MPHSIR_REQUIRE(a->KL >= a->C + 5 * a->r + 256 && a->KR >= 5 * a->r + 1 + a->C, "pg_gate_bwd: factor widths too small");
     PgBwdDev d{a->mu, a->dgate, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->dmu, a->L, a->R,
                a->nW, a->C, a->r, a->KL, a->KR};
-    const size_t shmem = (2 * (size_t)a->C + 256 + 448 + 1024) * sizeof(float);
+    const size_t shmem = (2 * (size_t)a->C + 256 + 448 + 1024 + 256 + (size_t)a->C) * sizeof(float);
     MPHSIR_LAUNCH(MPHSIR_K_PG_GATE_BWD, pg_gate_bwd_kernel, dim3(a->nW), dim3(256), shmem, reinterpret_cast<hipStream_t>(stream), d);
     return MPHSIR_OK;
 }

@@ -16,6 +16,7 @@
 // After (a) every step is wave-local (wave w owns query rows 16w..16w+15).
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
+#include "pg_gate_dev.h"
 
 namespace mphsir {
 
@@ -46,7 +47,7 @@ template <class T, int C, int HD> struct WinAttnCfg {
     static constexpr size_t F_WORDS = 225 + 64;                      // bias column of one head, region ids
     static constexpr size_t BYTES = T_ELEMS * sizeof(T) + F_WORDS * 4;
     static_assert(BYTES <= 160 * 1024, "window-attention tile does not fit LDS");
-    static_assert((C + 128 + 8 * 32) * 4 <= 2 * QS * sizeof(T), "PG scratch must fit in the q/k tiles");
+    static_assert((C + 128 + 8 * 32 + 256) * 4 <= 2 * QS * sizeof(T), "PG scratch must fit in the q/k tiles");
     static_assert(C % 32 == 0 && HD % 16 == 0 && C % HD == 0, "unsupported width");
 };
 
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
     float* mu = reinterpret_cast<float*>(Qs);     // [C]
     float* lg = mu + C;                           // [128] prompt logits -> weights
     float* sm = lg + 128;                         // small vectors, 32 floats apart
+    float* red = sm + 8 * 32;                     // [256] partial sums of pg_matvec_cols
     const int r = a.r;
     for (int c = tid; c < C; c += 256) {
         float acc = 0.f;
@@ -317,16 +319,13 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         lg[lane + 64] = e1 / tot;
     }
     __syncthreads();
-    if (tid < r) {                                // s = w^T P
-        float acc = 0.f;
-        for (int p = 0; p < 128; ++p) acc += lg[p] * a.Pp[p * r + tid];
-        sm[tid] = acc;
-    } else if (tid >= 64 && tid < 64 + 2 * r) {   // kv = Wkv d
+    if (tid >= 64 && tid < 64 + 2 * r) {          // kv = Wkv d
         const int i = tid - 64;
         float acc = 0.f;
         for (int j = 0; j < r; ++j) acc += a.Wkv[i * r + j] * sm[32 + j];
         sm[64 + i] = acc;                         // k at sm[64..64+r), v at sm[64+r..64+2r)
     }
+    pg_matvec_cols(a.Pp, 128, r, lg, sm, red);    // s = w^T P
     __syncthreads();
     if (tid < r) {                                // q = Wq s
         float acc = 0.f;

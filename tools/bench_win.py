@@ -1,0 +1,21 @@
+import sys, warnings
+sys.path.insert(0, '/root/repo')
+warnings.filterwarnings("ignore")
+import torch
+from mp_hsir_amd import ops
+from mp_hsir_amd.net.MP_HSIR import PGSSTB
+dev = torch.device("cuda"); dt = torch.bfloat16
+def t_us(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+for (B, H, C, heads, cr) in [(32, 64, 128, 2, 8), (32, 64, 64, 2, 8)]:
+    blk = PGSSTB(C, heads, [64, 64], 8, 4, 0.0, 2.66, cr, 128).to(dev)
+    pk = blk.packed(dt)
+    x = torch.randn(B, H, H, C, device=dev, dtype=dt)
+    for shift in (0, 4):
+        f = lambda: ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"], pk["bproj"], pk["pg"], heads, shift, save=True)
+        print("C=%d shift=%d win_attn_fwd %.1f us" % (C, shift, t_us(f)))
