@@ -34,4 +34,20 @@ __device__ __forceinline__ void pg_matvec_cols(const float* W, int np, int ncols
     }
 }
 
+// y[row] = sum_c W[row][c] * x[c]  for row < nrows (nrows <= 128); W row-major [nrows][C] in global memory.  The c axis
+// is split over 256/128 = 2 thread groups (each lane still walks its own row: no cross-lane reduction, which measured
+// slower than the serial loop it replaced), partials meet in LDS.  One __syncthreads(); y written by threads < nrows.
+__device__ __forceinline__ void pg_matvec_rows(const float* W, int nrows, int C, const float* x, float* y, float* red) {
+    const int tid = threadIdx.x, row = tid & 127, part = tid >> 7, half = C / 2;
+    float acc = 0.f;
+    if (row < nrows) {
+        const float* wr = W + (long)row * C + part * half;
+        const float* xr = x + part * half;
+        for (int c = 0; c < half; ++c) acc += wr[c] * xr[c];
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < nrows) y[tid] = red[tid] + red[tid + 128];
+}
+
 }  // namespace mphsir

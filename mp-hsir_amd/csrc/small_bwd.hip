@@ -239,16 +239,9 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
     for (int c = tid; c < C; c += 256) { mu[c] = a.mu[win * C + c]; dg[c] = a.dgate[win * C + c]; }
     __syncthreads();
     // ---- forward recompute -------------------------------------------------------------------------
-    if (tid < 128) {
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc += a.Wprompt[tid * C + c] * mu[c];
-        w[tid] = acc;
-    } else if (tid < 128 + r) {
-        const int i = tid - 128;
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc += a.Wdown[i * C + c] * mu[c];
-        d_[i] = acc;
-    }
+    pg_matvec_rows(a.Wprompt, 128, C, mu, w, red);
+    __syncthreads();
+    pg_matvec_rows(a.Wdown, r, C, mu, d_, red);
     __syncthreads();
     if (wv == 0) {
         const float l0 = w[lane], l1 = w[lane + 64];

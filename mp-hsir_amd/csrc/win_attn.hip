@@ -298,16 +298,9 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         if (a.mu) a.mu[(long)blockIdx.x * C + c] = mu[c];
     }
     __syncthreads();
-    if (tid < 128) {
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc += a.Wprompt[tid * C + c] * mu[c];
-        lg[tid] = acc;
-    } else if (tid < 128 + r) {                   // d = linear_down(mu)
-        const int i = tid - 128;
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc += a.Wdown[i * C + c] * mu[c];
-        sm[32 + i] = acc;
-    }
+    pg_matvec_rows(a.Wprompt, 128, C, mu, lg, red);      // prompt logits
+    __syncthreads();
+    pg_matvec_rows(a.Wdown, r, C, mu, sm + 32, red);     // d = linear_down(mu)
     __syncthreads();
     if (wv == 0) {                                // softmax over the 128 prompt logits
         const float l0 = lg[lane], l1 = lg[lane + 64];
