@@ -145,12 +145,31 @@ template <> __device__ __forceinline__ int tr_off<64>(int row, int ch) {        
     return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)));
 }
 
-// fragment (16 columns starting at col0, tokens kk..kk+31) of a swizzled [64][W] image
-template <int W> __device__ __forceinline__ bf16x8 tr_frag(const char* img, int col0, int kk) {
+// Fragment (16 columns starting at col0, tokens kk..kk+31) of a swizzled [64][W] image = two transposed reads (token
+// rows kk+8*(lane>>4)+q and +4).  With col0 a multiple of 16 and kk a multiple of 32 the swizzle term of tr_off depends
+// on the lane only, so the whole address is  lane_base + W*2*kk + ((2*col0) ^ lane_xor)  -- the lane parts are computed
+// once per kernel (TrLane), leaving one v_xor + one v_add per read instead of re-deriving the swizzle (the kernel was
+// issue-bound: 40 transposed reads per 32 MFMAs).
+struct TrLane {
+    int base[2];      // byte offset of the lane's row (+0 / +4 rows)
+    int lx[2];        // lane part of the chunk swizzle, incl. the 8-byte half
+};
+template <int W> __device__ __forceinline__ TrLane tr_lane() {
     const int l = lane_id(), g4 = l >> 4, q = (l & 15) >> 2, p = l & 3;
-    const int row = kk + 8 * g4 + q, ch = (col0 >> 3) + (p >> 1);
-    const bf16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(img + tr_off<W>(row, ch) + 8 * (p & 1)));
-    const bf16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(img + tr_off<W>(row + 4, ch) + 8 * (p & 1)));
+    TrLane t;
+    for (int hh = 0; hh < 2; ++hh) {
+        const int row = 8 * g4 + q + 4 * hh;
+        int sw;
+        if (W == 128) sw = ((row & 3) << 2) | ((row >> 2) & 3);
+        else sw = (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
+        t.base[hh] = W * 2 * row;
+        t.lx[hh] = (16 * ((p >> 1) ^ sw)) | (8 * (p & 1));
+    }
+    return t;
+}
+template <int W> __device__ __forceinline__ bf16x8 tr_frag(const char* img, const TrLane& t, int col0, int kk) {
+    const bf16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(img + t.base[0] + W * 2 * kk + ((2 * col0) ^ t.lx[0])));
+    const bf16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(img + t.base[1] + W * 2 * kk + ((2 * col0) ^ t.lx[1])));
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
@@ -210,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnDev a) {      // 2
             store16<T>(reinterpret_cast<T*>(dst), x[it]);
         }
     };
+    const TrLane tla = tr_lane<W1>(), tlb = tr_lane<W2>();
     gload(m_lo);
     int buf = 0;
     for (long m0 = m_lo; m0 < m_hi; m0 += KT, buf ^= 1) {
@@ -221,10 +241,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnDev a) {      // 2
         for (int kk = 0; kk < KT; kk += 32) {
             bf16x8 af[RW];
 #pragma unroll
-            for (int i = 0; i < RW; ++i) af[i] = tr_frag<W1>(stage, (wv * RW + i) * 16, kk);
+            for (int i = 0; i < RW; ++i) af[i] = tr_frag<W1>(stage, tla, (wv * RW + i) * 16, kk);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const bf16x8 bf = tr_frag<W2>(stage + IMG_A, nt * 16, kk);
+                const bf16x8 bf = tr_frag<W2>(stage + IMG_A, tlb, nt * 16, kk);
 #pragma unroll
                 for (int i = 0; i < RW; ++i) mma(acc[i][nt], af[i], bf);
             }
