@@ -137,11 +137,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
 // bank-conflict free), two LDS stages with ONE barrier per 64-token step, register-staged global loads in flight
 // during the MFMAs, and a (W1 x W2) in {64,128}^2 output tile per workgroup so the L1 fill rate (64 B/clk/CU) no
 // longer bounds the kernel: at 128x128 a step moves 32 KB for 2.1 MFLOP.
-template <int W> __device__ __forceinline__ int tr_off(int row, int ch);      // byte offset of 16-byte chunk ch of token row `row`
-template <> __device__ __forceinline__ int tr_off<128>(int row, int ch) {       // 256-byte rows (cdna_hip_programming.md T10, image (b))
+template <int W> __host__ __device__ constexpr int tr_off(int row, int ch);      // byte offset of 16-byte chunk ch of token row `row`
+template <> __host__ __device__ constexpr int tr_off<128>(int row, int ch) {       // 256-byte rows (cdna_hip_programming.md T10, image (b))
     return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
-template <> __device__ __forceinline__ int tr_off<64>(int row, int ch) {        // 128-byte rows: two rows per bank sweep
+template <> __host__ __device__ constexpr int tr_off<64>(int row, int ch) {        // 128-byte rows: two rows per bank sweep
     return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)));
 }
 
@@ -203,31 +203,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnDev a) {      // 2
     bf16x8 ones;
     for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
-    constexpr int CA = W1 / 8, CB = W2 / 8, ITEMS_A = KT * CA, ITEMS_B = KT * CB, NI = (ITEMS_A + ITEMS_B) / 256;
-    Vec16<T> x[NI];
-    auto gload = [&](long m0) {
+    // Staging: thread t moves 16-byte chunk (t % C*) of token rows t / C* + RS*·it of each operand.  Everything that
+    // depends on the thread only -- source pointer, swizzled LDS offset (the swizzle term is invariant under the row
+    // stride RS*), column guard -- is computed once; a step costs one pointer bump per operand.
+    constexpr int CA = W1 / 8, CB = W2 / 8, NIA = KT * CA / 256, NIB = KT * CB / 256, RSA = 256 / CA, RSB = 256 / CB;
+    const int rowA = tid / CA, chA = tid % CA, rowB = tid / CB, chB = tid % CB;
+    const bool okA = n1_0 + chA * 8 < a.N1, okB = n2_0 + chB * 8 < a.N2;
+    const T* pA = A + (m_lo + rowA) * a.lda + n1_0 + chA * 8;
+    const T* pB = B + (m_lo + rowB) * a.ldb + n2_0 + chB * 8;
+    const int ldsA = tr_off<W1>(rowA, chA), ldsB = IMG_A + tr_off<W2>(rowB, chB);
+    static_assert(tr_off<W1>(RSA, 0) == RSA * W1 * 2 && tr_off<W2>(RSB, 0) == RSB * W2 * 2, "row stride must not change the swizzle");
+    Vec16<T> xA[NIA], xB[NIB];
+    auto gload = [&](long m0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < NI; ++it) {
-            const int v = tid + 256 * it;
-            const bool isb = v >= ITEMS_A;                          // ITEMS_A is a multiple of 256: uniform per `it`
-            const int u = isb ? v - ITEMS_A : v, cpr = isb ? CB : CA;
-            const int row = u / cpr, ch = u % cpr;                  // chunk fastest: a wave reads whole 128/256-byte row pieces
-            const long m = m0 + row;
-            const int col = (isb ? n2_0 : n1_0) + ch * 8, nmax = isb ? a.N2 : a.N1;
-            if (m < m_hi && col < nmax) x[it] = load16<T>((isb ? B : A) + m * (isb ? a.ldb : a.lda) + col);
-            else x[it] = Vec16<T>{};
+        for (int it = 0; it < NIA; ++it) {
+            if (okA && m0 + rowA + RSA * it < m_hi) xA[it] = load16<T>(pA + (long)(RSA * it) * a.lda);
+            else xA[it] = Vec16<T>{};
         }
+#pragma unroll
+        for (int it = 0; it < NIB; ++it) {
+            if (okB && m0 + rowB + RSB * it < m_hi) xB[it] = load16<T>(pB + (long)(RSB * it) * a.ldb);
+            else xB[it] = Vec16<T>{};
+        }
+        pA += (long)KT * a.lda;
+        pB += (long)KT * a.ldb;
     };
-    auto sstore = [&](char* stage) {
+    auto sstore = [&](char* stage) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < NI; ++it) {
-            const int v = tid + 256 * it;
-            const bool isb = v >= ITEMS_A;
-            const int u = isb ? v - ITEMS_A : v, cpr = isb ? CB : CA;
-            const int row = u / cpr, ch = u % cpr;
-            char* dst = isb ? stage + IMG_A + tr_off<W2>(row, ch) : stage + tr_off<W1>(row, ch);
-            store16<T>(reinterpret_cast<T*>(dst), x[it]);
-        }
+        for (int it = 0; it < NIA; ++it) store16<T>(reinterpret_cast<T*>(stage + ldsA + RSA * it * W1 * 2), xA[it]);
+#pragma unroll
+        for (int it = 0; it < NIB; ++it) store16<T>(reinterpret_cast<T*>(stage + ldsB + RSB * it * W2 * 2), xB[it]);
     };
     const TrLane tla = tr_lane<W1>(), tlb = tr_lane<W2>();
     gload(m_lo);
