@@ -261,6 +261,15 @@ int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B, int32_t H
 int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
                    float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch,
                    int32_t tile128, int dtype, void* stream);
+/* Up to MPHSIR_TN_GROUP_MAX independent problems of the bf16 large-tile form in ONE launch (same outputs as n calls
+ * of mphsir_gemm_tn with batch = 1): the weight-gradient GEMMs of one backward function issued together.         */
+#define MPHSIR_TN_GROUP_MAX 8
+typedef struct mphsir_gemm_tn_problem {
+    const void* A; int64_t lda; const void* B; int64_t ldb;
+    float* Cpart; float* colsum_part;
+    int64_t M; int32_t N1, N2, nsplit, pad_;
+} mphsir_gemm_tn_problem;
+int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t n, int dtype, void* stream);
 
 /* ---- plain depthwise 3x3 (backward building blocks) ----------------------------------------------
  * mphsir_dwconv3x3: Y[p][c] = sum_taps X[p+tap][c] * w9[tap][c] (zero padding); flip=1 uses the spatially

@@ -83,6 +83,15 @@ class PgBwdArgs(ctypes.Structure):
                                          "dmu", "L", "R")] + [(n, c_int32) for n in ("nW", "C", "r", "KL", "KR")]
 
 
+class TnProblem(ctypes.Structure):
+    """mirror of struct mphsir_gemm_tn_problem"""
+    _fields_ = [("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64), ("Cpart", c_void_p), ("colsum_part", c_void_p),
+                ("M", c_int64), ("N1", c_int32), ("N2", c_int32), ("nsplit", c_int32), ("pad_", c_int32)]
+
+
+TN_GROUP_MAX = 8
+
+
 class ReduceSeg(ctypes.Structure):
     """mirror of struct mphsir_reduce_seg"""
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("n", c_int64), ("stride", c_int64), ("src_batch_stride", c_int64),
@@ -128,6 +137,7 @@ _SYMBOLS = {
     "mphsir_gated_mlp_bwd": (c_int, [ctypes.POINTER(MlpBwdArgs), c_int, c_void_p]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
     "mphsir_reduce_parts": (c_int, [ctypes.POINTER(ReduceSeg), c_int32, c_void_p]),
+    "mphsir_gemm_tn_group": (c_int, [ctypes.POINTER(TnProblem), c_int32, c_int, c_void_p]),
     "mphsir_pack_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }
 

@@ -174,16 +174,14 @@ template <int W> __device__ __forceinline__ bf16x8 tr_frag(const char* img, cons
 }
 
 template <int W1, int W2>
-__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnDev a) {      // 2 waves/SIMD = 2 workgroups/CU (2 x 64 KB LDS)
+__device__ __forceinline__ void tn_tr_body(const TnDev& a, char* smem, int L, int bz) {
     typedef bf16_t T;
     constexpr int KT = 64, RW = W1 / 64, NT = W2 / 16;
     constexpr int IMG_A = KT * W1 * 2, IMG_B = KT * W2 * 2, STAGE = IMG_A + IMG_B;
-    HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    char* smem = reinterpret_cast<char*>(smem_v);                  // [2 stages][A image | B image]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int t2n = (a.N2 + W2 - 1) / W2, ntiles = ((a.N1 + W1 - 1) / W1) * t2n;
-    const int L = blockIdx.x;                                       // XCD-aware map, as in gemm_tn_kernel
-    const int tile = (L >> 3) % ntiles, sp = (L & 7) + 8 * (L / (8 * ntiles)), bz = blockIdx.z;
+    // L: block index inside this problem; XCD-aware map, as in gemm_tn_kernel
+    const int tile = (L >> 3) % ntiles, sp = (L & 7) + 8 * (L / (8 * ntiles));
     if (sp >= a.nsplit) return;
     const int n1_0 = (tile / t2n) * W1, n2_0 = (tile % t2n) * W2;
     const long per = ((a.M + a.nsplit - 1) / a.nsplit + KT - 1) / KT * KT;
@@ -277,6 +275,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnDev a) {      // 2
 }
 
 template <int W1, int W2>
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnDev a) {      // 2 waves/SIMD = 2 workgroups/CU (2 x 64 KB LDS)
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    tn_tr_body<W1, W2>(a, reinterpret_cast<char*>(smem_v), blockIdx.x, blockIdx.z);      // [2 stages][A image | B image]
+}
+
+// Grouped form: up to MPHSIR_TN_GROUP_MAX independent token-reduction GEMMs in ONE launch (block ranges per problem).
+// The weight-gradient GEMMs of a backward function feed nothing but the final partial reduction, so they are all
+// issued together at its end: at the small pyramid levels (8k-32k tokens) each of them alone fills a fraction of the
+// chip for ~20 us; together they fill it once.
+struct TnGroupDev {
+    TnDev p[MPHSIR_TN_GROUP_MAX];
+    int blk0[MPHSIR_TN_GROUP_MAX + 1];
+    int n;
+};
+
+template <int W1, int W2>
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_group_kernel(TnGroupDev g) {
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    // constant indices only (a dynamically indexed by-value kernel argument is copied to scratch by every lane)
+    TnDev a = g.p[0];
+    int b0 = 0;
+#pragma unroll
+    for (int k = 1; k < MPHSIR_TN_GROUP_MAX; ++k)
+        if (k < g.n && (int)blockIdx.x >= g.blk0[k]) { a = g.p[k]; b0 = g.blk0[k]; }
+    tn_tr_body<W1, W2>(a, reinterpret_cast<char*>(smem_v), (int)blockIdx.x - b0, 0);
+}
+
+template <int W1, int W2>
+static int launch_tn_tr_group(const TnGroupDev& g, hipStream_t s) {
+    const size_t shmem = 2 * (size_t)(W1 + W2) * 64 * 2;
+    allow_big_lds(gemm_tn_tr_group_kernel<W1, W2>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_tr_group_kernel<W1, W2>), dim3(g.blk0[g.n]), dim3(256), shmem, s, g);
+    return MPHSIR_OK;
+}
+
+template <int W1, int W2>
 static int launch_tn_tr(const TnDev& d, int batch, hipStream_t s) {
     const int ntiles = ((d.N1 + W1 - 1) / W1) * ((d.N2 + W2 - 1) / W2);
     dim3 grid(ntiles * ((d.nsplit + 7) / 8 * 8), 1, batch);
@@ -319,4 +353,31 @@ extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride
     // bf16 "big": the transposed-read kernel; each operand's tile width follows its matrix width
     if (N1 > 64) return N2 > 64 ? launch_tn_tr<128, 128>(d, batch, s) : launch_tn_tr<128, 64>(d, batch, s);
     return N2 > 64 ? launch_tn_tr<64, 128>(d, batch, s) : launch_tn_tr<64, 64>(d, batch, s);
+}
+
+extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t n, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(probs && n > 0 && n <= MPHSIR_TN_GROUP_MAX, "gemm_tn_group: 1..%d problems per call", MPHSIR_TN_GROUP_MAX);
+    MPHSIR_REQUIRE(dtype == MPHSIR_BF16, "gemm_tn_group: bf16 only (the transposed-LDS-read kernel)");
+    TnGroupDev g;
+    g.n = n;
+    bool wide1 = false, wide2 = false;
+    for (int k = 0; k < n; ++k) { wide1 = wide1 || probs[k].N1 > 64; wide2 = wide2 || probs[k].N2 > 64; }
+    const int W1 = wide1 ? 128 : 64, W2 = wide2 ? 128 : 64;
+    int blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        const mphsir_gemm_tn_problem& q = probs[k];
+        MPHSIR_REQUIRE(q.A && q.B && q.Cpart && q.M > 0 && q.N1 > 0 && q.N2 > 0 && q.N1 % 8 == 0 && q.N2 % 8 == 0 && q.nsplit > 0 && q.nsplit < 65536,
+                       "gemm_tn_group: bad problem %d", k);
+        MPHSIR_REQUIRE(aligned16(q.A) && aligned16(q.B) && (q.lda * 2) % 16 == 0 && (q.ldb * 2) % 16 == 0, "gemm_tn_group: 16-byte alignment required");
+        g.p[k] = TnDev{q.A, (long)q.lda, 0, q.B, (long)q.ldb, 0, q.Cpart, q.colsum_part, (long)q.M, q.N1, q.N2, q.nsplit};
+        g.blk0[k] = blocks;
+        const int ntiles = ((q.N1 + W1 - 1) / W1) * ((q.N2 + W2 - 1) / W2);
+        blocks += ntiles * ((q.nsplit + 7) / 8 * 8);
+    }
+    g.blk0[n] = blocks;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (wide1) return wide2 ? launch_tn_tr_group<128, 128>(g, s) : launch_tn_tr_group<128, 64>(g, s);
+    return wide2 ? launch_tn_tr_group<64, 128>(g, s) : launch_tn_tr_group<64, 64>(g, s);
 }

@@ -98,7 +98,7 @@ class reduce_scope:
 
     def __enter__(self):
         global _SCOPE
-        self.prev, self.segs = _SCOPE, []
+        self.prev, self.segs, self.gemms = _SCOPE, [], []
         _SCOPE = self
         return self
 
@@ -106,9 +106,23 @@ class reduce_scope:
         global _SCOPE
         _SCOPE = self.prev
         if exc[0] is None:
-            _flush(self.segs)
-        self.segs = []
+            _flush_gemms(self.gemms)        # the deferred weight-gradient GEMMs, grouped ...
+            _flush(self.segs)               # ... then the ordered sums of everything they (and others) wrote
+        self.segs, self.gemms = [], []
         return False
+
+
+def _flush_gemms(gemms):
+    """gemms: deferred bf16 token-reduction GEMMs (dicts of mphsir_gemm_tn_problem fields + tensors kept alive)."""
+    lib = _lib.load()
+    for i in range(0, len(gemms), _lib.TN_GROUP_MAX):
+        chunk = gemms[i:i + _lib.TN_GROUP_MAX]
+        arr = (_lib.TnProblem * len(chunk))()
+        for k, g in enumerate(chunk):
+            q = arr[k]
+            q.A, q.lda, q.B, q.ldb, q.Cpart, q.colsum_part = g["A"], g["lda"], g["B"], g["ldb"], g["Cpart"], g["cs"]
+            q.M, q.N1, q.N2, q.nsplit = g["M"], g["N1"], g["N2"], g["nsplit"]
+        _lib.check(lib.mphsir_gemm_tn_group(arr, len(chunk), _DT[torch.bfloat16], _stream(chunk[0]["keep"][0])), "gemm_tn_group")
 
 
 def _flush(segs):
@@ -582,6 +596,7 @@ def ln_bwd_tok(x2, dxn, dres, ln_w, ln_b):
     return dx, g[0], g[1], xn
 
 
+TN_GROUPED = os.environ.get("MPHSIR_TN_GROUPED", "1") != "0"      # weight-gradient GEMMs of a backward function in one launch
 TN_BIG_TILES = True        # bf16 token-reduction GEMMs use the transposed-LDS-read kernel (ds_read_b64_tr_b16)
 TN_BIG_ROUNDS = float(os.environ.get("MPHSIR_TN_ROUNDS", "2.0"))        # ... and aim for this many full rounds of resident workgroups
 
@@ -609,10 +624,15 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, redu
             nsplit = max(1, min(M // 512, 64, max(1, 768 // tiles)))      # ~3 workgroups per CU (measured optimum)
     part = torch.empty((Bt, nsplit, N1, N2), dtype=torch.float32, device=a.device)
     cs = torch.empty((Bt, nsplit, N1), dtype=torch.float32, device=a.device) if colsum else None
-    _lib.check(lib.mphsir_gemm_tn(_p(a), a.stride(-2), a.stride(0) if batched else 0, _p(b), b.stride(-2),
-                                  b.stride(0) if batched else 0, _p(part), _p(cs), M, N1, N2, nsplit, Bt, int(bool(tile128)),
-                                  _DT[a.dtype], _stream(a)),
-               "gemm_tn")
+    if _SCOPE is not None and TN_GROUPED and not immediate and not batched and tile128 and a.dtype == torch.bfloat16:
+        # nothing but the partial reduction at the end of the scope reads the result: issue it there, grouped
+        _SCOPE.gemms.append(dict(A=a.data_ptr(), lda=a.stride(-2), B=b.data_ptr(), ldb=b.stride(-2), Cpart=part.data_ptr(),
+                                 cs=cs.data_ptr() if colsum else None, M=M, N1=N1, N2=N2, nsplit=nsplit, keep=(a, b, part, cs)))
+    else:
+        _lib.check(lib.mphsir_gemm_tn(_p(a), a.stride(-2), a.stride(0) if batched else 0, _p(b), b.stride(-2),
+                                      b.stride(0) if batched else 0, _p(part), _p(cs), M, N1, N2, nsplit, Bt, int(bool(tile128)),
+                                      _DT[a.dtype], _stream(a)),
+                   "gemm_tn")
     _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size() + part.numel() * 4.0)
     if not reduce:
         return (part, cs) if colsum else part
