@@ -235,8 +235,9 @@ typedef struct mphsir_pg_bwd_args {
     const float* mu; const float* dgate;
     const float* Wprompt; const float* prompt_param; const float* Wq; const float* Wkv; const float* Wdown;
     const float* Wpproj; const float* bpproj; const float* Wup;
-    float* dmu; float* L; float* R;
+    float* dmu; void* L; void* R;     /* L, R: fp32, or bf16 when lr_bf16 != 0 (then KL, KR multiples of 8) */
     int32_t nW, C, r, KL, KR;
+    int32_t lr_bf16;
 } mphsir_pg_bwd_args;
 int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream);
 

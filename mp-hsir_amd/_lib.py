@@ -80,7 +80,7 @@ class FoldBwdArgs(ctypes.Structure):
 class PgBwdArgs(ctypes.Structure):
     """mirror of struct mphsir_pg_bwd_args"""
     _fields_ = [(n, c_void_p) for n in ("mu", "dgate", "Wprompt", "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup",
-                                         "dmu", "L", "R")] + [(n, c_int32) for n in ("nW", "C", "r", "KL", "KR")]
+                                         "dmu", "L", "R")] + [(n, c_int32) for n in ("nW", "C", "r", "KL", "KR", "lr_bf16")]
 
 
 class TnProblem(ctypes.Structure):

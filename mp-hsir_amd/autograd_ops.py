@@ -192,7 +192,7 @@ class _PgsstbAttn(torch.autograd.Function):
             d_sa = d_sa.reshape(M, Cc).addmm_(dt3, sp["wqkv"])                       # + dt Wqkv  (1x1 conv backward)
             d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
             # (3) local spectral-prompt gate: one launch per block + one token-reduction GEMM over the windows
-            dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"])
+            dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=dt)
             dpg = tuple(gpg[k].reshape(getattr_path(blk.local_spectral_attn, k).shape) for k in _PG_KEYS)
             # (4) window attention core
             dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],

@@ -218,8 +218,8 @@ struct PgBwdDev {
     const float* Wprompt; const float* Pp; const float* Wq; const float* Wkv; const float* Wdown;
     const float* Wpproj; const float* bpproj; const float* Wup;
     float* dmu;                 // [nW][C]
-    float* L; float* R;         // [nW][KL], [nW][KR]
-    int nW, C, r, KL, KR;
+    void* L; void* R;           // [nW][KL], [nW][KR]: fp32, or bf16 (lr_bf16) so that their product joins the grouped bf16 GEMM launch
+    int nW, C, r, KL, KR, lr_bf16;
 };
 
 __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
@@ -346,8 +346,10 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
     }
     // ---- factor rows: L = [dg(C) | do2(r) | dkv(2r) | dq(r) | w(128) | dlogit(128) | dd(r) | 0..],
     //                   R = [o2(r) | o(r) | 1 | d(r) | s(r) | ds(r) | mu(C) | 0..]
-    float* L = a.L + win * a.KL;
-    float* R = a.R + win * a.KR;
+    float* L = reinterpret_cast<float*>(a.L) + win * a.KL;
+    float* R = reinterpret_cast<float*>(a.R) + win * a.KR;
+    bf16_t* Lh = reinterpret_cast<bf16_t*>(a.L) + win * a.KL;
+    bf16_t* Rh = reinterpret_cast<bf16_t*>(a.R) + win * a.KR;
     for (int c = tid; c < a.KL; c += 256) {
         float v = 0.f;
         int o = c;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
         else if ((o -= r) < 128) v = w[o];
         else if ((o -= 128) < 128) v = dl[o];
         else if ((o -= 128) < r) v = dd[o];
-        L[c] = v;
+        if (a.lr_bf16) Lh[c] = (bf16_t)v; else L[c] = v;
     }
     for (int c = tid; c < a.KR; c += 256) {
         float v = 0.f;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
         else if ((o -= r) < r) v = s_[o];
         else if ((o -= r) < r) v = ds[o];
         else if ((o -= r) < C) v = mu[o];
-        R[c] = v;
+        if (a.lr_bf16) Rh[c] = (bf16_t)v; else R[c] = v;
     }
 }
 
@@ -406,7 +408,8 @@ extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
     MPHSIR_REQUIRE(a->nW > 0 && a->C > 0 && a->r > 0 && a->r <= 32, "pg_gate_bwd: bad shape");
     MPHSIR_REQUIRE(a->KL >= a->C + 5 * a->r + 256 && a->KR >= 5 * a->r + 1 + a->C, "pg_gate_bwd: factor widths too small");
     PgBwdDev d{a->mu, a->dgate, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->dmu, a->L, a->R,
-               a->nW, a->C, a->r, a->KL, a->KR};
+               a->nW, a->C, a->r, a->KL, a->KR, a->lr_bf16};
+    MPHSIR_REQUIRE(!a->lr_bf16 || (a->KL % 8 == 0 && a->KR % 8 == 0), "pg_gate_bwd: bf16 factor rows need KL, KR multiples of 8");
     const size_t shmem = (2 * (size_t)a->C + 256 + 448 + 1024 + 256 + (size_t)a->C) * sizeof(float);
     MPHSIR_LAUNCH(MPHSIR_K_PG_GATE_BWD, pg_gate_bwd_kernel, dim3(a->nW), dim3(256), shmem, reinterpret_cast<hipStream_t>(stream), d);
     return MPHSIR_OK;

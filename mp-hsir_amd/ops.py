@@ -698,24 +698,25 @@ def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True):
     return W2, reduce_parts(dWo), reduce_parts(dtemp)
 
 
-def pg_gate_bwd(mu, dgate, pg):
+def pg_gate_bwd(mu, dgate, pg, factor_dtype=torch.float32):
     """mu, dgate (nW,C) fp32; pg = fp32 parameter dict (as for win_attn_fwd) -> dmu (nW,C) and the dict of
     parameter gradients of the local spectral-prompt branch."""
     lib = _lib.load()
     _check(mu, dgate, *pg.values())
     nW, C = mu.shape
     r = pg["linear_down.weight"].shape[0]
-    KL, KR = round_up(C + 5 * r + 256, 4), round_up(5 * r + 1 + C, 4)
+    KL, KR = round_up(C + 5 * r + 256, 8), round_up(5 * r + 1 + C, 8)
     dmu = torch.empty_like(mu)
-    L = torch.empty((nW, KL), dtype=torch.float32, device=mu.device)
-    R = torch.empty((nW, KR), dtype=torch.float32, device=mu.device)
+    # factor rows in the compute dtype: their product then rides in the grouped bf16 GEMM launch of the backward
+    L = torch.empty((nW, KL), dtype=factor_dtype, device=mu.device)
+    R = torch.empty((nW, KR), dtype=factor_dtype, device=mu.device)
     a = _lib.PgBwdArgs()
     a.mu, a.dgate = _p(mu), _p(dgate)
     a.Wprompt, a.prompt_param = _p(pg["linear_prompt.weight"]), _p(pg["prompt_param"])
     a.Wq, a.Wkv, a.Wdown = _p(pg["q.weight"]), _p(pg["kv.weight"]), _p(pg["linear_down.weight"])
     a.Wpproj, a.bpproj, a.Wup = _p(pg["proj.weight"]), _p(pg["proj.bias"]), _p(pg["linear_up.weight"])
     a.dmu, a.L, a.R = _p(dmu), _p(L), _p(R)
-    a.nW, a.C, a.r, a.KL, a.KR = nW, C, r, KL, KR
+    a.nW, a.C, a.r, a.KL, a.KR, a.lr_bf16 = nW, C, r, KL, KR, int(factor_dtype == torch.bfloat16)
     _lib.check(lib.mphsir_pg_gate_bwd(ctypes.byref(a), _stream(mu)), "pg_gate_bwd")
     _acct("pg_gate_bwd", 4.0 * nW * C * (128 + 2 * r), 4.0 * nW * (2 * C + KL + KR))
     part = gemm_tn(L, R, reduce=False)[0]                      # (nsplit, KL, KR): every parameter gradient is a sub-block
