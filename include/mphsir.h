@@ -183,6 +183,8 @@ typedef struct mphsir_mlp_bwd_args {
     void* dX; void* XN; void* H; void* DPRE; float* part;
     int64_t M; int32_t C, HP;
     int32_t variant;                  /* 0 = library's choice; 1..3 pin a kernel form (tests / tuning), see gated_mlp_bwd.hip */
+    const float* keep;                /* optional DropPath factors [M / rows_per_batch]: DM is then an OUTPUT, written */
+    int64_t rows_per_batch;           /* here as keep[b] * dY (rounded to the compute dtype) instead of by the caller   */
 } mphsir_mlp_bwd_args;
 int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream);
 

@@ -62,7 +62,7 @@ class GateArgs(ctypes.Structure):
 class MlpBwdArgs(ctypes.Structure):
     """mirror of struct mphsir_mlp_bwd_args"""
     _fields_ = [(n, c_void_p) for n in ("X", "dY", "DM", "ln_w", "ln_b", "W1", "b1", "W1T", "W2T", "dX", "XN", "H", "DPRE", "part")] + \
-               [("M", c_int64), ("C", c_int32), ("HP", c_int32), ("variant", c_int32)]
+               [("M", c_int64), ("C", c_int32), ("HP", c_int32), ("variant", c_int32), ("keep", c_void_p), ("rows_per_batch", c_int64)]
 
 
 class WinAttnBwdArgs(ctypes.Structure):

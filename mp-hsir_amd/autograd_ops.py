@@ -79,9 +79,13 @@ class _GatedMlp(torch.autograd.Function):
         dt = y.dtype
         pk = blk.packed(dt)
         dz2 = dz.reshape(-1, Cc).contiguous()
-        dm = dz2 if k2 is None else (dz.float() * k2.reshape(B, 1, 1, 1)).to(dt).reshape(-1, Cc)
-        dx, xn, h, dpre, part = ops.gated_mlp_bwd(y.reshape(-1, Cc), dz2, dm, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"],
-                                                  pk["W1T"], pk["W2T"])
+        if k2 is None:
+            dm = dz2
+            dx, xn, h, dpre, part = ops.gated_mlp_bwd(y.reshape(-1, Cc), dz2, dm, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"],
+                                                      pk["W1T"], pk["W2T"])
+        else:               # DropPath: dm = keep[b] * dz is formed (and kept for dW2 / db2) inside the kernel
+            dx, xn, h, dpre, part, dm = ops.gated_mlp_bwd(y.reshape(-1, Cc), dz2, None, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"],
+                                                          pk["W1T"], pk["W2T"], keep=k2, rows_per_batch=H * W)
         hid = blk.mlp.fc2.weight.shape[1]
         HP = h.shape[1]
         with ops.reduce_scope():                                   # one ordered-sum launch for all five partial buffers

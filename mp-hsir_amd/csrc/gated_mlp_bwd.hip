@@ -26,6 +26,7 @@ struct MlpBwdDev {
     void* XN; void* H; void* DPRE;                   // [M][C], [M][HP], [M][2*HP]
     float* part;                                     // [M/64][2][C]: d(ln weight), d(ln bias) partial sums
     int M, HP;
+    const float* keep; long rpb;                     // optional: DM is written here as keep[row / rpb] * dY
 };
 
 // STAGE = true: the fc1 rows of the hidden chunk ([64][C]) and the matching columns of W1^T ([C][64]) are loaded
@@ -87,7 +88,16 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
             for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
             store16<T>(Xs + r * LDX + c0, o);
             store16<T>(XN + c0, o);
-            store16<T>(Ds + r * LDX + c0, load16<T>(DM + (long)(m0 + r) * C + c0));
+            Vec16<T> dmv;
+            if (a.keep) {                             // DropPath backward fused: dm = keep[b] * dy, also kept for dW2 / db2
+                const float kf = a.keep[(m0 + r) / a.rpb];
+                const Vec16<T> dyv = load16<T>(dY + (long)(m0 + r) * C + c0);
+                for (int e = 0; e < VEC; ++e) dmv.set(e, kf * dyv.get(e));
+                store16<T>(const_cast<T*>(DM) + (long)(m0 + r) * C + c0, dmv);
+            } else {
+                dmv = load16<T>(DM + (long)(m0 + r) * C + c0);
+            }
+            store16<T>(Ds + r * LDX + c0, dmv);
         }
     }
     __syncthreads();
@@ -321,7 +331,16 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
             for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
             store16<T>(Xs + r * LDX + c0, o);
             store16<T>(XN + c0, o);
-            store16<T>(Ds + r * LDX + c0, load16<T>(DM + (m0 + r) * C + c0));
+            Vec16<T> dmv;
+            if (a.keep) {                             // DropPath backward fused: dm = keep[b] * dy, also kept for dW2 / db2
+                const float kf = a.keep[(m0 + r) / a.rpb];
+                const Vec16<T> dyv = load16<T>(dY + (m0 + r) * C + c0);
+                for (int e = 0; e < VEC; ++e) dmv.set(e, kf * dyv.get(e));
+                store16<T>(const_cast<T*>(DM) + (m0 + r) * C + c0, dmv);
+            } else {
+                dmv = load16<T>(DM + (m0 + r) * C + c0);
+            }
+            store16<T>(Ds + r * LDX + c0, dmv);
         }
     }
     __syncthreads();
@@ -601,7 +620,8 @@ extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, voi
                        aligned16(a->DPRE) && aligned16(a->W1) && aligned16(a->W1T) && aligned16(a->W2T), "gated_mlp_bwd: 16-byte alignment required");
     if (dtype == MPHSIR_F32) MPHSIR_REQUIRE(a->C <= 256, "gated_mlp_bwd: fp32 supports C <= 256 (LDS budget)");
     MlpBwdDev d{a->X, a->dY, a->DM, a->ln_w, a->ln_b, a->W1, a->b1, a->W1T, a->W2T, a->dX, a->XN, a->H, a->DPRE, a->part,
-                (int)a->M, a->HP};
+                (int)a->M, a->HP, a->keep, (long)a->rows_per_batch};
+    MPHSIR_REQUIRE(!a->keep || (a->rows_per_batch > 0 && a->M % a->rows_per_batch == 0), "gated_mlp_bwd: keep needs rows_per_batch dividing M");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     MPHSIR_REQUIRE(a->variant >= 0 && a->variant <= 3, "gated_mlp_bwd: variant must be 0..3");
     return dtype == MPHSIR_F32 ? dispatch_mlp_bwd<float>(d, a->C, a->variant, s) : dispatch_mlp_bwd<bf16_t>(d, a->C, a->variant, s);

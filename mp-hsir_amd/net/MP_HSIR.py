@@ -178,6 +178,9 @@ class PGSSTB(nn.Module):                                                        
         residual branches (ref :718-719); None in eval mode or when the rate is 0."""
         if not self.training or self.drop_prob == 0.0:
             return None, None
+        pre = self.__dict__.pop("_dp_factors", None)      # drawn for all blocks at once by MP_HSIR_Net.forward
+        if pre is not None and pre.shape[1] == B and pre.device == torch.device(device):
+            return pre[0], pre[1]
         keep = 1.0 - self.drop_prob
         m = torch.empty((2, B), dtype=torch.float32, device=device).bernoulli_(keep) / keep
         return m[0].contiguous(), m[1].contiguous()
@@ -425,8 +428,23 @@ class MP_HSIR_Net(nn.Module):                                                   
             return torch.bfloat16     # the reference trains with fp16 autocast (train.py:118); bf16 here
         return torch.float32
 
+    def _draw_drop_path(self, B, device):
+        """timm DropPath factors (Bernoulli(keep)/keep per sample, independent per residual branch) of ALL blocks in two
+        launches instead of two per block; each block picks its rows up in drop_path_factors."""
+        blks = [m for m in self.modules() if isinstance(m, PGSSTB) and m.drop_prob > 0.0]
+        if not self.training or not blks:
+            return
+        cache = self.__dict__.get("_dp_keep")
+        if cache is None or cache.device != torch.device(device) or cache.shape[0] != len(blks):
+            cache = self.__dict__["_dp_keep"] = torch.tensor([1.0 - m.drop_prob for m in blks], dtype=torch.float32, device=device)
+        keep = cache.reshape(-1, 1, 1).expand(len(blks), 2, B)
+        f = torch.bernoulli(keep) / keep
+        for i, m in enumerate(blks):
+            m.__dict__["_dp_factors"] = f[i]
+
     def forward(self, inp_img, task_id=None):
         dt = self._dtype()
+        self._draw_drop_path(inp_img.shape[0], inp_img.device)
         clip, w = self.text_prompt(inp_img, task_id)
         x_in = inp_img.to(dt).permute(0, 2, 3, 1).contiguous()                     # channels-last from here on
         e1 = self.encoder_level1(AG.conv3x3(x_in, self.patch_embed.proj))

@@ -504,13 +504,14 @@ def dwconv3x3_wgrad(x, dy, nblk=None, col_ranges=None):
     return out
 
 
-def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0):
-    """-> dx, xn, h, dpre, part (see include/mphsir.h).  x, dy, dm: contiguous (M,C)."""
+def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None, rows_per_batch=0):
+    """-> dx, xn, h, dpre, part (see include/mphsir.h).  x, dy, dm: contiguous (M,C).  With keep (DropPath factors, one
+    per rows_per_batch rows) dm is ignored as input: the kernel computes keep*dy itself and it is returned as a 6th value."""
     lib = _lib.load()
     _check(x, dy, dm, W1, W1T, W2T)
     M, C = x.shape
     HP = W2T.shape[0]
-    assert x.is_contiguous() and dy.is_contiguous() and dm.is_contiguous() and W1T.shape == (C, 2 * HP) and W2T.shape == (HP, C)
+    assert x.is_contiguous() and dy.is_contiguous() and (dm is None or dm.is_contiguous()) and W1T.shape == (C, 2 * HP) and W2T.shape == (HP, C)
     dev, dt = x.device, x.dtype
     dx = torch.empty_like(x)
     xn = torch.empty_like(x)
@@ -518,12 +519,19 @@ def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0):
     dpre = torch.empty((M, 2 * HP), dtype=dt, device=dev)
     part = torch.empty((M // 64, 2, C), dtype=torch.float32, device=dev)
     a = _lib.MlpBwdArgs()
+    if keep is not None:
+        _check(keep)
+        assert keep.dtype == torch.float32 and keep.is_contiguous() and rows_per_batch > 0
+        dm = torch.empty_like(dy)
+        a.keep, a.rows_per_batch = _p(keep), rows_per_batch
     a.X, a.dY, a.DM, a.ln_w, a.ln_b = _p(x), _p(dy), _p(dm), _p(ln_w), _p(ln_b)
     a.W1, a.b1, a.W1T, a.W2T = _p(W1), _p(b1), _p(W1T), _p(W2T)
     a.dX, a.XN, a.H, a.DPRE, a.part = _p(dx), _p(xn), _p(h), _p(dpre), _p(part)
     a.M, a.C, a.HP, a.variant = M, C, HP, variant
     _lib.check(lib.mphsir_gated_mlp_bwd(ctypes.byref(a), _DT[dt], _stream(x)), "gated_mlp_bwd")
     _acct("gated_mlp_bwd", 12.0 * M * C * HP, (3.0 * M * C + 3.0 * M * HP + M * C) * x.element_size())
+    if keep is not None:
+        return dx, xn, h, dpre, part, dm
     return dx, xn, h, dpre, part
 
 

@@ -211,6 +211,9 @@ def check_gated_mlp_bwd(dev, dtype, C, hid, variant=0):
     HP = W2.shape[1]
     dm = (dy.float() * keep.repeat_interleave(64)[:, None]).to(dtype)
     dx, xn, h, dpre, part = ops.gated_mlp_bwd(x, dy, dm, lnw, lnb, W1, b1, W1.t().contiguous(), W2.t().contiguous(), variant=variant)
+    # DropPath scaling fused into the kernel: same results, dm produced by the kernel
+    r2 = ops.gated_mlp_bwd(x, dy, None, lnw, lnb, W1, b1, W1.t().contiguous(), W2.t().contiguous(), variant=variant, keep=keep, rows_per_batch=64)
+    assert torch.equal(r2[5].cpu(), dm.cpu()) and torch.equal(r2[0].cpu(), dx.cpu()) and torch.equal(r2[3].cpu(), dpre.cpu())
     dW2 = (dm.float().t() @ h.float())[:, :hid]
     dW1p = dpre.float().t() @ xn.float()
     dW1 = torch.cat([dW1p[:hid], dW1p[HP:HP + hid]], 0)
