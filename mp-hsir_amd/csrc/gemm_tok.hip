@@ -46,17 +46,26 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
     const T* W = reinterpret_cast<const T*>(a.W) + (a.wbs ? (long)(m0 / a.rpb) * a.wbs : 0);
     const int K = a.K;
 
-    if (LN) {   // per-row mean / rstd over K (two passes over the row; second pass hits L1/L2)
-        for (int r = wv * 16; r < wv * 16 + 16; ++r) {
-            const T* row = X + (long)(m0 + r) * a.ldx;
-            float s = 0.f;
-            for (int k = lane; k < K; k += 64) s += to_f32(row[k]);
-            const float mean = wave_sum(s) / (float)K;
-            float q = 0.f;
-            for (int k = lane; k < K; k += 64) { float d = to_f32(row[k]) - mean; q += d * d; }
-            const float var = wave_sum(q) / (float)K;
-            if (lane == 0) { stat[r] = mean; stat[64 + r] = rsqrtf(var + 1e-5f); }
+    if (LN) {   // per-row mean / rstd over K: 4 adjacent lanes per token row, 16-byte loads, two passes (second hits L1)
+        constexpr int VECL = Vec16<T>::N;
+        const int r = tid >> 2, q = tid & 3, nv = K / VECL;
+        const T* row = X + (long)(m0 + r) * a.ldx;
+        float s = 0.f;
+        for (int i = q; i < nv; i += 4) {
+            const Vec16<T> v = load16<T>(row + i * VECL);
+            for (int e = 0; e < VECL; ++e) s += v.get(e);
         }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)K;
+        float d2 = 0.f;
+        for (int i = q; i < nv; i += 4) {
+            const Vec16<T> v = load16<T>(row + i * VECL);
+            for (int e = 0; e < VECL; ++e) { const float d = v.get(e) - mean; d2 += d * d; }
+        }
+        d2 += __shfl_xor(d2, 1);
+        d2 += __shfl_xor(d2, 2);
+        if (q == 0) { stat[r] = mean; stat[64 + r] = rsqrtf(d2 / (float)K + 1e-5f); }
         __syncthreads();
     }
 
