@@ -32,11 +32,11 @@ struct FoldBwdDev {
 // run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32; the first one gathers its K-strided fragments with scalar
 // LDS reads, no transposed copy); the softmax forward / backward rows are shared by 4 lanes each.  Everything is
 // fp32 and every sum has a fixed order: bitwise reproducible.
-constexpr int FB_CO_MAX = 64;
-__host__ __device__ constexpr int fb_co(int hd) { return hd > 64 ? 32 : 64; }     // LDS budget at head_dim 96
+constexpr int FB_THREADS = 512, FB_WAVES = FB_THREADS / 64;   // only B*heads (64..256) workgroups exist: make each one wide
+__host__ __device__ constexpr int fb_co(int hd) { return hd > 64 ? 32 : 128; }     // rows per chunk = 16 per wave (LDS budget at head_dim 96)
 
 template <class T>
-__global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
+__global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     const int HD = a.HD, C = a.C, HEADS = C / HD, LD = HD + 8, NT = HD / 16, FB_CO = fb_co(HD);
     float* G = reinterpret_cast<float*>(smem_v);      // raw Gram                  [HD][LD]
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
     const float temp = a.temperature[h];
 
-    for (int i = tid; i < HD * HD; i += 256) {        // ordered sum over the splits (1 when the forward saved the sums)
+    for (int i = tid; i < HD * HD; i += FB_THREADS) {        // ordered sum over the splits (1 when the forward saved the sums)
         const float* gp = a.Gpart + ((long)b * a.nsplit * HEADS + h) * HD * HD + i;
         const long gstride = (long)HEADS * HD * HD;
         float s = 0.f;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     const float* rq = rn;
     const float* rk = rn + HD;
     const int qd = tid & 3;                           // 4 adjacent lanes per row (rows >= HD idle but take part in the shuffles)
-    for (int row = tid >> 2; row < (HD + 63) / 64 * 64; row += 64) {      // A = softmax_rows(G / (nq nk^T) * temp)
+    for (int row = tid >> 2; row < (HD + FB_THREADS / 4 - 1) / (FB_THREADS / 4) * (FB_THREADS / 4); row += FB_THREADS / 4) {      // A = softmax_rows(G / (nq nk^T) * temp)
         const bool on = row < HD;
         const float tq = on ? temp * rq[row] : 0.f;
         float m = -3.0e38f;
@@ -96,14 +96,14 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     }
     const float* dM = a.dM + (long)b * C * C;
     float* dWo = a.dWo + (long)b * C * C;
-    constexpr int NS = 9;                             // dA tiles per wave: t = wv + 4*s < NT*NT <= 36 (head_dim <= 96)
+    constexpr int NS = (36 + FB_WAVES - 1) / FB_WAVES;   // dA tiles per wave: t = wv + FB_WAVES*s < NT*NT <= 36 (head_dim <= 96)
     f32x4 accA[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) accA[s] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int lr = lane & 15, lk = 4 * (lane >> 4);
     for (int c0 = 0; c0 < C; c0 += FB_CO) {
         __syncthreads();                              // previous chunk consumed (first time: A complete)
-        for (int idx = tid; idx < FB_CO * HD; idx += 256) {
+        for (int idx = tid; idx < FB_CO * HD; idx += FB_THREADS) {
             const int rr = idx / HD, cc = idx % HD;
             const bool in = c0 + rr < C;
             Ws[rr * LD + cc] = in ? a.Wo[(long)(c0 + rr) * C + h * HD + cc] : 0.f;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int t = wv + 4 * s;
+            const int t = wv + FB_WAVES * s;
             if (t < NT * NT) {                        // wave-uniform
                 const int ti = t / NT, tj = t % NT;
                 for (int k0 = 0; k0 < FB_CO; k0 += 16) {
@@ -139,14 +139,14 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int t = wv + 4 * s;
+        const int t = wv + FB_WAVES * s;
         if (t < NT * NT) {
             const int ti = t / NT, tj = t % NT;
             for (int r = 0; r < 4; ++r) D[(ti * 16 + (lane >> 4) * 4 + r) * LD + tj * 16 + lr] = accA[s][r];
         }
     }
     __syncthreads();
-    for (int row = tid >> 2; row < (HD + 63) / 64 * 64; row += 64) {      // softmax backward per row; logits = Gtilde * temp
+    for (int row = tid >> 2; row < (HD + FB_THREADS / 4 - 1) / (FB_THREADS / 4) * (FB_THREADS / 4); row += FB_THREADS / 4) {      // softmax backward per row; logits = Gtilde * temp
         const bool on = row < HD;
         float rs = 0.f;
         if (on) for (int j = qd; j < HD; j += 4) rs += A[row * LD + j] * D[row * LD + j];
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
         if (on && qd == 0) { red[row] = dt; dn[row] = dnq; }
     }
     __syncthreads();
-    for (int row = tid >> 2; row < (HD + 63) / 64 * 64; row += 64) {      // d nk[j] = -sum_i dGtilde[i][j] * Gtilde[i][j] / nk[j]
+    for (int row = tid >> 2; row < (HD + FB_THREADS / 4 - 1) / (FB_THREADS / 4) * (FB_THREADS / 4); row += FB_THREADS / 4) {      // d nk[j] = -sum_i dGtilde[i][j] * Gtilde[i][j] / nk[j]
         const bool on = row < HD;                     // "row" = column j here
         float s = 0.f;
         if (on) for (int i = qd; i < HD; i += 4) s -= D[i * LD + row] * G[i * LD + row] * rq[i] * rk[row] * rk[row];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
         if (lane == 0) a.dtemp[b * HEADS + h] = v;
     }
     __syncthreads();
-    for (int o = tid; o < HD * HD; o += 256) {        // dG[i][j] = dGtilde[i][j] / (nq[i] nk[j])
+    for (int o = tid; o < HD * HD; o += FB_THREADS) {        // dG[i][j] = dGtilde[i][j] / (nq[i] nk[j])
         const int i = o / HD, j = o % HD;
         D[i * LD + j] *= rq[i] * rk[j];
     }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     // W2_b rows of this head: q rows hHD+i and k rows C+hHD+j, all 2C columns
     T* W2 = reinterpret_cast<T*>(a.W2) + (long)b * 4 * C * C;
     const int C2 = 2 * C;
-    for (int o = tid; o < HD * C2; o += 256) {
+    for (int o = tid; o < HD * C2; o += FB_THREADS) {
         const int i = o / C2, col = o % C2;           // q-gradient row
         float v = 0.f;
         if (col < C) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void spectral_fold_bwd_kernel(FoldBwdDev a) {
         }
         W2[(long)(h * HD + i) * C2 + col] = from_f32<T>(v);
     }
-    for (int o = tid; o < HD * C2; o += 256) {
+    for (int o = tid; o < HD * C2; o += FB_THREADS) {
         const int j = o / C2, col = o % C2;           // k-gradient row
         float v = 0.f;
         if (col < C) {
@@ -392,10 +392,10 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32) {
         allow_big_lds(spectral_fold_bwd_kernel<float>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<float>), dim3(a->B * a->heads), dim3(256), shmem, s, d);
+        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<float>), dim3(a->B * a->heads), dim3(FB_THREADS), shmem, s, d);
     } else {
         allow_big_lds(spectral_fold_bwd_kernel<bf16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<bf16_t>), dim3(a->B * a->heads), dim3(256), shmem, s, d);
+        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<bf16_t>), dim3(a->B * a->heads), dim3(FB_THREADS), shmem, s, d);
     }
     return MPHSIR_OK;
 }
