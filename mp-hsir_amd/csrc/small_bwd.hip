@@ -32,7 +32,7 @@ struct FoldBwdDev {
 // run on the fp32 matrix cores (v_mfma_f32_16x16x4_f32; the first one gathers its K-strided fragments with scalar
 // LDS reads, no transposed copy); the softmax forward / backward rows are shared by 4 lanes each.  Everything is
 // fp32 and every sum has a fixed order: bitwise reproducible.
-constexpr int FB_THREADS = 512, FB_WAVES = FB_THREADS / 64;   // only B*heads (64..256) workgroups exist: make each one wide
+constexpr int FB_THREADS = 1024, FB_WAVES = FB_THREADS / 64;   // only B*heads (64..256) workgroups exist: make each one wide
 __host__ __device__ constexpr int fb_co(int hd) { return hd > 64 ? 32 : 128; }     // rows per chunk = 16 per wave (LDS budget at head_dim 96)
 
 template <class T>
