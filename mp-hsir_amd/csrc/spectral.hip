@@ -289,10 +289,10 @@ struct FoldDev {
 
 // grid = (B*HEADS, C/FOLD_CO): every workgroup redoes the (tiny) reduction + softmax of its head and
 // folds FOLD_CO output rows of project_out, whose head slice is staged through LDS.
-constexpr int FOLD_CO = 32;
+constexpr int FOLD_CO = 32, FOLD_THREADS = 1024;      // few workgroups (B*heads*C/32): make each one wide
 
 template <class T>
-__global__ __launch_bounds__(256) void spectral_fold_kernel(FoldDev a) {
+__global__ __launch_bounds__(FOLD_THREADS) void spectral_fold_kernel(FoldDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     const int HD = a.HD, C = a.C, HEADS = C / HD;
     float* G = reinterpret_cast<float*>(smem_v);      // [HD][HD+1] -> attention probabilities
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void spectral_fold_kernel(FoldDev a) {
     float* Ws = nk + HD;                              // [FOLD_CO][HD+1] project_out rows of this workgroup
     const int tid = threadIdx.x, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS, co0 = blockIdx.y * FOLD_CO;
 
-    for (int i = tid; i < HD * HD; i += 256) {        // ordered (deterministic) reduction over the splits
+    for (int i = tid; i < HD * HD; i += FOLD_THREADS) {        // ordered (deterministic) reduction over the splits
         // ordered sum over the splits; 8 independent loads in flight per step (the loads, not the adds, are the latency)
         const float* gp = a.Gpart + ((long)b * a.nsplit * HEADS + h) * HD * HD + i;
         const long gstride = (long)HEADS * HD * HD;
@@ -326,21 +326,28 @@ __global__ __launch_bounds__(256) void spectral_fold_kernel(FoldDev a) {
         nq[tid] = fmaxf(sqrtf(s), 1e-12f);            // F.normalize eps (nk follows nq in memory)
         if (a.Ssum && blockIdx.y == 0) a.Ssum[(long)b * 2 * C + (tid / HD) * C + h * HD + tid % HD] = s;
     }
-    for (int i = tid; i < FOLD_CO * HD; i += 256)
+    for (int i = tid; i < FOLD_CO * HD; i += FOLD_THREADS)
         Ws[(i / HD) * LDG + i % HD] = a.Wo[(long)(co0 + i / HD) * C + h * HD + i % HD];
     __syncthreads();
-    if (tid < HD) {                                   // row softmax of G/(nq nk^T) * temperature
-        const float tq = a.temperature[h] / nq[tid];
+    for (int row = tid >> 2; row < (HD + FOLD_THREADS / 4 - 1) / (FOLD_THREADS / 4) * (FOLD_THREADS / 4); row += FOLD_THREADS / 4) {
+        // row softmax of G/(nq nk^T) * temperature: 4 adjacent lanes per row (rows >= HD idle but take part in the shuffles)
+        const bool on = row < HD;
+        const int qd = tid & 3;
+        const float tq = on ? a.temperature[h] / nq[row] : 0.f;
         float m = -3.0e38f;
-        for (int j = 0; j < HD; ++j) m = fmaxf(m, G[tid * LDG + j] * tq / nk[j]);
+        if (on) for (int j = qd; j < HD; j += 4) m = fmaxf(m, G[row * LDG + j] * tq / nk[j]);
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
         float den = 0.f;
-        for (int j = 0; j < HD; ++j) { const float e = expf(G[tid * LDG + j] * tq / nk[j] - m); G[tid * LDG + j] = e; den += e; }
+        if (on) for (int j = qd; j < HD; j += 4) { const float e = expf(G[row * LDG + j] * tq / nk[j] - m); G[row * LDG + j] = e; den += e; }
+        den += __shfl_xor(den, 1);
+        den += __shfl_xor(den, 2);
         const float inv = 1.0f / den;
-        for (int j = 0; j < HD; ++j) G[tid * LDG + j] *= inv;
+        if (on) for (int j = qd; j < HD; j += 4) G[row * LDG + j] *= inv;
     }
     __syncthreads();
     T* M = reinterpret_cast<T*>(a.Mout) + (long)b * C * C;
-    for (int o = tid; o < FOLD_CO * HD; o += 256) {   // M[co][h*HD+j] = sum_i Wo[co][h*HD+i] A[i][j]
+    for (int o = tid; o < FOLD_CO * HD; o += FOLD_THREADS) {   // M[co][h*HD+j] = sum_i Wo[co][h*HD+i] A[i][j]
         const int cl = o / HD, j = o % HD;
         float s = 0.f;
         for (int i = 0; i < HD; ++i) s += Ws[cl * LDG + i] * G[i * LDG + j];
@@ -472,10 +479,10 @@ extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32) {
         allow_big_lds(spectral_fold_kernel<float>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<float>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(256), shmem, s, d);
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<float>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(FOLD_THREADS), shmem, s, d);
     } else {
         allow_big_lds(spectral_fold_kernel<bf16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<bf16_t>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(256), shmem, s, d);
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<bf16_t>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(FOLD_THREADS), shmem, s, d);
     }
     return MPHSIR_OK;
 }
