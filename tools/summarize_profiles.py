@@ -25,7 +25,7 @@ def short(name):
     if m:
         n = re.sub(r"^\d+", "", m.group(1))
         # kernel forms that share one C-ABI entry point / library kernel id
-        return {"gemm_tn_tr": "gemm_tn", "gated_mlp_bwd2": "gated_mlp_bwd", "gated_mlp_lds": "gated_mlp", "dwconv_gram2": "dwconv_gram"}.get(n, n)
+        return {"gemm_tn_tr": "gemm_tn", "gemm_tn_tr_group": "gemm_tn", "gated_mlp_bwd2": "gated_mlp_bwd", "gated_mlp_lds": "gated_mlp", "dwconv_gram2": "dwconv_gram"}.get(n, n)
     return name[:60]
 
 
