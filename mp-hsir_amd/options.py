@@ -5,7 +5,7 @@ options.py (options.py:6-37), so its command lines (README.md:36,38) work unchan
 
 Like the reference, the namespace is built at import time (`from options import options as opt`);
 unknown flags are tolerated so that importing this module under pytest/torchrun does not abort.
-Additions (not present in the reference, all optional): --model, --precision, --steps_per_epoch,
+Additions (not present in the reference, all optional): --model, --precision, --steps_per_epoch, --graph,
 --synthetic, --log_every.  Reference hazards kept on purpose: `--num_gpus type=list` turns "01"
 into ['0','1'] (options.py:36) and `--classifier type=bool` treats any non-empty string as True.
 """
@@ -42,6 +42,7 @@ _FLAGS = [
     ("--steps_per_epoch", dict(type=int, default=100, help="synthetic source: optimisation steps per epoch")),
     ("--synthetic", dict(type=int, default=1, help="1: GPU-side synthetic patch source (no datasets offline)")),
     ("--log_every", dict(type=int, default=10)),
+    ("--graph", dict(type=int, default=1, help="1: capture the training step in a hipGraph after two eager steps and replay it")),
 ]
 
 

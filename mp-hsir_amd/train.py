@@ -61,7 +61,7 @@ def main():
         n = load_warm_start(net, opt.ckpt_path, dev)
         if rank == 0:
             print("warm start: %d tensors from %s" % (n, opt.ckpt_path))
-    eng = DataParallelEngine(net, lr=opt.lr)
+    eng = DataParallelEngine(net, lr=opt.lr, use_graph=bool(opt.graph))
     src = SyntheticPatchSource(cfg["in_channel"], opt.patch_size, opt.batch_size, cfg["task_classes"], dev, opt.seed, rank)
     for epoch in range(opt.epochs):
         lr = warmup_cosine_lr(epoch, opt.lr, opt.epochs)
@@ -79,6 +79,7 @@ def main():
             os.makedirs(opt.ckpt_dir, exist_ok=True)
             torch.save({"state_dict": {"net." + k: v.detach().cpu().clone() for k, v in net.state_dict().items()},
                         "epoch": epoch}, os.path.join(opt.ckpt_dir, "epoch=%d.ckpt" % epoch))
+    eng.finish()
     if world > 1:
         dist.destroy_process_group()
 
