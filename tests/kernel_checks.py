@@ -331,3 +331,26 @@ def check_reduce_block(dev):
     assert rel_l2(b, full[4:12, 8:24]) < 3e-7 and rel_l2(c, full[:9, :24].t()) < 3e-7
     assert rel_l2(d, full[3:4, 5:12]) < 3e-7 and rel_l2(e, full[2:7, 3:13]) < 3e-7
     assert rel_l2(wide[:, 8:20], full[1:9, 4:16]) < 3e-7 and float(wide[:, :8].abs().sum()) == 0 and float(wide[:, 20:].abs().sum()) == 0
+
+
+def check_gemm_tn_grouped(dev):
+    """bf16 token-reduction GEMMs deferred inside a reduce_scope are issued as ONE grouped launch: mixed widths (64- and
+    128-wide tile classes in one group), column sums, un-padding blocks, > 8 problems (two launches) == separate calls."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    dt = torch.bfloat16
+    shapes = [(256, 64, 128), (192, 136, 48), (320, 40, 56), (256, 160, 136), (128, 64, 64), (256, 200, 72), (192, 96, 96),
+              (256, 24, 264), (128, 72, 40), (320, 128, 128)]
+    A = [rnd((m, n1), 150 + i, dt) for i, (m, n1, n2) in enumerate(shapes)]
+    B = [rnd((m, n2), 170 + i, dt) for i, (m, n1, n2) in enumerate(shapes)]
+    ref = [ops.gemm_tn(a, b, nsplit=2, colsum=True) for a, b in zip(A, B)]                      # immediate launches
+    ops.ACCOUNT = {}
+    with ops.reduce_scope():
+        got = [ops.gemm_tn(a, b, nsplit=2, colsum=True) for a, b in zip(A, B)]
+        blk = ops.gemm_tn_blocks(A[3], B[3], [(0, 40), (96, 40)], ncols=100, colsum=True)
+    acct, ops.ACCOUNT = ops.ACCOUNT, None
+    for (c0, s0), (c1, s1) in zip(ref, got):
+        assert torch.equal(c0.cpu(), c1.cpu()) and torch.equal(s0.cpu(), s1.cpu())
+    full = A[3].double().cpu().t() @ B[3].double().cpu()
+    assert rel_l2(blk[0], torch.cat([full[:40, :100], full[96:136, :100]])) < 1e-2
+    assert rel_l2(blk[1], torch.cat([A[3].double().cpu().sum(0)[:40], A[3].double().cpu().sum(0)[96:136]])) < 1e-2

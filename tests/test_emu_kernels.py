@@ -99,3 +99,7 @@ def test_pack_gather(dtype):
 
 def test_reduce_block():
     K.check_reduce_block("cpu")
+
+
+def test_gemm_tn_grouped():
+    K.check_gemm_tn_grouped("cpu")

@@ -133,3 +133,7 @@ def test_gemm_tn_transposed_read_widths(M, N1, N2, nsplit, batch):
 
 def test_reduce_block():
     K.check_reduce_block("cuda")
+
+
+def test_gemm_tn_grouped():
+    K.check_gemm_tn_grouped("cuda")
