@@ -121,8 +121,11 @@ typedef struct mphsir_gram_args {
     void* V; int64_t ldvo;
     float* Gpart; float* Spart;
     int32_t B, H, W, C, heads, nsplit;
+    void* QK; int64_t ldqk;     /* optional [B*H*W][ldqk >= 2C]: q | k after the depthwise conv (training keeps them for the
+                                   backward instead of recomputing them; only the sliding-window kernel form writes it)  */
 } mphsir_gram_args;
 int mphsir_dwconv_gram(const mphsir_gram_args* a, int dtype, void* stream);
+int mphsir_dwconv_gram_keeps_qk(int32_t C, int32_t W, int dtype);     /* 1 if QK can be requested for this shape */
 typedef struct mphsir_fold_args {
     const float* Gpart; const float* Spart;
     const float* temperature;   /* [heads] */

@@ -43,7 +43,8 @@ class GramArgs(ctypes.Structure):
     """mirror of struct mphsir_gram_args"""
     _fields_ = [("Tq", c_void_p), ("ldq", c_int64), ("Tk", c_void_p), ("ldk", c_int64), ("Tv", c_void_p), ("ldv", c_int64),
                 ("wq", c_void_p), ("wk", c_void_p), ("wv", c_void_p), ("ldw", c_int64), ("V", c_void_p), ("ldvo", c_int64),
-                ("Gpart", c_void_p), ("Spart", c_void_p)] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nsplit")]
+                ("Gpart", c_void_p), ("Spart", c_void_p)] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nsplit")] + \
+               [("QK", c_void_p), ("ldqk", c_int64)]
 
 
 class FoldArgs(ctypes.Structure):
@@ -114,6 +115,7 @@ _SYMBOLS = {
     "mphsir_win_attn_fwd": (c_int, [ctypes.POINTER(WinAttnArgs), c_int, c_void_p]),
     "mphsir_win_attn_hdp": (c_int, [c_int, c_int]),
     "mphsir_dwconv_gram": (c_int, [ctypes.POINTER(GramArgs), c_int, c_void_p]),
+    "mphsir_dwconv_gram_keeps_qk": (c_int, [c_int32, c_int32, c_int]),
     "mphsir_spectral_fold": (c_int, [ctypes.POINTER(FoldArgs), c_int, c_void_p]),
     "mphsir_dwconv_gate": (c_int, [ctypes.POINTER(GateArgs), c_int, c_void_p]),
     "mphsir_dwconv3x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,

@@ -95,7 +95,7 @@ class _GatedMlp(torch.autograd.Function):
         return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1], dW1, db1, dW2, db2)
 
 
-def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, MbT, temperature, wo, heads, B, H, W):
+def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, MbT, temperature, wo, heads, B, H, W, qk=None):
     """Backward of the folded channel attention  out = M_b v,  M_b = Wo blockdiag(softmax(normalised Gram)).
 
     d_out (M,C); t_q/t_k/t_v: (B,H,W,*) views of the 1x1-conv outputs that fed dwconv_gram (channels-last,
@@ -113,13 +113,15 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     with ops.side_stream(dM) as fork:
         W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temperature.detach().reshape(heads).float().contiguous(),
                                                    wo.detach().reshape(C, C).float().contiguous(), dM, dt, reduce=False)
-    # q, k of the forward (never stored) are recomputed by the depthwise kernel; when q|k|v are adjacent channel
+    # q, k of the forward: either kept by it (qk) or recomputed by the depthwise kernel; when q|k|v are adjacent channel
     # slices of one tensor (self-attention) every depthwise pass runs once over the joint channel range.
     joint = (t_q.data_ptr() + C * t_q.element_size() == t_k.data_ptr() and t_k.data_ptr() + C * t_k.element_size() == t_v.data_ptr()
              and t_q.stride() == t_k.stride() == t_v.stride() and w9q.data_ptr() + 4 * C == w9k.data_ptr()
              and w9k.data_ptr() + 4 * C == w9v.data_ptr())
     dall = torch.empty((M, 3 * C), dtype=dt, device=v.device)
-    if joint:
+    if qk is not None:
+        pass                                                    # kept by the forward (dwconv_gram keep_qk)
+    elif joint:
         qk = ops.dwconv3x3(torch.as_strided(t_q, (B, H, W, 2 * C), t_q.stride()), torch.as_strided(w9q, (9, 2 * C), w9q.stride()))
     else:
         qk = torch.cat([ops.dwconv3x3(t_q, w9q), ops.dwconv3x3(t_k, w9k)], dim=-1)
@@ -160,17 +162,20 @@ class _PgsstbAttn(torch.autograd.Function):
         sa2 = sa.reshape(-1, Cc)
         t = ops.gemm_tok(sa2, sp["wqkv"])
         w9 = sp["w9"]
-        v, gp, spart, _ = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
-                                          3 * Cc, B, H, W, Cc, heads)
+        # q | k after the depthwise conv are kept for the backward (2C values per token: cheaper than recomputing them)
+        v, gp, spart, _, qk = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
+                                              3 * Cc, B, H, W, Cc, heads, keep_qk=True)
         Mb, MbT, gp, spart = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt, transposed=True)   # keep the sums, drop the partials
         y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
         ctx.blk, ctx.k1 = blk, k1
-        ctx.save_for_backward(x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT)
+        ctx.has_qk = qk is not None
+        ctx.save_for_backward(x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT, *([qk] if qk is not None else []))
         return y.reshape(B, H, W, Cc)
 
     @staticmethod
     def backward(ctx, dy):
-        x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT = ctx.saved_tensors
+        x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT = ctx.saved_tensors[:11]
+        qk = ctx.saved_tensors[11] if ctx.has_qk else None
         blk, k1 = ctx.blk, ctx.k1
         B, H, W, Cc = x.shape
         dt = x.dtype
@@ -188,7 +193,7 @@ class _PgsstbAttn(torch.autograd.Function):
             tq, tk, tv = t4[..., :Cc], t4[..., Cc:2 * Cc], t4[..., 2 * Cc:]
             dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
                 d_out.reshape(M, Cc), tq, tk, tv, w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:], v, gp, spart, Mb, MbT,
-                blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W)
+                blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W, qk=qk)
             if dtq.data_ptr() + Cc * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * Cc:
                 dt3 = torch.as_strided(dtq, (M, 3 * Cc), (3 * Cc, 1))
             else:

@@ -26,6 +26,7 @@ struct GramDev {
     float* Gpart;   // [B][nsplit][HEADS][HD][HD]
     float* Spart;   // [B][nsplit][2][C]
     int B, H, W, nsplit;
+    void* QK; long ldqk;                                                              // optional [B*H*W][ldqk]: q | k (post-dwconv)
 };
 
 // depthwise 3x3 (zero padding) at pixel (y,x) for VEC consecutive channels starting at c0
@@ -223,6 +224,14 @@ __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
             if (which < 2) {
                 T* dst = (which == 0 ? qT : kT) + c0 * LDT + st * 8;
                 for (int e = 0; e < VEC; ++e) store8<T>(dst + e * LDT, out[e]);
+                if (a.QK) {                      // training: q | k are kept for the backward pass
+                    T* QK = reinterpret_cast<T*>(a.QK) + img * a.ldqk + which * C + c0;
+                    for (int i = 0; i < 8; ++i) {
+                        Vec16<T> o;
+                        for (int e = 0; e < VEC; ++e) o.set(e, out[e][i]);
+                        store16<T>(QK + (long)(p0 + i) * a.ldqk, o);
+                    }
+                }
             } else {
                 for (int i = 0; i < 8; ++i) {
                     Vec16<T> o;
@@ -458,10 +467,18 @@ extern "C" int mphsir_dwconv_gram(const mphsir_gram_args* a, int dtype, void* st
                        (a->ldk * esz) % 16 == 0 && (a->ldv * esz) % 16 == 0 && (a->ldvo * esz) % 16 == 0,
                    "dwconv_gram: 16-byte alignment required");
     GramDev d{a->Tq, (long)a->ldq, a->Tk, (long)a->ldk, a->Tv, (long)a->ldv, a->wq, a->wk, a->wv, (long)a->ldw,
-              a->V, (long)a->ldvo, a->Gpart, a->Spart, a->B, a->H, a->W, a->nsplit};
+              a->V, (long)a->ldvo, a->Gpart, a->Spart, a->B, a->H, a->W, a->nsplit, a->QK, (long)a->ldqk};
+    MPHSIR_REQUIRE(!a->QK || mphsir_dwconv_gram_keeps_qk(a->C, a->W, dtype), "dwconv_gram: this shape cannot emit q|k (ask mphsir_dwconv_gram_keeps_qk)");
+    MPHSIR_REQUIRE(!a->QK || (aligned16(a->QK) && (a->ldqk * esz) % 16 == 0 && a->ldqk >= 2 * a->C), "dwconv_gram: QK must be 16-byte aligned, ldqk >= 2C");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == MPHSIR_F32 ? dispatch_gram<float>(d, a->C, a->C / a->heads, s)
                                : dispatch_gram<bf16_t>(d, a->C, a->C / a->heads, s);
+}
+
+extern "C" int mphsir_dwconv_gram_keeps_qk(int32_t C, int32_t W, int dtype) {
+    // the sliding-window form (the one that can also emit q | k) needs both transposed tiles of all heads in LDS
+    const size_t esz = dtype == MPHSIR_F32 ? 4 : 2;
+    return (W % 8 == 0 && 2 * (size_t)C * (64 + mphsir::LDS_PAD_BYTES / esz) * esz <= 160 * 1024) ? 1 : 0;
 }
 
 extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* stream) {

@@ -343,9 +343,10 @@ def choose_nsplit(B, H, W):
     return n
 
 
-def dwconv_gram(tq, tk, tv, wq, wk, wv, ldw, B, H, W, C, heads, nsplit=None):
+def dwconv_gram(tq, tk, tv, wq, wk, wv, ldw, B, H, W, C, heads, nsplit=None, keep_qk=False):
     """tq/tk/tv: 2-D row-major views [B*H*W, >=C] of the 1x1-conv output starting at the first q/k/v
-    channel; wq/wk/wv fp32 tap-major views with row pitch ldw.  Returns (v (M,C), Gpart, Spart, nsplit)."""
+    channel; wq/wk/wv fp32 tap-major views with row pitch ldw.  Returns (v (M,C), Gpart, Spart, nsplit); with
+    keep_qk=True a 5th value: q|k after the depthwise conv as (M, 2C), or None when this shape cannot emit it."""
     lib = _lib.load()
     _check(tq, tk, tv, wq, wk, wv)
     M = B * H * W
@@ -359,8 +360,14 @@ def dwconv_gram(tq, tk, tv, wq, wk, wv, ldw, B, H, W, C, heads, nsplit=None):
     a.wq, a.wk, a.wv, a.ldw = _p(wq), _p(wk), _p(wv), ldw
     a.V, a.ldvo, a.Gpart, a.Spart = _p(v), C, _p(gp), _p(sp)
     a.B, a.H, a.W, a.C, a.heads, a.nsplit = B, H, W, C, heads, nsplit
+    qk = None
+    if keep_qk and lib.mphsir_dwconv_gram_keeps_qk(C, W, _DT[tq.dtype]):
+        qk = torch.empty((M, 2 * C), dtype=tq.dtype, device=tq.device)
+        a.QK, a.ldqk = _p(qk), 2 * C
     _lib.check(lib.mphsir_dwconv_gram(ctypes.byref(a), _DT[tq.dtype], _stream(tq)), "dwconv_gram")
-    _acct("dwconv_gram", M * (54.0 * C + 2.0 * C * hd), 4.0 * M * C * tq.element_size() + gp.numel() * 4 + sp.numel() * 4)
+    _acct("dwconv_gram", M * (54.0 * C + 2.0 * C * hd), (4.0 + (2.0 if qk is not None else 0.0)) * M * C * tq.element_size() + gp.numel() * 4 + sp.numel() * 4)
+    if keep_qk:
+        return v, gp, sp, nsplit, qk
     return v, gp, sp, nsplit
 
 
