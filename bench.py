@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
+    ap.add_argument("--patch", type=int, default=64, help="patch height = width (diagnostic: 512 = the test cubes of test.py)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: time inference only (not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,7 +110,7 @@ def main():
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(2024)
     net = MP_HSIR_Net(compute_dtype=dt).to(dev)
-    src = SyntheticPatchSource(31, 64, args.batch, 6, dev, 2024, rank)
+    src = SyntheticPatchSource(31, args.patch, args.batch, 6, dev, 2024, rank)
     if args.forward_only:
         net.eval()
         def step():
@@ -200,10 +201,10 @@ def main():
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_s / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "natural-scene MP_HSIR_Net(31,31,64,T=6) %s, 64x64x31 patches, batch %d/GPU, %s"
+            "config": {"workload": "natural-scene MP_HSIR_Net(31,31,64,T=6) %s, %dx%dx31 patches, batch %d/GPU, %s"
                                    % ("forward" if args.forward_only else "training step fwd+bwd+allreduce+AdamW",
-                                      args.batch, "dp%d" % world),
-                       "global_batch": world * args.batch, "patch": "64x64x31", "parallelism": "dp%d" % world, "launch": "eager" if (args.no_graph or args.forward_only) else "hipGraph replay",
+                                      args.patch, args.patch, args.batch, "dp%d" % world),
+                       "global_batch": world * args.batch, "patch": "%dx%dx31" % (args.patch, args.patch), "parallelism": "dp%d" % world, "launch": "eager" if (args.no_graph or args.forward_only) else "hipGraph replay",
                        "backward": "HIP kernels for every module (token-reduction GEMMs, fused block/prompt-module backward); hipBLASLt only for two plain dX GEMMs per block"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

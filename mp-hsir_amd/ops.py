@@ -379,6 +379,12 @@ def spectral_fold(gp, sp, temperature, Wo, dtype, transposed=False):
     B, nsplit, heads, hd, _ = gp.shape
     C = heads * hd
     assert Wo.dtype == torch.float32 and Wo.is_contiguous() and temperature.is_contiguous()
+    if nsplit > 64:
+        # few samples, large images (a 512x512 test cube: B = 1, 1024 partials): the fold kernel has only B*heads*C/32
+        # workgroups, so the long ordered sum is done by the wide reduction kernel first
+        gp = reduce_parts(gp, batched=True, immediate=True).unsqueeze(1)
+        sp = reduce_parts(sp, batched=True, immediate=True).unsqueeze(1)
+        nsplit = 1
     Mo = torch.empty((B, C, C), dtype=dtype, device=gp.device)
     a = _lib.FoldArgs()
     a.Gpart, a.Spart, a.temperature, a.Wo, a.M = _p(gp), _p(sp), _p(temperature), _p(Wo), _p(Mo)
