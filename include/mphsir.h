@@ -199,7 +199,7 @@ int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream);
  *   :193-218) for d_sa = dSA + dmu[win]/64 (dmu = gradient w.r.t. the window mean that feeds the gate).
  *   Outputs: dQKV [B*nW*64][3C] and XNw = LN(x) [B*nW*64][C], both in window-token order (row = window*64 +
  *   token), dSAt = the total d_sa (B,H,W,C), drpb [B*nW][225][heads] partials of the bias-table gradient.
- *   The caller finishes with library GEMMs: d_xn = dQKV Wqkv, dWqkv = dQKV^T XNw, dbqkv = colsum dQKV,
+ *   The caller finishes with: d_xn = dQKV Wqkv (plain GEMM), dWqkv = dQKV^T XNw, dbqkv = colsum dQKV (mphsir_gemm_tn),
  *   dWproj = dSAt^T Oattn, dbproj = colsum dSAt.  WprojT = proj.weight^T [C][C].
  *   mphsir_win_attn_bwd_fits(C, heads, dtype) tells whether the tile fits LDS (fp32: small widths only).
  * mphsir_ln_bwd_win: dX = dRes + LayerNorm_backward(dXNw) where dXNw [B*nW*64][C] is in window-token order

@@ -9,7 +9,7 @@
 //   dxn += [dval|dgate] W1   (C/16 persistent fp32 accumulator tiles per wave),
 // then LayerNorm backward per token and dx = dy + that.  h = value*gelu(gate), [dval|dgate] and LN(x)
 // are written out once so that the four weight gradients are plain token-reduction GEMMs
-// (dW2 = dm^T h, dW1 = [dval|dgate]^T xn, done by the caller with a library GEMM) and the bias / LN
+// (dW2 = dm^T h, dW1 = [dval|dgate]^T xn, done by the caller with mphsir_gemm_tn) and the bias / LN
 // parameter gradients are column sums (per-workgroup partials here, no atomics).
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
