@@ -260,8 +260,7 @@ class DataParallelEngine:
         self._hyper.copy_(torch.tensor(self._hyper_values(self.lr if lr is None else lr, self.step_count)), non_blocking=True)
         self._graph.replay()
         if self.world > 1:
-            for s, e, _ in self.buckets:
-                dist.all_reduce(self.flat_g[s:e], group=self.pg)
+            dist.all_reduce(self.flat_g, group=self.pg)     # nothing left to overlap with after the replay: one message
             ops.flat_adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 0.0, 0, self.betas[0], self.betas[1], self.eps,
                            self.wd, 1.0 / self.world, hyper=self._hyper)
             if self.plan is not None:
