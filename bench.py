@@ -147,7 +147,7 @@ def main():
     if not args.no_roofline:
         # algorithmic work per step and per kernel (one accounted step), then per-kernel HIP-event timing (eager launches)
         if not args.forward_only:
-            eng.use_graph = False
+            eng.force_eager = True          # same data flow (incl. the all-reduce for N > 1), individual launches
         ops.ACCOUNT = {}
         step()
         torch.cuda.synchronize()

@@ -147,6 +147,7 @@ class DataParallelEngine:
         # arena-wide reduction after the replay: 58 MB over xGMI is <1 ms next to a ~45 ms step).
         self.use_graph, self.graph_warmup, self._graph = use_graph, graph_warmup, None
         self.use_pack_plan, self.plan = use_pack_plan, None
+        self.force_eager = False        # diagnostics: run a graph-mode engine's step with eager launches (same data flow)
         if self.world > 1:      # DDP's initial parameter broadcast (rank 0 -> all), one flat message
             ps = [p for p in net.parameters()]
             flat = torch.cat([p.data.reshape(-1).float() for p in ps])
@@ -275,7 +276,8 @@ class DataParallelEngine:
     def train_step(self, degraded, clean, prompt, lr=None):
         if self.use_pack_plan and self.plan is None and self.arena is not None:
             self.plan = PackPlan(self.flat_p).build()      # caches were populated by the step(s) before
-        if self.use_graph and self.arena is not None and self.step_count >= self.graph_warmup and degraded.is_cuda:
+        if (self.use_graph and not self.force_eager and self.arena is not None and self.step_count >= self.graph_warmup
+                and degraded.is_cuda):
             return self._train_step_graph(degraded, clean, prompt, lr)
         first = self.arena is None
         if not first and self.world > 1 and not self.use_graph:
