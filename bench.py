@@ -113,10 +113,12 @@ def main():
     src = SyntheticPatchSource(31, args.patch, args.batch, 6, dev, 2024, rank)
     if args.forward_only:
         net.eval()
+        from mp_hsir_amd.engine import GraphedForward
+        fwd = net if args.no_graph else GraphedForward(net)
         def step():
             _, x, c, p = src.next()
             with torch.no_grad():
-                return net(x, p)
+                return fwd(x, p)
     else:
         net.train()
         eng = DataParallelEngine(net, lr=2e-4, use_graph=not args.no_graph)
@@ -148,6 +150,8 @@ def main():
         # algorithmic work per step and per kernel (one accounted step), then per-kernel HIP-event timing (eager launches)
         if not args.forward_only:
             eng.force_eager = True          # same data flow (incl. the all-reduce for N > 1), individual launches
+        else:
+            fwd = net
         ops.ACCOUNT = {}
         step()
         torch.cuda.synchronize()
@@ -204,7 +208,7 @@ def main():
             "config": {"workload": "natural-scene MP_HSIR_Net(31,31,64,T=6) %s, %dx%dx31 patches, batch %d/GPU, %s"
                                    % ("forward" if args.forward_only else "training step fwd+bwd+allreduce+AdamW",
                                       args.patch, args.patch, args.batch, "dp%d" % world),
-                       "global_batch": world * args.batch, "patch": "%dx%dx31" % (args.patch, args.patch), "parallelism": "dp%d" % world, "launch": "eager" if (args.no_graph or args.forward_only) else "hipGraph replay",
+                       "global_batch": world * args.batch, "patch": "%dx%dx31" % (args.patch, args.patch), "parallelism": "dp%d" % world, "launch": "eager" if args.no_graph else "hipGraph replay",
                        "backward": "HIP kernels for every module (token-reduction GEMMs, fused block/prompt-module backward); hipBLASLt only for two plain dX GEMMs per block"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
