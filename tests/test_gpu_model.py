@@ -176,3 +176,20 @@ def test_graph_replay_matches_eager_training():
 def test_pack_plan_matches_per_module_packers():
     M.check_pack_plan("cuda")
     M.check_pack_plan("cuda", torch.bfloat16)
+
+
+def test_graphed_forward_matches_eager():
+    """engine.GraphedForward (inference through a replayed hipGraph) returns exactly what the eager forward returns."""
+    from mp_hsir_amd.engine import GraphedForward
+    from golden.cases import TINY_CFG
+    net = M.build_net(TINY_CFG, "cuda", torch.bfloat16)
+    run = GraphedForward(net, warmup=1)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for i in range(4):
+        x = torch.rand((2, 8, 64, 64), generator=g, device="cuda")
+        p = torch.randint(0, 6, (2,), generator=g, device="cuda")
+        with torch.no_grad():
+            ref = net(x, p)
+        out = run(x, p)
+        assert torch.equal(out, ref), i
+    assert any("graph" in e for e in run.entries.values())
