@@ -94,7 +94,7 @@ typedef struct mphsir_win_attn_args {
     const float* Wdown; const float* Wpproj; const float* bpproj; const float* Wup;
     void* SA; float* gate;
     float* mu;      /* optional [B*nW][C] fp32: per-window mean of SA (input of the gate; saved for backward) */
-    void* Oattn;    /* optional (B,H,W,C): softmax(QK^T)V before proj, image order (saved for backward)     */
+    void* Oattn;    /* optional [B*nW*64][C]: softmax(QK^T)V before proj, window-token order (for backward)  */
     int32_t B, H, W, C, heads, shift, r;
 } mphsir_win_attn_args;
 int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream);
@@ -198,10 +198,11 @@ int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream);
  * mphsir_win_attn_bwd: backward of the attention core of mphsir_win_attn_fwd (Spatial_Attention.forward
  *   :193-218) for d_sa = dSA + dmu[win]/64 (dmu = gradient w.r.t. the window mean that feeds the gate).
  *   Outputs: dQKV [B*nW*64][3C] and XNw = LN(x) [B*nW*64][C], both in window-token order (row = window*64 +
- *   token), dSAt = the total d_sa (B,H,W,C), drpb [B*nW][225][heads] partials of the bias-table gradient.
+ *   token), dSAt = the total d_sa (window-token order, like Oattn), drpb [B*nW][225][heads] partials of the bias-table gradient.
  *   The caller finishes with: d_xn = dQKV Wqkv (plain GEMM), dWqkv = dQKV^T XNw, dbqkv = colsum dQKV (mphsir_gemm_tn),
  *   dWproj = dSAt^T Oattn, dbproj = colsum dSAt.  WprojT = proj.weight^T [C][C].
- *   mphsir_win_attn_bwd_fits(C, heads, dtype) tells whether the tile fits LDS (fp32: small widths only).
+ *   mphsir_win_attn_bwd_fits(C, heads, dtype): 1 for every instantiated (width, head_dim) in both dtypes (the per-head
+ *   tiles do not grow with C: the d_sa / LN(x) operands are re-read from the rows the workgroup has just written).
  * mphsir_ln_bwd_win: dX = dRes + LayerNorm_backward(dXNw) where dXNw [B*nW*64][C] is in window-token order
  *   (norm1 :667 + roll/partition :672-678 in reverse); part [B*nW][2][C] = partials of d(weight), d(bias).
  *   linear != 0: rows are plain token order (the pre-norms of TransformerBlock / CrossTransformer, :282,:286,:476,:477);

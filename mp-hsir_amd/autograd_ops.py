@@ -1,60 +1,11 @@
-"""autograd wiring of the fused ops: forward = HIP kernels through the C ABI; backward = gradient
-of the same math recomputed with torch ops on the GPU (see _composite.py; interim until the HIP
-backward kernels land).  Only the op inputs are saved for backward."""
+"""autograd wiring of the fused ops.  Forward AND backward of every module are HIP kernels called through the C ABI
+(include/mphsir.h): the backward functions below only sequence launches -- block / prompt-module data gradients, and
+every parameter gradient as a token-reduction GEMM (gemm_tn), column sum or ordered partial reduction.  There is no
+PyTorch-composite or library-GEMM path: a shape the kernels do not cover raises."""
 import torch
 import torch.nn.functional as F
 
-from . import _composite as C
 from . import ops
-
-
-class _Recompute(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, fwd_fn, comp_fn, names, n_in, *tensors):
-        ctx.comp_fn, ctx.names, ctx.n_in = comp_fn, names, n_in
-        ctx.save_for_backward(*tensors)
-        with torch.no_grad():
-            return fwd_fn(*tensors[:n_in])
-
-    @staticmethod
-    def backward(ctx, dy):
-        tensors = ctx.saved_tensors
-        n_in = ctx.n_in
-        leaves = [t.detach().requires_grad_(True) for t in tensors]
-        with torch.enable_grad():
-            y = ctx.comp_fn(*leaves[:n_in], dict(zip(ctx.names, leaves[n_in:])))
-        need = [i for i, need_i in enumerate(ctx.needs_input_grad[4:]) if need_i]
-        grads = torch.autograd.grad(y, [leaves[i] for i in need], dy.to(y.dtype), allow_unused=True)
-        out = [None] * len(tensors)
-        for i, g in zip(need, grads):
-            out[i] = g
-        return (None, None, None, None) + tuple(out)
-
-
-def _apply(fwd, comp, module, *inputs, only=None):
-    named = [(n, p) for n, p in module.named_parameters() if only is None or only(n)]
-    names = tuple(n for n, _ in named)
-    return _Recompute.apply(fwd, comp, names, len(inputs), *inputs, *[p for _, p in named])
-
-
-# ---- PGSSTB ---------------------------------------------------------------------------------------
-def _pgsstb_attn_forward(blk, x, k1):
-    B, H, W, Cc = x.shape
-    dt = x.dtype
-    pk = blk.packed(dt)
-    sp = blk.gobal_spectral_attn.packed(dt)
-    heads, shift = blk.num_heads, blk.shift_size
-    x2 = x.reshape(-1, Cc)
-    sa, gate = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"],
-                                pk["bproj"], pk["pg"], heads, shift)
-    sa2 = sa.reshape(-1, Cc)
-    t = ops.gemm_tok(sa2, sp["wqkv"])
-    w9 = sp["w9"]
-    v, gp, spart, _ = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
-                                      3 * Cc, B, H, W, Cc, heads)
-    Mb = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt)
-    y = ops.gemm_tok(v, Mb, epi=2, res=x2, sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
-    return y.reshape(B, H, W, Cc)
 
 
 class _GatedMlp(torch.autograd.Function):
@@ -148,7 +99,7 @@ _PG_KEYS = ("linear_down.weight", "linear_up.weight", "linear_prompt.weight", "p
 
 
 class _PgsstbAttn(torch.autograd.Function):
-    """First residual branch of a PGSSTB block: HIP forward (5 launches) and HIP/GEMM backward."""
+    """First residual branch of a PGSSTB block: HIP forward (5 launches) and HIP backward."""
 
     @staticmethod
     def forward(ctx, blk, k1, x, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, rpb, s_temp, s_qkv, s_dw, s_out, *pg):
@@ -198,7 +149,7 @@ class _PgsstbAttn(torch.autograd.Function):
                 dt3 = torch.as_strided(dtq, (M, 3 * Cc), (3 * Cc, 1))
             else:
                 dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
-            d_sa = d_sa.reshape(M, Cc).addmm_(dt3, sp["wqkv"])                       # + dt Wqkv  (1x1 conv backward)
+            d_sa = ops.gemm_tok(dt3, sp["wqkvT"], epi=1, res=d_sa.reshape(M, Cc))    # + dt Wqkv  (1x1 conv backward)
             d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
             # (3) local spectral-prompt gate: one launch per block + one token-reduction GEMM over the windows
             dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=dt)
@@ -206,7 +157,7 @@ class _PgsstbAttn(torch.autograd.Function):
             # (4) window attention core
             dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
                                                      pk["rpb"], pk["wprojT"], heads, shift)
-            dxn = dqkv @ pk["wqkv"]
+            dxn = ops.gemm_tok(dqkv, pk["wqkvT"])
             d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xnw, colsum=True)
             dsat2 = dsat.reshape(M, Cc)
             d_proj_w, d_proj_b = ops.gemm_tn(dsat2, oattn.reshape(M, Cc), colsum=True)
@@ -239,83 +190,20 @@ def getattr_path(mod, dotted):
 
 
 def pgsstb(blk, x, k1, k2):
-    heads, shifted = blk.num_heads, blk.shift_size > 0
-    Cc = x.shape[-1]
-    if ops.win_attn_bwd_fits(Cc, heads, x.dtype):
-        a, s, pgm = blk.attn, blk.gobal_spectral_attn, blk.local_spectral_attn
-        y = _PgsstbAttn.apply(blk, k1, x, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
-                              a.relative_position_bias_table, s.temperature, s.qkv.weight, s.qkv_dwconv.weight,
-                              s.project_out.weight, *[getattr_path(pgm, k) for k in _PG_KEYS])
-    else:   # LDS budget of the backward kernel (fp32 at larger widths): differentiate the torch composite instead
-        y = _apply(lambda x_: _pgsstb_attn_forward(blk, x_, k1), lambda x_, P: C.pgsstb_attn(P, x_, heads, shifted, k1), blk, x,
-                   only=lambda n: not (n.startswith("mlp.") or n.startswith("norm2.")))
-    if x.dtype == torch.float32 and Cc > 256:      # fp32 LDS budget of the MLP backward kernel
-        pk = blk.packed(x.dtype)
-
-        def fwd(y_):
-            B, H, W, _ = y_.shape
-            return ops.gated_mlp_fwd(y_.reshape(-1, Cc), pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"], pk["W2"], pk["b2"],
-                                     keep=k2, rows_per_batch=H * W).reshape(B, H, W, Cc)
-        return _apply(fwd, lambda y_, P: C.mlp_branch(P, y_, k2), blk, y,
-                      only=lambda n: n.startswith("mlp.") or n.startswith("norm2."))
+    """One PGSSTB block (ref :662-723): attention-side residual branch, then the gated-MLP residual branch."""
+    a, sp, pgm = blk.attn, blk.gobal_spectral_attn, blk.local_spectral_attn
+    y = _PgsstbAttn.apply(blk, k1, x, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                          a.relative_position_bias_table, sp.temperature, sp.qkv.weight, sp.qkv_dwconv.weight,
+                          sp.project_out.weight, *[getattr_path(pgm, k) for k in _PG_KEYS])
     m = blk.mlp
     return _GatedMlp.apply(blk, k2, y, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
 
 
 # ---- GDFN / channel attention sub-chains ------------------------------------------------------------
-def _gdfn_res(ffn, ln, a2, B, H, W):
-    pf = ffn.packed(a2.dtype)
-    t = ops.gemm_tok(a2, pf["w_in"], ln=ln.pair())
-    u = ops.dwconv_gate(t, pf["w9"], B, H, W)
-    return ops.gemm_tok(u, pf["w_out"], epi=1, res=a2)
-
-
-def _cross_transformer_forward(ct, text, vis):
-    B, ps, _, D = text.shape
-    dt = text.dtype
-    pa = ct.attn.packed(dt)
-    t2, v2 = text.reshape(-1, D), vis.reshape(-1, D)
-    tq = ops.gemm_tok(t2, pa["wq"], ln=ct.norm11.pair())
-    tkv = ops.gemm_tok(v2, pa["wkv"], ln=ct.norm12.pair())
-    w9 = pa["w9"]
-    v, gp, sp, _ = ops.dwconv_gram(tq, tkv[:, :D], tkv[:, D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
-                                   B, ps, ps, D, ct.attn.num_heads)
-    Mb = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt)
-    a = ops.gemm_tok(v, Mb, epi=1, res=t2)
-    return _gdfn_res(ct.ffn, ct.norm2, a, B, ps, ps).reshape(B, ps, ps, D)
-
-
-def _transformer_block_forward(tb, t):
-    B, H, W, D = t.shape
-    dt = t.dtype
-    pa = tb.attn.packed(dt)
-    t2 = t.reshape(-1, D)
-    q = ops.gemm_tok(t2, pa["wqkv"], ln=tb.norm1.pair())
-    w9 = pa["w9"]
-    v, gp, sp, _ = ops.dwconv_gram(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
-                                   B, H, W, D, tb.attn.num_heads)
-    Mb = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt)
-    a = ops.gemm_tok(v, Mb, epi=1, res=t2)
-    return _gdfn_res(tb.ffn, tb.norm2, a, B, H, W).reshape(B, H, W, D)
-
-
-def _ln_vjp(x2, w, b, dxn):
-    """LayerNorm over channels (torch kernels): returns (d x, d weight, d bias) for upstream dxn, and LN(x)."""
-    xl = x2.detach().requires_grad_(True)
-    wl, bl = w.detach().requires_grad_(True), b.detach().requires_grad_(True)
-    with torch.enable_grad():
-        xn = F.layer_norm(xl.float(), (xl.shape[-1],), wl.float(), bl.float(), 1e-5).to(x2.dtype)
-    return torch.autograd.grad(xn, [xl, wl, bl], dxn)
-
-
-def _ln_fwd(x2, w, b):
-    return F.layer_norm(x2.float(), (x2.shape[-1],), w.float(), b.float(), 1e-5).to(x2.dtype)
-
-
 class _GdfnRes(torch.autograd.Function):
     """y = a + project_out(gelu(x1) * x2), [x1|x2] = dwconv(project_in(LN(a)))   (ref FFN :251-265 / FeedForward
     :374-391 inside the pre-norm residual of :286 / :477).  HIP forward; backward = HIP depthwise / gate /
-    token-reduction kernels + library GEMMs for the two data gradients."""
+    token-reduction kernels, the two data gradients as gemm_tok on the pre-transposed weights."""
 
     @staticmethod
     def forward(ctx, ffn, ln, geom, a2, ln_w, ln_b, w_in, w_dw, w_out):
@@ -340,14 +228,14 @@ class _GdfnRes(torch.autograd.Function):
         t4 = t.reshape(B, H, W, 2 * HP)
         with ops.reduce_scope():
             tdw = ops.dwconv3x3(t4, pf["w9"]).reshape(-1, 2 * HP)
-            du = dy @ pf["w_out"]                                              # (M,HP)
+            du = ops.gemm_tok(dy, pf["w_outT"])                                 # (M,HP)
             u, dtdw = ops.gdfn_gate_bwd(tdw, du)
             d_out_w = ops.gemm_tn_blocks(dy, u, [(0, D)], ncols=hid).reshape(D, hid, 1, 1)
             dtdw4 = dtdw.reshape(B, H, W, 2 * HP)
             dt_ = ops.dwconv3x3(dtdw4, pf["w9"], flip=True).reshape(-1, 2 * HP)
             d_dw = ops.dwconv3x3_wgrad(t4, dtdw4, col_ranges=[(0, hid), (HP, hid)]).reshape(2 * hid, 1, 3, 3)
             lw, lb = ln.pair()
-            da, dlw, dlb, xn = ops.ln_bwd_tok(a2, dt_ @ pf["w_in"], dy, lw, lb)
+            da, dlw, dlb, xn = ops.ln_bwd_tok(a2, ops.gemm_tok(dt_, pf["w_inT"]), dy, lw, lb)
             d_in_w = ops.gemm_tn_blocks(dt_, xn, [(0, hid), (HP, hid)]).reshape(2 * hid, D, 1, 1)
         return None, None, None, da, dlw, dlb, d_in_w, d_dw, d_out_w
 
@@ -395,7 +283,7 @@ class _SelfChannelAttnRes(torch.autograd.Function):
             else:
                 dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * D)
             lw, lb = ln.pair()
-            dt_in, dlw, dlb, xn = ops.ln_bwd_tok(t2, dt3 @ pa["wqkv"], da, lw, lb)
+            dt_in, dlw, dlb, xn = ops.ln_bwd_tok(t2, ops.gemm_tok(dt3, pa["wqkvT"]), da, lw, lb)
             d_qkv = ops.gemm_tn(dt3, xn).reshape(3 * D, D, 1, 1)
         d_dw = _join_taps(dwq, dwk, dwv).reshape(3 * D, 1, 3, 3)
         return None, None, None, dt_in, dlw, dlb, d_qkv, d_dw, dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1)
@@ -440,8 +328,8 @@ class _CrossChannelAttnRes(torch.autograd.Function):
             dkv = torch.cat([dtk, dtv], dim=-1).reshape(M, 2 * D)
             n11w, n11b = ct.norm11.pair()
             n12w, n12b = ct.norm12.pair()
-            dtext, d11w, d11b, xq = ops.ln_bwd_tok(text2, dtq2.contiguous() @ pa["wq"], da, n11w, n11b)
-            dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis2, dkv @ pa["wkv"], torch.zeros_like(vis2), n12w, n12b)
+            dtext, d11w, d11b, xq = ops.ln_bwd_tok(text2, ops.gemm_tok(dtq2.contiguous(), pa["wqT"]), da, n11w, n11b)
+            dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis2, ops.gemm_tok(dkv, pa["wkvT"]), torch.zeros_like(vis2), n12w, n12b)
             d_wq = ops.gemm_tn(dtq2, xq).reshape(D, D, 1, 1)
             d_wkv = ops.gemm_tn(dkv, xv).reshape(2 * D, D, 1, 1)
         return (None, None, dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.reshape(D, 1, 3, 3),
@@ -518,7 +406,7 @@ class _Conv1x1(torch.autograd.Function):
         pk = _packed_conv1x1(ctx.conv, w, x.dtype)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = (ops.gemm_tok(dy2.contiguous(), pk["wT"]) if N % 32 == 0 and K % 16 == 0 else dy2 @ pk["w"]).reshape(x.shape)
+            dx = ops.gemm_tok(dy2.contiguous(), pk["wT"]).reshape(x.shape)
         dw = ops.gemm_tn(dy2.contiguous(), x2).reshape(w.shape) if ctx.needs_input_grad[1] else None
         return dx, dw, None
 

@@ -78,46 +78,54 @@ struct WinBwdDev {
     const void* WprojT;                 // [C][C]: WprojT[ci][co] = proj.weight[co][ci]
     void* dQKV;                         // [B*nW*64][3C]  window-token order
     void* XNw;                          // [B*nW*64][C]   LN(x), window-token order
-    void* dSAt;                         // (B,H,W,C) total d_sa (adds dmu/64), image order
+    void* dSAt;                         // [B*nW*64][C]   total d_sa (adds dmu/64), window-token order
     float* drpb;                        // [B*nW][225][HEADS]
     WinGeom g;
 };
 
-template <class T, int C, int HD> struct WinBwdCfg {
+// LDS plan.  Per head the kernel holds four row-major [64 tok][HDP] tiles (q, k, v, dO_h) and the two 64x64 matrices
+// P and dS, each stored ONCE as [query][key]: every product that needs an operand "the other way round" (dQ = dS K,
+// dK = dS^T Q, dV = P^T dO) reads it through load_frag_tr (ds_read_b64_tr_b16 for bf16, four strided reads for f32),
+// so there are no transposed copies and no scalar transposing stores.  The LN(x) tile (the B operand of the q/k/v
+// recompute, read 3x per head) stays in LDS when XL; otherwise its fragments come back from the XNw rows this
+// workgroup has just written (L1/L2 hits).  The total d_sa (read once per head) always comes from the dSAt rows.
+// With that the footprint no longer grows with 2*C: every shipped width fits in both dtypes.
+template <class T, int C, int HD, bool XL> struct WinBwdCfg {
     static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     static constexpr int HEADS = C / HD;
     static constexpr int KC = ElemTraits<T>::KCHUNK;
     static constexpr int HDP = (HD + KC - 1) / KC * KC;
     static constexpr int LDX = C + PAD;
     static constexpr int LDQ = HDP + PAD;        // row-major [64][HDP]
-    static constexpr int LDT = 64 + PAD;         // transposed [HD][64] and the 64x64 tiles
-    static constexpr bool ALIAS = HDP >= 64;     // P^T, dS, dS^T reuse the Q, K, V tiles
-    static constexpr size_t XS = 64 * LDX, QS = 64 * LDQ, TS = HD * LDT, SS = 64 * LDT;
-    static constexpr size_t T_ELEMS = 2 * XS + 4 * QS + 3 * TS + (ALIAS ? 0 : 3 * SS);
+    static constexpr int LDT = 64 + PAD;         // the 64x64 tiles
+    static constexpr bool ALIAS = HDP >= 64;     // P reuses the V tile (v is dead once dP is formed)
+    static constexpr size_t XS = XL ? 64 * LDX : 0, QS = 64 * LDQ, SS = 64 * LDT;
+    static constexpr size_t T_ELEMS = XS + 4 * QS + (ALIAS ? 1 : 2) * SS;
     static constexpr size_t BYTES = T_ELEMS * sizeof(T) + (225 + 64) * 4;
     static constexpr bool FITS = BYTES <= 160 * 1024;
 };
 
-template <class T, int C, int HD>
+// X tile in LDS whenever the whole footprint then still allows two workgroups per CU (80 KB each); beyond that the
+// tile is dropped (occupancy beats the L2 re-reads: measured on MI355X, tools/bench_win.py).
+template <class T, int C, int HD> struct WinBwdPick {
+    static constexpr bool XL = WinBwdCfg<T, C, HD, true>::BYTES <= 80 * 1024;
+};
+
+template <class T, int C, int HD, bool XL>
 __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
-    typedef WinBwdCfg<T, C, HD> CF;
+    typedef WinBwdCfg<T, C, HD, XL> CF;
     constexpr int VEC = Vec16<T>::N;
     constexpr int TPW = HD / 16;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    T* Xs = reinterpret_cast<T*>(smem_v);        // LN(x)            [64][LDX]
-    T* Ds = Xs + CF::XS;                         // total d_sa       [64][LDX]
-    T* Qr = Ds + CF::XS;                         // q (scaled)       [64][LDQ]
+    T* Xs = reinterpret_cast<T*>(smem_v);        // LN(x)            [64][LDX]   (XL only)
+    T* Qr = Xs + CF::XS;                         // q (scaled)       [64][LDQ]
     T* Kr = Qr + CF::QS;                         // k                [64][LDQ]
     T* Vr = Kr + CF::QS;                         // v                [64][LDQ]
     T* Or = Vr + CF::QS;                         // dO_h             [64][LDQ]
-    T* Qt = Or + CF::QS;                         // q^T              [HD][LDT]
-    T* Kt = Qt + CF::TS;                         // k^T
-    T* Ot = Kt + CF::TS;                         // dO_h^T
-    T* Pt = CF::ALIAS ? Qr : Ot + CF::TS;        // P^T   [key][q]   [64][LDT]
-    T* dS = CF::ALIAS ? Kr : Pt + CF::SS;        // dS    [q][key]
-    T* dSt = CF::ALIAS ? Vr : dS + CF::SS;       // dS^T  [key][q]
+    T* dS = Or + CF::QS;                         // dS   [q][key]    [64][LDT]
+    T* Ps = CF::ALIAS ? Vr : dS + CF::SS;        // P    [q][key]    [64][LDT]
     float* rpbs = reinterpret_cast<float*>(Xs + CF::T_ELEMS);
     int* reg = reinterpret_cast<int*>(rpbs + 225);
 
@@ -125,8 +133,10 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
     const T* X = reinterpret_cast<const T*>(a.X);
     const T* dSA = reinterpret_cast<const T*>(a.dSA);
     const long row0 = (long)blockIdx.x * 64;
+    const T* Xg = reinterpret_cast<const T*>(a.XNw) + row0 * C;      // this window's rows of the two side outputs,
+    const T* Dg = reinterpret_cast<const T*>(a.dSAt) + row0 * C;     // read back as MFMA operands after the barrier
 
-    // ---- stage LN(x) and the total d_sa; write both side outputs -----------------------------------
+    // ---- LN(x) and the total d_sa: both side outputs (window-token order); LN(x) also into LDS when XL ----------
     {
         constexpr int NV = C / VEC, VPT = NV / 4;
         const int t = tid >> 2, q = tid & 3;
@@ -150,18 +160,17 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
         d2 += __shfl_xor(d2, 2);
         const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
         T* xnw = reinterpret_cast<T*>(a.XNw) + (row0 + t) * C;
-        T* dst = reinterpret_cast<T*>(a.dSAt) + pix * C;
+        T* dst = reinterpret_cast<T*>(a.dSAt) + (row0 + t) * C;
         const float* dmu = a.dmu + (long)blockIdx.x * C;
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int c0 = (q + 4 * i) * VEC;
             Vec16<T> o;
             for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
-            store16<T>(Xs + t * CF::LDX + c0, o);
+            if (XL) store16<T>(Xs + t * CF::LDX + c0, o);
             store16<T>(xnw + c0, o);
             Vec16<T> d = load16<T>(dSA + pix * C + c0);
             for (int e = 0; e < VEC; ++e) d.set(e, d.get(e) + dmu[c0 + e] * (1.0f / 64.0f));
-            store16<T>(Ds + t * CF::LDX + c0, d);
             store16<T>(dst + c0, d);
         }
         if (tid < 64) {
@@ -183,14 +192,14 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
     const float scale = rsqrtf((float)HD);
 
     for (int h = 0; h < CF::HEADS; ++h) {
-        __syncthreads();
-        if (CF::ALIAS && CF::HDP != HD)   // the aliased 64x64 tiles overwrote the zero padding of q,k,v
-            for (int i = tid; i < 3 * 64 * (CF::HDP - HD); i += 256) {
+        __syncthreads();      // h = 0: the side outputs / X tile are visible to the whole workgroup; h > 0: tiles free
+        if (CF::ALIAS && CF::HDP != HD)   // P overwrote the zero padding of v
+            for (int i = tid; i < 64 * (CF::HDP - HD); i += 256) {
                 const int rr = i / (CF::HDP - HD), cc = HD + i % (CF::HDP - HD);
-                Qr[rr * CF::LDQ + cc] = from_f32<T>(0.f);
+                Vr[rr * CF::LDQ + cc] = from_f32<T>(0.f);
             }
         if (tid < 225) rpbs[tid] = a.rpb[tid * CF::HEADS + h];
-        // ---- (a) recompute q,k,v (row-major, q/k also transposed) and dO_h = d_sa W_proj[:, head] ------
+        // ---- (a) recompute q,k,v and dO_h = d_sa W_proj[:, head] (row-major [tok][hd]) -------------------------------
         // unit u = (16-channel tile of q|k|v|dO, half of the 64 tokens).  The weight fragments come straight from L2 and
         // feed two MFMAs each: the next unit's fragments are loaded into a second register set during the current unit.
         constexpr int NUNITS = 4 * TPW * 2, NKC = C / TR::KCHUNK, UPW = NUNITS / 4;      // units per wave (NUNITS % 4 == 0)
@@ -216,11 +225,25 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
                 const int ct = u >> 1, th = u & 1, which = ct / TPW, cti = ct % TPW;
                 f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
                 const int wrow = (which < 3 ? which * C : 0) + h * HD + cti * 16;
-                const T* Bsrc = which < 3 ? Xs : Ds;
+                if (XL && which < 3) {                   // wave-uniform: LDS operand
 #pragma unroll
-                for (int kc = 0; kc < NKC; ++kc) {
-                    mma(c0, wq[i & 1][kc], load_frag<T>(Bsrc, CF::LDX, th * 32, kc * TR::KCHUNK));
-                    mma(c1, wq[i & 1][kc], load_frag<T>(Bsrc, CF::LDX, th * 32 + 16, kc * TR::KCHUNK));
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        mma(c0, wq[i & 1][kc], load_frag<T>(Xs, CF::LDX, th * 32, kc * TR::KCHUNK));
+                        mma(c1, wq[i & 1][kc], load_frag<T>(Xs, CF::LDX, th * 32 + 16, kc * TR::KCHUNK));
+                    }
+                } else {                                 // global operand (rows written above by this workgroup)
+                    const T* Bsrc = which < 3 ? Xg : Dg;
+                    frag_t b0[NKC], b1[NKC];
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        b0[kc] = load_frag<T>(Bsrc, C, th * 32, kc * TR::KCHUNK);
+                        b1[kc] = load_frag<T>(Bsrc, C, th * 32 + 16, kc * TR::KCHUNK);
+                    }
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        mma(c0, wq[i & 1][kc], b0[kc]);
+                        mma(c1, wq[i & 1][kc], b1[kc]);
+                    }
                 }
                 const int cr = cti * 16 + (lane >> 4) * 4;
                 if (which < 3) {
@@ -234,13 +257,6 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
                 T* rowm = which == 0 ? Qr : which == 1 ? Kr : which == 2 ? Vr : Or;
                 store4<T>(rowm + (th * 32 + (lane & 15)) * CF::LDQ + cr, c0);
                 store4<T>(rowm + (th * 32 + 16 + (lane & 15)) * CF::LDQ + cr, c1);
-                if (which != 2) {
-                    T* tr = which == 0 ? Qt : which == 1 ? Kt : Ot;
-                    for (int r = 0; r < 4; ++r) {
-                        tr[(cr + r) * CF::LDT + th * 32 + (lane & 15)] = from_f32<T>(c0[r]);
-                        tr[(cr + r) * CF::LDT + th * 32 + 16 + (lane & 15)] = from_f32<T>(c1[r]);
-                    }
-                }
             }
         }
         __syncthreads();
@@ -285,17 +301,13 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
             for (int r = 0; r < 4; ++r) { s[kt][r] *= inv; dot += s[kt][r] * dp[kt][r]; }
         dot += __shfl_xor(dot, 16);
         dot += __shfl_xor(dot, 32);
-        if (CF::ALIAS) __syncthreads();          // every wave is done reading q,k,v before they are overwritten
+        if (CF::ALIAS) __syncthreads();          // every wave is done reading v before P overwrites it
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             f32x4 ds;
             for (int r = 0; r < 4; ++r) ds[r] = s[kt][r] * (dp[kt][r] - dot);
             store4<T>(dS + qi * CF::LDT + kt * 16 + (lane >> 4) * 4, ds);
-            for (int r = 0; r < 4; ++r) {
-                const int kj = kt * 16 + (lane >> 4) * 4 + r;
-                Pt[kj * CF::LDT + qi] = from_f32<T>(s[kt][r]);
-                dSt[kj * CF::LDT + qi] = from_f32<T>(ds[r]);
-            }
+            store4<T>(Ps + qi * CF::LDT + kt * 16 + (lane >> 4) * 4, s[kt]);
         }
         __syncthreads();
 
@@ -308,9 +320,9 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
                 f32x4 dq = {0, 0, 0, 0}, dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
 #pragma unroll
                 for (int kk = 0; kk < 64; kk += TR::KCHUNK) {
-                    mma(dq, load_frag<T>(Kt, CF::LDT, ct * 16, kk), load_frag<T>(dS, CF::LDT, wv * 16, kk));
-                    mma(dk, load_frag<T>(Qt, CF::LDT, ct * 16, kk), load_frag<T>(dSt, CF::LDT, wv * 16, kk));
-                    mma(dv, load_frag<T>(Ot, CF::LDT, ct * 16, kk), load_frag<T>(Pt, CF::LDT, wv * 16, kk));
+                    mma(dq, load_frag_tr<T>(Kr, CF::LDQ, ct * 16, kk), load_frag<T>(dS, CF::LDT, wv * 16, kk));
+                    mma(dk, load_frag_tr<T>(Qr, CF::LDQ, ct * 16, kk), load_frag_tr<T>(dS, CF::LDT, wv * 16, kk));
+                    mma(dv, load_frag_tr<T>(Or, CF::LDQ, ct * 16, kk), load_frag_tr<T>(Ps, CF::LDT, wv * 16, kk));
                 }
                 for (int r = 0; r < 4; ++r) dq[r] *= scale;
                 store4<T>(out + ct * 16, dq);
@@ -417,24 +429,21 @@ __global__ __launch_bounds__(256) void ln_bwd_win_kernel(LnBwdDev a) {
 
 template <class T, int C, int HD>
 static int launch_win_bwd(const WinBwdDev& d, hipStream_t s) {
-    typedef WinBwdCfg<T, C, HD> CF;
-    if constexpr (!CF::FITS) {
-        set_error("win_attn_bwd: (C=%d, head_dim=%d) needs %d bytes of LDS in this dtype", C, HD, (int)CF::BYTES);
-        return MPHSIR_EINVAL;
-    } else {
-        allow_big_lds(win_attn_bwd_kernel<T, C, HD>, CF::BYTES);
-        const int nblk = d.g.B * (d.g.H / 8) * (d.g.W / 8);
-        MPHSIR_LAUNCH(MPHSIR_K_WIN_ATTN_BWD, (win_attn_bwd_kernel<T, C, HD>), dim3(nblk), dim3(256), CF::BYTES, s, d);
-        return MPHSIR_OK;
-    }
+    constexpr bool XL = WinBwdPick<T, C, HD>::XL;
+    typedef WinBwdCfg<T, C, HD, XL> CF;
+    static_assert(CF::FITS, "win_attn_bwd tiles do not fit LDS");
+    allow_big_lds(win_attn_bwd_kernel<T, C, HD, XL>, CF::BYTES);
+    const int nblk = d.g.B * (d.g.H / 8) * (d.g.W / 8);
+    MPHSIR_LAUNCH(MPHSIR_K_WIN_ATTN_BWD, (win_attn_bwd_kernel<T, C, HD, XL>), dim3(nblk), dim3(256), CF::BYTES, s, d);
+    return MPHSIR_OK;
 }
+
+#define MPHSIR_WINB_SHAPES(X) X(32, 32) X(64, 32) X(64, 64) X(128, 32) X(128, 64) X(256, 32) X(96, 48) X(192, 48) X(192, 96) X(384, 48)
 
 template <class T>
 static int dispatch_win_bwd(const WinBwdDev& d, int C, int HD, hipStream_t s) {
 #define MPHSIR_WINB_CASE(c, hd) if (C == c && HD == hd) return launch_win_bwd<T, c, hd>(d, s);
-    MPHSIR_WINB_CASE(32, 32) MPHSIR_WINB_CASE(64, 32) MPHSIR_WINB_CASE(64, 64) MPHSIR_WINB_CASE(128, 32)
-    MPHSIR_WINB_CASE(128, 64) MPHSIR_WINB_CASE(256, 32)
-    MPHSIR_WINB_CASE(96, 48) MPHSIR_WINB_CASE(192, 48) MPHSIR_WINB_CASE(192, 96) MPHSIR_WINB_CASE(384, 48)
+    MPHSIR_WINB_SHAPES(MPHSIR_WINB_CASE)
 #undef MPHSIR_WINB_CASE
     set_error("win_attn_bwd: (C=%d, head_dim=%d) not instantiated", C, HD);
     return MPHSIR_EINVAL;
@@ -479,12 +488,13 @@ extern "C" int mphsir_win_attn_bwd(const mphsir_win_attn_bwd_args* a, int dtype,
 }
 
 extern "C" int mphsir_win_attn_bwd_fits(int32_t C, int32_t heads, int dtype) {
-    using namespace mphsir;
-    const int hd = C / heads, kc = dtype == MPHSIR_F32 ? 16 : 32, esz = dtype == MPHSIR_F32 ? 4 : 2, pad = LDS_PAD_BYTES / esz;
-    const int hdp = (hd + kc - 1) / kc * kc;
-    const size_t elems = 2 * 64 * (size_t)(C + pad) + 4 * 64 * (size_t)(hdp + pad) + 3 * (size_t)hd * (64 + pad) +
-                         (hdp >= 64 ? 0 : 3 * 64 * (size_t)(64 + pad));
-    return elems * esz + (225 + 64) * 4 <= 160 * 1024 ? 1 : 0;
+    // every instantiated (width, head_dim) fits in both dtypes since the kernel stopped holding [64][C] tiles of d_sa
+    if (heads <= 0 || C % heads != 0 || (dtype != MPHSIR_F32 && dtype != MPHSIR_BF16)) return 0;
+    const int hd = C / heads;
+#define MPHSIR_WINB_CASE(c, h_) if (C == c && hd == h_) return 1;
+    MPHSIR_WINB_SHAPES(MPHSIR_WINB_CASE)
+#undef MPHSIR_WINB_CASE
+    return 0;
 }
 
 extern "C" int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const float* ln_w, void* dX, float* part,

@@ -31,7 +31,9 @@ struct MlpBwdDev {
 
 // STAGE = true: the fc1 rows of the hidden chunk ([64][C]) and the matching columns of W1^T ([C][64]) are loaded
 // once per workgroup into LDS (coalesced) instead of every wave streaming its own fragments through L1.
-template <class T, int C, bool STAGE>
+// GX = true (widths whose two [64][C] token tiles do not fit LDS, i.e. fp32 at C = 384): the LN(x) / dm operands are
+// not kept in LDS; their fragments are read back from the XN / DM rows this workgroup has just written.
+template <class T, int C, bool STAGE, bool GX = false>
 __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
@@ -45,12 +47,13 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     T* Xs = reinterpret_cast<T*>(smem_v);               // [64][LDX]  LN(x)
     T* Ds = Xs + 64 * LDX;                              // [64][LDX]  dm = keep*dy
-    T* Hs = Ds + 64 * LDX;                              // [4][16][LDH]  per wave: [dval(32) | dgate(32)], also h staging
+    T* Hs = GX ? Xs + 64 * LDF * 4 / sizeof(T) : Ds + 64 * LDX;   // [4][16][LDH]  per wave: [dval(32) | dgate(32)], also h staging
     float* stat = reinterpret_cast<float*>(Hs + 4 * 16 * LDH);   // mean[64], rstd[64]
     T* W1s = reinterpret_cast<T*>(stat + 128);          // [64][LDX]   (STAGE) value rows 0..31, gate rows 32..63
     T* W1Ts = W1s + 64 * LDX;                           // [C][LDH]    (STAGE) W1^T columns: value 0..31 | gate 32..63
     float* Fs = reinterpret_cast<float*>(smem_v);       // [64][LDF] fp32 dxn (aliases Xs|Ds after the main loop)
-    static_assert(64 * LDF * 4 <= 2 * 64 * LDX * sizeof(T), "fp32 dxn stage must fit in the two token tiles");
+    static_assert(GX || 64 * LDF * 4 <= 2 * 64 * LDX * sizeof(T), "fp32 dxn stage must fit in the two token tiles");
+    static_assert(!(GX && STAGE), "the global-operand form streams its weights");
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m0 = blockIdx.x * 64;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
             const int c0 = (q + 4 * i) * VEC;
             Vec16<T> o;
             for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
-            store16<T>(Xs + r * LDX + c0, o);
+            if (!GX) store16<T>(Xs + r * LDX + c0, o);
             store16<T>(XN + c0, o);
             Vec16<T> dmv;
             if (a.keep) {                             // DropPath backward fused: dm = keep[b] * dy, also kept for dW2 / db2
@@ -97,10 +100,13 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
             } else {
                 dmv = load16<T>(DM + (long)(m0 + r) * C + c0);
             }
-            store16<T>(Ds + r * LDX + c0, dmv);
+            if (!GX) store16<T>(Ds + r * LDX + c0, dmv);
         }
     }
     __syncthreads();
+    const T* Xop = GX ? reinterpret_cast<const T*>(a.XN) + (long)m0 * C : Xs;      // B operands of the chunk loop
+    const T* Dop = GX ? DM + (long)m0 * C : Ds;
+    constexpr int LDO = GX ? C : LDX;
 
     const T* W1 = reinterpret_cast<const T*>(a.W1);
     const T* W1T = reinterpret_cast<const T*>(a.W1T);
@@ -131,8 +137,8 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
         f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};          // dh tiles
 #pragma unroll 4
         for (int kk = 0; kk < C; kk += TR::KCHUNK) {
-            const frag_t bx = load_frag<T>(Xs, LDX, wv * 16, kk);
-            const frag_t bd = load_frag<T>(Ds, LDX, wv * 16, kk);
+            const frag_t bx = load_frag<T>(Xop, LDO, wv * 16, kk);
+            const frag_t bd = load_frag<T>(Dop, LDO, wv * 16, kk);
             if (STAGE) {
                 mma(v0, load_frag<T>(W1s, LDX, 0, kk), bx);
                 mma(v1, load_frag<T>(W1s, LDX, 16, kk), bx);
@@ -585,6 +591,11 @@ static int launch_mlp_bwd(const MlpBwdDev& d, int variant, hipStream_t s) {
     if constexpr (staged <= 160 * 1024) {
         allow_big_lds(gated_mlp_bwd_kernel<T, C, true>, staged);
         MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd_kernel<T, C, true>), dim3(d.M / 64), dim3(256), staged, s, d);
+    } else if constexpr (base > 160 * 1024) {
+        constexpr size_t gx = 64 * (size_t)(C + 4) * 4 + 4 * 16 * (64 + PAD) * sizeof(T) + 128 * sizeof(float);
+        static_assert(gx <= 160 * 1024, "gated_mlp_bwd: width does not fit LDS");
+        allow_big_lds(gated_mlp_bwd_kernel<T, C, false, true>, gx);
+        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd_kernel<T, C, false, true>), dim3(d.M / 64), dim3(256), gx, s, d);
     } else {
         allow_big_lds(gated_mlp_bwd_kernel<T, C, false>, base);
         MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd_kernel<T, C, false>), dim3(d.M / 64), dim3(256), base, s, d);
@@ -618,7 +629,6 @@ extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, voi
     MPHSIR_REQUIRE(a->M > 0 && a->M % 64 == 0 && a->HP > 0 && a->HP % 32 == 0, "gated_mlp_bwd: M %% 64 and HP %% 32 must be 0");
     MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->dY) && aligned16(a->DM) && aligned16(a->dX) && aligned16(a->XN) && aligned16(a->H) &&
                        aligned16(a->DPRE) && aligned16(a->W1) && aligned16(a->W1T) && aligned16(a->W2T), "gated_mlp_bwd: 16-byte alignment required");
-    if (dtype == MPHSIR_F32) MPHSIR_REQUIRE(a->C <= 256, "gated_mlp_bwd: fp32 supports C <= 256 (LDS budget)");
     MlpBwdDev d{a->X, a->dY, a->DM, a->ln_w, a->ln_b, a->W1, a->b1, a->W1T, a->W2T, a->dX, a->XN, a->H, a->DPRE, a->part,
                 (int)a->M, a->HP, a->keep, (long)a->rows_per_batch};
     MPHSIR_REQUIRE(!a->keep || (a->rows_per_batch > 0 && a->M % a->rows_per_batch == 0), "gated_mlp_bwd: keep needs rows_per_batch dividing M");

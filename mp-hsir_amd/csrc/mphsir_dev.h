@@ -78,6 +78,23 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const bf16_t* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
 }
 
+// Fragment of a K-STRIDED operand held row-major as [k][col] in LDS (pitch ld elements): row (l&15) of the fragment is
+// column col0 + (l&15), its K elements are rows k0 + EPL*(l>>4) .. of the tile -- the same map load_frag yields for the
+// transposed tile, without a transposed copy.  bf16: two hardware-transposed reads (rows +0..3 / +4..7; ld % 4 == 0,
+// col0 % 4 == 0); f32: four strided 4-byte reads.
+template <class T> __device__ __forceinline__ typename ElemTraits<T>::frag_t load_frag_tr(const T* base, int ld, int col0, int k0);
+template <> __device__ __forceinline__ bf16x8 load_frag_tr<bf16_t>(const bf16_t* base, int ld, int col0, int k0) {
+    const int l = lane_id(), g = l >> 4, q = (l & 15) >> 2, p = l & 3;
+    const bf16_t* a = base + (size_t)(k0 + 8 * g + q) * ld + col0 + 4 * p;
+    const bf16x4 lo = lds_read_tr16(a), hi = lds_read_tr16(a + 4 * ld);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+template <> __device__ __forceinline__ f32x4 load_frag_tr<float>(const float* base, int ld, int col0, int k0) {
+    const int l = lane_id();
+    const float* a = base + (size_t)(k0 + 4 * (l >> 4)) * ld + col0 + (l & 15);
+    return f32x4{a[0], a[ld], a[2 * ld], a[3 * ld]};
+}
+
 template <class T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }

@@ -30,7 +30,7 @@ struct WinAttnDev {
     const float* Wpproj; const float* bpproj; const float* Wup;
     void* SA; float* gate;
     float* mu;      // optional [B*nW][C]: window mean of SA (training: input of the gate's autograd)
-    void* Oattn;    // optional (B,H,W,C): attention output before proj, image order (training: dWproj)
+    void* Oattn;    // optional [B*nW*64][C]: attention output before proj, window-token order (training: dWproj)
     int B, H, W, shift, r;
 };
 
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
             T* Oa = reinterpret_cast<T*>(a.Oattn);
             for (int idx = tid; idx < 64 * VPH; idx += 256) {
                 const int t = idx / VPH, c0 = (idx % VPH) * VEC;
-                store16<T>(Oa + pixel_of(t) * C + h * HD + c0, load16<T>(Qs + t * CF::LDQ + c0));
+                store16<T>(Oa + ((long)blockIdx.x * 64 + t) * C + h * HD + c0, load16<T>(Qs + t * CF::LDQ + c0));
             }
         }
 

@@ -85,6 +85,7 @@ class Spectral_Attention(nn.Module):                                            
 
         def build():
             return dict(wqkv=self.qkv.weight.reshape(3 * C, C).to(ops.cdt(dtype)).contiguous(),
+                        wqkvT=self.qkv.weight.reshape(3 * C, C).t().to(ops.cdt(dtype)).contiguous(),      # backward: dX = dY W
                         w9=ops.pack_dw(self.qkv_dwconv.weight),
                         wo=self.project_out.weight.reshape(C, C).float().contiguous(),
                         temp=self.temperature.reshape(-1).float().contiguous())
@@ -163,6 +164,7 @@ class PGSSTB(nn.Module):                                                        
             f = lambda t: t.detach().float().contiguous()
             return dict(
                 wqkv=a.qkv.weight.to(ops.cdt(dtype)).contiguous(), bqkv=f(a.qkv.bias),
+                wqkvT=a.qkv.weight.t().to(ops.cdt(dtype)).contiguous(),
                 wproj=ops.pack_win_proj(a.proj.weight, self.num_heads, dtype), bproj=f(a.proj.bias),
                 wprojT=a.proj.weight.t().to(ops.cdt(dtype)).contiguous(),
                 rpb=f(a.relative_position_bias_table), W1=W1, b1=b1, W2=W2, b2=f(m.fc2.bias),
@@ -244,7 +246,7 @@ class FeedForward(nn.Module):                                                   
             w9[:, :hid], w9[:, HP:HP + hid] = w9s[:, :hid], w9s[:, hid:]
             w_out = torch.zeros((D, HP), dtype=ops.cdt(dtype), device=dev)
             w_out[:, :hid] = self.project_out.weight.reshape(D, hid).to(ops.cdt(dtype))
-            return dict(w_in=w_in, w9=w9, w_out=w_out)
+            return dict(w_in=w_in, w9=w9, w_out=w_out, w_inT=w_in.t().contiguous(), w_outT=w_out.t().contiguous())
         return self._cache.get(ps, dtype, build)
 
 
@@ -270,6 +272,8 @@ class CrossAttention(nn.Module):                                                
         def build():
             return dict(wq=self.q.weight.reshape(D, D).to(ops.cdt(dtype)).contiguous(),
                         wkv=self.kv.weight.reshape(2 * D, D).to(ops.cdt(dtype)).contiguous(),
+                        wqT=self.q.weight.reshape(D, D).t().to(ops.cdt(dtype)).contiguous(),
+                        wkvT=self.kv.weight.reshape(2 * D, D).t().to(ops.cdt(dtype)).contiguous(),
                         w9=torch.cat([ops.pack_dw(self.q_dwconv.weight), ops.pack_dw(self.kv_dwconv.weight)], 1).contiguous(),
                         wo=self.project_out.weight.reshape(D, D).float().contiguous(),
                         temp=self.temperature.reshape(-1).float().contiguous())

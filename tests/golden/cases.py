@@ -24,16 +24,16 @@ TINY_CASES = {
 # One PGSSTB per shape class of both shipped configurations (SURVEY §8d stage table), plus the
 # prompt modules at natural level-2 width.
 BLOCK_CASES = {
-    "nat_enc1": dict(man="natural_mode0", prefix="encoder_level1.blocks.1.", kind="pgsstb", C=64, heads=2, cr=8, shift=4, shape=(2, 64, 32, 32), intermediates=True, grad=True),
-    "nat_enc2": dict(man="natural_mode0", prefix="encoder_level2.blocks.0.", kind="pgsstb", C=128, heads=4, cr=16, shift=0, shape=(1, 128, 32, 32)),
-    "nat_latent": dict(man="natural_mode0", prefix="latent.blocks.1.", kind="pgsstb", C=256, heads=8, cr=32, shift=4, shape=(1, 256, 16, 16)),
-    "nat_refine": dict(man="natural_mode0", prefix="refinement.blocks.1.", kind="pgsstb", C=128, heads=2, cr=8, shift=4, shape=(1, 128, 32, 32)),
-    "rs_enc1": dict(man="remote_mode8", prefix="encoder_level1.blocks.1.", kind="pgsstb", C=96, heads=2, cr=8, shift=4, shape=(1, 96, 32, 32)),
-    "rs_enc2": dict(man="remote_mode8", prefix="encoder_level2.blocks.0.", kind="pgsstb", C=192, heads=4, cr=16, shift=0, shape=(1, 192, 32, 32)),
-    "rs_latent": dict(man="remote_mode8", prefix="latent.blocks.1.", kind="pgsstb", C=384, heads=8, cr=32, shift=4, shape=(1, 384, 16, 16)),
-    "rs_refine": dict(man="remote_mode8", prefix="refinement.blocks.1.", kind="pgsstb", C=192, heads=2, cr=8, shift=4, shape=(1, 192, 32, 32)),
-    "tvsp_l2": dict(man="natural_mode0", prefix="prompt2.", kind="tvsp", T=6, ps=32, D=128, shape=(2, 128, 32, 32), task=[0, 3]),
-    "fusion_l2": dict(man="natural_mode0", prefix="fusion2.", kind="fusion", D=128, heads=8, shape=(1, 128, 32, 32)),
+    "nat_enc1": dict(man="natural_mode0", prefix="encoder_level1.blocks.1.", kind="pgsstb", C=64, heads=2, cr=8, shift=4, shape=(2, 64, 32, 32), intermediates=True, grad=True, grad_full=True),
+    "nat_enc2": dict(man="natural_mode0", prefix="encoder_level2.blocks.0.", kind="pgsstb", C=128, heads=4, cr=16, shift=0, shape=(1, 128, 32, 32), grad=True),
+    "nat_latent": dict(man="natural_mode0", prefix="latent.blocks.1.", kind="pgsstb", C=256, heads=8, cr=32, shift=4, shape=(1, 256, 16, 16), grad=True),
+    "nat_refine": dict(man="natural_mode0", prefix="refinement.blocks.1.", kind="pgsstb", C=128, heads=2, cr=8, shift=4, shape=(1, 128, 32, 32), grad=True),
+    "rs_enc1": dict(man="remote_mode8", prefix="encoder_level1.blocks.1.", kind="pgsstb", C=96, heads=2, cr=8, shift=4, shape=(1, 96, 32, 32), grad=True),
+    "rs_enc2": dict(man="remote_mode8", prefix="encoder_level2.blocks.0.", kind="pgsstb", C=192, heads=4, cr=16, shift=0, shape=(1, 192, 32, 32), grad=True),
+    "rs_latent": dict(man="remote_mode8", prefix="latent.blocks.1.", kind="pgsstb", C=384, heads=8, cr=32, shift=4, shape=(1, 384, 16, 16), grad=True),
+    "rs_refine": dict(man="remote_mode8", prefix="refinement.blocks.1.", kind="pgsstb", C=192, heads=2, cr=8, shift=4, shape=(1, 192, 32, 32), grad=True),
+    "tvsp_l2": dict(man="natural_mode0", prefix="prompt2.", kind="tvsp", T=6, ps=32, D=128, shape=(2, 128, 32, 32), task=[0, 3], grad=True),
+    "fusion_l2": dict(man="natural_mode0", prefix="fusion2.", kind="fusion", D=128, heads=8, shape=(1, 128, 32, 32), grad=True),
 }
 
 NATURAL_CFG = dict(in_channel=31, out_channel=31, dim=64, task_classes=6)       # test.py:39
@@ -49,6 +49,13 @@ FULL_CASES = {
 # parameter-gradient tensors stored in full in tiny_grad.npz (everything else: norm/sum/samples)
 GRAD_KEYS_FULL = ("encoder_level1.blocks.1.", "prompt1.", "fusion1.", "patch_embed.", "output.",
                   "reduce_chan_level2.", "down1_2.", "up2_1.")
+
+
+# block gradients (blocks.npz): tensors up to this many elements are stored in full, larger ones as their norm plus
+# GRAD_SAMPLES seeded samples (the fixture stays a few MB; full-tensor checks of the large ones run against the
+# oracle's fp64 autograd, which these fixtures pin)
+GRAD_FULL_MAX = 32768
+GRAD_SAMPLES = 4096
 
 
 def sample_indices(key, numel, n=12):

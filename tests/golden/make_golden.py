@@ -30,7 +30,7 @@ warnings.filterwarnings("ignore")
 
 from golden.detfill import det_fill_, seeded_input, surrogate_clip_prompt  # noqa: E402
 from golden.cases import (TINY_CFG, TINY_CASES, BLOCK_CASES, FULL_CASES, GRAD_KEYS_FULL,  # noqa: E402
-                          sample_indices, cotangent)
+                          GRAD_FULL_MAX, GRAD_SAMPLES, sample_indices, cotangent)
 import net.MP_HSIR as ref  # noqa: E402  (the reference)
 
 torch.set_num_threads(8)
@@ -122,6 +122,16 @@ def gen_tiny_grad():
     np.savez_compressed(os.path.join(HERE, "tiny_adamw.npz"), **out)
 
 
+def put_grad(out, name, key, g):
+    """gradient tensor -> fixture entries: full when small (or the case asks for it), else norm + seeded samples."""
+    if g.numel() <= GRAD_FULL_MAX or BLOCK_CASES[name].get("grad_full", False):
+        out["%s/%s" % (name, key)] = to_np(g)
+    else:
+        idx = sample_indices(name + ":" + key, g.numel(), GRAD_SAMPLES)
+        out["%s/samp/%s" % (name, key)] = to_np(g.flatten()[idx])
+        out["%s/norm/%s" % (name, key)] = np.array(float(g.norm()))
+
+
 def gen_blocks():
     out = {}
     for name, c in BLOCK_CASES.items():
@@ -144,9 +154,9 @@ def gen_blocks():
                     p.requires_grad_(True)
                 y = m(x)
                 (y * cotangent(name, y.shape).double()).sum().backward()
-                out[name + "/dx"] = to_np(x.grad)
+                put_grad(out, name, "dx", x.grad)
                 for k, p in m.named_parameters():
-                    out[name + "/dparam/" + k] = to_np(p.grad)
+                    put_grad(out, name, "dparam/" + k, p.grad)
             else:
                 with torch.no_grad():
                     y = m(x)
@@ -162,17 +172,28 @@ def gen_blocks():
             w = F.one_hot(task_tensor(c["task"]), c["T"])
             clip = (w.unsqueeze(-1) * surrogate_clip_prompt(c["T"]).double().unsqueeze(0)).mean(1)
             assert clip.shape == (B, 512)
-            with torch.no_grad():
-                y = m(x, clip, w)
+            for p in m.parameters():
+                p.requires_grad_(True)
+            y = m(x, clip, w)
+            (y * cotangent(name, y.shape).double()).sum().backward()
+            for k, p in m.named_parameters():
+                if p.grad is not None:          # text_linear / clip_linear never receive one
+                    put_grad(out, name, "dparam/" + k, p.grad)
             out[name + "/out"] = to_np(y)
         elif kind == "fusion":
             m = ref.PromptFusion(dim=c["D"] * 2, out_dim=c["D"], head=c["heads"]).eval()
             det_fill_(m)
             m = m.double()
-            x = seeded_input(name + ":x", c["shape"], "normal").double()
-            p = seeded_input(name + ":p", c["shape"], "normal").double()
-            with torch.no_grad():
-                y = m(x, p)
+            x = seeded_input(name + ":x", c["shape"], "normal").double().requires_grad_(True)
+            p = seeded_input(name + ":p", c["shape"], "normal").double().requires_grad_(True)
+            for q in m.parameters():
+                q.requires_grad_(True)
+            y = m(x, p)
+            (y * cotangent(name, y.shape).double()).sum().backward()
+            put_grad(out, name, "dx", x.grad)
+            put_grad(out, name, "dprompt", p.grad)
+            for k, q in m.named_parameters():
+                put_grad(out, name, "dparam/" + k, q.grad)
             out[name + "/out"] = to_np(y)
         print("block", name, tuple(y.shape), float(y.abs().mean()))
     np.savez_compressed(os.path.join(HERE, "blocks.npz"), **out)
