@@ -67,7 +67,7 @@ def cpu_baseline(batch=2, iters=2):
     from oracle import mp_hsir_oracle as O
     from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
     torch.manual_seed(2024)
-    net = MP_HSIR_Net()
+    net = MP_HSIR_Net(clip_prompt="surrogate")
     P = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()
          if not k.endswith("attn_mask")}
     cfg = O.make_cfg()
@@ -109,7 +109,7 @@ def main():
     lib = _lib.load()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(2024)
-    net = MP_HSIR_Net(compute_dtype=dt).to(dev)
+    net = MP_HSIR_Net(compute_dtype=dt, clip_prompt="surrogate").to(dev)      # no CLIP weights offline: seeded stand-in (timing only)
     src = SyntheticPatchSource(31, args.patch, args.batch, 6, dev, 2024, rank)
     if args.forward_only:
         net.eval()

@@ -222,6 +222,12 @@ int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const f
                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, const float* ln_b, void* XN, int32_t linear,
                       int dtype, void* stream);
 
+/* ---- stand-alone LayerNorm over channels (SURVEY 8b `layernorm_nhwc`; net/MP_HSIR.py:341-370) ---------------------------
+ * Y[m][:] = LN(X[m][:]) * ln_w + ln_b, biased variance, eps 1e-5, statistics in fp32.  X and Y may have different element
+ * types (x_dtype / y_dtype): TVSP's norm11 (:282) reads the fp32 rank-one text map and writes the compute dtype.        */
+int mphsir_layernorm_tok(const void* X, int x_dtype, const float* ln_w, const float* ln_b, void* Y, int y_dtype,
+                         int64_t M, int32_t C, void* stream);
+
 /* ---- backward of the two small per-sample / per-window stages -----------------------------------------
  * mphsir_spectral_fold_bwd: backward of mphsir_spectral_fold.  dM [B][C][C] fp32 = gradient w.r.t. M_b.  Outputs:
  *   W2 [B][2C][2C] (compute dtype) such that [dq | dk] = [q | k] W2_b^T is one mphsir_gemm_tok with a per-sample
@@ -352,6 +358,7 @@ int mphsir_pack_gather(const float* arena, const int32_t* index, void* dst, int6
 #define MPHSIR_K_IM2COL 18
 #define MPHSIR_K_REDUCE_PARTS 19
 #define MPHSIR_K_PACK_GATHER 20
+#define MPHSIR_K_LAYERNORM 21
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -290,33 +290,40 @@ class _SelfChannelAttnRes(torch.autograd.Function):
 
 
 class _CrossChannelAttnRes(torch.autograd.Function):
-    """a = x_q + M_b v, q from x_q, k/v from x_kv   (ref CrossAttention :220-249 inside :282)."""
+    """a = x_q + M_b v, q from x_q, k/v from x_kv   (ref CrossAttention :220-249 inside :282).
+
+    x_q is TVSP's text map and arrives in fp32: it is rank one (clip[i,j] * L[b,:]), which makes the gradients through
+    norm11 residuals of large cancelling sums -- rounding it to bf16 before the LayerNorm changes d(norm11.weight) and
+    d(q.weight) by 15 % (csrc/layernorm.hip).  So norm11 runs on the fp32 input (layernorm_tok, fp32 statistics, output
+    in the compute dtype) and its backward in fp32, as the reference's autocast does; everything after it is the
+    compute-dtype path."""
 
     @staticmethod
-    def forward(ctx, ct, geom, text2, vis2, n11w, n11b, n12w, n12b, w_q, w_kv, w_qdw, w_kvdw, w_out, temp):
+    def forward(ctx, ct, geom, dt, text32, vis2, n11w, n11b, n12w, n12b, w_q, w_kv, w_qdw, w_kvdw, w_out, temp):
         B, H, W = geom
-        D = text2.shape[1]
-        dt = text2.dtype
+        D = text32.shape[1]
         pa = ct.attn.packed(dt)
-        tq = ops.gemm_tok(text2, pa["wq"], ln=ct.norm11.pair())
+        lw, lb = ct.norm11.pair()
+        xq = ops.layernorm_tok(text32, lw, lb, dt)
+        tq = ops.gemm_tok(xq, pa["wq"])
         tkv = ops.gemm_tok(vis2, pa["wkv"], ln=ct.norm12.pair())
         w9 = pa["w9"]
         v, gp, sp, _ = ops.dwconv_gram(tq, tkv[:, :D], tkv[:, D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
                                        B, H, W, D, ct.attn.num_heads)
         Mb, MbT, gp, sp = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
-        a = ops.gemm_tok(v, Mb, epi=1, res=text2)
+        a = ops.gemm_tok(v, Mb, epi=1, res=text32.to(dt))
         ctx.ct, ctx.geom = ct, geom
-        ctx.save_for_backward(text2, vis2, tq, tkv, v, gp, sp, Mb, MbT)
+        ctx.save_for_backward(text32, vis2, xq, tq, tkv, v, gp, sp, Mb, MbT)
         return a
 
     @staticmethod
     def backward(ctx, da):
-        text2, vis2, tq, tkv, v, gp, sp, Mb, MbT = ctx.saved_tensors
+        text32, vis2, xq, tq, tkv, v, gp, sp, Mb, MbT = ctx.saved_tensors
         ct, (B, H, W) = ctx.ct, ctx.geom
         attn = ct.attn
-        D = text2.shape[1]
-        M = text2.shape[0]
-        pa = attn.packed(text2.dtype)
+        D = text32.shape[1]
+        M = text32.shape[0]
+        pa = attn.packed(vis2.dtype)
         w9 = pa["w9"]
         da = da.contiguous()
         tq4, tkv4 = tq.reshape(B, H, W, D), tkv.reshape(B, H, W, 2 * D)
@@ -324,15 +331,16 @@ class _CrossChannelAttnRes(torch.autograd.Function):
             dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
                 da, tq4, tkv4[..., :D], tkv4[..., D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
                 attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
-            dtq2 = dtq.reshape(M, D)
+            dtq2 = dtq.reshape(M, D).contiguous()
             dkv = torch.cat([dtk, dtv], dim=-1).reshape(M, 2 * D)
             n11w, n11b = ct.norm11.pair()
             n12w, n12b = ct.norm12.pair()
-            dtext, d11w, d11b, xq = ops.ln_bwd_tok(text2, ops.gemm_tok(dtq2.contiguous(), pa["wqT"]), da, n11w, n11b)
+            # norm11 backward in fp32 on the fp32 text map (see the class docstring); dres = the residual path of `a`
+            dtext, d11w, d11b, _ = ops.ln_bwd_tok(text32, ops.gemm_tok(dtq2, pa["wqT"]).float(), da.float(), n11w, n11b)
             dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis2, ops.gemm_tok(dkv, pa["wkvT"]), torch.zeros_like(vis2), n12w, n12b)
             d_wq = ops.gemm_tn(dtq2, xq).reshape(D, D, 1, 1)
             d_wkv = ops.gemm_tn(dkv, xv).reshape(2 * D, D, 1, 1)
-        return (None, None, dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.reshape(D, 1, 3, 3),
+        return (None, None, None, dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.reshape(D, 1, 3, 3),
                 _join_taps(dwk, dwv).reshape(2 * D, 1, 3, 3), dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1))
 
 
@@ -345,11 +353,11 @@ def tvsp(mod, x, clip_prompt, prompt_weights):
     L = (prompt_weights.to(torch.float32).unsqueeze(-1) * learn.unsqueeze(0)).mean(dim=1)      # (B,D)
     ar = torch.arange(ps, device=dev)
     clip_map = clip_prompt[(ar * B) // ps][:, (ar * 512) // ps]                       # (ps,ps)
-    text = (clip_map[None, :, :, None] * L[:, None, None, :]).to(dt).contiguous()
+    text = (clip_map[None, :, :, None] * L[:, None, None, :]).float().contiguous()     # fp32: see _CrossChannelAttnRes
     vis = mod.visual_prompt.permute(0, 2, 3, 1).expand(B, ps, ps, D).to(dt).contiguous()
     ct = mod.cross_transformer
     at = ct.attn
-    a = _CrossChannelAttnRes.apply(ct, (B, ps, ps), text.reshape(-1, D), vis.reshape(-1, D), ct.norm11.body.weight,
+    a = _CrossChannelAttnRes.apply(ct, (B, ps, ps), dt, text.reshape(-1, D), vis.reshape(-1, D), ct.norm11.body.weight,
                                    ct.norm11.body.bias, ct.norm12.body.weight, ct.norm12.body.bias, at.q.weight, at.kv.weight,
                                    at.q_dwconv.weight, at.kv_dwconv.weight, at.project_out.weight, at.temperature)
     y = _gdfn_res_ag(ct.ffn, ct.norm2, a, B, ps, ps).reshape(B, ps, ps, D)

@@ -1,0 +1,60 @@
+// layernorm_tok: stand-alone LayerNorm over channels of a token matrix, with independent input / output element types.
+//
+// Everywhere else LayerNorm is the prologue of the kernel that consumes it (gemm_tok, win_attn, gated_mlp).  The one
+// exception is norm11 of TVSP's CrossTransformer (net/MP_HSIR.py:282): its input, the text map
+// text[b,i,j,:] = clip[i,j] * L[b,:] (:575-577), is rank one, so the gradients that flow back through it are small
+// residuals of large cancelling sums -- rounding the INPUT to bf16 first changes d(norm11.weight) and d(q.weight) by
+// 15 % even in exact arithmetic (measured with the fp64 oracle).  The reference under autocast keeps that LayerNorm in
+// fp32 on the fp32 input; so does this kernel: fp32 in, statistics in fp32, output in the compute dtype.
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void layernorm_tok_kernel(const TI* __restrict__ X, const float* __restrict__ w,
+                                                            const float* __restrict__ b, TO* __restrict__ Y, long M, int C) {
+    // 4 adjacent lanes per token, 64 tokens per workgroup; element-wise (strided by 4) so any C % 4 == 0 works
+    const int tid = threadIdx.x, q = tid & 3;
+    const long t = (long)blockIdx.x * 64 + (tid >> 2);
+    if (t >= M) return;              // whole lane quads leave together (the shuffles below stay inside a quad)
+    const TI* x = X + t * C;
+    float s = 0.f;
+    for (int c = q; c < C; c += 4) s += to_f32(x[c]);
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const float mean = s / (float)C;
+    float d2 = 0.f;
+    for (int c = q; c < C; c += 4) { const float d = to_f32(x[c]) - mean; d2 += d * d; }
+    d2 += __shfl_xor(d2, 1);
+    d2 += __shfl_xor(d2, 2);
+    const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+    TO* y = Y + t * C;
+    for (int c = q; c < C; c += 4) y[c] = from_f32<TO>((to_f32(x[c]) - mean) * rstd * w[c] + b[c]);
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_layernorm_tok(const void* X, int x_dtype, const float* ln_w, const float* ln_b, void* Y, int y_dtype,
+                                    int64_t M, int32_t C, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(X && ln_w && ln_b && Y, "layernorm_tok: null pointer");
+    MPHSIR_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "layernorm_tok: M > 0 and C %% 4 == 0 required");
+    MPHSIR_REQUIRE((x_dtype == MPHSIR_F32 || x_dtype == MPHSIR_BF16) && (y_dtype == MPHSIR_F32 || y_dtype == MPHSIR_BF16),
+                   "layernorm_tok: dtype unsupported");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((M + 63) / 64)), block(256);
+#define MPHSIR_LN_CASE(xi, TI, yo, TO)                                                                          \
+    if (x_dtype == xi && y_dtype == yo) {                                                                      \
+        MPHSIR_LAUNCH(MPHSIR_K_LAYERNORM, (layernorm_tok_kernel<TI, TO>), grid, block, 0, s,                    \
+                      reinterpret_cast<const TI*>(X), ln_w, ln_b, reinterpret_cast<TO*>(Y), (long)M, (int)C);   \
+        return MPHSIR_OK;                                                                                      \
+    }
+    MPHSIR_LN_CASE(MPHSIR_F32, float, MPHSIR_F32, float)
+    MPHSIR_LN_CASE(MPHSIR_F32, float, MPHSIR_BF16, bf16_t)
+    MPHSIR_LN_CASE(MPHSIR_BF16, bf16_t, MPHSIR_BF16, bf16_t)
+    MPHSIR_LN_CASE(MPHSIR_BF16, bf16_t, MPHSIR_F32, float)
+#undef MPHSIR_LN_CASE
+    return MPHSIR_EINVAL;
+}

@@ -8,14 +8,25 @@ patch (utils/image_utils.py:437-439), a task id per sample, and the Gaussian-noi
 sigma ~ U(30,70)/255 (utils/degradation_utils.py:25-31).  Explicit torch.Generator seeding
 (seed 2024 = options.py:7) replaces the reference's global numpy/random state.
 """
+import os
+
+import numpy as np
 import torch
+
+from . import degrade
 
 
 class SyntheticPatchSource:
-    def __init__(self, bands=31, patch=64, batch=32, task_classes=6, device="cuda", seed=2024, rank=0):
+    """de_types=None: every sample gets the Gaussian-noise degradation (the bench workload: BASELINE configs[2]) and a
+    uniformly drawn task id; de_types=[...] (options.*_single_de_type): the full per-task menu through
+    degrade.DegradationSynthesizer, task id = index of the degradation applied (as ImageTransformDataset does)."""
+
+    def __init__(self, bands=31, patch=64, batch=32, task_classes=6, device="cuda", seed=2024, rank=0, de_types=None,
+                 data_type="natural_scene"):
         self.shape = (batch, bands, patch, patch)
         self.task_classes, self.device = task_classes, device
         self.gen = torch.Generator(device=device).manual_seed(seed + 7919 * rank)
+        self.syn = degrade.DegradationSynthesizer(data_type, de_types, device, seed + 7919 * rank + 1) if de_types else None
 
     def next(self):
         B = self.shape[0]
@@ -23,8 +34,109 @@ class SyntheticPatchSource:
         lo = clean.amin(dim=(1, 2, 3), keepdim=True)
         hi = clean.amax(dim=(1, 2, 3), keepdim=True)
         clean = (clean - lo) / (hi - lo)
+        if self.syn is not None:
+            degraded, clean, prompt = self.syn(clean)
+            return [["synthetic_%08d" % i for i in range(B)], prompt[:, 0]], degraded, clean, prompt
         sigma = (30.0 + 40.0 * torch.rand((B, 1, 1, 1), generator=self.gen, device=self.device)) / 255.0
         degraded = clean + sigma * torch.randn(self.shape, generator=self.gen, device=self.device)
         prompt = torch.randint(0, self.task_classes, (B, 1), generator=self.gen, device=self.device)
         names = ["synthetic_%08d" % i for i in range(B)]
+        return [names, prompt[:, 0]], degraded, clean, prompt
+
+
+# ---- the training patch database ------------------------------------------------------------------------------------------
+# The reference stores training patches in LMDB (utils/lmdb_patch.py:108-114): key '%08d' -> the raw float32 bytes of a
+# (C,H,W) patch, plus `meta_info.txt` with one line per record: "<key> (<h>,<w>,<c>) source_file=<name>".  `lmdb` is not
+# available offline and a B-tree buys nothing for sequential fixed-order records, so the same RECORDS live in one flat file
+# `data.bin` (concatenated in key order) next to the same meta_info.txt; offsets follow from the recorded dimensions.
+REMOTE_SENSING_SOURCES = ("BerlinUrGrad", "Chikusei", "Eagle", "Xiongan", "Houston", "PaviaC", "PaviaU", "WDC")   # dataset_utils.py:56
+
+
+def write_patch_db(db_path, patches, source_files):
+    """patches: iterable of (C,H,W) float32 arrays; writes data.bin + meta_info.txt in the reference's record format."""
+    os.makedirs(db_path, exist_ok=True)
+    with open(os.path.join(db_path, "data.bin"), "wb") as fb, open(os.path.join(db_path, "meta_info.txt"), "w") as ft:
+        for k, (x, fn) in enumerate(zip(patches, source_files)):
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            c, h, w = x.shape
+            ft.write("%08d (%d,%d,%d) source_file=%s\n" % (k, h, w, c, fn))
+            fb.write(x.tobytes())
+
+
+class PatchDB:
+    """LMDBDataset (utils/dataset_utils.py:39-100) over the flat record file: reads meta_info.txt the way the reference
+    does (including `strip('source_file=')`, a character-set strip), keeps the records whose source file starts with one
+    of `dataset_names` (None = all), returns (X (C,H,W) float32, source_file); index wraps modulo the length."""
+
+    def __init__(self, db_path, dataset_names=REMOTE_SENSING_SOURCES):
+        self.db_path = db_path
+        self.records = []                                  # (byte offset, (C,H,W), source_file)
+        off = 0
+        with open(os.path.join(db_path, "meta_info.txt")) as f:
+            for line in f:
+                parts = line.strip().split(" ")
+                if len(parts) < 3:
+                    continue
+                h, w, c = tuple(map(int, parts[1].strip("()").split(",")))
+                src = parts[2].strip("source_file=")
+                if dataset_names is None or any(src.startswith(n) for n in dataset_names):
+                    self.records.append((off, (c, h, w), src))
+                off += 4 * c * h * w
+        self.data = np.memmap(os.path.join(db_path, "data.bin"), dtype=np.uint8, mode="r")
+        if off != self.data.shape[0]:
+            raise ValueError("%s: data.bin has %d bytes, meta_info.txt describes %d" % (db_path, self.data.shape[0], off))
+
+    def __len__(self):
+        return len(self.records)
+
+    def __getitem__(self, index):
+        off, shape, src = self.records[index % len(self.records)]
+        n = 4 * shape[0] * shape[1] * shape[2]
+        return np.frombuffer(self.data[off:off + n], dtype=np.float32).reshape(shape), src
+
+
+class PatchDBSource:
+    """The training loader (LMDBDataset + ImageTransformDataset + DataLoader(shuffle=True, drop_last=True),
+    train.py:97-101) with the degradations moved to the GPU: per step `batch` records are gathered on the host (memmap ->
+    one pinned staging buffer -> one async copy), natural-scene cubes with another band count are band-interpolated to 31
+    (dataset_utils.py:131-132), and degrade.DegradationSynthesizer produces (degraded, clean, prompt) on the device.
+    Each rank walks its own seeded permutation (DistributedSampler-style shard: index = perm[rank::world])."""
+
+    def __init__(self, db, batch, de_types, data_type, device, seed=2024, rank=0, world=1, repeat=1):
+        self.db, self.batch, self.device, self.data_type = db, batch, torch.device(device), data_type
+        self.rank, self.world, self.repeat = rank, world, repeat
+        self.rng = np.random.RandomState(seed)                       # same permutation on every rank, then sharded
+        self.syn = degrade.DegradationSynthesizer(data_type, de_types, device, seed + 7919 * rank + 1)
+        self.order, self.pos, self._copied = None, 0, None
+        c, h, w = db.records[0][1]
+        self.stage = torch.empty((batch, c, h, w), dtype=torch.float32)
+        if self.device.type == "cuda":
+            self.stage = self.stage.pin_memory()
+
+    def steps_per_epoch(self):
+        return len(self.db) * self.repeat // (self.batch * self.world)
+
+    def _next_indices(self):
+        if self.order is None or self.pos + self.batch > len(self.order):
+            perm = self.rng.permutation(len(self.db) * self.repeat)
+            self.order, self.pos = perm[self.rank::self.world], 0
+        idx = self.order[self.pos:self.pos + self.batch]
+        self.pos += self.batch
+        return idx
+
+    def next(self):
+        names = []
+        if self._copied is not None:
+            self._copied.synchronize()                   # the previous step's async copy has left the staging buffer
+        for j, i in enumerate(self._next_indices()):
+            x, src = self.db[int(i)]
+            self.stage[j].copy_(torch.from_numpy(np.array(x)))
+            names.append(src)
+        clean = self.stage.to(self.device, non_blocking=True)
+        if self.device.type == "cuda":
+            self._copied = torch.cuda.Event()
+            self._copied.record()
+        if self.data_type == "natural_scene" and clean.shape[1] != 31:
+            clean = degrade.interpolate_bands(clean, 31)
+        degraded, clean, prompt = self.syn(clean)
         return [names, prompt[:, 0]], degraded, clean, prompt

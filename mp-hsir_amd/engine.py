@@ -145,7 +145,7 @@ class DataParallelEngine:
         # gradient gather and -- on one GPU -- the AdamW kernel) is captured once and replayed: ~2000 launches per
         # step make the eager loop host-bound.  With world > 1 the all-reduce stays outside the graph (one
         # arena-wide reduction after the replay: 58 MB over xGMI is <1 ms next to a ~45 ms step).
-        self.use_graph, self.graph_warmup, self._graph = use_graph, graph_warmup, None
+        self.use_graph, self.graph_warmup, self._graph, self._graph_key = use_graph, graph_warmup, None, None
         self.use_pack_plan, self.plan = use_pack_plan, None
         self.force_eager = False        # diagnostics: run a graph-mode engine's step with eager launches (same data flow)
         if self.world > 1:      # DDP's initial parameter broadcast (rank 0 -> all), one flat message
@@ -234,9 +234,20 @@ class DataParallelEngine:
         import math
         return [lr, 1.0 - self.betas[0] ** step, math.sqrt(1.0 - self.betas[1] ** step)]
 
+    def _capture_key(self, degraded, clean, prompt):
+        """everything the captured launch sequence depends on besides the buffer contents"""
+        return (tuple(degraded.shape), degraded.dtype, tuple(clean.shape), clean.dtype, tuple(prompt.shape), prompt.dtype,
+                self.net.training, getattr(self.net, "_dtype", lambda: None)())
+
     def _train_step_graph(self, degraded, clean, prompt, lr):
         dev = degraded.device
+        key = self._capture_key(degraded, clean, prompt)
+        if self._graph is not None and key != self._graph_key:
+            # another batch shape / dtype / train-eval mode / compute dtype: the captured launches no longer apply.
+            # Drop the graph and capture again (copy_ into the static buffers would otherwise broadcast or fail).
+            self._graph = None
         if self._graph is None:
+            self._graph_key = key
             self._sx, self._sc, self._sp = degraded.clone(), clean.clone(), prompt.clone()
             self._hyper = torch.zeros(3, dtype=torch.float32, device=dev)
             torch.cuda.synchronize()
@@ -254,6 +265,7 @@ class DataParallelEngine:
                         self.plan.refresh()
                 self._sloss = loss.detach()
             self._graph = g
+        assert self._sx.shape == degraded.shape and self._sc.shape == clean.shape and self._sp.shape == prompt.shape
         self._sx.copy_(degraded)
         self._sc.copy_(clean)
         self._sp.copy_(prompt)
@@ -267,6 +279,38 @@ class DataParallelEngine:
             if self.plan is not None:
                 self.plan.refresh()
         return self._sloss
+
+    # ---- optimizer state for checkpoints (the reference's Lightning checkpoints carry AdamW's moments and step) ----------
+    def optimizer_state(self):
+        """{'step', 'exp_avg': {param name: tensor}, 'exp_avg_sq': {...}} -- per parameter NAME, so it survives a different
+        arena layout; parameters without gradient have no entry."""
+        if self.arena is None:
+            return {"step": self.step_count, "exp_avg": {}, "exp_avg_sq": {}}
+        names = {id(p): n for n, p in self.net.named_parameters()}
+        used, offs, _ = self.arena
+        m = {names[id(p)]: self.flat_m[o:o + p.numel()].view(p.shape).detach().cpu().clone() for p, o in zip(used, offs)}
+        v = {names[id(p)]: self.flat_v[o:o + p.numel()].view(p.shape).detach().cpu().clone() for p, o in zip(used, offs)}
+        return {"step": self.step_count, "exp_avg": m, "exp_avg_sq": v}
+
+    def load_optimizer_state(self, state):
+        """restore what optimizer_state() returned; call any time before or after the first step (it is applied as soon
+        as the arenas exist)."""
+        self._resume = state
+        self.step_count = int(state["step"])
+        if self.arena is not None:
+            self._apply_resume()
+
+    def _apply_resume(self):
+        state, self._resume = getattr(self, "_resume", None), None
+        if state is None:
+            return
+        names = {id(p): n for n, p in self.net.named_parameters()}
+        used, offs, _ = self.arena
+        for p, o in zip(used, offs):
+            n = names[id(p)]
+            if n in state["exp_avg"]:
+                self.flat_m[o:o + p.numel()].copy_(state["exp_avg"][n].reshape(-1))
+                self.flat_v[o:o + p.numel()].copy_(state["exp_avg_sq"][n].reshape(-1))
 
     def finish(self):
         """call before using the network eagerly again after graph-mode training (packed-weight caches were last
@@ -293,6 +337,7 @@ class DataParallelEngine:
                     self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
         if first:
             self._build_arenas()
+            self._apply_resume()
             if self.world > 1:
                 for s, e, _ in self.buckets:
                     self._pending.append(dist.all_reduce(self.flat_g[s:e], group=self.pg, async_op=True))
@@ -310,18 +355,30 @@ class DataParallelEngine:
 class GraphedForward:
     """Inference through a replayed hipGraph: `net(x, prompt)` in eval mode is ~300 launches of which most are short, so
     at small batches the eager loop is host-bound (batch 16 and 32 take the same wall time).  The forward is captured
-    once per (input shape, dtype) after `warmup` eager calls and replayed on private input / output buffers.  Weights are
-    read through the per-module caches, which are static in eval mode."""
+    once per (input shape, dtype, compute dtype) after `warmup` eager calls and replayed on private input / output
+    buffers; the result is returned as a fresh tensor (the static output buffer is overwritten by the next call).
+    Captures are tied to the weights they were taken with: the key carries the package weight epoch and every
+    parameter's version counter, and entries of older weights (their graphs hold private memory pools -- GBs for
+    512x512 cubes) are evicted as soon as the weights change."""
 
     def __init__(self, net, warmup=2):
         self.net, self.warmup = net, warmup
         self.entries = {}
+        self._wkey = None
+
+    def _weights_key(self):
+        return (ops.weight_epoch(), tuple(p._version for p in self.net.parameters()), self.net.training,
+                getattr(self.net, "_dtype", lambda: None)())
 
     @torch.no_grad()
     def __call__(self, x, prompt):
         if not x.is_cuda:
             return self.net(x, prompt)
-        key = (tuple(x.shape), x.dtype, tuple(prompt.shape), prompt.dtype, ops.weight_epoch())
+        wkey = self._weights_key()
+        if wkey != self._wkey:                 # load_state_dict / optimizer step / mode change: stale graphs go
+            self.entries.clear()
+            self._wkey = wkey
+        key = (tuple(x.shape), x.dtype, tuple(prompt.shape), prompt.dtype)
         e = self.entries.get(key)
         if e is None:
             e = self.entries[key] = {"calls": 0}
@@ -338,7 +395,7 @@ class GraphedForward:
         e["x"].copy_(x)
         e["p"].copy_(prompt)
         e["graph"].replay()
-        return e["out"]
+        return e["out"].clone()
 
 
 def warmup_cosine_lr(epoch, base_lr, epochs, eta_min=1e-6):

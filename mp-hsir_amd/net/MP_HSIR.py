@@ -24,7 +24,6 @@ libmphsir.so, forward raises.
 `file:line` citations are relative to the reference repository's net/MP_HSIR.py.
 """
 import math
-import warnings
 
 import torch
 import torch.nn as nn
@@ -300,6 +299,14 @@ class TransformerBlock(nn.Module):                                              
         self.ffn = FeedForward(dim, ffn_expansion_factor, bias)
 
 
+def surrogate_clip_prompt(task_classes, seed=2024):
+    """Seeded stand-in for the CLIP ViT-B/32 text embeddings (T,512): for benchmarks and tests on machines without the
+    OpenAI `clip` package / weights.  A model built on it is NOT interchangeable with reference checkpoints."""
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn((task_classes, 512), generator=g)
+    return v / v.norm(dim=-1, keepdim=True) * 8.0
+
+
 class Text_Prompt(nn.Module):                                                      # ref :481-535
     def __init__(self, task_classes=7, clip_prompt=None):
         super().__init__()
@@ -307,24 +314,32 @@ class Text_Prompt(nn.Module):                                                   
             raise ValueError("task_classes must be 6 or 7")
         self.task_text_prompts = [_TASK_PROMPTS[k] for k in _TASK_SETS[task_classes]]
         self.task_classes = task_classes
-        if clip_prompt is None:
-            clip_prompt = self._encode_with_clip()
+        self.clip_source = "injected"
+        if isinstance(clip_prompt, str):
+            if clip_prompt != "surrogate":
+                raise ValueError("clip_prompt must be a (T,512) tensor, None (encode with OpenAI clip) or 'surrogate'")
+            clip_prompt, self.clip_source = surrogate_clip_prompt(task_classes), "surrogate"
+        elif clip_prompt is None:
+            clip_prompt, self.clip_source = self._encode_with_clip(), "clip ViT-B/32"
         assert tuple(clip_prompt.shape) == (task_classes, 512), clip_prompt.shape
         self.clip_prompt = clip_prompt.detach().float()      # plain attribute, not in state_dict
         self._on_device = {}                                  # device copies (no host->device copy inside a captured step)
 
     def _encode_with_clip(self):
+        """the reference's construction-time text encoding (:512-515).  Without the `clip` package this RAISES: silently
+        substituting other embeddings would make reference checkpoints evaluate wrongly (the table is not in the
+        state_dict).  Pass clip_prompt=<(T,512) tensor> or, for benchmarks/tests, clip_prompt="surrogate"."""
         try:
-            import clip  # OpenAI CLIP, as the reference uses it (:512-515)
-            model, _ = clip.load("ViT-B/32", device="cpu")
-            with torch.no_grad():
-                return model.encode_text(clip.tokenize(self.task_text_prompts)).float()
-        except ImportError:
-            warnings.warn("OpenAI `clip` is not installed: using a seeded surrogate for the (T,512) text "
-                          "embeddings.  Pass clip_prompt=... to MP_HSIR_Net to inject the real ones.")
-            g = torch.Generator().manual_seed(2024)
-            v = torch.randn((self.task_classes, 512), generator=g)
-            return v / v.norm(dim=-1, keepdim=True) * 8.0
+            import clip  # OpenAI CLIP, as the reference uses it
+        except ImportError as e:
+            raise RuntimeError(
+                "MP_HSIR_Net needs the CLIP ViT-B/32 text embeddings of its task sentences and the OpenAI `clip` package is "
+                "not installed.  Pass clip_prompt=<tensor (task_classes,512)> (e.g. saved from a machine that has it, or "
+                "read from a checkpoint written by this package), or clip_prompt='surrogate' to opt into a seeded stand-in "
+                "(benchmarks / tests only: not interchangeable with reference checkpoints).") from e
+        model, _ = clip.load("ViT-B/32", device="cpu")
+        with torch.no_grad():
+            return model.encode_text(clip.tokenize(self.task_text_prompts)).float()
 
     def forward(self, x, de_class=None):
         T = self.task_classes

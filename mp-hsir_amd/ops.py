@@ -247,6 +247,18 @@ def gemm_tok(x, w, bias=None, ln=None, epi=0, res=None, sa=None, gate=None, keep
     return y
 
 
+def layernorm_tok(x, ln_w, ln_b, out_dtype):
+    """x (M,C) contiguous, fp32 or compute dtype -> LN(x) in out_dtype (statistics in fp32)."""
+    lib = _lib.load()
+    _check(x, ln_w, ln_b)
+    M, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((M, C), dtype=out_dtype, device=x.device)
+    _lib.check(lib.mphsir_layernorm_tok(_p(x), _DT[x.dtype], _p(ln_w), _p(ln_b), _p(y), _DT[out_dtype], M, C, _stream(x)), "layernorm_tok")
+    _acct("layernorm_tok", 8.0 * M * C, M * C * (x.element_size() + y.element_size()))
+    return y
+
+
 def round_up(n, m):
     return (n + m - 1) // m * m
 

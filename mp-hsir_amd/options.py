@@ -6,7 +6,7 @@ options.py (options.py:6-37), so its command lines (README.md:36,38) work unchan
 Like the reference, the namespace is built at import time (`from options import options as opt`);
 unknown flags are tolerated so that importing this module under pytest/torchrun does not abort.
 Additions (not present in the reference, all optional): --model, --precision, --steps_per_epoch, --graph,
---synthetic, --log_every.  Reference hazards kept on purpose: `--num_gpus type=list` turns "01"
+--synthetic, --log_every, --allow_surrogate_clip, --all_sources.  Reference hazards kept on purpose: `--num_gpus type=list` turns "01"
 into ['0','1'] (options.py:36) and `--classifier type=bool` treats any non-empty string as True.
 """
 import argparse
@@ -38,7 +38,11 @@ _FLAGS = [
     # ---- additions -------------------------------------------------------------------------------
     ("--model", dict(type=str, default=None, choices=[None, "natural_scene", "remote_sensing"],
                      help="which MP_HSIR_Net to build (the reference edits train.py:44-45 by hand); default: --data_type")),
-    ("--precision", dict(type=str, default="bf16", choices=["bf16", "f32"], help="compute dtype of the HIP kernels")),
+    ("--precision", dict(type=str, default="bf16", choices=["bf16", "f32", "f16"], help="compute dtype of the HIP kernels "
+                         "(f16 = the reference's 16-mixed: fp16 compute + dynamic loss scaling)")),
+    ("--allow_surrogate_clip", dict(type=int, default=0, help="1: build the model on a seeded stand-in for the CLIP text "
+                                    "embeddings when the OpenAI clip package is missing (benchmarks only)")),
+    ("--all_sources", dict(type=int, default=0, help="1: do not filter remote-sensing records by source file name")),
     ("--steps_per_epoch", dict(type=int, default=100, help="synthetic source: optimisation steps per epoch")),
     ("--synthetic", dict(type=int, default=1, help="1: GPU-side synthetic patch source (no datasets offline)")),
     ("--log_every", dict(type=int, default=10)),

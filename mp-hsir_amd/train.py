@@ -8,8 +8,11 @@ one process per GPU with RCCL gradient all-reduce (engine.DataParallelEngine).
 Same loss (clamp + L1, :58-61), optimizer (AdamW(lr) defaults, :69), schedule (linear warm-up over
 0.1*epochs then cosine to 1e-6, stepped per epoch, :71-85 -- including lr(0) = 0), seed handling (:88-92),
 warm start from a Lightning checkpoint by key+shape filtering with the `net.` prefix (:109-116) and a
-checkpoint every 50 epochs (:104).  Datasets are not available offline: --synthetic 1 (default) feeds
-data.SyntheticPatchSource, which emits the reference's batch tuple on the GPU.
+checkpoint every 50 epochs (:104).  Data: --synthetic 1 (default; datasets are not available offline) feeds
+data.SyntheticPatchSource; --synthetic 0 --db_path <dir> reads the reference's patch records (data.PatchDB, the LMDB
+record format in a flat file).  Either way the per-task degradations of --*_single_de_type are synthesised on the GPU
+(degrade.DegradationSynthesizer).  Checkpoints carry, besides the `net.`-prefixed state_dict, AdamW's moments and step
+count (resumable, like the reference's Lightning checkpoints) and the CLIP text-embedding table the model was built with.
 """
 import os
 import random
@@ -21,7 +24,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from mp_hsir_amd.data import SyntheticPatchSource  # noqa: E402
+from mp_hsir_amd.data import REMOTE_SENSING_SOURCES, PatchDB, PatchDBSource, SyntheticPatchSource  # noqa: E402
 from mp_hsir_amd.engine import DataParallelEngine, warmup_cosine_lr  # noqa: E402
 from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net  # noqa: E402
 from mp_hsir_amd.options import options as opt  # noqa: E402
@@ -37,13 +40,31 @@ def set_seed(seed):
     torch.cuda.manual_seed_all(seed)
 
 
-def load_warm_start(net, path, device):
-    """keep checkpoint entries whose key AND shape match (train.py:109-116); keys carry the `net.` prefix."""
-    state = torch.load(path, map_location=device)["state_dict"]
+def load_warm_start(net, path, device, engine=None):
+    """keep checkpoint entries whose key AND shape match (train.py:109-116); keys carry the `net.` prefix.  A checkpoint
+    written by save_checkpoint also restores the optimizer state into `engine` and is checked against the model's CLIP
+    table (a model built on other text embeddings would silently mis-evaluate)."""
+    ckpt = torch.load(path, map_location=device)
+    state = ckpt["state_dict"]
     own = {"net." + k: v for k, v in net.state_dict().items()}
     kept = {k[4:]: v for k, v in state.items() if k in own and own[k].shape == v.shape}
     net.load_state_dict(kept, strict=False)
-    return len(kept)
+    table = ckpt.get("mphsir_clip_prompt")
+    if table is not None and not torch.allclose(table.float().cpu(), net.clip_prompts.float().cpu(), atol=1e-5):
+        raise RuntimeError("%s was trained with other CLIP text embeddings than this model was built with; build the model "
+                           "with clip_prompt=ckpt['mphsir_clip_prompt']" % path)
+    resume_epoch = 0
+    if engine is not None and "mphsir_optimizer" in ckpt:
+        engine.load_optimizer_state(ckpt["mphsir_optimizer"])
+        resume_epoch = int(ckpt.get("epoch", -1)) + 1
+    return len(kept), resume_epoch
+
+
+def save_checkpoint(path, net, engine, epoch):
+    """Lightning-compatible layout (`state_dict` with the `net.` prefix, `epoch`) + what resuming needs."""
+    torch.save({"state_dict": {"net." + k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, "epoch": epoch,
+                "mphsir_optimizer": engine.optimizer_state(), "mphsir_clip_prompt": net.clip_prompts.detach().cpu().clone(),
+                "mphsir_clip_source": net.text_prompt.clip_source}, path)
 
 
 def main():
@@ -56,17 +77,35 @@ def main():
         print("Options\n", opt)
     set_seed(opt.seed)
     cfg = MODELS[opt.model or opt.data_type]
-    net = MP_HSIR_Net(**cfg, compute_dtype=torch.bfloat16 if opt.precision == "bf16" else torch.float32).to(dev).train()
+    clip_prompt = "surrogate" if opt.allow_surrogate_clip else None      # None: encode with OpenAI clip, or raise
     if opt.ckpt_path is not None:
-        n = load_warm_start(net, opt.ckpt_path, dev)
-        if rank == 0:
-            print("warm start: %d tensors from %s" % (n, opt.ckpt_path))
+        saved = torch.load(opt.ckpt_path, map_location="cpu").get("mphsir_clip_prompt")
+        clip_prompt = saved if saved is not None else clip_prompt
+    dtypes = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}
+    net = MP_HSIR_Net(**cfg, clip_prompt=clip_prompt, compute_dtype=dtypes[opt.precision]).to(dev).train()
     eng = DataParallelEngine(net, lr=opt.lr, use_graph=bool(opt.graph))
-    src = SyntheticPatchSource(cfg["in_channel"], opt.patch_size, opt.batch_size, cfg["task_classes"], dev, opt.seed, rank)
-    for epoch in range(opt.epochs):
+    start_epoch = 0
+    if opt.ckpt_path is not None:
+        n, start_epoch = load_warm_start(net, opt.ckpt_path, dev, eng)
+        if rank == 0:
+            print("warm start: %d tensors from %s, continuing at epoch %d" % (n, opt.ckpt_path, start_epoch))
+    data_type = opt.model or opt.data_type
+    de_types = opt.natural_scene_single_de_type if data_type == "natural_scene" else opt.remote_sensing_single_de_type
+    if opt.synthetic:
+        src = SyntheticPatchSource(cfg["in_channel"], opt.patch_size, opt.batch_size, cfg["task_classes"], dev, opt.seed, rank,
+                                   de_types=de_types, data_type=data_type)
+        steps_per_epoch = opt.steps_per_epoch
+    else:
+        if not opt.db_path:
+            raise SystemExit("--synthetic 0 needs --db_path <directory with data.bin + meta_info.txt> (data.write_patch_db)")
+        keep_all = data_type == "natural_scene" or opt.all_sources          # dataset_utils.py:56 filters remote-sensing sources
+        db = PatchDB(opt.db_path, dataset_names=None if keep_all else REMOTE_SENSING_SOURCES)
+        src = PatchDBSource(db, opt.batch_size, de_types, data_type, dev, opt.seed, rank, world, opt.repeat)
+        steps_per_epoch = src.steps_per_epoch()
+    for epoch in range(start_epoch, opt.epochs):
         lr = warmup_cosine_lr(epoch, opt.lr, opt.epochs)
         running = 0.0
-        for it in range(opt.steps_per_epoch):
+        for it in range(steps_per_epoch):
             _, degraded, clean, prompt = src.next()
             loss = eng.train_step(degraded, clean, prompt, lr=lr)
             if (it + 1) % opt.log_every == 0:
@@ -77,8 +116,7 @@ def main():
                     print("epoch %d it %d lr %.3e train_loss %.5f" % (epoch, it + 1, lr, running), flush=True)
         if rank == 0 and opt.ckpt_dir and (epoch + 1) % 50 == 0:      # ModelCheckpoint(every_n_epochs=50), train.py:104
             os.makedirs(opt.ckpt_dir, exist_ok=True)
-            torch.save({"state_dict": {"net." + k: v.detach().cpu().clone() for k, v in net.state_dict().items()},
-                        "epoch": epoch}, os.path.join(opt.ckpt_dir, "epoch=%d.ckpt" % epoch))
+            save_checkpoint(os.path.join(opt.ckpt_dir, "epoch=%d.ckpt" % epoch), net, eng, epoch)
     eng.finish()
     if world > 1:
         dist.destroy_process_group()

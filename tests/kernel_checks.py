@@ -354,3 +354,167 @@ def check_gemm_tn_grouped(dev):
     full = A[3].double().cpu().t() @ B[3].double().cpu()
     assert rel_l2(blk[0], torch.cat([full[:40, :100], full[96:136, :100]])) < 1e-2
     assert rel_l2(blk[1], torch.cat([A[3].double().cpu().sum(0)[:40], A[3].double().cpu().sum(0)[96:136]])) < 1e-2
+
+
+# ---- backward kernels at the benchmarked widths: fp64 autograd of the oracle on dtype-rounded weights ------------------
+_ROUNDED = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight", "gobal_spectral_attn.qkv.weight")
+GTOL = {torch.float32: 2e-5, torch.bfloat16: 6e-2}
+
+
+def check_pgsstb_backward_oracle(dev, dtype, name, B=2, hw=(16, 16), drop_path=True):
+    """A whole PGSSTB block (win_attn_bwd + ln_bwd_win + combine_bwd + pg_gate_bwd + the channel-attention backward chain +
+    gated_mlp_bwd + every token-reduction GEMM) at one shape class of BLOCK_CASES, batch 2, WITH DropPath factors, against
+    fp64 autograd of the oracle run on the weights as the kernels see them (GEMM weights rounded to `dtype`).  Every
+    gradient is compared as a full tensor."""
+    _use(dev)
+    from golden.cases import BLOCK_CASES
+    from golden.detfill import det_value
+    from mp_hsir_amd import autograd_ops as AG
+    from mp_hsir_amd.net.MP_HSIR import PGSSTB
+    c = BLOCK_CASES[name]
+    C, heads, shift = c["C"], c["heads"], c["shift"]
+    H, W = hw
+    blk = PGSSTB(C, heads, [64, 64], 8, shift, 0.0, 2.66, c["cr"], 128).eval()
+    with torch.no_grad():
+        for k, p in blk.named_parameters():
+            p.copy_(det_value(k, p.shape).float())
+    blk = blk.to(dev)
+    x = rnd((B, H, W, C), 301, dtype).requires_grad_(True)
+    cot = rnd((B, H, W, C), 302, dtype)
+    k1 = torch.tensor([1.0 / 0.9, 0.0][:B] if drop_path else [1.0] * B).to(dev)
+    k2 = torch.tensor([0.0, 1.0 / 0.95][:B] if drop_path else [1.0] * B).to(dev)
+    y = AG.pgsstb(blk, x, k1, k2)
+    (y.float() * cot.float()).sum().backward()
+    # oracle
+    P = {}
+    for k, p in blk.named_parameters():
+        v = p.detach().cpu()
+        if k in _ROUNDED:
+            v = v.to(dtype)
+        P[k] = v.double().requires_grad_(True)
+    xd = x.detach().double().cpu().requires_grad_(True)
+    yr = O.pgsstb(P, "", xd, heads, shifted=shift > 0, keep=(k1.double().cpu(), k2.double().cpu()))
+    (yr * cot.double().cpu()).sum().backward()
+    tol = GTOL[dtype]
+    errs = {"out": rel_l2(y.detach().float(), yr.detach()), "dx": rel_l2(x.grad.float(), xd.grad)}
+    for k, p in blk.named_parameters():
+        errs[k] = rel_l2(p.grad.float(), P[k].grad)
+    bad = {k: v for k, v in errs.items() if not v < (TOL[dtype] * 2 if k == "out" else tol)}
+    assert not bad, (name, str(dtype), bad)
+    return errs
+
+
+def check_combine_bwd(dev, dtype, C=128, shift=4):
+    """mphsir_combine_bwd against its definition (backward of gemm_tok epilogue 2)."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W = 2, 16, 24
+    dy, sa = rnd((B, H, W, C), 311, dtype), rnd((B, H, W, C), 312, dtype)
+    gate = rnd((B * (H // 8) * (W // 8), C), 313)
+    keep = torch.tensor([1.25, 0.5]).to(dev)
+    d_out, d_sa, dgate = ops.combine_bwd(dy, sa, gate, keep, shift)
+    dyd, sad = dy.double().cpu(), sa.double().cpu()
+    do_ref = (keep.double().cpu().reshape(B, 1, 1, 1) * dyd).to(dtype).double()          # stored rounded
+    gw = gate.double().cpu()[:, None, :].expand(-1, 64, -1)
+    gimg = O.from_windows(gw, B, H, W)
+    if shift:
+        gimg = torch.roll(gimg, (shift, shift), (1, 2))
+    assert rel_l2(d_out, do_ref) < TOL[dtype]
+    assert rel_l2(d_sa, do_ref * gimg) < TOL[dtype]
+    prod = do_ref * sad
+    if shift:
+        prod = torch.roll(prod, (-shift, -shift), (1, 2))
+    assert rel_l2(dgate, O.to_windows(prod).sum(1)) < TOL[dtype]
+    # keep = None: d_out aliases dy
+    d_out2, d_sa2, _ = ops.combine_bwd(dy, sa, gate, None, shift)
+    assert d_out2.data_ptr() == dy.data_ptr() and rel_l2(d_sa2, dyd * gimg) < TOL[dtype]
+
+
+def check_pg_gate_bwd(dev, C, cr, nW=20, factor_dtype=torch.float32):
+    """mphsir_pg_gate_bwd (+ the factor-product GEMM that yields its eight parameter gradients) against fp64 autograd
+    of the oracle's pg_spectral_gate."""
+    _use(dev)
+    from golden.detfill import det_value
+    from mp_hsir_amd import ops
+    r = C // cr
+    shapes = {"linear_down.weight": (r, C), "linear_up.weight": (C, r), "linear_prompt.weight": (128, C), "prompt_param": (1, 1, 128, r),
+              "q.weight": (r, r), "kv.weight": (2 * r, r), "proj.weight": (r, r), "proj.bias": (r,)}
+    P = {k: det_value("local_spectral_attn." + k, shp).float() for k, shp in shapes.items()}
+    pg = {k: v.to(dev).contiguous() for k, v in P.items()}
+    pg["prompt_param"] = pg["prompt_param"].reshape(128, r).contiguous()
+    mu, dgate = rnd((nW, C), 321), rnd((nW, C), 322)
+    with ops.reduce_scope():
+        dmu, g = ops.pg_gate_bwd(mu, dgate, pg, factor_dtype=factor_dtype)
+    Pd = {"pg." + k: v.double().requires_grad_(True) for k, v in P.items()}
+    mud = mu.double().cpu().requires_grad_(True)
+    gate = O.pg_spectral_gate(Pd, "pg.", mud[:, None, :].expand(-1, 64, -1))
+    (gate * dgate.double().cpu()).sum().backward()
+    tol = 2e-5 if factor_dtype == torch.float32 else 2e-2
+    assert rel_l2(dmu, mud.grad) < 2e-5
+    for k in shapes:
+        assert rel_l2(g[k].reshape(shapes[k]), Pd["pg." + k].grad) < tol, (k, rel_l2(g[k].reshape(shapes[k]), Pd["pg." + k].grad))
+
+
+def check_channel_attention_bwd(dev, dtype, C, heads, shape, cross=False):
+    """The channel ("spectral") attention backward chain -- gemm_tn (dM), spectral_fold_bwd, the [dq|dk] / dv token GEMMs,
+    depthwise backward + tap gradients -- as the prompt modules use it (self: TransformerBlock :289-322; cross:
+    CrossTransformer :220-249), against fp64 autograd of the oracle."""
+    _use(dev)
+    from mp_hsir_amd import autograd_ops as AG
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    M = B * H * W
+    P = {"temperature": 1 + 0.3 * rnd((heads, 1, 1), 331), "project_out.weight": rnd((C, C, 1, 1), 332, scale=C ** -0.5)}
+    if cross:
+        P.update({"q.weight": rnd((C, C, 1, 1), 333, scale=C ** -0.5), "kv.weight": rnd((2 * C, C, 1, 1), 334, scale=C ** -0.5),
+                  "q_dwconv.weight": rnd((C, 1, 3, 3), 335, scale=1 / 3), "kv_dwconv.weight": rnd((2 * C, 1, 3, 3), 336, scale=1 / 3)})
+    else:
+        P.update({"qkv.weight": rnd((3 * C, C, 1, 1), 333, scale=C ** -0.5), "qkv_dwconv.weight": rnd((3 * C, 1, 3, 3), 335, scale=1 / 3)})
+    xq, xkv = rnd((B, H, W, C), 337, dtype), rnd((B, H, W, C), 338, dtype)
+    d_out = rnd((M, C), 339, dtype)
+    temp = P["temperature"].reshape(heads).contiguous()
+    wo = P["project_out.weight"].reshape(C, C).contiguous()
+    if cross:
+        tq = ops.gemm_tok(xq.reshape(M, C), P["q.weight"].reshape(C, C).to(dtype))
+        tkv = ops.gemm_tok(xkv.reshape(M, C), P["kv.weight"].reshape(2 * C, C).to(dtype))
+        w9 = torch.cat([ops.pack_dw(P["q_dwconv.weight"]), ops.pack_dw(P["kv_dwconv.weight"])], 1).contiguous()
+        t_q, t_k, t_v = tq, tkv[:, :C], tkv[:, C:]
+        v4 = lambda t, n: t.reshape(B, H, W, n)
+        tq4, tkv4 = v4(tq, C), v4(tkv, 2 * C)
+        views = (tq4, tkv4[..., :C], tkv4[..., C:])
+    else:
+        t = ops.gemm_tok(xq.reshape(M, C), P["qkv.weight"].reshape(3 * C, C).to(dtype))
+        w9 = ops.pack_dw(P["qkv_dwconv.weight"])
+        t_q, t_k, t_v = t[:, :C], t[:, C:2 * C], t[:, 2 * C:]
+        t4 = t.reshape(B, H, W, 3 * C)
+        views = (t4[..., :C], t4[..., C:2 * C], t4[..., 2 * C:])
+    v, gp, sp, _ = ops.dwconv_gram(t_q, t_k, t_v, w9[:, :C], w9[:, C:2 * C], w9[:, 2 * C:], 3 * C, B, H, W, C, heads)
+    Mb, MbT, gp, sp = ops.spectral_fold(gp, sp, temp, wo, dtype, transposed=True)
+    out = ops.gemm_tok(v, Mb)
+    with ops.reduce_scope():
+        dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = AG.channel_attention_bwd(
+            d_out, views[0], views[1], views[2], w9[:, :C], w9[:, C:2 * C], w9[:, 2 * C:], v, gp, sp, Mb, MbT,
+            P["temperature"], P["project_out.weight"], heads, B, H, W)
+    # oracle on the 1x1-conv outputs as the kernels saw them (dtype-rounded), fp64 from there on
+    tqd = views[0].detach().double().cpu().requires_grad_(True)
+    tkd = views[1].detach().double().cpu().requires_grad_(True)
+    tvd = views[2].detach().double().cpu().requires_grad_(True)
+    w9d = w9.double().cpu().requires_grad_(True)                                # [9][3C] tap-major
+    wd = w9d.t().reshape(3 * C, 1, 3, 3)
+    Td = {"temperature": P["temperature"].double().cpu().requires_grad_(True), "wo": P["project_out.weight"].double().cpu().requires_grad_(True)}
+    q = O.depthwise3x3(tqd, wd[:C])
+    k = O.depthwise3x3(tkd, wd[C:2 * C])
+    vv = O.depthwise3x3(tvd, wd[2 * C:])
+    ref = O._channel_attention_core(q, k, vv, Td["temperature"], Td["wo"], heads)
+    assert rel_l2(out.reshape(B, H, W, C), ref.detach()) < TOL[dtype] * 2
+    (ref * d_out.double().cpu().reshape(B, H, W, C)).sum().backward()
+    tol = GTOL[dtype] / (2 if dtype == torch.bfloat16 else 1)
+    got = {"dtq": dtq, "dtk": dtk, "dtv": dtv, "dtemp": dtemp.reshape(heads, 1, 1), "dwo": dwo.reshape(C, C, 1, 1),
+           "dw_q": dwq, "dw_k": dwk, "dw_v": dwv}
+    dw9 = w9d.grad.t()                                                          # (3C, 9)
+    want = {"dtq": tqd.grad, "dtk": tkd.grad, "dtv": tvd.grad, "dtemp": Td["temperature"].grad, "dwo": Td["wo"].grad,
+            "dw_q": dw9[:C], "dw_k": dw9[C:2 * C], "dw_v": dw9[2 * C:]}
+    errs = {n: rel_l2(got[n], want[n]) for n in got}
+    bad = {n: e for n, e in errs.items() if not e < tol}
+    assert not bad, (C, heads, shape, str(dtype), bad)
+    return errs

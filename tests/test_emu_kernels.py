@@ -2,6 +2,7 @@
 based stand-in for the HIP runtime) and compared with the oracle.  These do not replace the `-m gpu`
 parity tests -- they catch index/layout/fragment-map mistakes before a GPU run is spent on them."""
 import pytest
+import torch
 
 import kernel_checks as K
 from emu import bind_emulator
@@ -103,3 +104,23 @@ def test_reduce_block():
 
 def test_gemm_tn_grouped():
     K.check_gemm_tn_grouped("cpu")
+
+
+@pytest.mark.parametrize("dtype,name", [(torch.float32, "nat_refine"), (torch.bfloat16, "rs_refine"), (torch.float32, "nat_latent")])
+def test_pgsstb_backward_vs_oracle_autograd(dtype, name):
+    K.check_pgsstb_backward_oracle("cpu", dtype, name, B=2, hw=(8, 16))
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+def test_combine_bwd(dtype):
+    K.check_combine_bwd("cpu", dtype)
+
+
+def test_pg_gate_bwd():
+    K.check_pg_gate_bwd("cpu", 128, 8)
+    K.check_pg_gate_bwd("cpu", 384, 32, nW=5, factor_dtype=torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype,C,heads,shape,cross", [(torch.float32, 64, 2, (1, 16, 16), False), (torch.bfloat16, 128, 2, (2, 8, 16), True)])
+def test_channel_attention_bwd(dtype, C, heads, shape, cross):
+    K.check_channel_attention_bwd("cpu", dtype, C, heads, shape, cross)

@@ -137,3 +137,45 @@ def test_reduce_block():
 
 def test_gemm_tn_grouped():
     K.check_gemm_tn_grouped("cuda")
+
+
+# ---- backward kernels at every benchmarked width: fp64 autograd of the oracle, full tensors --------------
+from golden.cases import BLOCK_CASES
+
+PGSSTB_CASES = [n for n, c in BLOCK_CASES.items() if c["kind"] == "pgsstb"]
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("name", PGSSTB_CASES)
+def test_pgsstb_backward_vs_oracle_autograd(dtype, name):
+    """C in {64,96,128,192,256,384} x head_dim in {32,48,64,96}, batch 2, DropPath factors on, 32x32 (shifted windows
+    of every mask region): dX and all 29 parameter gradients <= 2e-5 (fp32) / 6e-2 (bf16) rel-L2."""
+    errs = K.check_pgsstb_backward_oracle("cuda", dtype, name, B=2, hw=(32, 32))
+    print(name, str(dtype), "worst", max(errs, key=errs.get), max(errs.values()))
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+def test_pgsstb_backward_vs_oracle_autograd_bench_shape(dtype):
+    """the benchmark's top level: C=128, 2 heads of 64, 64x64 patches, batch 4, no DropPath"""
+    K.check_pgsstb_backward_oracle("cuda", dtype, "nat_refine", B=4, hw=(64, 64), drop_path=False)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,shift", [(64, 4), (128, 0), (256, 4), (96, 4), (192, 0), (384, 4)])
+def test_combine_bwd(dtype, C, shift):
+    K.check_combine_bwd("cuda", dtype, C, shift)
+
+
+@pytest.mark.parametrize("factor_dtype", K.DTYPES)
+@pytest.mark.parametrize("C,cr", [(64, 8), (128, 16), (256, 32), (128, 8), (96, 8), (192, 16), (384, 32), (192, 8)])
+def test_pg_gate_bwd(factor_dtype, C, cr):
+    K.check_pg_gate_bwd("cuda", C, cr, nW=320, factor_dtype=factor_dtype)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,heads,shape,cross", [(64, 2, (2, 64, 64), True), (128, 2, (2, 32, 32), True), (128, 4, (2, 64, 64), False),
+                                                 (256, 8, (2, 32, 32), False), (96, 2, (1, 64, 64), True), (192, 4, (1, 64, 64), False),
+                                                 (384, 8, (1, 32, 32), False), (192, 2, (1, 32, 32), True)])
+def test_channel_attention_bwd(dtype, C, heads, shape, cross):
+    """the prompt modules' attention backward at both configurations' widths (TVSP: D, 2 heads; PromptFusion: 2D/4D, 4/8 heads)"""
+    K.check_channel_attention_bwd("cuda", dtype, C, heads, shape, cross)

@@ -1,7 +1,5 @@
 """Boundary checks that need no GPU: constructor surface, state_dict keys/shapes/dtypes against the
 manifest dumped from the reference, checkpoint filtering as train.py:109-116 does it."""
-import warnings
-
 import pytest
 import torch
 
@@ -10,9 +8,21 @@ from golden.cases import NATURAL_CFG, REMOTE_CFG, TINY_CFG
 
 def _net(cfg):
     from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        return MP_HSIR_Net(**cfg)
+    return MP_HSIR_Net(**cfg, clip_prompt="surrogate")
+
+
+def test_missing_clip_is_an_error_not_a_silent_surrogate():
+    """without the OpenAI `clip` package the constructor must not fall back to other text embeddings on its own
+    (reference checkpoints would evaluate wrongly): it raises unless a table is injected or the surrogate is requested."""
+    import importlib.util
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    if importlib.util.find_spec("clip") is not None:
+        pytest.skip("OpenAI clip is installed here")
+    with pytest.raises(RuntimeError, match="clip_prompt"):
+        MP_HSIR_Net(**TINY_CFG)
+    assert MP_HSIR_Net(**TINY_CFG, clip_prompt="surrogate").text_prompt.clip_source == "surrogate"
+    with pytest.raises(ValueError):
+        MP_HSIR_Net(**TINY_CFG, clip_prompt="random")
 
 
 @pytest.mark.parametrize("name,cfg", [("natural_mode0", NATURAL_CFG), ("remote_mode8", REMOTE_CFG), ("tiny", TINY_CFG)])

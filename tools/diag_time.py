@@ -10,7 +10,7 @@ import mp_hsir_amd.autograd_ops as AG
 
 dev = torch.device("cuda")
 torch.manual_seed(0)
-net = MP_HSIR_Net(compute_dtype=torch.bfloat16).to(dev).train()
+net = MP_HSIR_Net(compute_dtype=torch.bfloat16, clip_prompt="surrogate").to(dev).train()
 src = SyntheticPatchSource(31, 64, 32, 6, dev, 2024, 0)
 _, x, c, p = src.next()
 
