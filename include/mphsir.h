@@ -70,33 +70,41 @@ typedef struct mphsir_gemm_args {
 } mphsir_gemm_args;
 int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* stream);
 
-/* ---- fused LayerNorm + shifted 8x8 window attention + local spectral-prompt gate -----------------
- * Replaces, inside PGSSTB.forward (net/MP_HSIR.py:662-713): norm1 (:667), torch.roll(-shift) (:672),
+/* ---- fused LayerNorm + shifted 8x8 window attention; the local spectral-prompt gate -----------------
+ * mphsir_win_attn_fwd replaces, inside PGSSTB.forward (net/MP_HSIR.py:662-713): norm1 (:667), torch.roll(-shift) (:672),
  * window_partition (:21-30,:677), Spatial_Attention.forward (:193-218) incl. the relative-position
  * bias gather (:200-203) and the calculate_mask shift mask (:639-660, -100 across regions),
- * window_reverse + roll(+shift) (:690-696), and the gate of PG_Spectral_Attention.forward (:132-152).
+ * window_reverse + roll(+shift) (:690-696), and the window mean of PG_Spectral_Attention.forward (:135).
  * X, SA: (B,H,W,C) channels-last cubes; SA = window-attention output back in image order.
- * gate: [B*nW][C] fp32, one row per window in shifted-frame window order (window_partition order);
- *       the reference's x1 is SA * gate[window] (:153), applied by mphsir_gemm_tok epi 2.
+ * mu: [B*nW][C] fp32, the mean of SA over each window's 64 tokens, one row per window in shifted-frame window order
+ *       (window_partition order).
  * Wqkv [3C][C] (attn.qkv.weight), bqkv [3C]; rpb = relative_position_bias_table [225][heads] fp32;
  * Wproj [C][heads*HDP]: attn.proj.weight with every head's hd input columns zero-padded to
- * HDP = mphsir_win_attn_hdp(hd, dtype); the spectral-prompt weights are the fp32 parameters as stored:
- * Wprompt [128][C], prompt_param [128][r], Wq [r][r], Wkv [2r][r], Wdown [r][C], Wpproj [r][r] + bpproj
- * [r], Wup [C][r].  H, W multiples of 8; shift 0 or 4; (C, C/heads) in {(32,32),(64,32),(64,64),
- * (128,32),(128,64),(256,32),(96,48),(192,48),(192,96),(384,48)}.                                  */
+ * HDP = mphsir_win_attn_hdp(hd, dtype).  H, W multiples of 8; shift 0 or 4; (C, C/heads) in {(32,32),(64,32),(64,64),
+ * (128,32),(128,64),(256,32),(96,48),(192,48),(192,96),(384,48)}.
+ * mphsir_pg_gate_fwd: the gate of PG_Spectral_Attention.forward (:136-152) for every window, 16 windows per workgroup:
+ * gate [nW][C] fp32 from mu [nW][C]; the reference's x1 is SA * gate[window] (:153), applied by mphsir_gemm_tok epi 2.
+ * The spectral-prompt weights are the fp32 parameters as stored: Wprompt [128][C], prompt_param [128][r], Wq [r][r],
+ * Wkv [2r][r], Wdown [r][C], Wpproj [r][r] + bpproj [r], Wup [C][r]; C % 16 == 0, r <= 32.                          */
 typedef struct mphsir_win_attn_args {
     const void* X;
     const float* ln_w; const float* ln_b;
     const void* Wqkv; const float* bqkv;
     const float* rpb;
     const void* Wproj; const float* bproj;
-    const float* Wprompt; const float* prompt_param; const float* Wq; const float* Wkv;
-    const float* Wdown; const float* Wpproj; const float* bpproj; const float* Wup;
-    void* SA; float* gate;
-    float* mu;      /* optional [B*nW][C] fp32: per-window mean of SA (input of the gate; saved for backward) */
+    void* SA;
+    float* mu;      /* [B*nW][C] fp32: per-window mean of SA (input of the gate; also saved for backward)            */
     void* Oattn;    /* optional [B*nW*64][C]: softmax(QK^T)V before proj, window-token order (for backward)  */
-    int32_t B, H, W, C, heads, shift, r;
+    int32_t B, H, W, C, heads, shift;
 } mphsir_win_attn_args;
+typedef struct mphsir_pg_fwd_args {
+    const float* mu;
+    const float* Wprompt; const float* prompt_param; const float* Wq; const float* Wkv; const float* Wdown;
+    const float* Wpproj; const float* bpproj; const float* Wup;
+    float* gate;
+    int32_t nW, C, r;
+} mphsir_pg_fwd_args;
+int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream);
 int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream);
 int mphsir_win_attn_hdp(int head_dim, int dtype);
 
@@ -359,6 +367,7 @@ int mphsir_pack_gather(const float* arena, const int32_t* index, void* dst, int6
 #define MPHSIR_K_REDUCE_PARTS 19
 #define MPHSIR_K_PACK_GATHER 20
 #define MPHSIR_K_LAYERNORM 21
+#define MPHSIR_K_PG_GATE 22
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -33,10 +33,14 @@ class MlpArgs(ctypes.Structure):
 
 class WinAttnArgs(ctypes.Structure):
     """mirror of struct mphsir_win_attn_args"""
-    _fields_ = [(n, c_void_p) for n in ("X", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "Wproj", "bproj", "Wprompt",
-                                         "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup", "SA", "gate",
-                                         "mu", "Oattn")] + \
-               [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift", "r")]
+    _fields_ = [(n, c_void_p) for n in ("X", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "Wproj", "bproj", "SA", "mu", "Oattn")] + \
+               [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift")]
+
+
+class PgFwdArgs(ctypes.Structure):
+    """mirror of struct mphsir_pg_fwd_args"""
+    _fields_ = [(n, c_void_p) for n in ("mu", "Wprompt", "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup", "gate")] + \
+               [(n, c_int32) for n in ("nW", "C", "r")]
 
 
 class GramArgs(ctypes.Structure):
@@ -115,6 +119,7 @@ _SYMBOLS = {
     "mphsir_layernorm_tok": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int32, c_void_p]),
     "mphsir_win_attn_fwd": (c_int, [ctypes.POINTER(WinAttnArgs), c_int, c_void_p]),
     "mphsir_win_attn_hdp": (c_int, [c_int, c_int]),
+    "mphsir_pg_gate_fwd": (c_int, [ctypes.POINTER(PgFwdArgs), c_void_p]),
     "mphsir_dwconv_gram": (c_int, [ctypes.POINTER(GramArgs), c_int, c_void_p]),
     "mphsir_dwconv_gram_keeps_qk": (c_int, [c_int32, c_int32, c_int]),
     "mphsir_spectral_fold": (c_int, [ctypes.POINTER(FoldArgs), c_int, c_void_p]),

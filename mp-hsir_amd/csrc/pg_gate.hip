@@ -1,0 +1,373 @@
+// pg_gate_fwd / pg_gate_bwd: the local spectral-prompt gate of PG_Spectral_Attention (net/MP_HSIR.py:132-152) and its
+// backward, for 16 windows per workgroup.
+//
+// Per window the gate is a chain of small products on the window mean mu (C):  w = softmax(Wprompt mu) (128),
+// s = w^T P (r), q = Wq s, [k;v] = Wkv (Wdown mu), A = softmax_rows(q k^T / sqrt r) (r x r), o = A v,
+// g = Wup (Wproj o + b) (C).  Round 1 ran it as the tail of win_attn (one window per workgroup: ~10 barrier-separated
+// mat-vecs, every weight re-read from L2 per window; a third of that kernel) and its backward the same way (25 links,
+// 0.8 ms per training step).  Here a workgroup owns NWIN = 16 windows, so every link is a small mat-MAT: the two
+// C-sized products (Wprompt mu, Wdown mu; in the backward also Wup^T dg and Wprompt^T dlogit) are fp32 MFMA tiles
+// (v_mfma_f32_16x16x4_f32: exact f32, windows on the N axis) whose weight fragments are read from L2 once per 16
+// windows, the r-sized links run one thread per (window, index), and one barrier serves 16 windows.
+// Everything is fp32 (the reference's gate is a handful of fp32 Linear layers on a mean).
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+constexpr int PG_NWIN = 16;     // windows per workgroup = N of the MFMA tiles
+constexpr int PG_RMAX = 32;     // low-rank width bound (r = C / compress_ratio: 8..24 in the shipped models)
+
+struct PgDev {
+    const float* mu; const float* dgate;
+    const float* Wprompt; const float* Pp; const float* Wq; const float* Wkv; const float* Wdown;
+    const float* Wpproj; const float* bpproj; const float* Wup;
+    float* gate;                // forward:  [nW][C]
+    float* dmu;                 // backward: [nW][C]
+    void* L; void* R;           // backward: [nW][KL], [nW][KR] factor rows (fp32 or bf16)
+    int nW, C, r, KL, KR, lr_bf16;
+};
+
+// fragment of rows row0..row0+15 of a row-major [nrows][ld] fp32 matrix in global memory; rows past nrows-1 are clamped
+// (their products land in accumulator rows nobody reads)
+__device__ __forceinline__ f32x4 pg_frag_rows(const float* W, int ld, int nrows, int row0, int k0) {
+    const int l = lane_id();
+    int row = row0 + (l & 15);
+    row = row < nrows ? row : nrows - 1;
+    return *reinterpret_cast<const f32x4*>(W + (long)row * ld + k0 + 4 * (l >> 4));
+}
+// fragment of COLUMNS col0..col0+15 of a row-major [K][ld] fp32 matrix in global memory (the operand transposed):
+// row (l&15) of the fragment = column col0+(l&15), its K elements = rows k0 + 4*(l>>4) .. +3; columns / rows past the
+// matrix are clamped
+__device__ __forceinline__ f32x4 pg_frag_cols(const float* W, int ld, int ncols, int nk, int col0, int k0) {
+    const int l = lane_id();
+    int col = col0 + (l & 15);
+    col = col < ncols ? col : ncols - 1;
+    const int kb = k0 + 4 * (l >> 4);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = kb + j < nk ? kb + j : nk - 1;
+        v[j] = kb + j < nk ? W[(long)k * ld + col] : 0.f;
+        (void)k;
+    }
+    return v;
+}
+
+struct PgLds {
+    float* mu;      // [16][LDC]
+    float* dg;      // [16][LDC]   (backward)
+    float* w;       // [16][LDW]   prompt logits -> weights
+    float* dl;      // [16][LDW]   (backward) d weights -> d logits
+    float* P;       // [128][r]    prompt_param staged once
+    float* sm;      // [16][SMW]   small per-window vectors
+    float* At;      // [16][r*r]   (backward) attention probabilities
+    int LDC, LDW, SMW;
+};
+// offsets of the small vectors inside a window's sm row (r <= 32)
+enum { PG_S = 0, PG_D = 32, PG_KV = 64, PG_Q = 128, PG_O = 160, PG_O2 = 192, PG_DO2 = 224, PG_DO = 256, PG_DQ = 288, PG_DKV = 320,
+       PG_DD = 384, PG_DS = 416, PG_SMW = 448 };
+
+__device__ __forceinline__ PgLds pg_lds(float* base, int C, int r, bool bwd) {
+    PgLds s;
+    s.LDC = C + 8;                 // 32-byte row padding: conflict-free ds_read_b128 fragments (mphsir_dev.h)
+    s.LDW = 128 + 8;
+    s.SMW = PG_SMW;
+    s.mu = base;
+    s.dg = s.mu + PG_NWIN * s.LDC;
+    s.w = s.dg + (bwd ? PG_NWIN * s.LDC : 0);
+    s.dl = s.w + PG_NWIN * s.LDW;
+    s.P = s.dl + (bwd ? PG_NWIN * s.LDW : 0);
+    s.sm = s.P + 128 * r;
+    s.At = s.sm + PG_NWIN * PG_SMW;
+    return s;
+}
+static size_t pg_lds_bytes(int C, int r, bool bwd) {
+    size_t n = (size_t)PG_NWIN * (C + 8) * (bwd ? 2 : 1) + (size_t)PG_NWIN * 136 * (bwd ? 2 : 1) + 128 * (size_t)r + (size_t)PG_NWIN * PG_SMW;
+    if (bwd) n += (size_t)PG_NWIN * r * r;
+    return n * sizeof(float);
+}
+
+// ---- the forward chain for the workgroup's 16 windows (shared by both kernels); ends with o2 in sm[.][PG_O2] --------------
+template <bool KEEP_AT>
+__device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s, int win0) {
+    const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // mu tile (windows past nW: zeros), prompt_param
+    for (int i = tid; i < PG_NWIN * C; i += 256) {
+        const int w = i / C, c = i % C;
+        s.mu[w * s.LDC + c] = win0 + w < a.nW ? a.mu[(long)(win0 + w) * C + c] : 0.f;
+    }
+    for (int i = tid; i < 128 * r; i += 256) s.P[i] = a.Pp[i];
+    __syncthreads();
+    // logits = Wprompt mu (128 rows: two 16-row tiles per wave) and d = Wdown mu (r rows: waves 0..ceil(r/16)-1)
+    {
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, accd = {0, 0, 0, 0};
+        const bool has_d = wv * 16 < r;
+        for (int kc = 0; kc < C; kc += 16) {
+            const f32x4 b = load_frag<float>(s.mu, s.LDC, 0, kc);
+            mma(acc0, pg_frag_rows(a.Wprompt, C, 128, wv * 32, kc), b);
+            mma(acc1, pg_frag_rows(a.Wprompt, C, 128, wv * 32 + 16, kc), b);
+            if (has_d) mma(accd, pg_frag_rows(a.Wdown, C, r, wv * 16, kc), b);
+        }
+        const int w = lane & 15, rr = (lane >> 4) * 4;
+        for (int j = 0; j < 4; ++j) {
+            s.w[w * s.LDW + wv * 32 + rr + j] = acc0[j];
+            s.w[w * s.LDW + wv * 32 + 16 + rr + j] = acc1[j];
+            if (has_d && wv * 16 + rr + j < r) s.sm[w * PG_SMW + PG_D + wv * 16 + rr + j] = accd[j];
+        }
+    }
+    __syncthreads();
+    // softmax over the 128 logits: wave wv owns windows 4wv .. 4wv+3
+    for (int ww = 0; ww < 4; ++ww) {
+        float* lw = s.w + (wv * 4 + ww) * s.LDW;
+        const float l0 = lw[lane], l1 = lw[lane + 64];
+        float m = fmaxf(l0, l1);
+        for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float tot = wave_sum(e0 + e1);
+        lw[lane] = e0 / tot;
+        lw[lane + 64] = e1 / tot;
+    }
+    // kv = Wkv d  (one thread per (window, row))
+    for (int i = tid; i < PG_NWIN * 2 * r; i += 256) {
+        const int w = i / (2 * r), m = i % (2 * r);
+        const float* d = s.sm + w * PG_SMW + PG_D;
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += a.Wkv[m * r + j] * d[j];
+        s.sm[w * PG_SMW + PG_KV + m] = acc;
+    }
+    __syncthreads();
+    // s = w^T P
+    for (int i = tid; i < PG_NWIN * r; i += 256) {
+        const int w = i / r, j = i % r;
+        const float* lw = s.w + w * s.LDW;
+        float acc = 0.f;
+        for (int p = 0; p < 128; ++p) acc += lw[p] * s.P[p * r + j];
+        s.sm[w * PG_SMW + PG_S + j] = acc;
+    }
+    __syncthreads();
+    // q = Wq s
+    for (int i = tid; i < PG_NWIN * r; i += 256) {
+        const int w = i / r, m = i % r;
+        const float* sv = s.sm + w * PG_SMW + PG_S;
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += a.Wq[m * r + j] * sv[j];
+        s.sm[w * PG_SMW + PG_Q + m] = acc;
+    }
+    __syncthreads();
+    // o_i = sum_j softmax_j(q_i k_j / sqrt r) v_j
+    const float sc = rsqrtf((float)r);
+    for (int i = tid; i < PG_NWIN * r; i += 256) {
+        const int w = i / r, m = i % r;
+        const float* kv = s.sm + w * PG_SMW + PG_KV;
+        const float qs = s.sm[w * PG_SMW + PG_Q + m] * sc;
+        float mx = -3.0e38f;
+        for (int j = 0; j < r; ++j) mx = fmaxf(mx, qs * kv[j]);
+        float den = 0.f, num = 0.f;
+        for (int j = 0; j < r; ++j) {
+            const float e = expf(qs * kv[j] - mx);
+            if (KEEP_AT) s.At[(w * r + m) * r + j] = e;
+            den += e;
+            num += e * kv[r + j];
+        }
+        if (KEEP_AT)
+            for (int j = 0; j < r; ++j) s.At[(w * r + m) * r + j] /= den;
+        s.sm[w * PG_SMW + PG_O + m] = num / den;
+    }
+    __syncthreads();
+    // o2 = Wproj o + b
+    for (int i = tid; i < PG_NWIN * r; i += 256) {
+        const int w = i / r, m = i % r;
+        const float* o = s.sm + w * PG_SMW + PG_O;
+        float acc = a.bpproj[m];
+        for (int j = 0; j < r; ++j) acc += a.Wpproj[m * r + j] * o[j];
+        s.sm[w * PG_SMW + PG_O2 + m] = acc;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), a.C, a.r, false);
+    const int C = a.C, r = a.r, tid = threadIdx.x, win0 = blockIdx.x * PG_NWIN;
+    pg_forward_chain<false>(a, s, win0);
+    // g = Wup o2: one thread per (window, channel), coalesced along c
+    for (int i = tid; i < PG_NWIN * C; i += 256) {
+        const int w = i / C, c = i % C;
+        if (win0 + w >= a.nW) continue;
+        const float* o2 = s.sm + w * PG_SMW + PG_O2;
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += a.Wup[c * r + j] * o2[j];
+        a.gate[(long)(win0 + w) * C + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), a.C, a.r, true);
+    const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, win0 = blockIdx.x * PG_NWIN;
+    for (int i = tid; i < PG_NWIN * C; i += 256) {
+        const int w = i / C, c = i % C;
+        s.dg[w * s.LDC + c] = win0 + w < a.nW ? a.dgate[(long)(win0 + w) * C + c] : 0.f;
+    }
+    pg_forward_chain<true>(a, s, win0);           // its first barrier also covers the dg tile
+    const float sc = rsqrtf((float)r);
+    // do2 = Wup^T dg  (r rows x 16 windows, K = C): MFMA with the weight read column-wise
+    if (wv * 16 < r) {
+        f32x4 acc = {0, 0, 0, 0};
+        for (int kc = 0; kc < C; kc += 16)
+            mma(acc, pg_frag_cols(a.Wup, r, r, C, wv * 16, kc), load_frag<float>(s.dg, s.LDC, 0, kc));
+        const int w = lane & 15, rr = wv * 16 + (lane >> 4) * 4;
+        for (int j = 0; j < 4; ++j)
+            if (rr + j < r) s.sm[w * PG_SMW + PG_DO2 + rr + j] = acc[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < PG_NWIN * r; i += 256) {          // do = Wproj^T do2
+        const int w = i / r, m = i % r;
+        const float* do2 = s.sm + w * PG_SMW + PG_DO2;
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += a.Wpproj[j * r + m] * do2[j];
+        s.sm[w * PG_SMW + PG_DO + m] = acc;
+    }
+    __syncthreads();
+    // row i: dS_ij = A_ij (do_i v_j - sum_j' A_ij' do_i v_j');  dq_i = sc sum_j dS_ij k_j.  dS overwrites A in place.
+    for (int i = tid; i < PG_NWIN * r; i += 256) {
+        const int w = i / r, m = i % r;
+        float* A = s.At + (w * r + m) * r;
+        const float* kv = s.sm + w * PG_SMW + PG_KV;
+        const float dov = s.sm[w * PG_SMW + PG_DO + m];
+        float rs = 0.f;
+        for (int j = 0; j < r; ++j) rs += A[j] * dov * kv[r + j];
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += A[j] * (dov * kv[r + j] - rs) * kv[j];
+        s.sm[w * PG_SMW + PG_DQ + m] = acc * sc;
+    }
+    __syncthreads();
+    // column j: dk_j = sc sum_i dS_ij q_i ; dv_j = sum_i A_ij do_i   (dS recomputed from A: cheap, no second tile)
+    for (int i = tid; i < PG_NWIN * r; i += 256) {
+        const int w = i / r, j = i % r;
+        const float* kv = s.sm + w * PG_SMW + PG_KV;
+        const float* q = s.sm + w * PG_SMW + PG_Q;
+        const float* dov = s.sm + w * PG_SMW + PG_DO;
+        float dk = 0.f, dv = 0.f;
+        for (int m = 0; m < r; ++m) {
+            const float* A = s.At + (w * r + m) * r;
+            float rs = 0.f;
+            for (int jj = 0; jj < r; ++jj) rs += A[jj] * dov[m] * kv[r + jj];
+            dk += A[j] * (dov[m] * kv[r + j] - rs) * q[m];
+            dv += A[j] * dov[m];
+        }
+        s.sm[w * PG_SMW + PG_DKV + j] = dk * sc;
+        s.sm[w * PG_SMW + PG_DKV + r + j] = dv;
+    }
+    __syncthreads();
+    for (int i = tid; i < PG_NWIN * r; i += 256) {          // dd = Wkv^T dkv ; ds = Wq^T dq
+        const int w = i / r, j = i % r;
+        const float* dkv = s.sm + w * PG_SMW + PG_DKV;
+        const float* dq = s.sm + w * PG_SMW + PG_DQ;
+        float acc = 0.f, acc2 = 0.f;
+        for (int m = 0; m < 2 * r; ++m) acc += a.Wkv[m * r + j] * dkv[m];
+        for (int m = 0; m < r; ++m) acc2 += a.Wq[m * r + j] * dq[m];
+        s.sm[w * PG_SMW + PG_DD + j] = acc;
+        s.sm[w * PG_SMW + PG_DS + j] = acc2;
+    }
+    __syncthreads();
+    for (int i = tid; i < PG_NWIN * 128; i += 256) {        // dw[p] = P[p] . ds
+        const int w = i >> 7, p = i & 127;
+        const float* ds = s.sm + w * PG_SMW + PG_DS;
+        float acc = 0.f;
+        for (int j = 0; j < r; ++j) acc += s.P[p * r + j] * ds[j];
+        s.dl[w * s.LDW + p] = acc;
+    }
+    __syncthreads();
+    for (int ww = 0; ww < 4; ++ww) {                        // dlogit = w (dw - sum w dw)
+        const int w = wv * 4 + ww;
+        const float w0 = s.w[w * s.LDW + lane], w1 = s.w[w * s.LDW + lane + 64];
+        const float d0 = s.dl[w * s.LDW + lane], d1 = s.dl[w * s.LDW + lane + 64];
+        const float tot = wave_sum(w0 * d0 + w1 * d1);
+        s.dl[w * s.LDW + lane] = w0 * (d0 - tot);
+        s.dl[w * s.LDW + lane + 64] = w1 * (d1 - tot);
+    }
+    __syncthreads();
+    // dmu = Wprompt^T dlogit + Wdown^T dd:  C rows x 16 windows, K = 128 by MFMA, the rank-r term in the epilogue
+    for (int ct = wv; ct < C / 16; ct += 4) {
+        f32x4 acc = {0, 0, 0, 0};
+        for (int kc = 0; kc < 128; kc += 16)
+            mma(acc, pg_frag_cols(a.Wprompt, C, C, 128, ct * 16, kc), load_frag<float>(s.dl, s.LDW, 0, kc));
+        const int w = lane & 15, c0 = ct * 16 + (lane >> 4) * 4;
+        const float* dd = s.sm + w * PG_SMW + PG_DD;
+        for (int m = 0; m < r; ++m) {
+            const f32x4 wd = *reinterpret_cast<const f32x4*>(a.Wdown + (long)m * C + c0);
+            for (int j = 0; j < 4; ++j) acc[j] += wd[j] * dd[m];
+        }
+        if (win0 + w < a.nW) *reinterpret_cast<f32x4*>(a.dmu + (long)(win0 + w) * C + c0) = acc;
+    }
+    // ---- factor rows: L = [dg(C) | do2(r) | dkv(2r) | dq(r) | w(128) | dlogit(128) | dd(r) | 0..],
+    //                   R = [o2(r) | o(r) | 1 | d(r) | s(r) | ds(r) | mu(C) | 0..]
+    for (int w = 0; w < PG_NWIN; ++w) {
+        if (win0 + w >= a.nW) break;
+        const float* sm = s.sm + w * PG_SMW;
+        float* L = reinterpret_cast<float*>(a.L) + (long)(win0 + w) * a.KL;
+        float* R = reinterpret_cast<float*>(a.R) + (long)(win0 + w) * a.KR;
+        bf16_t* Lh = reinterpret_cast<bf16_t*>(a.L) + (long)(win0 + w) * a.KL;
+        bf16_t* Rh = reinterpret_cast<bf16_t*>(a.R) + (long)(win0 + w) * a.KR;
+        for (int c = tid; c < a.KL; c += 256) {
+            float v = 0.f;
+            int o = c;
+            if (o < C) v = s.dg[w * s.LDC + o];
+            else if ((o -= C) < r) v = sm[PG_DO2 + o];
+            else if ((o -= r) < 2 * r) v = sm[PG_DKV + o];
+            else if ((o -= 2 * r) < r) v = sm[PG_DQ + o];
+            else if ((o -= r) < 128) v = s.w[w * s.LDW + o];
+            else if ((o -= 128) < 128) v = s.dl[w * s.LDW + o];
+            else if ((o -= 128) < r) v = sm[PG_DD + o];
+            if (a.lr_bf16) Lh[c] = (bf16_t)v; else L[c] = v;
+        }
+        for (int c = tid; c < a.KR; c += 256) {
+            float v = 0.f;
+            int o = c;
+            if (o < r) v = sm[PG_O2 + o];
+            else if ((o -= r) < r) v = sm[PG_O + o];
+            else if ((o -= r) < 1) v = 1.f;
+            else if ((o -= 1) < r) v = sm[PG_D + o];
+            else if ((o -= r) < r) v = sm[PG_S + o];
+            else if ((o -= r) < r) v = sm[PG_DS + o];
+            else if ((o -= r) < C) v = s.mu[w * s.LDC + o];
+            if (a.lr_bf16) Rh[c] = (bf16_t)v; else R[c] = v;
+        }
+    }
+}
+
+}  // namespace mphsir
+
+extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->mu && a->Wprompt && a->prompt_param && a->Wq && a->Wkv && a->Wdown && a->Wpproj && a->bpproj && a->Wup && a->gate,
+                   "pg_gate_fwd: null pointer");
+    MPHSIR_REQUIRE(a->nW > 0 && a->C > 0 && a->C % 16 == 0 && a->r > 0 && a->r <= PG_RMAX, "pg_gate_fwd: need C %% 16 == 0 and 0 < r <= 32");
+    PgDev d{a->mu, nullptr, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->gate, nullptr, nullptr,
+            nullptr, a->nW, a->C, a->r, 0, 0, 0};
+    const size_t shmem = pg_lds_bytes(a->C, a->r, false);
+    allow_big_lds(pg_gate_fwd_kernel, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_PG_GATE, pg_gate_fwd_kernel, dim3((a->nW + PG_NWIN - 1) / PG_NWIN), dim3(256), shmem,
+                  reinterpret_cast<hipStream_t>(stream), d);
+    return MPHSIR_OK;
+}
+
+extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->mu && a->dgate && a->Wprompt && a->prompt_param && a->Wq && a->Wkv && a->Wdown && a->Wpproj && a->bpproj &&
+                       a->Wup && a->dmu && a->L && a->R, "pg_gate_bwd: null pointer");
+    MPHSIR_REQUIRE(a->nW > 0 && a->C > 0 && a->C % 16 == 0 && a->r > 0 && a->r <= PG_RMAX, "pg_gate_bwd: need C %% 16 == 0 and 0 < r <= 32");
+    MPHSIR_REQUIRE(a->KL >= a->C + 5 * a->r + 256 && a->KR >= 5 * a->r + 1 + a->C, "pg_gate_bwd: factor widths too small");
+    MPHSIR_REQUIRE(!a->lr_bf16 || (a->KL % 8 == 0 && a->KR % 8 == 0), "pg_gate_bwd: bf16 factor rows need KL, KR multiples of 8");
+    PgDev d{a->mu, a->dgate, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, nullptr, a->dmu, a->L, a->R,
+            a->nW, a->C, a->r, a->KL, a->KR, a->lr_bf16};
+    const size_t shmem = pg_lds_bytes(a->C, a->r, true);
+    allow_big_lds(pg_gate_bwd_kernel, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_PG_GATE_BWD, pg_gate_bwd_kernel, dim3((a->nW + PG_NWIN - 1) / PG_NWIN), dim3(256), shmem,
+                  reinterpret_cast<hipStream_t>(stream), d);
+    return MPHSIR_OK;
+}

@@ -12,7 +12,6 @@
 //       windows) contains every parameter gradient of the branch as a sub-block.
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
-#include "pg_gate_dev.h"
 
 namespace mphsir {
 
@@ -212,170 +211,6 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-struct PgBwdDev {
-    const float* mu; const float* dgate;
-    const float* Wprompt; const float* Pp; const float* Wq; const float* Wkv; const float* Wdown;
-    const float* Wpproj; const float* bpproj; const float* Wup;
-    float* dmu;                 // [nW][C]
-    void* L; void* R;           // [nW][KL], [nW][KR]: fp32, or bf16 (lr_bf16) so that their product joins the grouped bf16 GEMM launch
-    int nW, C, r, KL, KR, lr_bf16;
-};
-
-__global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgBwdDev a) {
-    HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float* mu = reinterpret_cast<float*>(smem_v);     // [C]
-    float* dg = mu + C;                               // [C]
-    float* w = dg + C;                                // [128] prompt weights
-    float* dl = w + 128;                              // [128] d logits
-    float* sm = dl + 128;                             // small vectors, 32 apart (r <= 32)
-    float* s_ = sm, *d_ = sm + 32, *kv = sm + 64, *q_ = sm + 128, *o_ = sm + 160, *o2 = sm + 192;
-    float* do2 = sm + 224, *do_ = sm + 256, *dq = sm + 288, *dkv = sm + 320, *dd = sm + 384, *ds = sm + 416;
-    float* At = sm + 448;                             // [r][r] attention probabilities (r*r <= 1024)
-    float* red = At + 1024;                           // [256] partial sums of pg_matvec_cols
-    float* tmp = red + 256;                           // [C] Wprompt^T dlogit
-    const long win = blockIdx.x;
-    for (int c = tid; c < C; c += 256) { mu[c] = a.mu[win * C + c]; dg[c] = a.dgate[win * C + c]; }
-    __syncthreads();
-    // ---- forward recompute -------------------------------------------------------------------------
-    pg_matvec_rows(a.Wprompt, 128, C, mu, w, red);
-    __syncthreads();
-    pg_matvec_rows(a.Wdown, r, C, mu, d_, red);
-    __syncthreads();
-    if (wv == 0) {
-        const float l0 = w[lane], l1 = w[lane + 64];
-        float m = fmaxf(l0, l1);
-        for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
-        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
-        const float tot = wave_sum(e0 + e1);
-        w[lane] = e0 / tot;
-        w[lane + 64] = e1 / tot;
-    }
-    __syncthreads();
-    if (tid >= 64 && tid < 64 + 2 * r) {
-        const int i = tid - 64;
-        float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += a.Wkv[i * r + j] * d_[j];
-        kv[i] = acc;
-    }
-    pg_matvec_cols(a.Pp, 128, r, w, s_, red);
-    __syncthreads();
-    if (tid < r) {
-        float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += a.Wq[tid * r + j] * s_[j];
-        q_[tid] = acc;
-    }
-    __syncthreads();
-    const float sc = rsqrtf((float)r);
-    if (tid < r) {
-        const float qs = q_[tid] * sc;
-        float m = -3.0e38f;
-        for (int j = 0; j < r; ++j) m = fmaxf(m, qs * kv[j]);
-        float den = 0.f, num = 0.f;
-        for (int j = 0; j < r; ++j) { const float e = expf(qs * kv[j] - m); At[tid * r + j] = e; den += e; num += e * kv[r + j]; }
-        for (int j = 0; j < r; ++j) At[tid * r + j] /= den;
-        o_[tid] = num / den;
-    }
-    __syncthreads();
-    if (tid < r) {
-        float acc = a.bpproj[tid];
-        for (int j = 0; j < r; ++j) acc += a.Wpproj[tid * r + j] * o_[j];
-        o2[tid] = acc;
-    }
-    // ---- backward --------------------------------------------------------------------------------------
-    __syncthreads();                                  // red is free again (its last readers were before two barriers)
-    pg_matvec_cols(a.Wup, C, r, dg, do2, red);        // do2 = Wup^T dg
-    __syncthreads();
-    if (tid < r) {                                    // do = Wpproj^T do2
-        float acc = 0.f;
-        for (int i = 0; i < r; ++i) acc += a.Wpproj[i * r + tid] * do2[i];
-        do_[tid] = acc;
-    }
-    __syncthreads();
-    if (tid < r) {                                    // row i: dS_ij = A_ij (do_i v_j - sum_j' A_ij' do_i v_j'); dq_i = sc sum_j dS_ij k_j
-        const int i = tid;
-        float rs = 0.f;
-        for (int j = 0; j < r; ++j) rs += At[i * r + j] * do_[i] * kv[r + j];
-        float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += At[i * r + j] * (do_[i] * kv[r + j] - rs) * kv[j];
-        dq[i] = acc * sc;
-    }
-    __syncthreads();
-    if (tid < r) {                                    // column j: dk_j = sc sum_i dS_ij q_i ; dv_j = sum_i A_ij do_i
-        const int j = tid;
-        float dk = 0.f, dv = 0.f;
-        for (int i = 0; i < r; ++i) {
-            float rs = 0.f;
-            for (int jj = 0; jj < r; ++jj) rs += At[i * r + jj] * do_[i] * kv[r + jj];
-            dk += At[i * r + j] * (do_[i] * kv[r + j] - rs) * q_[i];
-            dv += At[i * r + j] * do_[i];
-        }
-        dkv[j] = dk * sc;
-        dkv[r + j] = dv;
-    }
-    __syncthreads();
-    if (tid < r) {                                    // dd = Wkv^T dkv ; ds = Wq^T dq
-        float acc = 0.f, acc2 = 0.f;
-        for (int m = 0; m < 2 * r; ++m) acc += a.Wkv[m * r + tid] * dkv[m];
-        for (int i = 0; i < r; ++i) acc2 += a.Wq[i * r + tid] * dq[i];
-        dd[tid] = acc;
-        ds[tid] = acc2;
-    }
-    __syncthreads();
-    if (tid < 128) {                                  // dw[p] = Pp[p] . ds
-        float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += a.Pp[tid * r + j] * ds[j];
-        dl[tid] = acc;
-    }
-    __syncthreads();
-    if (wv == 0) {                                    // dlogit = w (dw - sum w dw)
-        const float t0 = w[lane] * dl[lane], t1 = w[lane + 64] * dl[lane + 64];
-        const float tot = wave_sum(t0 + t1);
-        const float a0 = w[lane] * (dl[lane] - tot), a1 = w[lane + 64] * (dl[lane + 64] - tot);
-        dl[lane] = a0;
-        dl[lane + 64] = a1;
-    }
-    __syncthreads();
-    pg_matvec_cols(a.Wprompt, 128, C, dl, tmp, red);  // Wprompt^T dlogit
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {              // dmu = Wprompt^T dlogit + Wdown^T dd
-        float acc = tmp[c];
-        for (int i = 0; i < r; ++i) acc += a.Wdown[i * C + c] * dd[i];
-        a.dmu[win * C + c] = acc;
-    }
-    // ---- factor rows: L = [dg(C) | do2(r) | dkv(2r) | dq(r) | w(128) | dlogit(128) | dd(r) | 0..],
-    //                   R = [o2(r) | o(r) | 1 | d(r) | s(r) | ds(r) | mu(C) | 0..]
-    float* L = reinterpret_cast<float*>(a.L) + win * a.KL;
-    float* R = reinterpret_cast<float*>(a.R) + win * a.KR;
-    bf16_t* Lh = reinterpret_cast<bf16_t*>(a.L) + win * a.KL;
-    bf16_t* Rh = reinterpret_cast<bf16_t*>(a.R) + win * a.KR;
-    for (int c = tid; c < a.KL; c += 256) {
-        float v = 0.f;
-        int o = c;
-        if (o < C) v = dg[o];
-        else if ((o -= C) < r) v = do2[o];
-        else if ((o -= r) < 2 * r) v = dkv[o];
-        else if ((o -= 2 * r) < r) v = dq[o];
-        else if ((o -= r) < 128) v = w[o];
-        else if ((o -= 128) < 128) v = dl[o];
-        else if ((o -= 128) < r) v = dd[o];
-        if (a.lr_bf16) Lh[c] = (bf16_t)v; else L[c] = v;
-    }
-    for (int c = tid; c < a.KR; c += 256) {
-        float v = 0.f;
-        int o = c;
-        if (o < r) v = o2[o];
-        else if ((o -= r) < r) v = o_[o];
-        else if ((o -= r) < 1) v = 1.f;
-        else if ((o -= 1) < r) v = d_[o];
-        else if ((o -= r) < r) v = s_[o];
-        else if ((o -= r) < r) v = ds[o];
-        else if ((o -= r) < C) v = mu[o];
-        if (a.lr_bf16) Rh[c] = (bf16_t)v; else R[c] = v;
-    }
-}
-
 }  // namespace mphsir
 
 extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype, void* stream) {
@@ -397,20 +232,5 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
         allow_big_lds(spectral_fold_bwd_kernel<bf16_t>, shmem);
         MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<bf16_t>), dim3(a->B * a->heads), dim3(FB_THREADS), shmem, s, d);
     }
-    return MPHSIR_OK;
-}
-
-extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
-    using namespace mphsir;
-    clear_error();
-    MPHSIR_REQUIRE(a && a->mu && a->dgate && a->Wprompt && a->prompt_param && a->Wq && a->Wkv && a->Wdown && a->Wpproj && a->bpproj &&
-                       a->Wup && a->dmu && a->L && a->R, "pg_gate_bwd: null pointer");
-    MPHSIR_REQUIRE(a->nW > 0 && a->C > 0 && a->r > 0 && a->r <= 32, "pg_gate_bwd: bad shape");
-    MPHSIR_REQUIRE(a->KL >= a->C + 5 * a->r + 256 && a->KR >= 5 * a->r + 1 + a->C, "pg_gate_bwd: factor widths too small");
-    PgBwdDev d{a->mu, a->dgate, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->dmu, a->L, a->R,
-               a->nW, a->C, a->r, a->KL, a->KR, a->lr_bf16};
-    MPHSIR_REQUIRE(!a->lr_bf16 || (a->KL % 8 == 0 && a->KR % 8 == 0), "pg_gate_bwd: bf16 factor rows need KL, KR multiples of 8");
-    const size_t shmem = (2 * (size_t)a->C + 256 + 448 + 1024 + 256 + (size_t)a->C) * sizeof(float);
-    MPHSIR_LAUNCH(MPHSIR_K_PG_GATE_BWD, pg_gate_bwd_kernel, dim3(a->nW), dim3(256), shmem, reinterpret_cast<hipStream_t>(stream), d);
     return MPHSIR_OK;
 }

@@ -1,10 +1,10 @@
-// win_attn_fwd: LayerNorm -> cyclic shift -> 8x8 window MSA -> proj, plus the local spectral-prompt gate.
+// win_attn_fwd: LayerNorm -> cyclic shift -> 8x8 window MSA -> proj, plus the window mean the spectral-prompt gate reads.
 //
 // Replaces, per PGSSTB block (net/MP_HSIR.py:662-713): norm1 (:667), torch.roll (:672),
 // window_partition (:677), Spatial_Attention.forward (:193-218: qkv Linear, q*scale, QK^T,
 // relative-position bias gather, -100 shift mask, softmax, AV, proj), window_reverse + roll back
-// (:690-696) and the gate of PG_Spectral_Attention.forward (:132-152; the final `out*shortcut`
-// multiply, :153, is folded into gemm_tok's epilogue 2).
+// (:690-696) and the window mean of PG_Spectral_Attention.forward (:135; the gate itself is csrc/pg_gate.hip, 16 windows
+// per workgroup, and the final `out*shortcut` multiply, :153, is folded into gemm_tok's epilogue 2).
 //
 // One 256-thread workgroup = one window (64 tokens).  Roll/partition/reverse are address arithmetic
 // on the channels-last cube; the shift mask is computed from coordinates (no mask tensor).  Per head:
@@ -16,7 +16,6 @@
 // After (a) every step is wave-local (wave w owns query rows 16w..16w+15).
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
-#include "pg_gate_dev.h"
 
 namespace mphsir {
 
@@ -26,12 +25,10 @@ struct WinAttnDev {
     const void* Wqkv; const float* bqkv;
     const float* rpb;
     const void* Wproj; const float* bproj;
-    const float* Wprompt; const float* Pp; const float* Wq; const float* Wkv; const float* Wdown;
-    const float* Wpproj; const float* bpproj; const float* Wup;
-    void* SA; float* gate;
-    float* mu;      // optional [B*nW][C]: window mean of SA (training: input of the gate's autograd)
+    void* SA;
+    float* mu;      // [B*nW][C]: window mean of SA = the input of the spectral-prompt gate (mphsir_pg_gate_fwd)
     void* Oattn;    // optional [B*nW*64][C]: attention output before proj, window-token order (training: dWproj)
-    int B, H, W, shift, r;
+    int B, H, W, shift;
 };
 
 template <class T, int C, int HD> struct WinAttnCfg {
@@ -47,7 +44,6 @@ template <class T, int C, int HD> struct WinAttnCfg {
     static constexpr size_t F_WORDS = 225 + 64;                      // bias column of one head, region ids
     static constexpr size_t BYTES = T_ELEMS * sizeof(T) + F_WORDS * 4;
     static_assert(BYTES <= 160 * 1024, "window-attention tile does not fit LDS");
-    static_assert((C + 128 + 8 * 32 + 256) * 4 <= 2 * QS * sizeof(T), "PG scratch must fit in the q/k tiles");
     static_assert(C % 32 == 0 && HD % 16 == 0 && C % HD == 0, "unsupported width");
 };
 
@@ -285,66 +281,11 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         }
     }
 
-    // ---- local spectral-prompt gate (PG_Spectral_Attention, :132-152), fp32, tiny ----------------
-    float* mu = reinterpret_cast<float*>(Qs);     // [C]
-    float* lg = mu + C;                           // [128] prompt logits -> weights
-    float* sm = lg + 128;                         // small vectors, 32 floats apart
-    float* red = sm + 8 * 32;                     // [256] partial sums of pg_matvec_cols
-    const int r = a.r;
+    // ---- window mean of the attention output: the input of the local spectral-prompt gate (csrc/pg_gate.hip) ---------
     for (int c = tid; c < C; c += 256) {
         float acc = 0.f;
         for (int t = 0; t < 64; ++t) acc += to_f32(Xs[t * CF::LDX + c]);
-        mu[c] = acc * (1.0f / 64.0f);
-        if (a.mu) a.mu[(long)blockIdx.x * C + c] = mu[c];
-    }
-    __syncthreads();
-    pg_matvec_rows(a.Wprompt, 128, C, mu, lg, red);      // prompt logits
-    __syncthreads();
-    pg_matvec_rows(a.Wdown, r, C, mu, sm + 32, red);     // d = linear_down(mu)
-    __syncthreads();
-    if (wv == 0) {                                // softmax over the 128 prompt logits
-        const float l0 = lg[lane], l1 = lg[lane + 64];
-        float m = fmaxf(l0, l1);
-        for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
-        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
-        const float tot = wave_sum(e0 + e1);
-        lg[lane] = e0 / tot;
-        lg[lane + 64] = e1 / tot;
-    }
-    __syncthreads();
-    if (tid >= 64 && tid < 64 + 2 * r) {          // kv = Wkv d
-        const int i = tid - 64;
-        float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += a.Wkv[i * r + j] * sm[32 + j];
-        sm[64 + i] = acc;                         // k at sm[64..64+r), v at sm[64+r..64+2r)
-    }
-    pg_matvec_cols(a.Pp, 128, r, lg, sm, red);    // s = w^T P
-    __syncthreads();
-    if (tid < r) {                                // q = Wq s
-        float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += a.Wq[tid * r + j] * sm[j];
-        sm[128 + tid] = acc;
-    }
-    __syncthreads();
-    if (tid < r) {                                // o_i = sum_j softmax_j(q_i k_j r^-1/2) v_j
-        const float qs = sm[128 + tid] * rsqrtf((float)r);
-        float m = -3.0e38f;
-        for (int j = 0; j < r; ++j) m = fmaxf(m, qs * sm[64 + j]);
-        float den = 0.f, num = 0.f;
-        for (int j = 0; j < r; ++j) { const float e = expf(qs * sm[64 + j] - m); den += e; num += e * sm[64 + r + j]; }
-        sm[160 + tid] = num / den;
-    }
-    __syncthreads();
-    if (tid < r) {                                // o2 = proj(o)
-        float acc = a.bpproj[tid];
-        for (int j = 0; j < r; ++j) acc += a.Wpproj[tid * r + j] * sm[160 + j];
-        sm[192 + tid] = acc;
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {          // g = linear_up(o2)
-        float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += a.Wup[c * r + j] * sm[192 + j];
-        a.gate[(long)blockIdx.x * C + c] = acc;
+        a.mu[(long)blockIdx.x * C + c] = acc * (1.0f / 64.0f);
     }
 }
 
@@ -378,18 +319,14 @@ extern "C" int mphsir_win_attn_hdp(int head_dim, int dtype) {
 extern "C" int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
-    MPHSIR_REQUIRE(a && a->X && a->SA && a->gate && a->Wqkv && a->bqkv && a->rpb && a->Wproj && a->bproj && a->ln_w && a->ln_b,
+    MPHSIR_REQUIRE(a && a->X && a->SA && a->mu && a->Wqkv && a->bqkv && a->rpb && a->Wproj && a->bproj && a->ln_w && a->ln_b,
                    "win_attn: null pointer");
-    MPHSIR_REQUIRE(a->Wprompt && a->prompt_param && a->Wq && a->Wkv && a->Wdown && a->Wpproj && a->bpproj && a->Wup,
-                   "win_attn: null spectral-prompt weight");
     MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "win_attn: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->H % 8 == 0 && a->W % 8 == 0, "win_attn: H,W must be multiples of 8");
     MPHSIR_REQUIRE(a->shift == 0 || a->shift == 4, "win_attn: shift must be 0 or 4");
     MPHSIR_REQUIRE(a->heads > 0 && a->C % a->heads == 0, "win_attn: C %% heads != 0");
-    MPHSIR_REQUIRE(a->r > 0 && a->r <= 32, "win_attn: low-rank width r=%d out of range (1..32)", a->r);
     MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->SA) && aligned16(a->Wqkv) && aligned16(a->Wproj), "win_attn: 16-byte alignment required");
-    WinAttnDev d{a->X, a->ln_w, a->ln_b, a->Wqkv, a->bqkv, a->rpb, a->Wproj, a->bproj, a->Wprompt, a->prompt_param,
-                 a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->SA, a->gate, a->mu, a->Oattn, a->B, a->H, a->W, a->shift, a->r};
+    WinAttnDev d{a->X, a->ln_w, a->ln_b, a->Wqkv, a->bqkv, a->rpb, a->Wproj, a->bproj, a->SA, a->mu, a->Oattn, a->B, a->H, a->W, a->shift};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == MPHSIR_F32 ? dispatch_win<float>(d, a->C, a->C / a->heads, s)
                                : dispatch_win<bf16_t>(d, a->C, a->C / a->heads, s);

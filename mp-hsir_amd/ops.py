@@ -312,32 +312,48 @@ def pack_win_proj(proj_w, heads, dtype):
 
 def win_attn_fwd(x, ln_w, ln_b, Wqkv, bqkv, rpb, Wproj, bproj, pg, heads, shift, save=False):
     """x (B,H,W,C) contiguous.  pg = dict of the fp32 local_spectral_attn parameters.
-    Returns (sa (B,H,W,C), gate (B*nW, C) fp32) and, with save=True, also (mu (B*nW,C) fp32, o_attn (B,H,W,C))."""
+    Returns (sa (B,H,W,C), gate (B*nW, C) fp32) and, with save=True, also (mu (B*nW,C) fp32, o_attn [B*nW*64][C] in
+    window-token order).  Two launches: the window attention (which also emits the window means) and the gate."""
     lib = _lib.load()
     _check(x, Wqkv, Wproj, *pg.values())
     B, H, W, C = x.shape
     assert x.is_contiguous() and Wqkv.shape == (3 * C, C) and Wqkv.dtype == x.dtype and Wproj.dtype == x.dtype
     sa = torch.empty_like(x)
-    gate = torch.empty((B * (H // 8) * (W // 8), C), dtype=torch.float32, device=x.device)
+    mu = torch.empty((B * (H // 8) * (W // 8), C), dtype=torch.float32, device=x.device)
     a = _lib.WinAttnArgs()
     a.X, a.ln_w, a.ln_b = _p(x), _p(ln_w), _p(ln_b)
     a.Wqkv, a.bqkv, a.rpb, a.Wproj, a.bproj = _p(Wqkv), _p(bqkv), _p(rpb), _p(Wproj), _p(bproj)
-    a.Wprompt, a.prompt_param = _p(pg["linear_prompt.weight"]), _p(pg["prompt_param"])
-    a.Wq, a.Wkv, a.Wdown = _p(pg["q.weight"]), _p(pg["kv.weight"]), _p(pg["linear_down.weight"])
-    a.Wpproj, a.bpproj, a.Wup = _p(pg["proj.weight"]), _p(pg["proj.bias"]), _p(pg["linear_up.weight"])
-    a.SA, a.gate = _p(sa), _p(gate)
-    mu = oattn = None
+    a.SA, a.mu = _p(sa), _p(mu)
+    oattn = None
     if save:
-        mu, oattn = torch.empty_like(gate), torch.empty_like(x)
-        a.mu, a.Oattn = _p(mu), _p(oattn)
+        oattn = torch.empty_like(x)
+        a.Oattn = _p(oattn)
     a.B, a.H, a.W, a.C, a.heads, a.shift = B, H, W, C, heads, shift
-    a.r = pg["linear_down.weight"].shape[0]
     _lib.check(lib.mphsir_win_attn_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "win_attn_fwd")
     M = B * H * W
-    _acct("win_attn", M * (8.0 * C * C + 4.0 * 64 * C), 2.0 * M * C * x.element_size() + gate.numel() * 4 + 4.0 * C * C * x.element_size())
+    _acct("win_attn", M * (8.0 * C * C + 4.0 * 64 * C), 2.0 * M * C * x.element_size() + mu.numel() * 4 + 4.0 * C * C * x.element_size())
+    gate = pg_gate_fwd(mu, pg)
     if save:
         return sa, gate, mu, oattn
     return sa, gate
+
+
+def pg_gate_fwd(mu, pg):
+    """mu (nW,C) fp32 window means -> gate (nW,C) fp32 (PG_Spectral_Attention.forward :136-152)."""
+    lib = _lib.load()
+    _check(mu, *pg.values())
+    nW, C = mu.shape
+    r = pg["linear_down.weight"].shape[0]
+    gate = torch.empty_like(mu)
+    a = _lib.PgFwdArgs()
+    a.mu, a.gate = _p(mu), _p(gate)
+    a.Wprompt, a.prompt_param = _p(pg["linear_prompt.weight"]), _p(pg["prompt_param"])
+    a.Wq, a.Wkv, a.Wdown = _p(pg["q.weight"]), _p(pg["kv.weight"]), _p(pg["linear_down.weight"])
+    a.Wpproj, a.bpproj, a.Wup = _p(pg["proj.weight"]), _p(pg["proj.bias"]), _p(pg["linear_up.weight"])
+    a.nW, a.C, a.r = nW, C, r
+    _lib.check(lib.mphsir_pg_gate_fwd(ctypes.byref(a), _stream(mu)), "pg_gate_fwd")
+    _acct("pg_gate", 2.0 * nW * C * (128 + 2 * r), 4.0 * nW * 2 * C)
+    return gate
 
 
 def pack_dw(w):
