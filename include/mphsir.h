@@ -32,6 +32,7 @@ extern "C" {
 
 #define MPHSIR_F32 0
 #define MPHSIR_BF16 1
+#define MPHSIR_F16 2   /* IEEE half storage, fp32 accumulation: the reference's 16-mixed precision (train.py:118) */
 
 /* "1.0.0-gfx950"; never NULL. */
 const char* mphsir_version(void);
@@ -315,6 +316,19 @@ int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void* dT, int64
  * launch can be replayed with per-step values.                                                      */
 int mphsir_flat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int32_t step, float grad_scale, const float* hyper, void* stream);
+
+/* ---- dynamic loss scaling for the fp16 path (the reference trains precision="16-mixed", train.py:118 = torch GradScaler) ----
+ * scaler: device fp32[4] = [loss scale, good steps in a row, found-inf flag of this step, optimizer steps taken].
+ * mphsir_grad_check sets scaler[2] = 1 if any of g[0..n) is inf / NaN (run it AFTER the gradient all-reduce: a non-finite
+ *   value on one rank reaches every rank through the sum, so all ranks take the same decision without another collective).
+ * mphsir_flat_adamw_scaled = mphsir_flat_adamw with g additionally divided by scaler[0]; the whole update is skipped when
+ *   scaler[2] != 0; Adam's bias corrections use step = scaler[3] + 1 (skipped steps do not count); hyper (optional) = [lr].
+ * mphsir_scaler_update = GradScaler.update(): on overflow scale *= backoff and the streak restarts, else scaler[3] += 1 and
+ *   after growth_interval good steps scale *= growth; clears the flag.  All three are plain launches: capturable.       */
+int mphsir_grad_check(const float* g, int64_t n, float* scaler, void* stream);
+int mphsir_flat_adamw_scaled(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, float grad_scale, const float* hyper, const float* scaler, void* stream);
+int mphsir_scaler_update(float* scaler, float growth_factor, float backoff_factor, int32_t growth_interval, void* stream);
 
 /* ---- flat-arena utilities -------------------------------------------------------------------------
  * reduce_parts: dst[b][i] = sum_{s < nsplit} src[b*src_batch_stride + s*stride + i], i < n, b < nbatch, summed in a

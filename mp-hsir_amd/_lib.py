@@ -130,6 +130,10 @@ _SYMBOLS = {
                                        c_int32, c_int, c_void_p]),
     "mphsir_flat_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,
                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int32, ctypes.c_float, c_void_p, c_void_p]),
+    "mphsir_grad_check": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "mphsir_flat_adamw_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p]),
+    "mphsir_scaler_update": (c_int, [c_void_p, ctypes.c_float, ctypes.c_float, c_int32, c_void_p]),
     "mphsir_combine_bwd": (c_int, [c_void_p] * 7 + [c_int32] * 5 + [c_int, c_void_p]),
     "mphsir_win_attn_bwd": (c_int, [ctypes.POINTER(WinAttnBwdArgs), c_int, c_void_p]),
     "mphsir_win_attn_bwd_fits": (c_int, [c_int32, c_int32, c_int]),

@@ -152,7 +152,9 @@ class _PgsstbAttn(torch.autograd.Function):
             d_sa = ops.gemm_tok(dt3, sp["wqkvT"], epi=1, res=d_sa.reshape(M, Cc))    # + dt Wqkv  (1x1 conv backward)
             d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
             # (3) local spectral-prompt gate: one launch per block + one token-reduction GEMM over the windows
-            dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=dt)
+            # factor rows in the compute dtype ride in the grouped 16-bit GEMM launch; fp16's narrow exponent would flush the
+            # gate's tiny d-logits (w ~ 1/128 of an already small gradient), so that path keeps them in fp32
+            dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=torch.float32 if dt == torch.float16 else dt)
             dpg = tuple(gpg[k].reshape(getattr_path(blk.local_spectral_attn, k).shape) for k in _PG_KEYS)
             # (4) window attention core
             dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],

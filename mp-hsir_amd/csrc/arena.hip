@@ -111,7 +111,7 @@ extern "C" int mphsir_pack_gather(const float* arena, const int32_t* index, void
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(arena && index && dst, "pack_gather: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "pack_gather: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "pack_gather: dtype %d unsupported", dtype);
     const int vec = dtype == MPHSIR_F32 ? 4 : 8;
     MPHSIR_REQUIRE(n > 0 && n % vec == 0 && aligned16(index) && aligned16(dst), "pack_gather: n must be a multiple of %d, 16-byte alignment", vec);
     long blocks = (n / vec + 255) / 256;
@@ -119,8 +119,10 @@ extern "C" int mphsir_pack_gather(const float* arena, const int32_t* index, void
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32) {
         MPHSIR_LAUNCH(MPHSIR_K_PACK_GATHER, pack_gather_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, arena, index, reinterpret_cast<float*>(dst), (long)n);
-    } else {
+    } else if (dtype == MPHSIR_BF16) {
         MPHSIR_LAUNCH(MPHSIR_K_PACK_GATHER, pack_gather_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, arena, index, reinterpret_cast<bf16_t*>(dst), (long)n);
+    } else {
+        MPHSIR_LAUNCH(MPHSIR_K_PACK_GATHER, pack_gather_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, s, arena, index, reinterpret_cast<f16_t*>(dst), (long)n);
     }
     return MPHSIR_OK;
 }

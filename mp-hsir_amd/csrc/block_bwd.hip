@@ -460,7 +460,7 @@ extern "C" int mphsir_combine_bwd(const void* dY, const void* SA, const float* g
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(dY && SA && gate && dSA && dgate, "combine_bwd: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "combine_bwd: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "combine_bwd: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(geom_ok(B, H, W, shift) && C > 0 && C % 8 == 0, "combine_bwd: bad geometry");
     MPHSIR_REQUIRE(aligned16(dY) && aligned16(SA) && aligned16(dSA) && (!dOut || aligned16(dOut)), "combine_bwd: 16-byte alignment required");
     CombBwdDev d{dY, SA, gate, keep, dOut, dSA, dgate, WinGeom{B, H, W, shift}, C};
@@ -468,8 +468,10 @@ extern "C" int mphsir_combine_bwd(const void* dY, const void* SA, const float* g
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_COMBINE_BWD, (combine_bwd_kernel<float>), dim3(nblk), dim3(256), 0, s, d);
-    else
+    else if (dtype == MPHSIR_BF16)
         MPHSIR_LAUNCH(MPHSIR_K_COMBINE_BWD, (combine_bwd_kernel<bf16_t>), dim3(nblk), dim3(256), 0, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_COMBINE_BWD, (combine_bwd_kernel<f16_t>), dim3(nblk), dim3(256), 0, s, d);
     return MPHSIR_OK;
 }
 
@@ -478,18 +480,17 @@ extern "C" int mphsir_win_attn_bwd(const mphsir_win_attn_bwd_args* a, int dtype,
     clear_error();
     MPHSIR_REQUIRE(a && a->X && a->dSA && a->dmu && a->ln_w && a->ln_b && a->Wqkv && a->bqkv && a->rpb && a->WprojT && a->dQKV &&
                        a->XNw && a->dSAt && a->drpb, "win_attn_bwd: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "win_attn_bwd: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "win_attn_bwd: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(geom_ok(a->B, a->H, a->W, a->shift) && a->heads > 0 && a->C % a->heads == 0, "win_attn_bwd: bad geometry");
     WinBwdDev d{a->X, a->dSA, a->dmu, a->ln_w, a->ln_b, a->Wqkv, a->bqkv, a->rpb, a->WprojT, a->dQKV, a->XNw, a->dSAt, a->drpb,
                 WinGeom{a->B, a->H, a->W, a->shift}};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return dtype == MPHSIR_F32 ? dispatch_win_bwd<float>(d, a->C, a->C / a->heads, s)
-                               : dispatch_win_bwd<bf16_t>(d, a->C, a->C / a->heads, s);
+    return MPHSIR_DISPATCH_T(dtype, (dispatch_win_bwd<T_>(d, a->C, a->C / a->heads, s)));
 }
 
 extern "C" int mphsir_win_attn_bwd_fits(int32_t C, int32_t heads, int dtype) {
     // every instantiated (width, head_dim) fits in both dtypes since the kernel stopped holding [64][C] tiles of d_sa
-    if (heads <= 0 || C % heads != 0 || (dtype != MPHSIR_F32 && dtype != MPHSIR_BF16)) return 0;
+    if (heads <= 0 || C % heads != 0 || !MPHSIR_DTYPE_OK(dtype)) return 0;
     const int hd = C / heads;
 #define MPHSIR_WINB_CASE(c, h_) if (C == c && hd == h_) return 1;
     MPHSIR_WINB_SHAPES(MPHSIR_WINB_CASE)
@@ -503,7 +504,7 @@ extern "C" int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dR
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(X && dXNw && dRes && ln_w && dX && part, "ln_bwd_win: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "ln_bwd_win: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "ln_bwd_win: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(geom_ok(B, H, W, shift) && C > 0 && C % 32 == 0 && C <= 512, "ln_bwd_win: bad geometry");
     MPHSIR_REQUIRE(aligned16(X) && aligned16(dXNw) && aligned16(dRes) && aligned16(dX), "ln_bwd_win: 16-byte alignment required");
     MPHSIR_REQUIRE(!XN || ln_b, "ln_bwd_win: XN output needs ln_b");
@@ -514,9 +515,12 @@ extern "C" int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dR
     if (dtype == MPHSIR_F32) {
         allow_big_lds(ln_bwd_win_kernel<float>, shmem);
         MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_kernel<float>), dim3(nblk), dim3(256), shmem, s, d);
-    } else {
+    } else if (dtype == MPHSIR_BF16) {
         allow_big_lds(ln_bwd_win_kernel<bf16_t>, shmem);
         MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_kernel<bf16_t>), dim3(nblk), dim3(256), shmem, s, d);
+    } else {
+        allow_big_lds(ln_bwd_win_kernel<f16_t>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_kernel<f16_t>), dim3(nblk), dim3(256), shmem, s, d);
     }
     return MPHSIR_OK;
 }

@@ -106,7 +106,7 @@ extern "C" int mphsir_conv3x3_tok(const void* X, int64_t ldx, const void* W, voi
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(X && W && Y, "conv3x3_tok: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "conv3x3_tok: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "conv3x3_tok: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2;
     MPHSIR_REQUIRE(B > 0 && H > 0 && Wd > 0 && ((long)B * H * Wd) % 64 == 0, "conv3x3_tok: B*H*W must be a multiple of 64");
     MPHSIR_REQUIRE(Cin > 0 && Cin % 32 == 0 && N > 0 && N % 16 == 0, "conv3x3_tok: Cin %% 32 and N %% 16 must be 0 (pad the channels)");
@@ -117,8 +117,10 @@ extern "C" int mphsir_conv3x3_tok(const void* X, int64_t ldx, const void* W, voi
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_CONV3X3, (conv3x3_tok_kernel<float>), grid, dim3(256), shmem, s, d);
-    else
+    else if (dtype == MPHSIR_BF16)
         MPHSIR_LAUNCH(MPHSIR_K_CONV3X3, (conv3x3_tok_kernel<bf16_t>), grid, dim3(256), shmem, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_CONV3X3, (conv3x3_tok_kernel<f16_t>), grid, dim3(256), shmem, s, d);
     return MPHSIR_OK;
 }
 
@@ -126,7 +128,7 @@ extern "C" int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(X && Col, "im2col3x3: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "im2col3x3: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "im2col3x3: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2, vec = 16 / esz;
     MPHSIR_REQUIRE(B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cin % vec == 0, "im2col3x3: bad shape");
     MPHSIR_REQUIRE(aligned16(X) && aligned16(Col) && (ldx * esz) % 16 == 0, "im2col3x3: 16-byte alignment required");
@@ -136,7 +138,9 @@ extern "C" int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_IM2COL, (im2col3x3_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
-    else
+    else if (dtype == MPHSIR_BF16)
         MPHSIR_LAUNCH(MPHSIR_K_IM2COL, (im2col3x3_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_IM2COL, (im2col3x3_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
     return MPHSIR_OK;
 }

@@ -183,7 +183,7 @@ extern "C" int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(T && dU && U && dT, "gdfn_gate_bwd: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "gdfn_gate_bwd: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "gdfn_gate_bwd: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(M > 0 && HP > 0 && HP % 8 == 0, "gdfn_gate_bwd: bad shape");
     MPHSIR_REQUIRE(aligned16(T) && aligned16(dU) && aligned16(U) && aligned16(dT), "gdfn_gate_bwd: 16-byte alignment required");
     GateBwdDev d{T, dU, U, dT, (long)M, HP};
@@ -193,8 +193,10 @@ extern "C" int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_GDFN_GATE_BWD, (gdfn_gate_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
-    else
+    else if (dtype == MPHSIR_BF16)
         MPHSIR_LAUNCH(MPHSIR_K_GDFN_GATE_BWD, (gdfn_gate_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_GDFN_GATE_BWD, (gdfn_gate_bwd_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
     return MPHSIR_OK;
 }
 
@@ -203,7 +205,7 @@ extern "C" int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(X && w9 && Y, "dwconv3x3: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "dwconv3x3: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "dwconv3x3: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2, vec = 16 / esz;
     MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0, "dwconv3x3: C must be a multiple of %d", vec);
     MPHSIR_REQUIRE(aligned16(X) && aligned16(Y) && (ldx * esz) % 16 == 0 && (ldy * esz) % 16 == 0, "dwconv3x3: 16-byte alignment required");
@@ -213,8 +215,10 @@ extern "C" int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV, (dwconv3x3_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
-    else
+    else if (dtype == MPHSIR_BF16)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV, (dwconv3x3_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_DWCONV, (dwconv3x3_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
     return MPHSIR_OK;
 }
 
@@ -223,7 +227,7 @@ extern "C" int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(X && dY && partial, "dwconv3x3_wgrad: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "dwconv3x3_wgrad: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "dwconv3x3_wgrad: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2, vec = 16 / esz;
     MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % vec == 0 && nblk > 0 && W % DW_S == 0, "dwconv3x3_wgrad: bad shape");
     MPHSIR_REQUIRE(aligned16(X) && aligned16(dY) && (ldx * esz) % 16 == 0 && (lddy * esz) % 16 == 0, "dwconv3x3_wgrad: 16-byte alignment required");
@@ -234,9 +238,12 @@ extern "C" int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY
     if (dtype == MPHSIR_F32) {
         allow_big_lds(dwconv3x3_wgrad_kernel<float>, shmem);
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_WGRAD, (dwconv3x3_wgrad_kernel<float>), grid, dim3(256), shmem, s, d);
-    } else {
+    } else if (dtype == MPHSIR_BF16) {
         allow_big_lds(dwconv3x3_wgrad_kernel<bf16_t>, shmem);
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_WGRAD, (dwconv3x3_wgrad_kernel<bf16_t>), grid, dim3(256), shmem, s, d);
+    } else {
+        allow_big_lds(dwconv3x3_wgrad_kernel<f16_t>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_DWCONV_WGRAD, (dwconv3x3_wgrad_kernel<f16_t>), grid, dim3(256), shmem, s, d);
     }
     return MPHSIR_OK;
 }

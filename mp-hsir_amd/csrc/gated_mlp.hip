@@ -369,7 +369,7 @@ extern "C" int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* s
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(a && a->X && a->Y && a->W1 && a->W2 && a->b1 && a->b2 && a->ln_w && a->ln_b, "gated_mlp: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "gated_mlp: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "gated_mlp: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2;
     MPHSIR_REQUIRE(a->M > 0 && a->M % 64 == 0, "gated_mlp: M must be a positive multiple of 64");
     MPHSIR_REQUIRE(a->HP > 0 && a->HP % 32 == 0, "gated_mlp: padded hidden width must be a multiple of 32");
@@ -379,5 +379,5 @@ extern "C" int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* s
     MlpDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->W1, a->b1, a->W2, a->b2, a->keep,
              (long)(a->rows_per_batch > 0 ? a->rows_per_batch : a->M), a->Y, (long)a->ldy, (int)a->M, a->HP, a->tiles_per_wave};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return dtype == MPHSIR_F32 ? dispatch_mlp<float>(d, a->C, s) : dispatch_mlp<bf16_t>(d, a->C, s);
+    return MPHSIR_DISPATCH_T(dtype, (dispatch_mlp<T_>(d, a->C, s)));
 }

@@ -625,7 +625,7 @@ extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, voi
     clear_error();
     MPHSIR_REQUIRE(a && a->X && a->dY && a->DM && a->ln_w && a->ln_b && a->W1 && a->b1 && a->W1T && a->W2T && a->dX && a->XN &&
                        a->H && a->DPRE && a->part, "gated_mlp_bwd: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "gated_mlp_bwd: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "gated_mlp_bwd: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->M > 0 && a->M % 64 == 0 && a->HP > 0 && a->HP % 32 == 0, "gated_mlp_bwd: M %% 64 and HP %% 32 must be 0");
     MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->dY) && aligned16(a->DM) && aligned16(a->dX) && aligned16(a->XN) && aligned16(a->H) &&
                        aligned16(a->DPRE) && aligned16(a->W1) && aligned16(a->W1T) && aligned16(a->W2T), "gated_mlp_bwd: 16-byte alignment required");
@@ -634,5 +634,5 @@ extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, voi
     MPHSIR_REQUIRE(!a->keep || (a->rows_per_batch > 0 && a->M % a->rows_per_batch == 0), "gated_mlp_bwd: keep needs rows_per_batch dividing M");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     MPHSIR_REQUIRE(a->variant >= 0 && a->variant <= 3, "gated_mlp_bwd: variant must be 0..3");
-    return dtype == MPHSIR_F32 ? dispatch_mlp_bwd<float>(d, a->C, a->variant, s) : dispatch_mlp_bwd<bf16_t>(d, a->C, a->variant, s);
+    return MPHSIR_DISPATCH_T(dtype, (dispatch_mlp_bwd<T_>(d, a->C, a->variant, s)));
 }

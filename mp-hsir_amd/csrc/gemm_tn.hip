@@ -167,15 +167,14 @@ template <int W> __device__ __forceinline__ TrLane tr_lane() {
     }
     return t;
 }
-template <int W> __device__ __forceinline__ bf16x8 tr_frag(const char* img, const TrLane& t, int col0, int kk) {
-    const bf16x4 lo = lds_read_tr16(reinterpret_cast<const bf16_t*>(img + t.base[0] + W * 2 * kk + ((2 * col0) ^ t.lx[0])));
-    const bf16x4 hi = lds_read_tr16(reinterpret_cast<const bf16_t*>(img + t.base[1] + W * 2 * kk + ((2 * col0) ^ t.lx[1])));
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+template <class T, int W> __device__ __forceinline__ typename ElemTraits<T>::frag_t tr_frag(const char* img, const TrLane& t, int col0, int kk) {
+    const auto lo = lds_read_tr16(reinterpret_cast<const T*>(img + t.base[0] + W * 2 * kk + ((2 * col0) ^ t.lx[0])));
+    const auto hi = lds_read_tr16(reinterpret_cast<const T*>(img + t.base[1] + W * 2 * kk + ((2 * col0) ^ t.lx[1])));
+    return typename ElemTraits<T>::frag_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int W1, int W2>
+template <class T, int W1, int W2>          // T: a 16-bit element type (bf16_t / f16_t)
 __device__ __forceinline__ void tn_tr_body(const TnDev& a, char* smem, int L, int bz) {
-    typedef bf16_t T;
     constexpr int KT = 64, RW = W1 / 64, NT = W2 / 16;
     constexpr int IMG_A = KT * W1 * 2, IMG_B = KT * W2 * 2, STAGE = IMG_A + IMG_B;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -198,8 +197,8 @@ __device__ __forceinline__ void tn_tr_body(const TnDev& a, char* smem, int L, in
     f32x4 accs[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 ones;
-    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    typename ElemTraits<T>::frag_t ones;
+    for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
 
     // Staging: thread t moves 16-byte chunk (t % C*) of token rows t / C* + RS*·it of each operand.  Everything that
     // depends on the thread only -- source pointer, swizzled LDS offset (the swizzle term is invariant under the row
@@ -242,12 +241,12 @@ __device__ __forceinline__ void tn_tr_body(const TnDev& a, char* smem, int L, in
         if (m0 + KT < m_hi) gload(m0 + KT);
 #pragma unroll
         for (int kk = 0; kk < KT; kk += 32) {
-            bf16x8 af[RW];
+            typename ElemTraits<T>::frag_t af[RW];
 #pragma unroll
-            for (int i = 0; i < RW; ++i) af[i] = tr_frag<W1>(stage, tla, (wv * RW + i) * 16, kk);
+            for (int i = 0; i < RW; ++i) af[i] = tr_frag<T, W1>(stage, tla, (wv * RW + i) * 16, kk);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const bf16x8 bf = tr_frag<W2>(stage + IMG_A, tlb, nt * 16, kk);
+                const typename ElemTraits<T>::frag_t bf = tr_frag<T, W2>(stage + IMG_A, tlb, nt * 16, kk);
 #pragma unroll
                 for (int i = 0; i < RW; ++i) mma(acc[i][nt], af[i], bf);
             }
@@ -274,10 +273,10 @@ __device__ __forceinline__ void tn_tr_body(const TnDev& a, char* smem, int L, in
             }
 }
 
-template <int W1, int W2>
+template <class T, int W1, int W2>
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnDev a) {      // 2 waves/SIMD = 2 workgroups/CU (2 x 64 KB LDS)
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    tn_tr_body<W1, W2>(a, reinterpret_cast<char*>(smem_v), blockIdx.x, blockIdx.z);      // [2 stages][A image | B image]
+    tn_tr_body<T, W1, W2>(a, reinterpret_cast<char*>(smem_v), blockIdx.x, blockIdx.z);      // [2 stages][A image | B image]
 }
 
 // Grouped form: up to MPHSIR_TN_GROUP_MAX independent token-reduction GEMMs in ONE launch (block ranges per problem).
@@ -290,7 +289,7 @@ struct TnGroupDev {
     int n;
 };
 
-template <int W1, int W2>
+template <class T, int W1, int W2>
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_group_kernel(TnGroupDev g) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     // constant indices only (a dynamically indexed by-value kernel argument is copied to scratch by every lane)
@@ -299,24 +298,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_group_kernel(TnGroupDev g) 
 #pragma unroll
     for (int k = 1; k < MPHSIR_TN_GROUP_MAX; ++k)
         if (k < g.n && (int)blockIdx.x >= g.blk0[k]) { a = g.p[k]; b0 = g.blk0[k]; }
-    tn_tr_body<W1, W2>(a, reinterpret_cast<char*>(smem_v), (int)blockIdx.x - b0, 0);
+    tn_tr_body<T, W1, W2>(a, reinterpret_cast<char*>(smem_v), (int)blockIdx.x - b0, 0);
 }
 
-template <int W1, int W2>
+template <class T, int W1, int W2>
 static int launch_tn_tr_group(const TnGroupDev& g, hipStream_t s) {
     const size_t shmem = 2 * (size_t)(W1 + W2) * 64 * 2;
-    allow_big_lds(gemm_tn_tr_group_kernel<W1, W2>, shmem);
-    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_tr_group_kernel<W1, W2>), dim3(g.blk0[g.n]), dim3(256), shmem, s, g);
+    allow_big_lds(gemm_tn_tr_group_kernel<T, W1, W2>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_tr_group_kernel<T, W1, W2>), dim3(g.blk0[g.n]), dim3(256), shmem, s, g);
     return MPHSIR_OK;
 }
 
-template <int W1, int W2>
+template <class T, int W1, int W2>
 static int launch_tn_tr(const TnDev& d, int batch, hipStream_t s) {
     const int ntiles = ((d.N1 + W1 - 1) / W1) * ((d.N2 + W2 - 1) / W2);
     dim3 grid(ntiles * ((d.nsplit + 7) / 8 * 8), 1, batch);
     const size_t shmem = 2 * (size_t)(W1 + W2) * 64 * 2;
-    allow_big_lds(gemm_tn_tr_kernel<W1, W2>, shmem);
-    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_tr_kernel<W1, W2>), grid, dim3(256), shmem, s, d);
+    allow_big_lds(gemm_tn_tr_kernel<T, W1, W2>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_tr_kernel<T, W1, W2>), grid, dim3(256), shmem, s, d);
     return MPHSIR_OK;
 }
 
@@ -339,7 +338,7 @@ extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(A && B && Cpart, "gemm_tn: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "gemm_tn: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "gemm_tn: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2, vec = 16 / esz;
     MPHSIR_REQUIRE(M > 0 && N1 > 0 && N2 > 0 && N1 % vec == 0 && N2 % vec == 0 && nsplit > 0 && batch > 0 && nsplit < 65536 && batch < 65536,
                    "gemm_tn: bad shape (N1, N2 must be multiples of %d)", vec);
@@ -349,17 +348,21 @@ extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool big = tile128 > 0;
     if (dtype == MPHSIR_F32) return big ? launch_tn<float, 2, 2>(d, batch, s) : launch_tn<float, 1, 1>(d, batch, s);
-    if (!big) return launch_tn<bf16_t, 1, 1>(d, batch, s);
-    // bf16 "big": the transposed-read kernel; each operand's tile width follows its matrix width
-    if (N1 > 64) return N2 > 64 ? launch_tn_tr<128, 128>(d, batch, s) : launch_tn_tr<128, 64>(d, batch, s);
-    return N2 > 64 ? launch_tn_tr<64, 128>(d, batch, s) : launch_tn_tr<64, 64>(d, batch, s);
+    if (!big) return dtype == MPHSIR_BF16 ? launch_tn<bf16_t, 1, 1>(d, batch, s) : launch_tn<f16_t, 1, 1>(d, batch, s);
+    // 16-bit "big": the transposed-read kernel; each operand's tile width follows its matrix width
+#define MPHSIR_TN_TR(T16)                                                                                             \
+    if (N1 > 64) return N2 > 64 ? launch_tn_tr<T16, 128, 128>(d, batch, s) : launch_tn_tr<T16, 128, 64>(d, batch, s); \
+    return N2 > 64 ? launch_tn_tr<T16, 64, 128>(d, batch, s) : launch_tn_tr<T16, 64, 64>(d, batch, s);
+    if (dtype == MPHSIR_BF16) { MPHSIR_TN_TR(bf16_t) }
+    MPHSIR_TN_TR(f16_t)
+#undef MPHSIR_TN_TR
 }
 
 extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t n, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(probs && n > 0 && n <= MPHSIR_TN_GROUP_MAX, "gemm_tn_group: 1..%d problems per call", MPHSIR_TN_GROUP_MAX);
-    MPHSIR_REQUIRE(dtype == MPHSIR_BF16, "gemm_tn_group: bf16 only (the transposed-LDS-read kernel)");
+    MPHSIR_REQUIRE(dtype == MPHSIR_BF16 || dtype == MPHSIR_F16, "gemm_tn_group: 16-bit element types only (the transposed-LDS-read kernel)");
     TnGroupDev g;
     g.n = n;
     bool wide1 = false, wide2 = false;
@@ -378,6 +381,10 @@ extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t
     }
     g.blk0[n] = blocks;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (wide1) return wide2 ? launch_tn_tr_group<128, 128>(g, s) : launch_tn_tr_group<128, 64>(g, s);
-    return wide2 ? launch_tn_tr_group<64, 128>(g, s) : launch_tn_tr_group<64, 64>(g, s);
+#define MPHSIR_TN_GRP(T16)                                                                                    \
+    if (wide1) return wide2 ? launch_tn_tr_group<T16, 128, 128>(g, s) : launch_tn_tr_group<T16, 128, 64>(g, s); \
+    return wide2 ? launch_tn_tr_group<T16, 64, 128>(g, s) : launch_tn_tr_group<T16, 64, 64>(g, s);
+    if (dtype == MPHSIR_BF16) { MPHSIR_TN_GRP(bf16_t) }
+    MPHSIR_TN_GRP(f16_t)
+#undef MPHSIR_TN_GRP
 }

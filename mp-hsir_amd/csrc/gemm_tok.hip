@@ -204,7 +204,7 @@ extern "C" int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* strea
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(a && a->X && a->W && a->Y, "gemm_tok: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "gemm_tok: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "gemm_tok: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2;
     MPHSIR_REQUIRE(a->M > 0 && a->M % 64 == 0, "gemm_tok: M=%lld must be a positive multiple of 64", (long long)a->M);
     MPHSIR_REQUIRE(a->N > 0 && a->N % 16 == 0, "gemm_tok: N=%lld must be a multiple of 16", (long long)a->N);
@@ -227,6 +227,5 @@ extern "C" int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* strea
               a->Y, (long)a->ldy, (int)a->M, (int)a->N, (int)a->K, a->R, (long)a->ldr, a->SA, (long)a->ldsa,
               a->gate, a->keep, a->H, a->Wimg, a->shift};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return dtype == MPHSIR_F32 ? dispatch_gemm<float>(d, a->epi, a->ln_w != nullptr, s)
-                               : dispatch_gemm<bf16_t>(d, a->epi, a->ln_w != nullptr, s);
+    return MPHSIR_DISPATCH_T(dtype, (dispatch_gemm<T_>(d, a->epi, a->ln_w != nullptr, s)));
 }

@@ -41,8 +41,7 @@ extern "C" int mphsir_layernorm_tok(const void* X, int x_dtype, const float* ln_
     clear_error();
     MPHSIR_REQUIRE(X && ln_w && ln_b && Y, "layernorm_tok: null pointer");
     MPHSIR_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "layernorm_tok: M > 0 and C %% 4 == 0 required");
-    MPHSIR_REQUIRE((x_dtype == MPHSIR_F32 || x_dtype == MPHSIR_BF16) && (y_dtype == MPHSIR_F32 || y_dtype == MPHSIR_BF16),
-                   "layernorm_tok: dtype unsupported");
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(x_dtype) && MPHSIR_DTYPE_OK(y_dtype), "layernorm_tok: dtype unsupported");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((M + 63) / 64)), block(256);
 #define MPHSIR_LN_CASE(xi, TI, yo, TO)                                                                          \
@@ -55,6 +54,10 @@ extern "C" int mphsir_layernorm_tok(const void* X, int x_dtype, const float* ln_
     MPHSIR_LN_CASE(MPHSIR_F32, float, MPHSIR_BF16, bf16_t)
     MPHSIR_LN_CASE(MPHSIR_BF16, bf16_t, MPHSIR_BF16, bf16_t)
     MPHSIR_LN_CASE(MPHSIR_BF16, bf16_t, MPHSIR_F32, float)
+    MPHSIR_LN_CASE(MPHSIR_F32, float, MPHSIR_F16, f16_t)
+    MPHSIR_LN_CASE(MPHSIR_F16, f16_t, MPHSIR_F16, f16_t)
+    MPHSIR_LN_CASE(MPHSIR_F16, f16_t, MPHSIR_F32, float)
 #undef MPHSIR_LN_CASE
+    set_error("layernorm_tok: dtype pair (%d -> %d) not instantiated", x_dtype, y_dtype);
     return MPHSIR_EINVAL;
 }

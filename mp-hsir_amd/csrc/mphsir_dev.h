@@ -15,9 +15,12 @@
 namespace mphsir {
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 constexpr int WAVE = 64;
 
@@ -44,6 +47,14 @@ template <> struct ElemTraits<bf16_t> {
     static constexpr int DTYPE = 1;
 };
 
+template <> struct ElemTraits<f16_t> {          // fp16 storage (the reference's 16-mixed precision, train.py:118): same tile
+    typedef f16x8 frag_t;                        // shapes as bf16, v_mfma_f32_16x16x32_f16, fp32 accumulation
+    typedef f16x4 vec4_t;
+    static constexpr int EPL = 8;
+    static constexpr int KCHUNK = 32;
+    static constexpr int DTYPE = 2;
+};
+
 template <class T> __device__ __forceinline__ constexpr int round_up_k(int k) {
     return (k + ElemTraits<T>::KCHUNK - 1) / ElemTraits<T>::KCHUNK * ElemTraits<T>::KCHUNK;
 }
@@ -63,6 +74,9 @@ __device__ __forceinline__ typename ElemTraits<T>::frag_t load_frag(const T* bas
 __device__ __forceinline__ void mma(f32x4& acc, bf16x8 a, bf16x8 b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
+__device__ __forceinline__ void mma(f32x4& acc, f16x8 a, f16x8 b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
 __device__ __forceinline__ void mma(f32x4& acc, f32x4 a, f32x4 b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
@@ -77,6 +91,11 @@ __device__ __forceinline__ void mma(f32x4& acc, f32x4 a, f32x4 b) {
 __device__ __forceinline__ bf16x4 lds_read_tr16(const bf16_t* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
 }
+__device__ __forceinline__ f16x4 lds_read_tr16(const f16_t* p) {
+    typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_b;       // the builtin's own vector type
+    const fp16x4_b r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_b*)(p));
+    return __builtin_bit_cast(f16x4, r);
+}
 
 // Fragment of a K-STRIDED operand held row-major as [k][col] in LDS (pitch ld elements): row (l&15) of the fragment is
 // column col0 + (l&15), its K elements are rows k0 + EPL*(l>>4) .. of the tile -- the same map load_frag yields for the
@@ -89,6 +108,12 @@ template <> __device__ __forceinline__ bf16x8 load_frag_tr<bf16_t>(const bf16_t*
     const bf16x4 lo = lds_read_tr16(a), hi = lds_read_tr16(a + 4 * ld);
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+template <> __device__ __forceinline__ f16x8 load_frag_tr<f16_t>(const f16_t* base, int ld, int col0, int k0) {
+    const int l = lane_id(), g = l >> 4, q = (l & 15) >> 2, p = l & 3;
+    const f16_t* a = base + (size_t)(k0 + 8 * g + q) * ld + col0 + 4 * p;
+    const f16x4 lo = lds_read_tr16(a), hi = lds_read_tr16(a + 4 * ld);
+    return f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 template <> __device__ __forceinline__ f32x4 load_frag_tr<float>(const float* base, int ld, int col0, int k0) {
     const int l = lane_id();
     const float* a = base + (size_t)(k0 + 4 * (l >> 4)) * ld + col0 + (l & 15);
@@ -98,6 +123,7 @@ template <> __device__ __forceinline__ f32x4 load_frag_tr<float>(const float* ba
 template <class T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) { return (f16_t)x; }
 template <class T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 
 // store 4 consecutive elements (from an accumulator column) -- 8 B (bf16) / 16 B (f32) aligned.
@@ -109,6 +135,12 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, f32x4 v) {
+    f16x4 o;
+    o[0] = (f16_t)v[0]; o[1] = (f16_t)v[1]; o[2] = (f16_t)v[2]; o[3] = (f16_t)v[3];
+    *reinterpret_cast<f16x4*>(p) = o;
+}
+
 // 4 consecutive elements -> fp32 (the counterpart of store4)
 template <class T> __device__ __forceinline__ f32x4 load4(const T* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -117,7 +149,12 @@ template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 
-// 16-byte vector of T (8 bf16 / 4 f32) <-> fp32 registers, for coalesced global/LDS traffic.
+template <> __device__ __forceinline__ f32x4 load4<f16_t>(const f16_t* p) {
+    const f16x4 v = *reinterpret_cast<const f16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+// 16-byte vector of T (8 bf16 / 8 f16 / 4 f32) <-> fp32 registers, for coalesced global/LDS traffic.
 template <class T> struct Vec16;
 template <> struct Vec16<float> {
     static constexpr int N = 4;
@@ -131,6 +168,12 @@ template <> struct Vec16<bf16_t> {
     __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
     __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
 };
+template <> struct Vec16<f16_t> {
+    static constexpr int N = 8;
+    f16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (f16_t)x; }
+};
 // gather element e of four 16-byte vectors into 4 consecutive elements at p (a 4-row transpose step) without a
 // float round trip: pure register shuffles
 __device__ __forceinline__ void store_quad(float* p, const Vec16<float>& a, const Vec16<float>& b, const Vec16<float>& c,
@@ -140,6 +183,11 @@ __device__ __forceinline__ void store_quad(float* p, const Vec16<float>& a, cons
 __device__ __forceinline__ void store_quad(bf16_t* p, const Vec16<bf16_t>& a, const Vec16<bf16_t>& b, const Vec16<bf16_t>& c,
                                            const Vec16<bf16_t>& d, int e) {
     *reinterpret_cast<bf16x4*>(p) = bf16x4{a.v[e], b.v[e], c.v[e], d.v[e]};
+}
+
+__device__ __forceinline__ void store_quad(f16_t* p, const Vec16<f16_t>& a, const Vec16<f16_t>& b, const Vec16<f16_t>& c,
+                                           const Vec16<f16_t>& d, int e) {
+    *reinterpret_cast<f16x4*>(p) = f16x4{a.v[e], b.v[e], c.v[e], d.v[e]};
 }
 
 template <class T> __device__ __forceinline__ Vec16<T> load16(const T* p) {
@@ -201,6 +249,7 @@ template <> struct Math<bf16_t> {
     }
     static __device__ __forceinline__ float gelu(float x) { float g, dg; gelu_pair(x, g, dg); return g; }
 };
+template <> struct Math<f16_t> : Math<bf16_t> {};      // 16-bit storage either way: the hardware exp / rcp policy
 
 // wave-wide reductions by xor shuffles over the lanes selected by `mask_bits` (e.g. 1|2 = 4 lanes).
 __device__ __forceinline__ float wave_sum(float v) {

@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include "../../include/mphsir.h"
+#include "mphsir_dev.h"
 
 namespace mphsir {
 
@@ -36,6 +37,14 @@ void prof_after(int kid, hipStream_t s);
             return MPHSIR_ELAUNCH;                                                                  \
         }                                                                                           \
     } while (0)
+
+// element-type dispatch of the templated kernels: EXPR is evaluated with T_ bound to float / bf16_t / f16_t
+#define MPHSIR_DTYPE_OK(dt) ((dt) == MPHSIR_F32 || (dt) == MPHSIR_BF16 || (dt) == MPHSIR_F16)
+#define MPHSIR_DISPATCH_T(dt, EXPR)                                                  \
+    ((dt) == MPHSIR_F32    ? [&]() -> int { using T_ = float; return EXPR; }()       \
+     : (dt) == MPHSIR_BF16 ? [&]() -> int { using T_ = mphsir::bf16_t; return EXPR; }() \
+                           : [&]() -> int { using T_ = mphsir::f16_t; return EXPR; }())
+inline int dtype_size(int dt) { return dt == MPHSIR_F32 ? 4 : 2; }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -60,32 +60,67 @@ struct PgLds {
     float* w;       // [16][LDW]   prompt logits -> weights
     float* dl;      // [16][LDW]   (backward) d weights -> d logits
     float* P;       // [128][r]    prompt_param staged once
+    float* Wq;      // [r][r]  |
+    float* Wkv;     // [2r][r] |   the r-sized weights, staged once (one L2 round trip instead of one per link)
+    float* Wpp;     // [r][r]  |
+    float* bpp;     // [r]     |
     float* sm;      // [16][SMW]   small per-window vectors
-    float* At;      // [16][r*r]   (backward) attention probabilities
-    int LDC, LDW, SMW;
+    float* At;      // [16][LDA]   (backward) attention probabilities, LDA = r*r + 4
+    int LDC, LDW, LDA;
 };
 // offsets of the small vectors inside a window's sm row (r <= 32)
+// (row pitch 484 = 4 mod 32: the windows of one wave start 4 banks apart, so the per-window broadcast reads of the r-sized
+// links do not collide)
 enum { PG_S = 0, PG_D = 32, PG_KV = 64, PG_Q = 128, PG_O = 160, PG_O2 = 192, PG_DO2 = 224, PG_DO = 256, PG_DQ = 288, PG_DKV = 320,
-       PG_DD = 384, PG_DS = 416, PG_SMW = 448 };
+       PG_DD = 384, PG_DS = 416, PG_RS = 448, PG_SMW = 484 };
 
 __device__ __forceinline__ PgLds pg_lds(float* base, int C, int r, bool bwd) {
     PgLds s;
     s.LDC = C + 8;                 // 32-byte row padding: conflict-free ds_read_b128 fragments (mphsir_dev.h)
     s.LDW = 128 + 8;
-    s.SMW = PG_SMW;
+    s.LDA = r * r + 4;
     s.mu = base;
     s.dg = s.mu + PG_NWIN * s.LDC;
     s.w = s.dg + (bwd ? PG_NWIN * s.LDC : 0);
     s.dl = s.w + PG_NWIN * s.LDW;
     s.P = s.dl + (bwd ? PG_NWIN * s.LDW : 0);
-    s.sm = s.P + 128 * r;
+    s.Wq = s.P + 128 * r;
+    s.Wkv = s.Wq + r * r;
+    s.Wpp = s.Wkv + 2 * r * r;
+    s.bpp = s.Wpp + r * r;
+    s.sm = s.bpp + ((r + 3) & ~3);
     s.At = s.sm + PG_NWIN * PG_SMW;
     return s;
 }
 static size_t pg_lds_bytes(int C, int r, bool bwd) {
-    size_t n = (size_t)PG_NWIN * (C + 8) * (bwd ? 2 : 1) + (size_t)PG_NWIN * 136 * (bwd ? 2 : 1) + 128 * (size_t)r + (size_t)PG_NWIN * PG_SMW;
-    if (bwd) n += (size_t)PG_NWIN * r * r;
+    size_t n = (size_t)PG_NWIN * (C + 8) * (bwd ? 2 : 1) + (size_t)PG_NWIN * 136 * (bwd ? 2 : 1) + 128 * (size_t)r + 4 * (size_t)r * r +
+               ((r + 3) & ~3) + (size_t)PG_NWIN * PG_SMW;
+    if (bwd) n += (size_t)PG_NWIN * (r * r + 4);
     return n * sizeof(float);
+}
+
+// acc[t] += W-tile t (16 rows each, read row-wise or column-wise from L2) x the 16-window LDS operand, over K.  The
+// weight fragments of 8 K-steps are requested together before their MFMAs run: one L2 round trip per 128 of K instead
+// of one per step (a workgroup has the CU to itself, nothing else hides that latency).
+template <int NT, bool COLS>
+__device__ __forceinline__ void pg_mfma_rows(f32x4 (&acc)[NT], const float* W, int ld, int nrows, int nk, const int (&row0)[NT],
+                                             const float* B, int ldb, int K) {
+    for (int k0 = 0; k0 < K; k0 += 128) {
+        f32x4 wf[8][NT];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (k0 + 16 * i < K)
+                    wf[i][t] = COLS ? pg_frag_cols(W, ld, nrows, nk, row0[t], k0 + 16 * i) : pg_frag_rows(W, ld, nrows, row0[t], k0 + 16 * i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (k0 + 16 * i < K) {
+                const f32x4 b = load_frag<float>(B, ldb, 0, k0 + 16 * i);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) mma(acc[t], wf[i][t], b);
+            }
+    }
 }
 
 // ---- the forward chain for the workgroup's 16 windows (shared by both kernels); ends with o2 in sm[.][PG_O2] --------------
@@ -98,22 +133,25 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         s.mu[w * s.LDC + c] = win0 + w < a.nW ? a.mu[(long)(win0 + w) * C + c] : 0.f;
     }
     for (int i = tid; i < 128 * r; i += 256) s.P[i] = a.Pp[i];
+    for (int i = tid; i < r * r; i += 256) { s.Wq[i] = a.Wq[i]; s.Wpp[i] = a.Wpproj[i]; s.Wkv[i] = a.Wkv[i]; s.Wkv[r * r + i] = a.Wkv[r * r + i]; }
+    if (tid < r) s.bpp[tid] = a.bpproj[tid];
     __syncthreads();
     // logits = Wprompt mu (128 rows: two 16-row tiles per wave) and d = Wdown mu (r rows: waves 0..ceil(r/16)-1)
     {
-        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, accd = {0, 0, 0, 0};
-        const bool has_d = wv * 16 < r;
-        for (int kc = 0; kc < C; kc += 16) {
-            const f32x4 b = load_frag<float>(s.mu, s.LDC, 0, kc);
-            mma(acc0, pg_frag_rows(a.Wprompt, C, 128, wv * 32, kc), b);
-            mma(acc1, pg_frag_rows(a.Wprompt, C, 128, wv * 32 + 16, kc), b);
-            if (has_d) mma(accd, pg_frag_rows(a.Wdown, C, r, wv * 16, kc), b);
-        }
+        f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        const int rows[2] = {wv * 32, wv * 32 + 16};
+        pg_mfma_rows<2, false>(acc, a.Wprompt, C, 128, 0, rows, s.mu, s.LDC, C);
         const int w = lane & 15, rr = (lane >> 4) * 4;
         for (int j = 0; j < 4; ++j) {
-            s.w[w * s.LDW + wv * 32 + rr + j] = acc0[j];
-            s.w[w * s.LDW + wv * 32 + 16 + rr + j] = acc1[j];
-            if (has_d && wv * 16 + rr + j < r) s.sm[w * PG_SMW + PG_D + wv * 16 + rr + j] = accd[j];
+            s.w[w * s.LDW + wv * 32 + rr + j] = acc[0][j];
+            s.w[w * s.LDW + wv * 32 + 16 + rr + j] = acc[1][j];
+        }
+        if (wv * 16 < r) {
+            f32x4 accd[1] = {{0, 0, 0, 0}};
+            const int rowd[1] = {wv * 16};
+            pg_mfma_rows<1, false>(accd, a.Wdown, C, r, 0, rowd, s.mu, s.LDC, C);
+            for (int j = 0; j < 4; ++j)
+                if (wv * 16 + rr + j < r) s.sm[w * PG_SMW + PG_D + wv * 16 + rr + j] = accd[0][j];
         }
     }
     __syncthreads();
@@ -133,7 +171,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         const int w = i / (2 * r), m = i % (2 * r);
         const float* d = s.sm + w * PG_SMW + PG_D;
         float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += a.Wkv[m * r + j] * d[j];
+        for (int j = 0; j < r; ++j) acc += s.Wkv[m * r + j] * d[j];
         s.sm[w * PG_SMW + PG_KV + m] = acc;
     }
     __syncthreads();
@@ -151,7 +189,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         const int w = i / r, m = i % r;
         const float* sv = s.sm + w * PG_SMW + PG_S;
         float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += a.Wq[m * r + j] * sv[j];
+        for (int j = 0; j < r; ++j) acc += s.Wq[m * r + j] * sv[j];
         s.sm[w * PG_SMW + PG_Q + m] = acc;
     }
     __syncthreads();
@@ -166,12 +204,12 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         float den = 0.f, num = 0.f;
         for (int j = 0; j < r; ++j) {
             const float e = expf(qs * kv[j] - mx);
-            if (KEEP_AT) s.At[(w * r + m) * r + j] = e;
+            if (KEEP_AT) s.At[w * s.LDA + m * r + j] = e;
             den += e;
             num += e * kv[r + j];
         }
         if (KEEP_AT)
-            for (int j = 0; j < r; ++j) s.At[(w * r + m) * r + j] /= den;
+            for (int j = 0; j < r; ++j) s.At[w * s.LDA + m * r + j] /= den;
         s.sm[w * PG_SMW + PG_O + m] = num / den;
     }
     __syncthreads();
@@ -179,8 +217,8 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     for (int i = tid; i < PG_NWIN * r; i += 256) {
         const int w = i / r, m = i % r;
         const float* o = s.sm + w * PG_SMW + PG_O;
-        float acc = a.bpproj[m];
-        for (int j = 0; j < r; ++j) acc += a.Wpproj[m * r + j] * o[j];
+        float acc = s.bpp[m];
+        for (int j = 0; j < r; ++j) acc += s.Wpp[m * r + j] * o[j];
         s.sm[w * PG_SMW + PG_O2 + m] = acc;
     }
     __syncthreads();
@@ -214,26 +252,26 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     const float sc = rsqrtf((float)r);
     // do2 = Wup^T dg  (r rows x 16 windows, K = C): MFMA with the weight read column-wise
     if (wv * 16 < r) {
-        f32x4 acc = {0, 0, 0, 0};
-        for (int kc = 0; kc < C; kc += 16)
-            mma(acc, pg_frag_cols(a.Wup, r, r, C, wv * 16, kc), load_frag<float>(s.dg, s.LDC, 0, kc));
+        f32x4 acc[1] = {{0, 0, 0, 0}};
+        const int col0[1] = {wv * 16};
+        pg_mfma_rows<1, true>(acc, a.Wup, r, r, C, col0, s.dg, s.LDC, C);
         const int w = lane & 15, rr = wv * 16 + (lane >> 4) * 4;
         for (int j = 0; j < 4; ++j)
-            if (rr + j < r) s.sm[w * PG_SMW + PG_DO2 + rr + j] = acc[j];
+            if (rr + j < r) s.sm[w * PG_SMW + PG_DO2 + rr + j] = acc[0][j];
     }
     __syncthreads();
     for (int i = tid; i < PG_NWIN * r; i += 256) {          // do = Wproj^T do2
         const int w = i / r, m = i % r;
         const float* do2 = s.sm + w * PG_SMW + PG_DO2;
         float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += a.Wpproj[j * r + m] * do2[j];
+        for (int j = 0; j < r; ++j) acc += s.Wpp[j * r + m] * do2[j];
         s.sm[w * PG_SMW + PG_DO + m] = acc;
     }
     __syncthreads();
-    // row i: dS_ij = A_ij (do_i v_j - sum_j' A_ij' do_i v_j');  dq_i = sc sum_j dS_ij k_j.  dS overwrites A in place.
+    // row i: rs_i = sum_j A_ij do_i v_j;  dS_ij = A_ij (do_i v_j - rs_i);  dq_i = sc sum_j dS_ij k_j
     for (int i = tid; i < PG_NWIN * r; i += 256) {
         const int w = i / r, m = i % r;
-        float* A = s.At + (w * r + m) * r;
+        const float* A = s.At + w * s.LDA + m * r;
         const float* kv = s.sm + w * PG_SMW + PG_KV;
         const float dov = s.sm[w * PG_SMW + PG_DO + m];
         float rs = 0.f;
@@ -241,21 +279,19 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         float acc = 0.f;
         for (int j = 0; j < r; ++j) acc += A[j] * (dov * kv[r + j] - rs) * kv[j];
         s.sm[w * PG_SMW + PG_DQ + m] = acc * sc;
+        s.sm[w * PG_SMW + PG_RS + m] = rs;
     }
     __syncthreads();
-    // column j: dk_j = sc sum_i dS_ij q_i ; dv_j = sum_i A_ij do_i   (dS recomputed from A: cheap, no second tile)
+    // column j: dk_j = sc sum_i dS_ij q_i ; dv_j = sum_i A_ij do_i   (dS re-formed from A and the row sums rs_i)
     for (int i = tid; i < PG_NWIN * r; i += 256) {
         const int w = i / r, j = i % r;
-        const float* kv = s.sm + w * PG_SMW + PG_KV;
-        const float* q = s.sm + w * PG_SMW + PG_Q;
-        const float* dov = s.sm + w * PG_SMW + PG_DO;
+        const float* sm = s.sm + w * PG_SMW;
+        const float vj = sm[PG_KV + r + j];
         float dk = 0.f, dv = 0.f;
         for (int m = 0; m < r; ++m) {
-            const float* A = s.At + (w * r + m) * r;
-            float rs = 0.f;
-            for (int jj = 0; jj < r; ++jj) rs += A[jj] * dov[m] * kv[r + jj];
-            dk += A[j] * (dov[m] * kv[r + j] - rs) * q[m];
-            dv += A[j] * dov[m];
+            const float A = s.At[w * s.LDA + m * r + j], dov = sm[PG_DO + m];
+            dk += A * (dov * vj - sm[PG_RS + m]) * sm[PG_Q + m];
+            dv += A * dov;
         }
         s.sm[w * PG_SMW + PG_DKV + j] = dk * sc;
         s.sm[w * PG_SMW + PG_DKV + r + j] = dv;
@@ -266,8 +302,8 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         const float* dkv = s.sm + w * PG_SMW + PG_DKV;
         const float* dq = s.sm + w * PG_SMW + PG_DQ;
         float acc = 0.f, acc2 = 0.f;
-        for (int m = 0; m < 2 * r; ++m) acc += a.Wkv[m * r + j] * dkv[m];
-        for (int m = 0; m < r; ++m) acc2 += a.Wq[m * r + j] * dq[m];
+        for (int m = 0; m < 2 * r; ++m) acc += s.Wkv[m * r + j] * dkv[m];
+        for (int m = 0; m < r; ++m) acc2 += s.Wq[m * r + j] * dq[m];
         s.sm[w * PG_SMW + PG_DD + j] = acc;
         s.sm[w * PG_SMW + PG_DS + j] = acc2;
     }
@@ -291,16 +327,16 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     __syncthreads();
     // dmu = Wprompt^T dlogit + Wdown^T dd:  C rows x 16 windows, K = 128 by MFMA, the rank-r term in the epilogue
     for (int ct = wv; ct < C / 16; ct += 4) {
-        f32x4 acc = {0, 0, 0, 0};
-        for (int kc = 0; kc < 128; kc += 16)
-            mma(acc, pg_frag_cols(a.Wprompt, C, C, 128, ct * 16, kc), load_frag<float>(s.dl, s.LDW, 0, kc));
+        f32x4 acc[1] = {{0, 0, 0, 0}};
+        const int col0[1] = {ct * 16};
+        pg_mfma_rows<1, true>(acc, a.Wprompt, C, C, 128, col0, s.dl, s.LDW, 128);
         const int w = lane & 15, c0 = ct * 16 + (lane >> 4) * 4;
         const float* dd = s.sm + w * PG_SMW + PG_DD;
         for (int m = 0; m < r; ++m) {
             const f32x4 wd = *reinterpret_cast<const f32x4*>(a.Wdown + (long)m * C + c0);
-            for (int j = 0; j < 4; ++j) acc[j] += wd[j] * dd[m];
+            for (int j = 0; j < 4; ++j) acc[0][j] += wd[j] * dd[m];
         }
-        if (win0 + w < a.nW) *reinterpret_cast<f32x4*>(a.dmu + (long)(win0 + w) * C + c0) = acc;
+        if (win0 + w < a.nW) *reinterpret_cast<f32x4*>(a.dmu + (long)(win0 + w) * C + c0) = acc[0];
     }
     // ---- factor rows: L = [dg(C) | do2(r) | dkv(2r) | dq(r) | w(128) | dlogit(128) | dd(r) | 0..],
     //                   R = [o2(r) | o(r) | 1 | d(r) | s(r) | ds(r) | mu(C) | 0..]
@@ -309,8 +345,10 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         const float* sm = s.sm + w * PG_SMW;
         float* L = reinterpret_cast<float*>(a.L) + (long)(win0 + w) * a.KL;
         float* R = reinterpret_cast<float*>(a.R) + (long)(win0 + w) * a.KR;
-        bf16_t* Lh = reinterpret_cast<bf16_t*>(a.L) + (long)(win0 + w) * a.KL;
-        bf16_t* Rh = reinterpret_cast<bf16_t*>(a.R) + (long)(win0 + w) * a.KR;
+        bf16_t* Lh = reinterpret_cast<bf16_t*>(a.L) + (long)(win0 + w) * a.KL;      // lr_bf16: the factor rows' dtype code
+        bf16_t* Rh = reinterpret_cast<bf16_t*>(a.R) + (long)(win0 + w) * a.KR;      // (0 fp32, 1 bf16, 2 f16: both 2 bytes)
+        f16_t* Lf = reinterpret_cast<f16_t*>(a.L) + (long)(win0 + w) * a.KL;
+        f16_t* Rf = reinterpret_cast<f16_t*>(a.R) + (long)(win0 + w) * a.KR;
         for (int c = tid; c < a.KL; c += 256) {
             float v = 0.f;
             int o = c;
@@ -321,7 +359,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
             else if ((o -= r) < 128) v = s.w[w * s.LDW + o];
             else if ((o -= 128) < 128) v = s.dl[w * s.LDW + o];
             else if ((o -= 128) < r) v = sm[PG_DD + o];
-            if (a.lr_bf16) Lh[c] = (bf16_t)v; else L[c] = v;
+            if (a.lr_bf16 == MPHSIR_BF16) Lh[c] = (bf16_t)v; else if (a.lr_bf16 == MPHSIR_F16) Lf[c] = (f16_t)v; else L[c] = v;
         }
         for (int c = tid; c < a.KR; c += 256) {
             float v = 0.f;
@@ -333,7 +371,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
             else if ((o -= r) < r) v = sm[PG_S + o];
             else if ((o -= r) < r) v = sm[PG_DS + o];
             else if ((o -= r) < C) v = s.mu[w * s.LDC + o];
-            if (a.lr_bf16) Rh[c] = (bf16_t)v; else R[c] = v;
+            if (a.lr_bf16 == MPHSIR_BF16) Rh[c] = (bf16_t)v; else if (a.lr_bf16 == MPHSIR_F16) Rf[c] = (f16_t)v; else R[c] = v;
         }
     }
 }

@@ -217,7 +217,7 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(a && a->Gpart && a->Spart && a->temperature && a->Wo && a->dM && a->W2 && a->dWo && a->dtemp, "spectral_fold_bwd: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "spectral_fold_bwd: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "spectral_fold_bwd: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold_bwd: bad shape");
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 96, "spectral_fold_bwd: head_dim %d > 96", HD);
@@ -228,9 +228,12 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
     if (dtype == MPHSIR_F32) {
         allow_big_lds(spectral_fold_bwd_kernel<float>, shmem);
         MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<float>), dim3(a->B * a->heads), dim3(FB_THREADS), shmem, s, d);
-    } else {
+    } else if (dtype == MPHSIR_BF16) {
         allow_big_lds(spectral_fold_bwd_kernel<bf16_t>, shmem);
         MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<bf16_t>), dim3(a->B * a->heads), dim3(FB_THREADS), shmem, s, d);
+    } else {
+        allow_big_lds(spectral_fold_bwd_kernel<f16_t>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<f16_t>), dim3(a->B * a->heads), dim3(FB_THREADS), shmem, s, d);
     }
     return MPHSIR_OK;
 }

@@ -147,6 +147,11 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
     for (int i = 0; i < 8; ++i) o.set(i, v[i]);
     store16<bf16_t>(p, o);
 }
+template <> __device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&v)[8]) {
+    Vec16<f16_t> o;
+    for (int i = 0; i < 8; ++i) o.set(i, v[i]);
+    store16<f16_t>(p, o);
+}
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
     *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -162,7 +167,8 @@ __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
     constexpr int NT = HD / 16;
     constexpr int SLOTS = (NT * NT + 3) / 4;
     constexpr int CV = C / VEC;
-    constexpr int NSQ = (2 * C + 255) / 256;             // rows of [q;k] per thread for the sums of squares
+    constexpr int NSQ = (2 * C + 255) / 256;             // rows of [q;k] per thread for the final sums of squares
+    constexpr int NITEM = (3 * CV * 8 + 255) / 256;      // (q|k|v, channel vector, 8-pixel strip) items per thread: fixed per thread
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     T* qT = reinterpret_cast<T*>(smem_v);                // [C][LDT]
     T* kT = qT + C * LDT;                                // [C][LDT]
@@ -174,16 +180,24 @@ __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
     T* V = reinterpret_cast<T*>(a.V) + img * a.ldvo;
 
     f32x4 g[HEADS][SLOTS];
-    float ssq[NSQ];
+    // sums of squares of the (rounded) q / k values: accumulated where the values are produced -- a thread owns the same
+    // (channel vector, strip) items in every tile -- and reduced over the 8 strips once at the end.  (Reading the rows back
+    // from the transposed LDS tiles, one 2-byte element per lane at a 160-byte pitch, was an 8-way bank conflict and cost
+    // more than the Gram MFMAs of the tile.)
+    float ssq[NITEM][VEC];
 #pragma unroll
     for (int h = 0; h < HEADS; ++h)
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) g[h][s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < NSQ; ++i) ssq[i] = 0.f;
+    for (int i = 0; i < NITEM; ++i)
+        for (int e = 0; e < VEC; ++e) ssq[i][e] = 0.f;
 
     for (int tile = sp * tpw; tile < (sp + 1) * tpw; ++tile) {
-        for (int it = tid; it < 3 * CV * 8; it += 256) {
+#pragma unroll
+        for (int slot = 0; slot < NITEM; ++slot) {
+            const int it = tid + 256 * slot;
+            if (it >= 3 * CV * 8) break;
             const int which = it / (CV * 8), rem = it % (CV * 8), cvec = rem % CV, st = rem / CV;
             const int c0 = cvec * VEC;
             const int p0 = tile * 64 + st * 8, y = p0 / a.W, x0 = p0 % a.W;
@@ -223,7 +237,12 @@ __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
             }
             if (which < 2) {
                 T* dst = (which == 0 ? qT : kT) + c0 * LDT + st * 8;
-                for (int e = 0; e < VEC; ++e) store8<T>(dst + e * LDT, out[e]);
+                for (int e = 0; e < VEC; ++e) {
+                    store8<T>(dst + e * LDT, out[e]);
+                    float s2 = 0.f;
+                    for (int i = 0; i < 8; ++i) { const float r = to_f32(from_f32<T>(out[e][i])); s2 += r * r; }     // the values the Gram sees
+                    ssq[slot][e] += s2;
+                }
                 if (a.QK) {                      // training: q | k are kept for the backward pass
                     T* QK = reinterpret_cast<T*>(a.QK) + img * a.ldqk + which * C + c0;
                     for (int i = 0; i < 8; ++i) {
@@ -241,16 +260,6 @@ __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NSQ; ++i) {
-            const int row = tid + 256 * i;
-            if (row < 2 * C) {
-                const T* rp = qT + row * LDT;                // rows C..2C-1 are kT (contiguous)
-                float s = 0.f;
-                for (int j = 0; j < 64; ++j) { const float v = to_f32(rp[j]); s += v * v; }
-                ssq[i] += s;
-            }
-        }
 #pragma unroll
         for (int h = 0; h < HEADS; ++h)
 #pragma unroll
@@ -279,10 +288,25 @@ __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
                     Gp[(h * HD + ti * 16 + (lane >> 4) * 4 + r) * HD + tj * 16 + (lane & 15)] = g[h][s][r];
             }
         }
+    // strip partials -> LDS [2C][8] (the q/k tiles are free: the loop ended with a barrier), ordered sum over the 8 strips
+    float* red = reinterpret_cast<float*>(smem_v);
+#pragma unroll
+    for (int slot = 0; slot < NITEM; ++slot) {
+        const int it = tid + 256 * slot;
+        if (it < 2 * CV * 8) {                               // which < 2
+            const int which = it / (CV * 8), rem = it % (CV * 8), cvec = rem % CV, st = rem / CV;
+            for (int e = 0; e < VEC; ++e) red[(which * C + cvec * VEC + e) * 8 + st] = ssq[slot][e];
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NSQ; ++i) {
         const int row = tid + 256 * i;
-        if (row < 2 * C) Sp[row] = ssq[i];                   // [2][C]: q rows then k rows
+        if (row < 2 * C) {
+            float s = 0.f;
+            for (int st = 0; st < 8; ++st) s += red[row * 8 + st];
+            Sp[row] = s;                                     // [2][C]: q rows then k rows
+        }
     }
 }
 
@@ -457,7 +481,7 @@ extern "C" int mphsir_dwconv_gram(const mphsir_gram_args* a, int dtype, void* st
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(a && a->Tq && a->Tk && a->Tv && a->wq && a->wk && a->wv && a->V && a->Gpart && a->Spart, "dwconv_gram: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "dwconv_gram: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "dwconv_gram: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2;
     MPHSIR_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && ((int64_t)a->H * a->W) % 64 == 0, "dwconv_gram: H*W must be a multiple of 64");
     MPHSIR_REQUIRE(a->heads > 0 && a->C % a->heads == 0, "dwconv_gram: C %% heads != 0");
@@ -471,8 +495,7 @@ extern "C" int mphsir_dwconv_gram(const mphsir_gram_args* a, int dtype, void* st
     MPHSIR_REQUIRE(!a->QK || mphsir_dwconv_gram_keeps_qk(a->C, a->W, dtype), "dwconv_gram: this shape cannot emit q|k (ask mphsir_dwconv_gram_keeps_qk)");
     MPHSIR_REQUIRE(!a->QK || (aligned16(a->QK) && (a->ldqk * esz) % 16 == 0 && a->ldqk >= 2 * a->C), "dwconv_gram: QK must be 16-byte aligned, ldqk >= 2C");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return dtype == MPHSIR_F32 ? dispatch_gram<float>(d, a->C, a->C / a->heads, s)
-                               : dispatch_gram<bf16_t>(d, a->C, a->C / a->heads, s);
+    return MPHSIR_DISPATCH_T(dtype, (dispatch_gram<T_>(d, a->C, a->C / a->heads, s)));
 }
 
 extern "C" int mphsir_dwconv_gram_keeps_qk(int32_t C, int32_t W, int dtype) {
@@ -485,7 +508,7 @@ extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* 
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(a && a->Gpart && a->Spart && a->temperature && a->Wo && a->M, "spectral_fold: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "spectral_fold: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "spectral_fold: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold: bad shape");
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 128, "spectral_fold: head_dim %d > 128", HD);
@@ -497,9 +520,12 @@ extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* 
     if (dtype == MPHSIR_F32) {
         allow_big_lds(spectral_fold_kernel<float>, shmem);
         MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<float>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(FOLD_THREADS), shmem, s, d);
-    } else {
+    } else if (dtype == MPHSIR_BF16) {
         allow_big_lds(spectral_fold_kernel<bf16_t>, shmem);
         MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<bf16_t>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(FOLD_THREADS), shmem, s, d);
+    } else {
+        allow_big_lds(spectral_fold_kernel<f16_t>, shmem);
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<f16_t>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(FOLD_THREADS), shmem, s, d);
     }
     return MPHSIR_OK;
 }
@@ -508,7 +534,7 @@ extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* st
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(a && a->T && a->w9 && a->U, "dwconv_gate: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "dwconv_gate: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "dwconv_gate: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2;
     MPHSIR_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->HP > 0 && a->HP % 8 == 0, "dwconv_gate: bad shape");
     MPHSIR_REQUIRE(aligned16(a->T) && aligned16(a->U) && (a->ldt * esz) % 16 == 0 && (a->ldu * esz) % 16 == 0, "dwconv_gate: 16-byte alignment required");
@@ -519,7 +545,9 @@ extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* st
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
-    else
+    else if (dtype == MPHSIR_BF16)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
+    else
+        MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
     return MPHSIR_OK;
 }

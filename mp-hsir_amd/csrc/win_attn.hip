@@ -312,7 +312,7 @@ static int dispatch_win(const WinAttnDev& d, int C, int HD, hipStream_t s) {
 }  // namespace mphsir
 
 extern "C" int mphsir_win_attn_hdp(int head_dim, int dtype) {
-    const int kc = dtype == MPHSIR_F32 ? 16 : 32;
+    const int kc = dtype == MPHSIR_F32 ? 16 : 32;      // bf16 and f16 share the 32-wide MFMA K-chunk
     return (head_dim + kc - 1) / kc * kc;
 }
 
@@ -321,13 +321,12 @@ extern "C" int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, voi
     clear_error();
     MPHSIR_REQUIRE(a && a->X && a->SA && a->mu && a->Wqkv && a->bqkv && a->rpb && a->Wproj && a->bproj && a->ln_w && a->ln_b,
                    "win_attn: null pointer");
-    MPHSIR_REQUIRE(dtype == MPHSIR_F32 || dtype == MPHSIR_BF16, "win_attn: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "win_attn: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->H % 8 == 0 && a->W % 8 == 0, "win_attn: H,W must be multiples of 8");
     MPHSIR_REQUIRE(a->shift == 0 || a->shift == 4, "win_attn: shift must be 0 or 4");
     MPHSIR_REQUIRE(a->heads > 0 && a->C % a->heads == 0, "win_attn: C %% heads != 0");
     MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->SA) && aligned16(a->Wqkv) && aligned16(a->Wproj), "win_attn: 16-byte alignment required");
     WinAttnDev d{a->X, a->ln_w, a->ln_b, a->Wqkv, a->bqkv, a->rpb, a->Wproj, a->bproj, a->SA, a->mu, a->Oattn, a->B, a->H, a->W, a->shift};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return dtype == MPHSIR_F32 ? dispatch_win<float>(d, a->C, a->C / a->heads, s)
-                               : dispatch_win<bf16_t>(d, a->C, a->C / a->heads, s);
+    return MPHSIR_DISPATCH_T(dtype, (dispatch_win<T_>(d, a->C, a->C / a->heads, s)));
 }

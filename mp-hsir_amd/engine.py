@@ -132,7 +132,8 @@ class PackPlan:
 
 class DataParallelEngine:
     def __init__(self, net, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, bucket_mb=32, process_group=None,
-                 loss_fn=l1_after_clamp, use_graph=False, graph_warmup=2, use_pack_plan=True):
+                 loss_fn=l1_after_clamp, use_graph=False, graph_warmup=2, use_pack_plan=True, loss_scaling="auto",
+                 init_scale=65536.0, growth_interval=2000):
         self.net, self.lr, self.betas, self.eps, self.wd = net, lr, betas, eps, weight_decay
         self.loss_fn = loss_fn
         self.pg = process_group
@@ -148,6 +149,12 @@ class DataParallelEngine:
         self.use_graph, self.graph_warmup, self._graph, self._graph_key = use_graph, graph_warmup, None, None
         self.use_pack_plan, self.plan = use_pack_plan, None
         self.force_eager = False        # diagnostics: run a graph-mode engine's step with eager launches (same data flow)
+        # fp16 compute (the reference's precision="16-mixed", train.py:118) needs dynamic loss scaling: the loss is
+        # multiplied by a device-resident scale before backward, the optimizer kernel divides it out again and skips
+        # the step when a gradient overflowed, and the scale adapts (ops.scaled_adamw_step = torch GradScaler).
+        # "auto": on exactly when the network computes in float16.
+        self.loss_scaling, self.init_scale, self.growth_interval = loss_scaling, init_scale, growth_interval
+        self.scaler = None
         if self.world > 1:      # DDP's initial parameter broadcast (rank 0 -> all), one flat message
             ps = [p for p in net.parameters()]
             flat = torch.cat([p.data.reshape(-1).float() for p in ps])
@@ -230,6 +237,32 @@ class DataParallelEngine:
         return hook
 
     # ---- one optimisation step ---------------------------------------------------------------------
+    def _use_scaler(self, device):
+        want = self.loss_scaling is True or (self.loss_scaling == "auto" and getattr(self.net, "_dtype", lambda: None)() == torch.float16)
+        if want and self.scaler is None:
+            self.scaler = ops.new_loss_scaler(device, self.init_scale)
+        return want
+
+    def _backward(self, loss):
+        """loss.backward(), through the loss scale when the fp16 path is on"""
+        if self._use_scaler(loss.device):
+            (loss * self.scaler[0]).backward()
+        else:
+            loss.backward()
+
+    def _optimizer_step(self, lr, hyper=None):
+        """AdamW over the arenas (1/world folded in); fp16 path: non-finite check + unscale + skip + scale update"""
+        gs = 1.0 / self.world
+        if self.scaler is not None:
+            ops.scaled_adamw_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.scaler, 0.0 if hyper is not None else lr,
+                                  self.betas[0], self.betas[1], self.eps, self.wd, gs, hyper=hyper, interval=self.growth_interval)
+        elif hyper is not None:
+            ops.flat_adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 0.0, 0, self.betas[0], self.betas[1], self.eps, self.wd,
+                           gs, hyper=hyper)
+        else:
+            ops.flat_adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, lr, self.step_count, self.betas[0], self.betas[1],
+                           self.eps, self.wd, gs)
+
     def _hyper_values(self, lr, step):
         import math
         return [lr, 1.0 - self.betas[0] ** step, math.sqrt(1.0 - self.betas[1] ** step)]
@@ -255,12 +288,11 @@ class DataParallelEngine:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 restored = self.net(self._sx, self._sp)
                 loss = self.loss_fn(restored, self._sc)
-                loss.backward()
+                self._backward(loss)
                 for bi in range(len(self.buckets)):
                     self._gather_bucket(bi)
                 if self.world == 1:
-                    ops.flat_adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 0.0, 0, self.betas[0], self.betas[1],
-                                   self.eps, self.wd, 1.0, hyper=self._hyper)
+                    self._optimizer_step(None, hyper=self._hyper)
                     if self.plan is not None:
                         self.plan.refresh()
                 self._sloss = loss.detach()
@@ -274,8 +306,7 @@ class DataParallelEngine:
         self._graph.replay()
         if self.world > 1:
             dist.all_reduce(self.flat_g, group=self.pg)     # nothing left to overlap with after the replay: one message
-            ops.flat_adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, 0.0, 0, self.betas[0], self.betas[1], self.eps,
-                           self.wd, 1.0 / self.world, hyper=self._hyper)
+            self._optimizer_step(None, hyper=self._hyper)
             if self.plan is not None:
                 self.plan.refresh()
         return self._sloss
@@ -290,13 +321,16 @@ class DataParallelEngine:
         used, offs, _ = self.arena
         m = {names[id(p)]: self.flat_m[o:o + p.numel()].view(p.shape).detach().cpu().clone() for p, o in zip(used, offs)}
         v = {names[id(p)]: self.flat_v[o:o + p.numel()].view(p.shape).detach().cpu().clone() for p, o in zip(used, offs)}
-        return {"step": self.step_count, "exp_avg": m, "exp_avg_sq": v}
+        return {"step": self.step_count, "exp_avg": m, "exp_avg_sq": v,
+                "loss_scaler": None if self.scaler is None else self.scaler.detach().cpu().clone()}
 
     def load_optimizer_state(self, state):
         """restore what optimizer_state() returned; call any time before or after the first step (it is applied as soon
         as the arenas exist)."""
         self._resume = state
         self.step_count = int(state["step"])
+        if state.get("loss_scaler") is not None:
+            self.scaler = state["loss_scaler"].to(next(self.net.parameters()).device).float()
         if self.arena is not None:
             self._apply_resume()
 
@@ -328,7 +362,7 @@ class DataParallelEngine:
             self._remaining = [b[2] for b in self.buckets]
         restored = self.net(degraded, prompt)
         loss = self.loss_fn(restored, clean)
-        loss.backward()
+        self._backward(loss)
         if not first and (self.world == 1 or self.use_graph):
             for bi in range(len(self.buckets)):
                 self._gather_bucket(bi)
@@ -345,8 +379,7 @@ class DataParallelEngine:
             h.wait()
         self._pending = []
         self.step_count += 1
-        ops.flat_adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr if lr is None else lr, self.step_count,
-                       self.betas[0], self.betas[1], self.eps, self.wd, 1.0 / self.world)
+        self._optimizer_step(self.lr if lr is None else lr)
         if self.plan is not None:
             self.plan.refresh()
         return loss.detach()

@@ -436,7 +436,8 @@ class MP_HSIR_Net(nn.Module):                                                   
         self.compute_dtype = compute_dtype
 
     def set_compute_dtype(self, dtype):
-        """torch.float32 (exact-f32 MFMA, parity path), torch.bfloat16, or None = follow autocast."""
+        """torch.float32 (exact-f32 MFMA, parity path), torch.bfloat16, torch.float16 (the reference's 16-mixed: train it
+        through engine.DataParallelEngine, which then turns on dynamic loss scaling), or None = follow autocast."""
         self.compute_dtype = dtype
         return self
 
@@ -444,7 +445,8 @@ class MP_HSIR_Net(nn.Module):                                                   
         if self.compute_dtype is not None:
             return self.compute_dtype
         if torch.is_autocast_enabled():
-            return torch.bfloat16     # the reference trains with fp16 autocast (train.py:118); bf16 here
+            dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.bfloat16
+            return dt if dt in (torch.bfloat16, torch.float16) else torch.bfloat16
         return torch.float32
 
     def _draw_drop_path(self, B, device):

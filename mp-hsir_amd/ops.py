@@ -8,7 +8,8 @@ import torch
 
 from . import _lib
 
-_DT = {torch.float32: 0, torch.bfloat16: 1}
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}     # dtype codes of include/mphsir.h
+_HALF = (torch.bfloat16, torch.float16)                            # 16-bit storage, fp32 accumulation
 
 # optional algorithmic work accounting (bench.py roofline leg): kernel name -> [launches, flops, bytes]
 ACCOUNT = None
@@ -122,7 +123,7 @@ def _flush_gemms(gemms):
             q = arr[k]
             q.A, q.lda, q.B, q.ldb, q.Cpart, q.colsum_part = g["A"], g["lda"], g["B"], g["ldb"], g["Cpart"], g["cs"]
             q.M, q.N1, q.N2, q.nsplit = g["M"], g["N1"], g["N2"], g["nsplit"]
-        _lib.check(lib.mphsir_gemm_tn_group(arr, len(chunk), _DT[torch.bfloat16], _stream(chunk[0]["keep"][0])), "gemm_tn_group")
+        _lib.check(lib.mphsir_gemm_tn_group(arr, len(chunk), _DT[chunk[0]["keep"][0].dtype], _stream(chunk[0]["keep"][0])), "gemm_tn_group")
 
 
 def _flush(segs):
@@ -394,6 +395,7 @@ def dwconv_gram(tq, tk, tv, wq, wk, wv, ldw, B, H, W, C, heads, nsplit=None, kee
         a.QK, a.ldqk = _p(qk), 2 * C
     _lib.check(lib.mphsir_dwconv_gram(ctypes.byref(a), _DT[tq.dtype], _stream(tq)), "dwconv_gram")
     _acct("dwconv_gram", M * (54.0 * C + 2.0 * C * hd), (4.0 + (2.0 if qk is not None else 0.0)) * M * C * tq.element_size() + gp.numel() * 4 + sp.numel() * 4)
+    _acct("dwconv_gram:qk", 2.0 * M * C * hd, 0.0)            # the QK^T (Gram) FLOPs alone, for bench.py's spectral roofline
     if keep_qk:
         return v, gp, sp, nsplit, qk
     return v, gp, sp, nsplit
@@ -506,6 +508,27 @@ def flat_adamw(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
     assert p.dtype == torch.float32 and p.is_contiguous() and p.numel() == g.numel() == m.numel() == v.numel()
     _lib.check(lib.mphsir_flat_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                      grad_scale, _p(hyper), _stream(p)), "flat_adamw")
+    bump_weight_epoch()
+
+
+def new_loss_scaler(device, init_scale=65536.0):
+    """device state of the dynamic loss scaler (torch GradScaler defaults: 2^16, x2 every 2000 good steps, x0.5 on overflow):
+    fp32 [scale, good steps in a row, found-inf flag, optimizer steps taken]."""
+    return torch.tensor([init_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+
+
+def scaled_adamw_step(p, g, m, v, scaler, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, grad_scale=1.0, hyper=None,
+                      growth=2.0, backoff=0.5, interval=2000):
+    """the fp16 path's optimizer step: non-finite check of the (all-reduced) gradients, AdamW on g / scale unless the check
+    fired, scaler update -- three capturable launches (include/mphsir.h)."""
+    lib = _lib.load()
+    _check(p, g, m, v, scaler)
+    assert scaler.dtype == torch.float32 and scaler.numel() == 4 and p.numel() == g.numel()
+    st = _stream(p)
+    _lib.check(lib.mphsir_grad_check(_p(g), g.numel(), _p(scaler), st), "grad_check")
+    _lib.check(lib.mphsir_flat_adamw_scaled(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, grad_scale,
+                                            _p(hyper), _p(scaler), st), "flat_adamw_scaled")
+    _lib.check(lib.mphsir_scaler_update(_p(scaler), growth, backoff, interval, st), "scaler_update")
     bump_weight_epoch()
 
 
@@ -661,9 +684,9 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, redu
     M, N1, N2 = a.shape[-2], a.shape[-1], b.shape[-1]
     assert a.stride(-1) == 1 and b.stride(-1) == 1 and b.shape[-2] == M and a.dtype == b.dtype
     if tile128 is None:
-        tile128 = TN_BIG_TILES and a.dtype == torch.bfloat16
+        tile128 = TN_BIG_TILES and a.dtype in _HALF
     if nsplit is None:
-        if tile128 and a.dtype == torch.bfloat16:     # transposed-read kernel: 64/128-wide tile per operand, 2 workgroups per CU
+        if tile128 and a.dtype in _HALF:     # transposed-read kernel: 64/128-wide tile per operand, 2 workgroups per CU
             tiles = ((N1 + 127) // 128 if N1 > 64 else 1) * ((N2 + 127) // 128 if N2 > 64 else 1) * Bt
             resident = 2 if (N1 > 64 and N2 > 64) else (4 if (N1 <= 64 and N2 <= 64) else 3)    # workgroups per CU (LDS, VGPRs)
             nsplit = max(1, min(M // 256, 128, max(1, int(256 * resident * TN_BIG_ROUNDS) // tiles)))
@@ -673,7 +696,7 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, redu
             nsplit = max(1, min(M // 512, 64, max(1, 768 // tiles)))      # ~3 workgroups per CU (measured optimum)
     part = torch.empty((Bt, nsplit, N1, N2), dtype=torch.float32, device=a.device)
     cs = torch.empty((Bt, nsplit, N1), dtype=torch.float32, device=a.device) if colsum else None
-    if _SCOPE is not None and TN_GROUPED and not immediate and not batched and tile128 and a.dtype == torch.bfloat16:
+    if _SCOPE is not None and TN_GROUPED and not immediate and not batched and tile128 and a.dtype in _HALF:
         # nothing but the partial reduction at the end of the scope reads the result: issue it there, grouped
         _SCOPE.gemms.append(dict(A=a.data_ptr(), lda=a.stride(-2), B=b.data_ptr(), ldb=b.stride(-2), Cpart=part.data_ptr(),
                                  cs=cs.data_ptr() if colsum else None, M=M, N1=N1, N2=N2, nsplit=nsplit, keep=(a, b, part, cs)))
@@ -765,7 +788,7 @@ def pg_gate_bwd(mu, dgate, pg, factor_dtype=torch.float32):
     a.Wq, a.Wkv, a.Wdown = _p(pg["q.weight"]), _p(pg["kv.weight"]), _p(pg["linear_down.weight"])
     a.Wpproj, a.bpproj, a.Wup = _p(pg["proj.weight"]), _p(pg["proj.bias"]), _p(pg["linear_up.weight"])
     a.dmu, a.L, a.R = _p(dmu), _p(L), _p(R)
-    a.nW, a.C, a.r, a.KL, a.KR, a.lr_bf16 = nW, C, r, KL, KR, int(factor_dtype == torch.bfloat16)
+    a.nW, a.C, a.r, a.KL, a.KR, a.lr_bf16 = nW, C, r, KL, KR, _DT[factor_dtype]
     _lib.check(lib.mphsir_pg_gate_bwd(ctypes.byref(a), _stream(mu)), "pg_gate_bwd")
     _acct("pg_gate_bwd", 4.0 * nW * C * (128 + 2 * r), 4.0 * nW * (2 * C + KL + KR))
     part = gemm_tn(L, R, reduce=False)[0]                      # (nsplit, KL, KR): every parameter gradient is a sub-block

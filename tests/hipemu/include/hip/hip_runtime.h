@@ -303,6 +303,16 @@ inline bf16x4_t ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p) hipemu::ds_read_tr16_b64((const void*)(p))
+namespace hipemu {
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_b;
+inline fp16x4_b ds_read_tr16_b64_f16(const void* p) {         // same lane exchange, 2-byte elements moved bit-wise
+    const bf16x4_t r = ds_read_tr16_b64(p);
+    fp16x4_b o;
+    memcpy(&o, &r, sizeof(o));
+    return o;
+}
+}  // namespace hipemu
+#define __builtin_amdgcn_ds_read_tr16_b64_v4f16(p) hipemu::ds_read_tr16_b64_f16((const void*)(p))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu::mfma_16x16x32<hipemu::bf16x8_t>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hipemu::mfma_16x16x32<hipemu::f16x8_t>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4_f32(a, b, c)

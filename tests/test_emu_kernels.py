@@ -124,3 +124,32 @@ def test_pg_gate_bwd():
 @pytest.mark.parametrize("dtype,C,heads,shape,cross", [(torch.float32, 64, 2, (1, 16, 16), False), (torch.bfloat16, 128, 2, (2, 8, 16), True)])
 def test_channel_attention_bwd(dtype, C, heads, shape, cross):
     K.check_channel_attention_bwd("cpu", dtype, C, heads, shape, cross)
+
+
+# ---- fp16 storage (dtype code 2, the reference's 16-mixed precision): same kernels, v_mfma_f32_16x16x32_f16 ------------------
+F16 = torch.float16
+
+
+def test_fp16_forward_kernels(manifest):
+    K.check_gemm_tok("cpu", F16, 128, 96, 96, True, 0)
+    K.check_gemm_tok("cpu", F16, 64, 48, 192, False, 1)
+    K.check_gemm_tok_per_sample_combine("cpu", F16)
+    K.check_gated_mlp("cpu", F16, 96, 255)
+    K.check_win_attn("cpu", F16, "remote_mode8", "encoder_level1.blocks.1.", 2, 4, (1, 16, 8, 96), manifest)
+    K.check_spectral_attention_chain("cpu", F16, 64, 2, (1, 16, 16), 2)
+    K.check_gdfn_chain("cpu", F16)
+    K.check_conv3x3("cpu", F16, 1, 8, 8, 31, 32)
+
+
+def test_fp16_backward_kernels():
+    K.check_gated_mlp_bwd("cpu", F16, 96, 255)
+    K.check_gemm_tn("cpu", F16, 200, 96, 32, 3, 0)
+    K.check_gemm_tn("cpu", F16, 256, 136, 72, 2, 0, tile128=True)
+    K.check_dwconv_plain("cpu", F16, (2, 8, 8, 32))
+    K.check_combine_bwd("cpu", F16, 96, 4)
+    K.check_channel_attention_bwd("cpu", F16, 64, 2, (1, 16, 16), True)
+    K.check_pgsstb_backward_oracle("cpu", F16, "rs_enc1", B=2, hw=(8, 16))
+
+
+def test_loss_scaler_kernels():
+    K.check_loss_scaler("cpu")

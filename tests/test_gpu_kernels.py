@@ -179,3 +179,44 @@ def test_pg_gate_bwd(factor_dtype, C, cr):
 def test_channel_attention_bwd(dtype, C, heads, shape, cross):
     """the prompt modules' attention backward at both configurations' widths (TVSP: D, 2 heads; PromptFusion: 2D/4D, 4/8 heads)"""
     K.check_channel_attention_bwd("cuda", dtype, C, heads, shape, cross)
+
+
+# ---- fp16 storage (dtype code 2; BASELINE configs[4]: remote-sensing training in fp16 + loss scaling) ------------------------
+F16 = torch.float16
+
+
+def test_fp16_forward_kernels(manifest):
+    K.check_gemm_tok("cuda", F16, 4096, 192, 64, True, 0)
+    K.check_gemm_tok("cuda", F16, 65536, 208, 96, True, 1)
+    K.check_gemm_tok_per_sample_combine("cuda", F16)
+    for C, hid in [(96, 255), (192, 510), (384, 1021), (128, 340)]:
+        K.check_gated_mlp("cuda", F16, C, hid)
+    for man, prefix, heads, shift, shape in GPU_WIN_CASES:
+        K.check_win_attn("cuda", F16, man, prefix, heads, shift, shape, manifest)
+    for C, heads, shape, nsplit in GPU_SPEC_CASES:
+        K.check_spectral_attention_chain("cuda", F16, C, heads, shape, nsplit)
+    K.check_gdfn_chain("cuda", F16)
+    K.check_conv3x3("cuda", F16, 4, 64, 64, 31, 64)
+    K.check_pack_gather("cuda", F16)
+
+
+@pytest.mark.parametrize("name", PGSSTB_CASES)
+def test_pgsstb_backward_vs_oracle_autograd_fp16(name):
+    """every shape class in fp16: dX and all parameter gradients <= 2e-2 rel-L2 against fp64 autograd of the oracle (VERDICT r1 #8)"""
+    errs = K.check_pgsstb_backward_oracle("cuda", F16, name, B=2, hw=(32, 32))
+    print(name, "fp16 worst", max(errs, key=errs.get), max(errs.values()))
+
+
+def test_fp16_backward_kernels():
+    for C, hid in [(96, 255), (192, 510), (384, 1021), (128, 340)]:
+        K.check_gated_mlp_bwd("cuda", F16, C, hid)
+    K.check_gemm_tn("cuda", F16, 131072, 704, 128, None, 0)
+    K.check_gemm_tn("cuda", F16, 4096, 128, 352, 5, 0, tile128=True)
+    K.check_gemm_tn_grouped("cuda", F16)
+    K.check_dwconv_plain("cuda", F16, (4, 64, 64, 384))
+    K.check_channel_attention_bwd("cuda", F16, 96, 2, (1, 64, 64), True)
+    K.check_channel_attention_bwd("cuda", F16, 384, 8, (1, 32, 32), False)
+
+
+def test_loss_scaler_kernels():
+    K.check_loss_scaler("cuda")

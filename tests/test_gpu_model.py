@@ -214,6 +214,41 @@ def test_remote_sensing_training_step_bf16():
     assert not lib_ops, "library GEMM / conv / norm ops on the training step: %s" % lib_ops
 
 
+def test_remote_sensing_training_fp16_loss_scaling():
+    """BASELINE configs[4]: the remote-sensing model (100 bands, dim 96, T=7), batch 16, fp16 compute with dynamic loss scaling
+    (the reference's precision="16-mixed", train.py:118) through the engine: the scale adapts (overflowing steps are skipped and
+    halve it), steps are taken, the loss stays finite, and the parameters with tiny gradient paths (temperature, prompt_param,
+    relative_position_bias_table, text_prompt_learnable, visual_prompt) receive non-zero finite updates."""
+    from mp_hsir_amd.data import SyntheticPatchSource
+    from mp_hsir_amd.engine import DataParallelEngine
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    torch.manual_seed(0)
+    net = MP_HSIR_Net(100, 100, 96, task_classes=7, compute_dtype=torch.float16, clip_prompt="surrogate").cuda().train()
+    watch = {k: p for k, p in net.named_parameters() if k.endswith(("temperature", "prompt_param", "relative_position_bias_table",
+                                                                     "text_prompt_learnable", "visual_prompt"))}
+    before = {k: p.detach().clone() for k, p in watch.items()}
+    eng = DataParallelEngine(net, lr=1e-4)
+    src = SyntheticPatchSource(100, 64, 16, 7, "cuda", 2024, 0)
+    losses = []
+    for _ in range(8):
+        _, x, c, p = src.next()
+        losses.append(float(eng.train_step(x, c, p)))
+    sc = eng.scaler.cpu()
+    print("fp16 losses", losses, "scaler", sc.tolist())
+    assert all(torch.isfinite(torch.tensor(losses))) and eng.scaler is not None
+    assert float(sc[3]) >= 3 and 1.0 <= float(sc[0]) <= 65536.0 and float(sc[2]) == 0.0, sc.tolist()
+    for k, p in watch.items():
+        d = (p.detach() - before[k]).abs()
+        assert torch.isfinite(p).all() and float(d.max()) > 0.0, k
+    assert losses[-1] < 1.5 * losses[0]
+
+
+def test_full_width_forward_fp16():
+    for name in FULL_CASES:
+        err, dp = M.check_full_forward("cuda", name, torch.float16, tol=8e-3, dpsnr=0.05)
+        print(name, "fp16 rel-L2 %.3e dPSNR %.4f" % (err, dp))
+
+
 def test_512x512_172band_forward_bf16():
     """BASELINE configs[3] shape: (1,172,512,512) inpainting input through MP_HSIR_Net(172,172,96,T=7) in bf16:
     runs whole (no tiling), finite, and the 64x64 top-left crop of the output depends on the rest of the cube
