@@ -308,6 +308,18 @@ int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY, int64_t l
  * given dU [M][HP] writes U (recomputed, for d project_out) and dT [M][2*HP].                          */
 int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void* dT, int64_t M, int32_t HP, int dtype, void* stream);
 
+/* ---- the resamplers of TVSP.forward (net/MP_HSIR.py:572-583), channels-last ----------------------------------------------
+ * mphsir_tvsp_text_map: text [B][ps][ps][D] fp32 = L[b][d] * clip[floor(i*B/ps)][floor(j*512/ps)] -- the reference's broadcast
+ *   of (B,D,1,1) x (B,512) followed by F.interpolate(nearest) to (ps,ps) (:575-577; the batch axis lands on image rows).
+ *   L [B][D] fp32 (task-weighted mean of text_prompt_learnable), clip [B][512] fp32.
+ * mphsir_tvsp_text_map_bwd: part [B][ps][D] fp32, part[b][i][d] = sum_j dtext[b,i,j,d] * clip_map[i][j]; dL = sum over i.
+ * mphsir_resize_bilinear: F.interpolate(mode="bilinear", align_corners=False) (:580) X (B,h,w,C) -> Y (B,H,W,C);
+ *   backward != 0: X = dY (B,H,W,C) -> Y = dX (B,h,w,C), a gather (deterministic).  C a multiple of 16 bytes of elements.   */
+int mphsir_tvsp_text_map(const float* L, const float* clip, float* text, int32_t B, int32_t ps, int32_t D, void* stream);
+int mphsir_tvsp_text_map_bwd(const float* dtext, const float* clip, float* part, int32_t B, int32_t ps, int32_t D, void* stream);
+int mphsir_resize_bilinear(const void* X, void* Y, int32_t B, int32_t h, int32_t w, int32_t H, int32_t W, int32_t C, int32_t backward,
+                           int dtype, void* stream);
+
 /* ---- fused AdamW over the flat parameter arena ---------------------------------------------------
  * One decoupled-weight-decay Adam step on n contiguous fp32 parameters (n % 4 == 0) with gradient g,
  * moments m, v; g is multiplied by grad_scale first (1/world_size after a sum all-reduce).
@@ -382,6 +394,7 @@ int mphsir_pack_gather(const float* arena, const int32_t* index, void* dst, int6
 #define MPHSIR_K_PACK_GATHER 20
 #define MPHSIR_K_LAYERNORM 21
 #define MPHSIR_K_PG_GATE 22
+#define MPHSIR_K_RESAMPLE 23
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -116,6 +116,9 @@ _SYMBOLS = {
     "mphsir_prof_enable": (c_int, [c_int]),
     "mphsir_prof_read": (c_int, [ctypes.POINTER(c_int), c_float_p]),
     "mphsir_gemm_tok": (c_int, [ctypes.POINTER(GemmArgs), c_int, c_void_p]),
+    "mphsir_tvsp_text_map": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "mphsir_tvsp_text_map_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "mphsir_resize_bilinear": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_layernorm_tok": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int32, c_void_p]),
     "mphsir_win_attn_fwd": (c_int, [ctypes.POINTER(WinAttnArgs), c_int, c_void_p]),
     "mphsir_win_attn_hdp": (c_int, [c_int, c_int]),

@@ -346,6 +346,34 @@ class _CrossChannelAttnRes(torch.autograd.Function):
                 _join_taps(dwk, dwv).reshape(2 * D, 1, 3, 3), dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1))
 
 
+class _TextMap(torch.autograd.Function):
+    """text[b,i,j,:] = L[b,:] * clip[floor(i*B/ps), floor(j*512/ps)]  (ref :575-577)"""
+
+    @staticmethod
+    def forward(ctx, L, clip, ps):
+        clip = clip.float().contiguous()
+        ctx.save_for_backward(clip)
+        return ops.tvsp_text_map(L.float().contiguous(), clip, ps)
+
+    @staticmethod
+    def backward(ctx, dtext):
+        (clip,) = ctx.saved_tensors
+        return ops.tvsp_text_map_bwd(dtext.float().contiguous(), clip), None, None
+
+
+class _Bilinear(torch.autograd.Function):
+    """F.interpolate(mode="bilinear", align_corners=False) on channels-last data (ref :580)"""
+
+    @staticmethod
+    def forward(ctx, x, H, W):
+        ctx.hw = x.shape[1:3]
+        return ops.resize_bilinear(x.contiguous(), H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.resize_bilinear(dy.contiguous(), ctx.hw[0], ctx.hw[1], backward=True), None, None
+
+
 def tvsp(mod, x, clip_prompt, prompt_weights):
     """TVSP.forward (ref :572-583) with the batch-coupling broadcast of SURVEY Q1 made explicit:
     text[b,i,j,d] = L[b,d] * clip[floor(i*B/ps), floor(j*512/ps)]."""
@@ -353,9 +381,7 @@ def tvsp(mod, x, clip_prompt, prompt_weights):
     ps, dt, dev = mod.prompt_size, x.dtype, x.device
     learn = mod.text_prompt_learnable[0, :, :, 0, 0]                                   # (T,D)
     L = (prompt_weights.to(torch.float32).unsqueeze(-1) * learn.unsqueeze(0)).mean(dim=1)      # (B,D)
-    ar = torch.arange(ps, device=dev)
-    clip_map = clip_prompt[(ar * B) // ps][:, (ar * 512) // ps]                       # (ps,ps)
-    text = (clip_map[None, :, :, None] * L[:, None, None, :]).float().contiguous()     # fp32: see _CrossChannelAttnRes
+    text = _TextMap.apply(L, clip_prompt, ps)                                          # fp32: see _CrossChannelAttnRes
     vis = mod.visual_prompt.permute(0, 2, 3, 1).expand(B, ps, ps, D).to(dt).contiguous()
     ct = mod.cross_transformer
     at = ct.attn
@@ -364,7 +390,7 @@ def tvsp(mod, x, clip_prompt, prompt_weights):
                                    at.q_dwconv.weight, at.kv_dwconv.weight, at.project_out.weight, at.temperature)
     y = _gdfn_res_ag(ct.ffn, ct.norm2, a, B, ps, ps).reshape(B, ps, ps, D)
     if (H, W) != (ps, ps):                                                             # ref :580
-        y = F.interpolate(y.permute(0, 3, 1, 2), (H, W), mode="bilinear").permute(0, 2, 3, 1).contiguous()
+        y = _Bilinear.apply(y, H, W)
     return conv3x3(y, mod.conv_last)
 
 

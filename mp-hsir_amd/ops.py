@@ -260,6 +260,46 @@ def layernorm_tok(x, ln_w, ln_b, out_dtype):
     return y
 
 
+def tvsp_text_map(L, clip, ps):
+    """L (B,D) fp32, clip (B,512) fp32 -> text (B,ps,ps,D) fp32 (TVSP.forward :575-577 incl. its batch-on-rows broadcast)."""
+    lib = _lib.load()
+    _check(L, clip)
+    B, D = L.shape
+    assert L.dtype == torch.float32 and clip.dtype == torch.float32 and clip.shape == (B, 512) and L.is_contiguous() and clip.is_contiguous()
+    text = torch.empty((B, ps, ps, D), dtype=torch.float32, device=L.device)
+    _lib.check(lib.mphsir_tvsp_text_map(_p(L), _p(clip), _p(text), B, ps, D, _stream(L)), "tvsp_text_map")
+    _acct("resample", 1.0 * text.numel(), 4.0 * text.numel())
+    return text
+
+
+def tvsp_text_map_bwd(dtext, clip):
+    """dtext (B,ps,ps,D) fp32 -> dL (B,D) fp32"""
+    lib = _lib.load()
+    _check(dtext, clip)
+    B, ps, _, D = dtext.shape
+    assert dtext.dtype == torch.float32 and dtext.is_contiguous() and clip.is_contiguous()
+    part = torch.empty((B, ps, D), dtype=torch.float32, device=dtext.device)
+    _lib.check(lib.mphsir_tvsp_text_map_bwd(_p(dtext), _p(clip), _p(part), B, ps, D, _stream(dtext)), "tvsp_text_map_bwd")
+    _acct("resample", 2.0 * dtext.numel(), 4.0 * dtext.numel())
+    return reduce_parts(part, batched=True, immediate=True)
+
+
+def resize_bilinear(x, H, W, backward=False):
+    """x (B,h,w,C) channels-last -> (B,H,W,C) bilinear, align_corners=False; backward=True: x is dY (B,hh,ww,C) of a forward
+    to (hh,ww) from (H,W) and the result is dX (B,H,W,C)."""
+    lib = _lib.load()
+    _check(x)
+    B, h, w, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    if backward:
+        _lib.check(lib.mphsir_resize_bilinear(_p(x), _p(y), B, H, W, h, w, C, 1, _DT[x.dtype], _stream(x)), "resize_bilinear")
+    else:
+        _lib.check(lib.mphsir_resize_bilinear(_p(x), _p(y), B, h, w, H, W, C, 0, _DT[x.dtype], _stream(x)), "resize_bilinear")
+    _acct("resample", 8.0 * y.numel(), (x.numel() + y.numel()) * x.element_size())
+    return y
+
+
 def round_up(n, m):
     return (n + m - 1) // m * m
 

@@ -548,3 +548,27 @@ def check_loss_scaler(dev):
         assert rel_l2(p, ref.detach()) < 2e-6, (step, rel_l2(p, ref.detach()))
     # steps 0,1 good -> x2 after the second; step 2 overflow -> /2; steps 3,4 good -> x2
     assert float(sc[0]) == 1024.0 * 2 * 0.5 * 2 and float(sc[3]) == 4.0
+
+
+def check_resamplers(dev, dtype, B=3, ps=16, D=32, H=40, W=24):
+    """mphsir_tvsp_text_map (+bwd) against the reference's own expression (broadcast multiply + F.interpolate nearest,
+    net/MP_HSIR.py:575-577) and mphsir_resize_bilinear (+bwd) against F.interpolate(bilinear) (:580), fp64 autograd."""
+    _use(dev)
+    import torch.nn.functional as F
+    from mp_hsir_amd import ops
+    L, clip = rnd((B, D), 501), rnd((B, 512), 502)
+    text = ops.tvsp_text_map(L, clip, ps)
+    Ld, cd = L.double().cpu().requires_grad_(True), clip.double().cpu()
+    ref = F.interpolate(Ld.reshape(B, D, 1, 1) * cd.reshape(1, 1, B, 512).expand(B, 1, B, 512), (ps, ps), mode="nearest")   # (B,D,ps,ps)
+    assert rel_l2(text, ref.detach().permute(0, 2, 3, 1)) < 2e-7
+    dt = rnd((B, ps, ps, D), 503)
+    ref.backward(dt.double().cpu().permute(0, 3, 1, 2))
+    assert rel_l2(ops.tvsp_text_map_bwd(dt, clip), Ld.grad) < 2e-6
+    x = rnd((B, ps, ps, D), 504, dtype)
+    y = ops.resize_bilinear(x, H, W)
+    xd = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.interpolate(xd, (H, W), mode="bilinear", align_corners=False)
+    assert rel_l2(y, yr.detach().permute(0, 2, 3, 1)) < TOL[dtype]
+    dy = rnd((B, H, W, D), 505, dtype)
+    yr.backward(dy.double().cpu().permute(0, 3, 1, 2))
+    assert rel_l2(ops.resize_bilinear(dy, ps, ps, backward=True), xd.grad.permute(0, 2, 3, 1)) < TOL[dtype]

@@ -153,3 +153,9 @@ def test_fp16_backward_kernels():
 
 def test_loss_scaler_kernels():
     K.check_loss_scaler("cpu")
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+def test_resamplers(dtype):
+    K.check_resamplers("cpu", dtype)
+    K.check_resamplers("cpu", dtype, B=2, ps=8, D=16, H=64, W=64)       # the 8x upsample of the 512x512 path, scaled down

@@ -220,3 +220,10 @@ def test_fp16_backward_kernels():
 
 def test_loss_scaler_kernels():
     K.check_loss_scaler("cuda")
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES + [F16])
+def test_resamplers(dtype):
+    K.check_resamplers("cuda", dtype)
+    K.check_resamplers("cuda", dtype, B=2, ps=64, D=64, H=512, W=512)
+    K.check_resamplers("cuda", dtype, B=4, ps=32, D=128, H=32, W=48)
