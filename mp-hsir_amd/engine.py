@@ -130,6 +130,47 @@ class PackPlan:
                 c.pinned = None
 
 
+_EXT_EVENTS = {}
+
+
+def _external_events_work(dev):
+    """Does this PyTorch / HIP stack support external event record nodes in a captured graph, with a later
+    stream.wait_event() honouring the record of the replay?  Probed once per device with a tiny graph whose event node
+    follows a kernel writing a new value each replay; anything unexpected -> False (the engine then falls back to one
+    all-reduce after the replay)."""
+    key = str(dev)
+    if key in _EXT_EVENTS:
+        return _EXT_EVENTS[key]
+    ok = False
+    try:
+        ev = torch.cuda.Event(external=True)
+        src = torch.zeros(1 << 22, device=dev)
+        val = torch.zeros((), device=dev)
+        out = torch.zeros(8, device=dev)
+        side = torch.cuda.Stream(dev)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for _ in range(8):
+                src.add_(1.0)                   # something that takes a while
+            val.copy_(src[0])
+            ev.record()
+            src.mul_(1.0)
+        ok = True
+        for i in range(4):
+            g.replay()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                out[i].copy_(val)
+            torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        ok = out[:4].tolist() == [8.0, 16.0, 24.0, 32.0]
+    except Exception:
+        ok = False
+    _EXT_EVENTS[key] = ok
+    return ok
+
+
 class DataParallelEngine:
     def __init__(self, net, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, bucket_mb=32, process_group=None,
                  loss_fn=l1_after_clamp, use_graph=False, graph_warmup=2, use_pack_plan=True, loss_scaling="auto",
@@ -148,6 +189,7 @@ class DataParallelEngine:
         # arena-wide reduction after the replay: 58 MB over xGMI is <1 ms next to a ~45 ms step).
         self.use_graph, self.graph_warmup, self._graph, self._graph_key = use_graph, graph_warmup, None, None
         self.use_pack_plan, self.plan = use_pack_plan, None
+        self.graph_overlap = True       # graph mode, world > 1: bucket all-reduces start while the replay is still running
         self.force_eager = False        # diagnostics: run a graph-mode engine's step with eager launches (same data flow)
         # fp16 compute (the reference's precision="16-mixed", train.py:118) needs dynamic loss scaling: the loss is
         # multiplied by a device-resident scale before backward, the optimizer kernel divides it out again and skips
@@ -215,9 +257,20 @@ class DataParallelEngine:
                     bi += 1
                 bucket_of[p] = bi
             self._remaining = [b[2] for b in self.buckets]
+            self._capturing, self._bucket_order = False, []
+            self._overlap = self.use_graph and self.graph_overlap and _external_events_work(dev)
             if not self.use_graph:
                 for p in used:
                     p.register_post_accumulate_grad_hook(self._make_hook(bucket_of[p]))
+            elif self._overlap:
+                # graph mode: the all-reduce cannot live inside the captured step, but it can start while the replay is
+                # still running.  While capturing, each bucket's gather is followed by an EXTERNAL event record node; after
+                # graph.replay() the communication stream waits for bucket k's event and reduces it while the rest of
+                # backward is still executing (DDP's overlap, re-expressed for a replayed hipGraph).
+                self._bucket_events = [torch.cuda.Event(external=True) for _ in self.buckets]
+                self._comm = torch.cuda.Stream(dev)
+                for p in used:
+                    p.register_post_accumulate_grad_hook(self._make_capture_hook(bucket_of[p]))
 
     def _gather_bucket(self, bi):
         """autograd hands every gradient over as a fresh tensor (p.grad was None): move the bucket's gradients into
@@ -226,6 +279,17 @@ class DataParallelEngine:
         torch._foreach_copy_(views, [p.grad for p in ps])
         for p in ps:
             p.grad = None
+
+    def _make_capture_hook(self, bi):
+        def hook(_p):
+            if not self._capturing:
+                return
+            self._remaining[bi] -= 1
+            if self._remaining[bi] == 0:
+                self._gather_bucket(bi)
+                self._bucket_events[bi].record()          # external event record node of the graph being captured
+                self._bucket_order.append(bi)
+        return hook
 
     def _make_hook(self, bi):
         def hook(_p):
@@ -288,9 +352,17 @@ class DataParallelEngine:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 restored = self.net(self._sx, self._sp)
                 loss = self.loss_fn(restored, self._sc)
-                self._backward(loss)
+                overlap = self.world > 1 and getattr(self, "_overlap", False)
+                if overlap:
+                    self._remaining = [b[2] for b in self.buckets]
+                    self._bucket_order, self._capturing = [], True
+                try:
+                    self._backward(loss)
+                finally:
+                    self._capturing = False
                 for bi in range(len(self.buckets)):
-                    self._gather_bucket(bi)
+                    if not (overlap and bi in self._bucket_order):
+                        self._gather_bucket(bi)
                 if self.world == 1:
                     self._optimizer_step(None, hyper=self._hyper)
                     if self.plan is not None:
@@ -305,7 +377,18 @@ class DataParallelEngine:
         self._hyper.copy_(torch.tensor(self._hyper_values(self.lr if lr is None else lr, self.step_count)), non_blocking=True)
         self._graph.replay()
         if self.world > 1:
-            dist.all_reduce(self.flat_g, group=self.pg)     # nothing left to overlap with after the replay: one message
+            if getattr(self, "_overlap", False) and len(self._bucket_order) == len(self.buckets):
+                handles = []
+                for bi in self._bucket_order:           # completion order of the captured backward
+                    self._comm.wait_event(self._bucket_events[bi])
+                    st, en, _ = self.buckets[bi]
+                    with torch.cuda.stream(self._comm):
+                        handles.append(dist.all_reduce(self.flat_g[st:en], group=self.pg, async_op=True))
+                for h in handles:
+                    h.wait()
+                torch.cuda.current_stream(dev).wait_stream(self._comm)
+            else:
+                dist.all_reduce(self.flat_g, group=self.pg)     # no external events on this stack: one message after the replay
             self._optimizer_step(None, hyper=self._hyper)
             if self.plan is not None:
                 self.plan.refresh()

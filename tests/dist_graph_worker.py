@@ -39,7 +39,9 @@ def main():
         assert eng._graph is not None, "the captured step never ran"
         eng.finish()
     torch.cuda.synchronize()
-    torch.save({"losses": losses, "state": {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}}, out + str(rank))
+    torch.save({"losses": losses, "state": {k: v.detach().cpu().clone() for k, v in net.state_dict().items()},
+                "overlap": bool(getattr(eng, "_overlap", False)), "nbuckets": len(eng.buckets),
+                "bucket_order": list(getattr(eng, "_bucket_order", []))}, out + str(rank))
     dist.destroy_process_group()
 
 

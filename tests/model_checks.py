@@ -217,3 +217,45 @@ def check_pack_plan(dev, dtype=torch.float32, steps=3):
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+def check_tiny_adamw(dev, use_graph=False, steps=2):
+    """a18 on the HIP path: two optimisation steps of the tiny net through engine.DataParallelEngine (HIP forward /
+    backward, mphsir_flat_adamw on the flat arenas) against tests/golden/tiny_adamw.npz, i.e. the REFERENCE model
+    stepped by torch.optim.AdamW(lr=2e-4) (train.py:69): losses, and per parameter the norm and seeded samples of
+    (p_after - p_before)."""
+    from golden.cases import sample_indices
+    from mp_hsir_amd.engine import DataParallelEngine
+    net = build_net(TINY_CFG, dev, torch.float32)
+    p0 = {k: p.detach().clone() for k, p in net.named_parameters()}
+    eng = DataParallelEngine(net, lr=2e-4, use_graph=use_graph, graph_warmup=0 if use_graph else 2)
+    task = torch.tensor([[1], [3]]).to(dev)
+    losses = []
+    for step in range(steps):
+        xs = seeded_input("adam_x%d" % step, (2, 8, 64, 64)).to(dev)
+        cs = seeded_input("adam_c%d" % step, (2, 8, 64, 64)).to(dev)
+        losses.append(float(eng.train_step(xs, cs, task)))
+    if use_graph:
+        eng.finish()
+    g = np.load(os.path.join(GOLDEN, "tiny_adamw.npz"))
+    np.testing.assert_allclose(losses, g["losses"][:steps], rtol=1e-5)
+    # Adam turns every gradient element into an update of about lr * sign(g): elements whose gradient is comparable to
+    # eps = 1e-8 are ill-conditioned (fp32-vs-fp64 noise in g moves them by a sizeable fraction of lr), so the per-tensor
+    # NORM of the update is held to 2e-3 and the sampled elements to 5 % of the largest sampled update; the loss after
+    # the first update (losses[1], above, 1e-5) pins the step as a whole.
+    bad, worst = [], 0.0
+    for k, p in net.named_parameters():
+        d = (p.detach() - p0[k]).double().cpu()
+        want = float(g["delta_norm/" + k])
+        if want == 0.0:                                   # the 8 parameters without gradient (SURVEY Q3): untouched
+            assert float(d.abs().max()) == 0.0, k
+            continue
+        e_norm = abs(float(d.norm()) - want) / want
+        idx = sample_indices(k, d.numel())
+        ws = torch.as_tensor(g["delta_samp/" + k], dtype=torch.float64)
+        e_samp = float((d.flatten()[idx] - ws).abs().max() / ws.abs().max().clamp_min(1e-30))
+        worst = max(worst, e_norm, e_samp)
+        if not (e_norm < 2e-3 and e_samp < 5e-2):
+            bad.append((k, e_norm, e_samp))
+    assert not bad, sorted(bad, key=lambda t: -max(t[1], t[2]))[:8]
+    return worst

@@ -125,6 +125,14 @@ def test_data_parallel_world2_on_one_gpu(mode, tmp_path):
     res = _spawn_ranks(mode, steps, str(tmp_path / "res"), port=29541 if mode == "graph" else 29543)
     for k in res[0]["state"]:
         assert torch.equal(res[0]["state"][k], res[1]["state"][k]), "ranks diverged: " + k
+    print("world-2 %s mode: %d buckets, all-reduce overlapped with the replay: %s (bucket order %s)"
+          % (mode, res[0]["nbuckets"], res[0]["overlap"], res[0]["bucket_order"]))
+    assert res[0]["nbuckets"] >= 2
+    if mode == "graph":
+        from mp_hsir_amd.engine import _external_events_work
+        assert res[0]["overlap"] == _external_events_work(torch.device("cuda", 0))
+        if res[0]["overlap"]:
+            assert sorted(res[0]["bucket_order"]) == list(range(res[0]["nbuckets"]))
     net = M.build_net(TINY_CFG, "cuda", torch.float32)
     p0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
     opt = torch.optim.AdamW([p for p in net.parameters()], lr=2e-3)
