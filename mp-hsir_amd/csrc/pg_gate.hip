@@ -26,6 +26,7 @@ struct PgDev {
     float* dmu;                 // backward: [nW][C]
     void* L; void* R;           // backward: [nW][KL], [nW][KR] factor rows (fp32 or bf16)
     int nW, C, r, KL, KR, lr_bf16;
+    int stage_wdn;              // backward: linear_down also staged in LDS (when the budget allows)
 };
 
 // fragment of rows row0..row0+15 of a row-major [nrows][ld] fp32 matrix in global memory; rows past nrows-1 are clamped
@@ -64,6 +65,8 @@ struct PgLds {
     float* Wkv;     // [2r][r] |   the r-sized weights, staged once (one L2 round trip instead of one per link)
     float* Wpp;     // [r][r]  |
     float* bpp;     // [r]     |
+    float* Wup;     // [C][r] (+32 floats of slack: column fragments read 16 columns at a time)
+    float* Wdn;     // [r][C]      (backward: the rank-r term of d mu)
     float* sm;      // [16][SMW]   small per-window vectors
     float* At;      // [16][LDA]   (backward) attention probabilities, LDA = r*r + 4
     int LDC, LDW, LDA;
@@ -74,7 +77,7 @@ struct PgLds {
 enum { PG_S = 0, PG_D = 32, PG_KV = 64, PG_Q = 128, PG_O = 160, PG_O2 = 192, PG_DO2 = 224, PG_DO = 256, PG_DQ = 288, PG_DKV = 320,
        PG_DD = 384, PG_DS = 416, PG_RS = 448, PG_SMW = 484 };
 
-__device__ __forceinline__ PgLds pg_lds(float* base, int C, int r, bool bwd) {
+__device__ __forceinline__ PgLds pg_lds(float* base, int C, int r, bool bwd, bool wdn = false) {
     PgLds s;
     s.LDC = C + 8;                 // 32-byte row padding: conflict-free ds_read_b128 fragments (mphsir_dev.h)
     s.LDW = 128 + 8;
@@ -88,38 +91,50 @@ __device__ __forceinline__ PgLds pg_lds(float* base, int C, int r, bool bwd) {
     s.Wkv = s.Wq + r * r;
     s.Wpp = s.Wkv + 2 * r * r;
     s.bpp = s.Wpp + r * r;
-    s.sm = s.bpp + ((r + 3) & ~3);
+    s.Wup = s.bpp + ((r + 3) & ~3);
+    s.Wdn = s.Wup + C * r + 32;
+    s.sm = s.Wdn + (bwd && wdn ? r * C : 0);
     s.At = s.sm + PG_NWIN * PG_SMW;
     return s;
 }
-static size_t pg_lds_bytes(int C, int r, bool bwd) {
+static size_t pg_lds_bytes(int C, int r, bool bwd, bool wdn = false) {
     size_t n = (size_t)PG_NWIN * (C + 8) * (bwd ? 2 : 1) + (size_t)PG_NWIN * 136 * (bwd ? 2 : 1) + 128 * (size_t)r + 4 * (size_t)r * r +
-               ((r + 3) & ~3) + (size_t)PG_NWIN * PG_SMW;
-    if (bwd) n += (size_t)PG_NWIN * (r * r + 4);
+               ((r + 3) & ~3) + (size_t)C * r + 32 + (size_t)PG_NWIN * PG_SMW;
+    if (bwd) n += (size_t)PG_NWIN * (r * r + 4) + (wdn ? (size_t)r * C : 0);
     return n * sizeof(float);
 }
 
-// acc[t] += W-tile t (16 rows each, read row-wise or column-wise from L2) x the 16-window LDS operand, over K.  The
-// weight fragments of 8 K-steps are requested together before their MFMAs run: one L2 round trip per 128 of K instead
-// of one per step (a workgroup has the CU to itself, nothing else hides that latency).
+// acc[t] += W-tile t (16 rows each, read row-wise or column-wise from L2) x the 16-window LDS operand, over K.  A
+// workgroup has its CU to itself, so nothing hides an L2 / HBM round trip but the kernel's own ordering: the weight
+// fragments of 8 K-steps (128 of K) are requested together (pg_load_chunk), and the first chunk of every product is
+// requested at the very top of the kernel, before the staging loads and their barrier.
 template <int NT, bool COLS>
-__device__ __forceinline__ void pg_mfma_rows(f32x4 (&acc)[NT], const float* W, int ld, int nrows, int nk, const int (&row0)[NT],
-                                             const float* B, int ldb, int K) {
-    for (int k0 = 0; k0 < K; k0 += 128) {
-        f32x4 wf[8][NT];
+__device__ __forceinline__ void pg_load_chunk(f32x4 (&wf)[8][NT], const float* W, int ld, int nrows, int nk, const int (&row0)[NT], int k0, int K) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (k0 + 16 * i < K)
-                    wf[i][t] = COLS ? pg_frag_cols(W, ld, nrows, nk, row0[t], k0 + 16 * i) : pg_frag_rows(W, ld, nrows, row0[t], k0 + 16 * i);
+        for (int t = 0; t < NT; ++t)
+            if (k0 + 16 * i < K)
+                wf[i][t] = COLS ? pg_frag_cols(W, ld, nrows, nk, row0[t], k0 + 16 * i) : pg_frag_rows(W, ld, nrows, row0[t], k0 + 16 * i);
+}
+template <int NT>
+__device__ __forceinline__ void pg_mma_chunk(f32x4 (&acc)[NT], const f32x4 (&wf)[8][NT], const float* B, int ldb, int k0, int K) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (k0 + 16 * i < K) {
-                const f32x4 b = load_frag<float>(B, ldb, 0, k0 + 16 * i);
+    for (int i = 0; i < 8; ++i)
+        if (k0 + 16 * i < K) {
+            const f32x4 b = load_frag<float>(B, ldb, 0, k0 + 16 * i);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) mma(acc[t], wf[i][t], b);
-            }
+            for (int t = 0; t < NT; ++t) mma(acc[t], wf[i][t], b);
+        }
+}
+// chunk 0 already in `wf` (prefetched); the remaining chunks (K > 128) are loaded as they come
+template <int NT, bool COLS>
+__device__ __forceinline__ void pg_mfma_rows(f32x4 (&acc)[NT], f32x4 (&wf)[8][NT], const float* W, int ld, int nrows, int nk,
+                                             const int (&row0)[NT], const float* B, int ldb, int K) {
+    pg_mma_chunk<NT>(acc, wf, B, ldb, 0, K);
+    for (int k0 = 128; k0 < K; k0 += 128) {
+        pg_load_chunk<NT, COLS>(wf, W, ld, nrows, nk, row0, k0, K);
+        pg_mma_chunk<NT>(acc, wf, B, ldb, k0, K);
     }
 }
 
@@ -127,7 +142,14 @@ __device__ __forceinline__ void pg_mfma_rows(f32x4 (&acc)[NT], const float* W, i
 template <bool KEEP_AT>
 __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s, int win0) {
     const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // mu tile (windows past nW: zeros), prompt_param
+    // the weight fragments of the two C-sized products are requested first ...
+    const int rows[2] = {wv * 32, wv * 32 + 16}, rowd[1] = {wv * 16};
+    const bool has_d = wv * 16 < r;
+    f32x4 wfp[8][2], wfd[8][1];
+    pg_load_chunk<2, false>(wfp, a.Wprompt, C, 128, 0, rows, 0, C);
+    if (has_d) pg_load_chunk<1, false>(wfd, a.Wdown, C, r, 0, rowd, 0, C);
+    // ... then everything else the chain will read: the mu tile (windows past nW: zeros), prompt_param, the r-sized
+    // weights, linear_up (and linear_down for the backward's rank-r term) -- all in flight together, one barrier
     for (int i = tid; i < PG_NWIN * C; i += 256) {
         const int w = i / C, c = i % C;
         s.mu[w * s.LDC + c] = win0 + w < a.nW ? a.mu[(long)(win0 + w) * C + c] : 0.f;
@@ -135,21 +157,23 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     for (int i = tid; i < 128 * r; i += 256) s.P[i] = a.Pp[i];
     for (int i = tid; i < r * r; i += 256) { s.Wq[i] = a.Wq[i]; s.Wpp[i] = a.Wpproj[i]; s.Wkv[i] = a.Wkv[i]; s.Wkv[r * r + i] = a.Wkv[r * r + i]; }
     if (tid < r) s.bpp[tid] = a.bpproj[tid];
+    for (int i = tid; i < C * r; i += 256) s.Wup[i] = a.Wup[i];
+    if (tid < 32) s.Wup[C * r + tid] = 0.f;
+    if (KEEP_AT && a.stage_wdn)
+        for (int i = tid; i < r * C; i += 256) s.Wdn[i] = a.Wdown[i];
     __syncthreads();
     // logits = Wprompt mu (128 rows: two 16-row tiles per wave) and d = Wdown mu (r rows: waves 0..ceil(r/16)-1)
     {
         f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        const int rows[2] = {wv * 32, wv * 32 + 16};
-        pg_mfma_rows<2, false>(acc, a.Wprompt, C, 128, 0, rows, s.mu, s.LDC, C);
+        pg_mfma_rows<2, false>(acc, wfp, a.Wprompt, C, 128, 0, rows, s.mu, s.LDC, C);
         const int w = lane & 15, rr = (lane >> 4) * 4;
         for (int j = 0; j < 4; ++j) {
             s.w[w * s.LDW + wv * 32 + rr + j] = acc[0][j];
             s.w[w * s.LDW + wv * 32 + 16 + rr + j] = acc[1][j];
         }
-        if (wv * 16 < r) {
+        if (has_d) {
             f32x4 accd[1] = {{0, 0, 0, 0}};
-            const int rowd[1] = {wv * 16};
-            pg_mfma_rows<1, false>(accd, a.Wdown, C, r, 0, rowd, s.mu, s.LDC, C);
+            pg_mfma_rows<1, false>(accd, wfd, a.Wdown, C, r, 0, rowd, s.mu, s.LDC, C);
             for (int j = 0; j < 4; ++j)
                 if (wv * 16 + rr + j < r) s.sm[w * PG_SMW + PG_D + wv * 16 + rr + j] = accd[0][j];
         }
@@ -235,15 +259,22 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
         if (win0 + w >= a.nW) continue;
         const float* o2 = s.sm + w * PG_SMW + PG_O2;
         float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += a.Wup[c * r + j] * o2[j];
+        for (int j = 0; j < r; ++j) acc += s.Wup[c * r + j] * o2[j];
         a.gate[(long)(win0 + w) * C + c] = acc;
     }
 }
 
 __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), a.C, a.r, true);
+    const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), a.C, a.r, true, a.stage_wdn != 0);
     const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, win0 = blockIdx.x * PG_NWIN;
+    // Wprompt column fragments of this wave's first two d-mu tiles (used at the very end): requested now, they cost no
+    // round trip later
+    const int nct = C / 16;
+    const int colA[1] = {wv * 16}, colB[1] = {(wv + 4) * 16};
+    f32x4 wfa[8][1], wfb[8][1];
+    if (wv < nct) pg_load_chunk<1, true>(wfa, a.Wprompt, C, C, 128, colA, 0, 128);
+    if (wv + 4 < nct) pg_load_chunk<1, true>(wfb, a.Wprompt, C, C, 128, colB, 0, 128);
     for (int i = tid; i < PG_NWIN * C; i += 256) {
         const int w = i / C, c = i % C;
         s.dg[w * s.LDC + c] = win0 + w < a.nW ? a.dgate[(long)(win0 + w) * C + c] : 0.f;
@@ -251,13 +282,13 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     pg_forward_chain<true>(a, s, win0);           // its first barrier also covers the dg tile
     const float sc = rsqrtf((float)r);
     // do2 = Wup^T dg  (r rows x 16 windows, K = C): MFMA with the weight read column-wise
-    if (wv * 16 < r) {
-        f32x4 acc[1] = {{0, 0, 0, 0}};
-        const int col0[1] = {wv * 16};
-        pg_mfma_rows<1, true>(acc, a.Wup, r, r, C, col0, s.dg, s.LDC, C);
+    if (wv * 16 < r) {                            // linear_up is in LDS as [C][r]: its column fragments are transposed reads
+        f32x4 acc = {0, 0, 0, 0};
+        for (int kc = 0; kc < C; kc += 16)
+            mma(acc, load_frag_tr<float>(s.Wup, r, wv * 16, kc), load_frag<float>(s.dg, s.LDC, 0, kc));
         const int w = lane & 15, rr = wv * 16 + (lane >> 4) * 4;
         for (int j = 0; j < 4; ++j)
-            if (rr + j < r) s.sm[w * PG_SMW + PG_DO2 + rr + j] = acc[0][j];
+            if (rr + j < r) s.sm[w * PG_SMW + PG_DO2 + rr + j] = acc[j];
     }
     __syncthreads();
     for (int i = tid; i < PG_NWIN * r; i += 256) {          // do = Wproj^T do2
@@ -326,14 +357,21 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     }
     __syncthreads();
     // dmu = Wprompt^T dlogit + Wdown^T dd:  C rows x 16 windows, K = 128 by MFMA, the rank-r term in the epilogue
-    for (int ct = wv; ct < C / 16; ct += 4) {
+    for (int ct = wv; ct < nct; ct += 4) {
         f32x4 acc[1] = {{0, 0, 0, 0}};
         const int col0[1] = {ct * 16};
-        pg_mfma_rows<1, true>(acc, a.Wprompt, C, C, 128, col0, s.dl, s.LDW, 128);
+        if (ct == wv) pg_mma_chunk<1>(acc, wfa, s.dl, s.LDW, 0, 128);              // prefetched at the top of the kernel
+        else if (ct == wv + 4) pg_mma_chunk<1>(acc, wfb, s.dl, s.LDW, 0, 128);
+        else {
+            f32x4 wf[8][1];
+            pg_load_chunk<1, true>(wf, a.Wprompt, C, C, 128, col0, 0, 128);
+            pg_mma_chunk<1>(acc, wf, s.dl, s.LDW, 0, 128);
+        }
         const int w = lane & 15, c0 = ct * 16 + (lane >> 4) * 4;
         const float* dd = s.sm + w * PG_SMW + PG_DD;
+        const float* wdn = a.stage_wdn ? s.Wdn : a.Wdown;
         for (int m = 0; m < r; ++m) {
-            const f32x4 wd = *reinterpret_cast<const f32x4*>(a.Wdown + (long)m * C + c0);
+            const f32x4 wd = *reinterpret_cast<const f32x4*>(wdn + (long)m * C + c0);
             for (int j = 0; j < 4; ++j) acc[0][j] += wd[j] * dd[m];
         }
         if (win0 + w < a.nW) *reinterpret_cast<f32x4*>(a.dmu + (long)(win0 + w) * C + c0) = acc[0];
@@ -385,8 +423,9 @@ extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
                    "pg_gate_fwd: null pointer");
     MPHSIR_REQUIRE(a->nW > 0 && a->C > 0 && a->C % 16 == 0 && a->r > 0 && a->r <= PG_RMAX, "pg_gate_fwd: need C %% 16 == 0 and 0 < r <= 32");
     PgDev d{a->mu, nullptr, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->gate, nullptr, nullptr,
-            nullptr, a->nW, a->C, a->r, 0, 0, 0};
+            nullptr, a->nW, a->C, a->r, 0, 0, 0, 0};
     const size_t shmem = pg_lds_bytes(a->C, a->r, false);
+    MPHSIR_REQUIRE(shmem <= 160 * 1024, "pg_gate_fwd: (C=%d, r=%d) needs %d bytes of LDS", a->C, a->r, (int)shmem);
     allow_big_lds(pg_gate_fwd_kernel, shmem);
     MPHSIR_LAUNCH(MPHSIR_K_PG_GATE, pg_gate_fwd_kernel, dim3((a->nW + PG_NWIN - 1) / PG_NWIN), dim3(256), shmem,
                   reinterpret_cast<hipStream_t>(stream), d);
@@ -402,8 +441,10 @@ extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
     MPHSIR_REQUIRE(a->KL >= a->C + 5 * a->r + 256 && a->KR >= 5 * a->r + 1 + a->C, "pg_gate_bwd: factor widths too small");
     MPHSIR_REQUIRE(!a->lr_bf16 || (a->KL % 8 == 0 && a->KR % 8 == 0), "pg_gate_bwd: bf16 factor rows need KL, KR multiples of 8");
     PgDev d{a->mu, a->dgate, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, nullptr, a->dmu, a->L, a->R,
-            a->nW, a->C, a->r, a->KL, a->KR, a->lr_bf16};
-    const size_t shmem = pg_lds_bytes(a->C, a->r, true);
+            a->nW, a->C, a->r, a->KL, a->KR, a->lr_bf16, 0};
+    d.stage_wdn = pg_lds_bytes(a->C, a->r, true, true) <= 160 * 1024 ? 1 : 0;
+    const size_t shmem = pg_lds_bytes(a->C, a->r, true, d.stage_wdn != 0);
+    MPHSIR_REQUIRE(shmem <= 160 * 1024, "pg_gate_bwd: (C=%d, r=%d) needs %d bytes of LDS", a->C, a->r, (int)shmem);
     allow_big_lds(pg_gate_bwd_kernel, shmem);
     MPHSIR_LAUNCH(MPHSIR_K_PG_GATE_BWD, pg_gate_bwd_kernel, dim3((a->nW + PG_NWIN - 1) / PG_NWIN), dim3(256), shmem,
                   reinterpret_cast<hipStream_t>(stream), d);
