@@ -106,6 +106,8 @@ typedef struct mphsir_pg_fwd_args {
     int32_t nW, C, r;
 } mphsir_pg_fwd_args;
 int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream);
+int mphsir_pg_debug(void* stamps);   /* diagnostics: device uint64[17] receiving workgroup 0's shader-clock stamps at the phase
+                                        boundaries of the next pg_gate launches (NULL = off)                                  */
 int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream);
 int mphsir_win_attn_hdp(int head_dim, int dtype);
 

@@ -27,7 +27,10 @@ struct PgDev {
     void* L; void* R;           // backward: [nW][KL], [nW][KR] factor rows (fp32 or bf16)
     int nW, C, r, KL, KR, lr_bf16;
     int stage_wdn;              // backward: linear_down also staged in LDS (when the budget allows)
+    unsigned long long* dbg;    // diagnostics (mphsir_pg_debug): shader-clock stamps of workgroup 0 at the phase boundaries
 };
+static unsigned long long* g_pg_dbg = nullptr;
+#define PG_MARK(k) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // fragment of rows row0..row0+15 of a row-major [nrows][ld] fp32 matrix in global memory; rows past nrows-1 are clamped
 // (their products land in accumulator rows nobody reads)
@@ -145,6 +148,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     // the weight fragments of the two C-sized products are requested first ...
     const int rows[2] = {wv * 32, wv * 32 + 16}, rowd[1] = {wv * 16};
     const bool has_d = wv * 16 < r;
+    PG_MARK(0);
     f32x4 wfp[8][2], wfd[8][1];
     pg_load_chunk<2, false>(wfp, a.Wprompt, C, 128, 0, rows, 0, C);
     if (has_d) pg_load_chunk<1, false>(wfd, a.Wdown, C, r, 0, rowd, 0, C);
@@ -162,6 +166,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     if (KEEP_AT && a.stage_wdn)
         for (int i = tid; i < r * C; i += 256) s.Wdn[i] = a.Wdown[i];
     __syncthreads();
+    PG_MARK(1);
     // logits = Wprompt mu (128 rows: two 16-row tiles per wave) and d = Wdown mu (r rows: waves 0..ceil(r/16)-1)
     {
         f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -179,6 +184,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         }
     }
     __syncthreads();
+    PG_MARK(2);
     // softmax over the 128 logits: wave wv owns windows 4wv .. 4wv+3
     for (int ww = 0; ww < 4; ++ww) {
         float* lw = s.w + (wv * 4 + ww) * s.LDW;
@@ -199,6 +205,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         s.sm[w * PG_SMW + PG_KV + m] = acc;
     }
     __syncthreads();
+    PG_MARK(3);
     // s = w^T P
     for (int i = tid; i < PG_NWIN * r; i += 256) {
         const int w = i / r, j = i % r;
@@ -208,6 +215,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         s.sm[w * PG_SMW + PG_S + j] = acc;
     }
     __syncthreads();
+    PG_MARK(4);
     // q = Wq s
     for (int i = tid; i < PG_NWIN * r; i += 256) {
         const int w = i / r, m = i % r;
@@ -217,6 +225,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         s.sm[w * PG_SMW + PG_Q + m] = acc;
     }
     __syncthreads();
+    PG_MARK(5);
     // o_i = sum_j softmax_j(q_i k_j / sqrt r) v_j
     const float sc = rsqrtf((float)r);
     for (int i = tid; i < PG_NWIN * r; i += 256) {
@@ -237,6 +246,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         s.sm[w * PG_SMW + PG_O + m] = num / den;
     }
     __syncthreads();
+    PG_MARK(6);
     // o2 = Wproj o + b
     for (int i = tid; i < PG_NWIN * r; i += 256) {
         const int w = i / r, m = i % r;
@@ -253,6 +263,7 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
     const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), a.C, a.r, false);
     const int C = a.C, r = a.r, tid = threadIdx.x, win0 = blockIdx.x * PG_NWIN;
     pg_forward_chain<false>(a, s, win0);
+    PG_MARK(7);
     // g = Wup o2: one thread per (window, channel), coalesced along c
     for (int i = tid; i < PG_NWIN * C; i += 256) {
         const int w = i / C, c = i % C;
@@ -262,6 +273,7 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
         for (int j = 0; j < r; ++j) acc += s.Wup[c * r + j] * o2[j];
         a.gate[(long)(win0 + w) * C + c] = acc;
     }
+    PG_MARK(8);
 }
 
 __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
@@ -280,6 +292,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         s.dg[w * s.LDC + c] = win0 + w < a.nW ? a.dgate[(long)(win0 + w) * C + c] : 0.f;
     }
     pg_forward_chain<true>(a, s, win0);           // its first barrier also covers the dg tile
+    PG_MARK(7);
     const float sc = rsqrtf((float)r);
     // do2 = Wup^T dg  (r rows x 16 windows, K = C): MFMA with the weight read column-wise
     if (wv * 16 < r) {                            // linear_up is in LDS as [C][r]: its column fragments are transposed reads
@@ -291,6 +304,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
             if (rr + j < r) s.sm[w * PG_SMW + PG_DO2 + rr + j] = acc[j];
     }
     __syncthreads();
+    PG_MARK(8);
     for (int i = tid; i < PG_NWIN * r; i += 256) {          // do = Wproj^T do2
         const int w = i / r, m = i % r;
         const float* do2 = s.sm + w * PG_SMW + PG_DO2;
@@ -299,6 +313,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         s.sm[w * PG_SMW + PG_DO + m] = acc;
     }
     __syncthreads();
+    PG_MARK(9);
     // row i: rs_i = sum_j A_ij do_i v_j;  dS_ij = A_ij (do_i v_j - rs_i);  dq_i = sc sum_j dS_ij k_j
     for (int i = tid; i < PG_NWIN * r; i += 256) {
         const int w = i / r, m = i % r;
@@ -313,6 +328,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         s.sm[w * PG_SMW + PG_RS + m] = rs;
     }
     __syncthreads();
+    PG_MARK(10);
     // column j: dk_j = sc sum_i dS_ij q_i ; dv_j = sum_i A_ij do_i   (dS re-formed from A and the row sums rs_i)
     for (int i = tid; i < PG_NWIN * r; i += 256) {
         const int w = i / r, j = i % r;
@@ -328,6 +344,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         s.sm[w * PG_SMW + PG_DKV + r + j] = dv;
     }
     __syncthreads();
+    PG_MARK(11);
     for (int i = tid; i < PG_NWIN * r; i += 256) {          // dd = Wkv^T dkv ; ds = Wq^T dq
         const int w = i / r, j = i % r;
         const float* dkv = s.sm + w * PG_SMW + PG_DKV;
@@ -339,6 +356,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         s.sm[w * PG_SMW + PG_DS + j] = acc2;
     }
     __syncthreads();
+    PG_MARK(12);
     for (int i = tid; i < PG_NWIN * 128; i += 256) {        // dw[p] = P[p] . ds
         const int w = i >> 7, p = i & 127;
         const float* ds = s.sm + w * PG_SMW + PG_DS;
@@ -347,6 +365,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         s.dl[w * s.LDW + p] = acc;
     }
     __syncthreads();
+    PG_MARK(13);
     for (int ww = 0; ww < 4; ++ww) {                        // dlogit = w (dw - sum w dw)
         const int w = wv * 4 + ww;
         const float w0 = s.w[w * s.LDW + lane], w1 = s.w[w * s.LDW + lane + 64];
@@ -356,6 +375,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         s.dl[w * s.LDW + lane + 64] = w1 * (d1 - tot);
     }
     __syncthreads();
+    PG_MARK(14);
     // dmu = Wprompt^T dlogit + Wdown^T dd:  C rows x 16 windows, K = 128 by MFMA, the rank-r term in the epilogue
     for (int ct = wv; ct < nct; ct += 4) {
         f32x4 acc[1] = {{0, 0, 0, 0}};
@@ -376,6 +396,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         }
         if (win0 + w < a.nW) *reinterpret_cast<f32x4*>(a.dmu + (long)(win0 + w) * C + c0) = acc[0];
     }
+    PG_MARK(15);
     // ---- factor rows: L = [dg(C) | do2(r) | dkv(2r) | dq(r) | w(128) | dlogit(128) | dd(r) | 0..],
     //                   R = [o2(r) | o(r) | 1 | d(r) | s(r) | ds(r) | mu(C) | 0..]
     for (int w = 0; w < PG_NWIN; ++w) {
@@ -412,9 +433,15 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
             if (a.lr_bf16 == MPHSIR_BF16) Rh[c] = (bf16_t)v; else if (a.lr_bf16 == MPHSIR_F16) Rf[c] = (f16_t)v; else R[c] = v;
         }
     }
+    PG_MARK(16);
 }
 
 }  // namespace mphsir
+
+extern "C" int mphsir_pg_debug(void* stamps) {      // diagnostics: device buffer of >= 17 uint64 (NULL = off)
+    mphsir::g_pg_dbg = reinterpret_cast<unsigned long long*>(stamps);
+    return MPHSIR_OK;
+}
 
 extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
     using namespace mphsir;
@@ -423,7 +450,7 @@ extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
                    "pg_gate_fwd: null pointer");
     MPHSIR_REQUIRE(a->nW > 0 && a->C > 0 && a->C % 16 == 0 && a->r > 0 && a->r <= PG_RMAX, "pg_gate_fwd: need C %% 16 == 0 and 0 < r <= 32");
     PgDev d{a->mu, nullptr, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->gate, nullptr, nullptr,
-            nullptr, a->nW, a->C, a->r, 0, 0, 0, 0};
+            nullptr, a->nW, a->C, a->r, 0, 0, 0, 0, g_pg_dbg};
     const size_t shmem = pg_lds_bytes(a->C, a->r, false);
     MPHSIR_REQUIRE(shmem <= 160 * 1024, "pg_gate_fwd: (C=%d, r=%d) needs %d bytes of LDS", a->C, a->r, (int)shmem);
     allow_big_lds(pg_gate_fwd_kernel, shmem);
@@ -441,7 +468,7 @@ extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
     MPHSIR_REQUIRE(a->KL >= a->C + 5 * a->r + 256 && a->KR >= 5 * a->r + 1 + a->C, "pg_gate_bwd: factor widths too small");
     MPHSIR_REQUIRE(!a->lr_bf16 || (a->KL % 8 == 0 && a->KR % 8 == 0), "pg_gate_bwd: bf16 factor rows need KL, KR multiples of 8");
     PgDev d{a->mu, a->dgate, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, nullptr, a->dmu, a->L, a->R,
-            a->nW, a->C, a->r, a->KL, a->KR, a->lr_bf16, 0};
+            a->nW, a->C, a->r, a->KL, a->KR, a->lr_bf16, 0, g_pg_dbg};
     d.stage_wdn = pg_lds_bytes(a->C, a->r, true, true) <= 160 * 1024 ? 1 : 0;
     const size_t shmem = pg_lds_bytes(a->C, a->r, true, d.stage_wdn != 0);
     MPHSIR_REQUIRE(shmem <= 160 * 1024, "pg_gate_bwd: (C=%d, r=%d) needs %d bytes of LDS", a->C, a->r, (int)shmem);

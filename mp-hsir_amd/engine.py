@@ -276,7 +276,23 @@ class DataParallelEngine:
         """autograd hands every gradient over as a fresh tensor (p.grad was None): move the bucket's gradients into
         the arena with one multi-tensor copy instead of one accumulate kernel per parameter."""
         ps, views = self._bucket_members[bi]
-        torch._foreach_copy_(views, [p.grad for p in ps])
+        # _foreach_copy_ takes its multi-tensor kernel only when EVERY pair has identical dense strides; one transposed /
+        # strided gradient view in the list silently turns the whole bucket into one copy launch per parameter (measured:
+        # ~530 tiny copies, 1.6 ms of a 28.8 ms step).  So the list is split: contiguous gradients (all but a handful) go
+        # through the multi-tensor kernel, the rest are copied one by one; gradients a backward function already wrote
+        # into the arena view (ops.grad_sink) need no copy at all.
+        fv, fg = [], []
+        for p, v in zip(ps, views):
+            g = p.grad
+            if g is None or g.data_ptr() == v.data_ptr():
+                continue
+            if g.is_contiguous() and g.dtype == v.dtype:
+                fv.append(v)
+                fg.append(g)
+            else:
+                v.copy_(g)
+        if fv:
+            torch._foreach_copy_(fv, fg)
         for p in ps:
             p.grad = None
 
