@@ -72,7 +72,7 @@ struct PgLds {
     float* Wdn;     // [r][C]      (backward: the rank-r term of d mu)
     float* sm;      // [16][SMW]   small per-window vectors
     float* At;      // [16][LDA]   (backward) attention probabilities, LDA = r*r + 4
-    int LDC, LDW, LDA;
+    int LDC, LDW, LDA, RP;      // RP = r + 1: the pitch of every r-wide LDS matrix (odd: lanes striding rows or columns never collide)
 };
 // offsets of the small vectors inside a window's sm row (r <= 32)
 // (row pitch 484 = 4 mod 32: the windows of one wave start 4 banks apart, so the per-window broadcast reads of the r-sized
@@ -84,26 +84,28 @@ __device__ __forceinline__ PgLds pg_lds(float* base, int C, int r, bool bwd, boo
     PgLds s;
     s.LDC = C + 8;                 // 32-byte row padding: conflict-free ds_read_b128 fragments (mphsir_dev.h)
     s.LDW = 128 + 8;
-    s.LDA = r * r + 4;
+    s.RP = r + 1;
+    s.LDA = r * (r + 1) + 4;
     s.mu = base;
     s.dg = s.mu + PG_NWIN * s.LDC;
     s.w = s.dg + (bwd ? PG_NWIN * s.LDC : 0);
     s.dl = s.w + PG_NWIN * s.LDW;
     s.P = s.dl + (bwd ? PG_NWIN * s.LDW : 0);
-    s.Wq = s.P + 128 * r;
-    s.Wkv = s.Wq + r * r;
-    s.Wpp = s.Wkv + 2 * r * r;
-    s.bpp = s.Wpp + r * r;
+    s.Wq = s.P + 128 * (r + 1);
+    s.Wkv = s.Wq + r * (r + 1);
+    s.Wpp = s.Wkv + 2 * r * (r + 1);
+    s.bpp = s.Wpp + r * (r + 1) + (4 - (132 * (r + 1)) % 4) % 4;     // keep the following tiles 16-byte aligned
     s.Wup = s.bpp + ((r + 3) & ~3);
-    s.Wdn = s.Wup + C * r + 32;
+    s.Wdn = s.Wup + C * (r + 1) + 32 + (4 - (C * (r + 1)) % 4) % 4;
     s.sm = s.Wdn + (bwd && wdn ? r * C : 0);
     s.At = s.sm + PG_NWIN * PG_SMW;
     return s;
 }
 static size_t pg_lds_bytes(int C, int r, bool bwd, bool wdn = false) {
-    size_t n = (size_t)PG_NWIN * (C + 8) * (bwd ? 2 : 1) + (size_t)PG_NWIN * 136 * (bwd ? 2 : 1) + 128 * (size_t)r + 4 * (size_t)r * r +
-               ((r + 3) & ~3) + (size_t)C * r + 32 + (size_t)PG_NWIN * PG_SMW;
-    if (bwd) n += (size_t)PG_NWIN * (r * r + 4) + (wdn ? (size_t)r * C : 0);
+    const size_t rp = r + 1;
+    size_t n = (size_t)PG_NWIN * (C + 8) * (bwd ? 2 : 1) + (size_t)PG_NWIN * 136 * (bwd ? 2 : 1) + 132 * rp + 3 + 4 * (size_t)r * rp +
+               ((r + 3) & ~3) + (size_t)C * rp + 32 + 3 + (size_t)PG_NWIN * PG_SMW;
+    if (bwd) n += (size_t)PG_NWIN * (r * rp + 4) + (wdn ? (size_t)r * C : 0);
     return n * sizeof(float);
 }
 
@@ -154,15 +156,22 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     if (has_d) pg_load_chunk<1, false>(wfd, a.Wdown, C, r, 0, rowd, 0, C);
     // ... then everything else the chain will read: the mu tile (windows past nW: zeros), prompt_param, the r-sized
     // weights, linear_up (and linear_down for the backward's rank-r term) -- all in flight together, one barrier
+#pragma unroll 4
     for (int i = tid; i < PG_NWIN * C; i += 256) {
         const int w = i / C, c = i % C;
         s.mu[w * s.LDC + c] = win0 + w < a.nW ? a.mu[(long)(win0 + w) * C + c] : 0.f;
     }
-    for (int i = tid; i < 128 * r; i += 256) s.P[i] = a.Pp[i];
-    for (int i = tid; i < r * r; i += 256) { s.Wq[i] = a.Wq[i]; s.Wpp[i] = a.Wpproj[i]; s.Wkv[i] = a.Wkv[i]; s.Wkv[r * r + i] = a.Wkv[r * r + i]; }
+    const int RP = s.RP;
+#pragma unroll 4
+    for (int i = tid; i < 128 * r; i += 256) s.P[(i / r) * RP + i % r] = a.Pp[i];
+    for (int i = tid; i < r * r; i += 256) {
+        const int o = (i / r) * RP + i % r;
+        s.Wq[o] = a.Wq[i]; s.Wpp[o] = a.Wpproj[i]; s.Wkv[o] = a.Wkv[i]; s.Wkv[r * RP + o] = a.Wkv[r * r + i];
+    }
     if (tid < r) s.bpp[tid] = a.bpproj[tid];
-    for (int i = tid; i < C * r; i += 256) s.Wup[i] = a.Wup[i];
-    if (tid < 32) s.Wup[C * r + tid] = 0.f;
+#pragma unroll 4
+    for (int i = tid; i < C * r; i += 256) s.Wup[(i / r) * RP + i % r] = a.Wup[i];
+    if (tid < 32) s.Wup[C * RP + tid] = 0.f;                    // the slack behind the last row (column fragments overrun by < 32)
     if (KEEP_AT && a.stage_wdn)
         for (int i = tid; i < r * C; i += 256) s.Wdn[i] = a.Wdown[i];
     __syncthreads();
@@ -201,7 +210,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         const int w = i / (2 * r), m = i % (2 * r);
         const float* d = s.sm + w * PG_SMW + PG_D;
         float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += s.Wkv[m * r + j] * d[j];
+        for (int j = 0; j < r; ++j) acc += s.Wkv[m * RP + j] * d[j];
         s.sm[w * PG_SMW + PG_KV + m] = acc;
     }
     __syncthreads();
@@ -211,7 +220,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         const int w = i / r, j = i % r;
         const float* lw = s.w + w * s.LDW;
         float acc = 0.f;
-        for (int p = 0; p < 128; ++p) acc += lw[p] * s.P[p * r + j];
+        for (int p = 0; p < 128; ++p) acc += lw[p] * s.P[p * RP + j];
         s.sm[w * PG_SMW + PG_S + j] = acc;
     }
     __syncthreads();
@@ -221,7 +230,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         const int w = i / r, m = i % r;
         const float* sv = s.sm + w * PG_SMW + PG_S;
         float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += s.Wq[m * r + j] * sv[j];
+        for (int j = 0; j < r; ++j) acc += s.Wq[m * RP + j] * sv[j];
         s.sm[w * PG_SMW + PG_Q + m] = acc;
     }
     __syncthreads();
@@ -237,12 +246,12 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         float den = 0.f, num = 0.f;
         for (int j = 0; j < r; ++j) {
             const float e = expf(qs * kv[j] - mx);
-            if (KEEP_AT) s.At[w * s.LDA + m * r + j] = e;
+            if (KEEP_AT) s.At[w * s.LDA + m * RP + j] = e;
             den += e;
             num += e * kv[r + j];
         }
         if (KEEP_AT)
-            for (int j = 0; j < r; ++j) s.At[w * s.LDA + m * r + j] /= den;
+            for (int j = 0; j < r; ++j) s.At[w * s.LDA + m * RP + j] /= den;
         s.sm[w * PG_SMW + PG_O + m] = num / den;
     }
     __syncthreads();
@@ -252,7 +261,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         const int w = i / r, m = i % r;
         const float* o = s.sm + w * PG_SMW + PG_O;
         float acc = s.bpp[m];
-        for (int j = 0; j < r; ++j) acc += s.Wpp[m * r + j] * o[j];
+        for (int j = 0; j < r; ++j) acc += s.Wpp[m * RP + j] * o[j];
         s.sm[w * PG_SMW + PG_O2 + m] = acc;
     }
     __syncthreads();
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
         if (win0 + w >= a.nW) continue;
         const float* o2 = s.sm + w * PG_SMW + PG_O2;
         float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += s.Wup[c * r + j] * o2[j];
+        for (int j = 0; j < r; ++j) acc += s.Wup[c * s.RP + j] * o2[j];
         a.gate[(long)(win0 + w) * C + c] = acc;
     }
     PG_MARK(8);
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     f32x4 wfa[8][1], wfb[8][1];
     if (wv < nct) pg_load_chunk<1, true>(wfa, a.Wprompt, C, C, 128, colA, 0, 128);
     if (wv + 4 < nct) pg_load_chunk<1, true>(wfb, a.Wprompt, C, C, 128, colB, 0, 128);
+#pragma unroll 4
     for (int i = tid; i < PG_NWIN * C; i += 256) {
         const int w = i / C, c = i % C;
         s.dg[w * s.LDC + c] = win0 + w < a.nW ? a.dgate[(long)(win0 + w) * C + c] : 0.f;
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     if (wv * 16 < r) {                            // linear_up is in LDS as [C][r]: its column fragments are transposed reads
         f32x4 acc = {0, 0, 0, 0};
         for (int kc = 0; kc < C; kc += 16)
-            mma(acc, load_frag_tr<float>(s.Wup, r, wv * 16, kc), load_frag<float>(s.dg, s.LDC, 0, kc));
+            mma(acc, load_frag_tr<float>(s.Wup, s.RP, wv * 16, kc), load_frag<float>(s.dg, s.LDC, 0, kc));
         const int w = lane & 15, rr = wv * 16 + (lane >> 4) * 4;
         for (int j = 0; j < 4; ++j)
             if (rr + j < r) s.sm[w * PG_SMW + PG_DO2 + rr + j] = acc[j];
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         const int w = i / r, m = i % r;
         const float* do2 = s.sm + w * PG_SMW + PG_DO2;
         float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += s.Wpp[j * r + m] * do2[j];
+        for (int j = 0; j < r; ++j) acc += s.Wpp[j * s.RP + m] * do2[j];
         s.sm[w * PG_SMW + PG_DO + m] = acc;
     }
     __syncthreads();
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     // row i: rs_i = sum_j A_ij do_i v_j;  dS_ij = A_ij (do_i v_j - rs_i);  dq_i = sc sum_j dS_ij k_j
     for (int i = tid; i < PG_NWIN * r; i += 256) {
         const int w = i / r, m = i % r;
-        const float* A = s.At + w * s.LDA + m * r;
+        const float* A = s.At + w * s.LDA + m * s.RP;
         const float* kv = s.sm + w * PG_SMW + PG_KV;
         const float dov = s.sm[w * PG_SMW + PG_DO + m];
         float rs = 0.f;
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         const float vj = sm[PG_KV + r + j];
         float dk = 0.f, dv = 0.f;
         for (int m = 0; m < r; ++m) {
-            const float A = s.At[w * s.LDA + m * r + j], dov = sm[PG_DO + m];
+            const float A = s.At[w * s.LDA + m * s.RP + j], dov = sm[PG_DO + m];
             dk += A * (dov * vj - sm[PG_RS + m]) * sm[PG_Q + m];
             dv += A * dov;
         }
@@ -350,8 +360,8 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         const float* dkv = s.sm + w * PG_SMW + PG_DKV;
         const float* dq = s.sm + w * PG_SMW + PG_DQ;
         float acc = 0.f, acc2 = 0.f;
-        for (int m = 0; m < 2 * r; ++m) acc += s.Wkv[m * r + j] * dkv[m];
-        for (int m = 0; m < r; ++m) acc2 += s.Wq[m * r + j] * dq[m];
+        for (int m = 0; m < 2 * r; ++m) acc += s.Wkv[m * s.RP + j] * dkv[m];
+        for (int m = 0; m < r; ++m) acc2 += s.Wq[m * s.RP + j] * dq[m];
         s.sm[w * PG_SMW + PG_DD + j] = acc;
         s.sm[w * PG_SMW + PG_DS + j] = acc2;
     }
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         const int w = i >> 7, p = i & 127;
         const float* ds = s.sm + w * PG_SMW + PG_DS;
         float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += s.P[p * r + j] * ds[j];
+        for (int j = 0; j < r; ++j) acc += s.P[p * s.RP + j] * ds[j];
         s.dl[w * s.LDW + p] = acc;
     }
     __syncthreads();
@@ -399,39 +409,40 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     PG_MARK(15);
     // ---- factor rows: L = [dg(C) | do2(r) | dkv(2r) | dq(r) | w(128) | dlogit(128) | dd(r) | 0..],
     //                   R = [o2(r) | o(r) | 1 | d(r) | s(r) | ds(r) | mu(C) | 0..]
-    for (int w = 0; w < PG_NWIN; ++w) {
-        if (win0 + w >= a.nW) break;
+    // one flat loop per row kind over (window, column): the element's source is selected by a short ladder on the column
+    const int nwin = a.nW - win0 < PG_NWIN ? a.nW - win0 : PG_NWIN;
+    auto put = [&](void* base, long idx, float v) __attribute__((always_inline)) {
+        if (a.lr_bf16 == MPHSIR_BF16) reinterpret_cast<bf16_t*>(base)[idx] = (bf16_t)v;
+        else if (a.lr_bf16 == MPHSIR_F16) reinterpret_cast<f16_t*>(base)[idx] = (f16_t)v;
+        else reinterpret_cast<float*>(base)[idx] = v;
+    };
+    for (int i = tid; i < nwin * a.KL; i += 256) {
+        const int w = i / a.KL, c = i % a.KL;
         const float* sm = s.sm + w * PG_SMW;
-        float* L = reinterpret_cast<float*>(a.L) + (long)(win0 + w) * a.KL;
-        float* R = reinterpret_cast<float*>(a.R) + (long)(win0 + w) * a.KR;
-        bf16_t* Lh = reinterpret_cast<bf16_t*>(a.L) + (long)(win0 + w) * a.KL;      // lr_bf16: the factor rows' dtype code
-        bf16_t* Rh = reinterpret_cast<bf16_t*>(a.R) + (long)(win0 + w) * a.KR;      // (0 fp32, 1 bf16, 2 f16: both 2 bytes)
-        f16_t* Lf = reinterpret_cast<f16_t*>(a.L) + (long)(win0 + w) * a.KL;
-        f16_t* Rf = reinterpret_cast<f16_t*>(a.R) + (long)(win0 + w) * a.KR;
-        for (int c = tid; c < a.KL; c += 256) {
-            float v = 0.f;
-            int o = c;
-            if (o < C) v = s.dg[w * s.LDC + o];
-            else if ((o -= C) < r) v = sm[PG_DO2 + o];
-            else if ((o -= r) < 2 * r) v = sm[PG_DKV + o];
-            else if ((o -= 2 * r) < r) v = sm[PG_DQ + o];
-            else if ((o -= r) < 128) v = s.w[w * s.LDW + o];
-            else if ((o -= 128) < 128) v = s.dl[w * s.LDW + o];
-            else if ((o -= 128) < r) v = sm[PG_DD + o];
-            if (a.lr_bf16 == MPHSIR_BF16) Lh[c] = (bf16_t)v; else if (a.lr_bf16 == MPHSIR_F16) Lf[c] = (f16_t)v; else L[c] = v;
-        }
-        for (int c = tid; c < a.KR; c += 256) {
-            float v = 0.f;
-            int o = c;
-            if (o < r) v = sm[PG_O2 + o];
-            else if ((o -= r) < r) v = sm[PG_O + o];
-            else if ((o -= r) < 1) v = 1.f;
-            else if ((o -= 1) < r) v = sm[PG_D + o];
-            else if ((o -= r) < r) v = sm[PG_S + o];
-            else if ((o -= r) < r) v = sm[PG_DS + o];
-            else if ((o -= r) < C) v = s.mu[w * s.LDC + o];
-            if (a.lr_bf16 == MPHSIR_BF16) Rh[c] = (bf16_t)v; else if (a.lr_bf16 == MPHSIR_F16) Rf[c] = (f16_t)v; else R[c] = v;
-        }
+        float v = 0.f;
+        int o = c;
+        if (o < C) v = s.dg[w * s.LDC + o];
+        else if ((o -= C) < r) v = sm[PG_DO2 + o];
+        else if ((o -= r) < 2 * r) v = sm[PG_DKV + o];
+        else if ((o -= 2 * r) < r) v = sm[PG_DQ + o];
+        else if ((o -= r) < 128) v = s.w[w * s.LDW + o];
+        else if ((o -= 128) < 128) v = s.dl[w * s.LDW + o];
+        else if ((o -= 128) < r) v = sm[PG_DD + o];
+        put(a.L, (long)(win0 + w) * a.KL + c, v);
+    }
+    for (int i = tid; i < nwin * a.KR; i += 256) {
+        const int w = i / a.KR, c = i % a.KR;
+        const float* sm = s.sm + w * PG_SMW;
+        float v = 0.f;
+        int o = c;
+        if (o < r) v = sm[PG_O2 + o];
+        else if ((o -= r) < r) v = sm[PG_O + o];
+        else if ((o -= r) < 1) v = 1.f;
+        else if ((o -= 1) < r) v = sm[PG_D + o];
+        else if ((o -= r) < r) v = sm[PG_S + o];
+        else if ((o -= r) < r) v = sm[PG_DS + o];
+        else if ((o -= r) < C) v = s.mu[w * s.LDC + o];
+        put(a.R, (long)(win0 + w) * a.KR + c, v);
     }
     PG_MARK(16);
 }
