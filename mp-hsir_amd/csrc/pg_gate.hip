@@ -58,6 +58,13 @@ __device__ __forceinline__ f32x4 pg_frag_cols(const float* W, int ld, int ncols,
     return v;
 }
 
+// i / d for 0 <= i < 2^17 and small runtime d without the ~40-instruction integer division: one v_mul_hi_u32
+struct FastDiv {
+    unsigned d, m;
+    __device__ __forceinline__ explicit FastDiv(int dd) : d((unsigned)dd), m(0xFFFFFFFFu / (unsigned)dd + 1u) {}
+    __device__ __forceinline__ int div(int i) const { return (int)(((unsigned long long)(unsigned)i * m) >> 32); }
+};
+
 struct PgLds {
     float* mu;      // [16][LDC]
     float* dg;      // [16][LDC]   (backward)
@@ -156,21 +163,22 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     if (has_d) pg_load_chunk<1, false>(wfd, a.Wdown, C, r, 0, rowd, 0, C);
     // ... then everything else the chain will read: the mu tile (windows past nW: zeros), prompt_param, the r-sized
     // weights, linear_up (and linear_down for the backward's rank-r term) -- all in flight together, one barrier
+    const FastDiv byC(C), byR(r);
 #pragma unroll 4
     for (int i = tid; i < PG_NWIN * C; i += 256) {
-        const int w = i / C, c = i % C;
+        const int w = byC.div(i), c = i - w * C;
         s.mu[w * s.LDC + c] = win0 + w < a.nW ? a.mu[(long)(win0 + w) * C + c] : 0.f;
     }
     const int RP = s.RP;
 #pragma unroll 4
-    for (int i = tid; i < 128 * r; i += 256) s.P[(i / r) * RP + i % r] = a.Pp[i];
+    for (int i = tid; i < 128 * r; i += 256) { const int q = byR.div(i); s.P[q * RP + i - q * r] = a.Pp[i]; }
     for (int i = tid; i < r * r; i += 256) {
-        const int o = (i / r) * RP + i % r;
+        const int q = byR.div(i), o = q * RP + i - q * r;
         s.Wq[o] = a.Wq[i]; s.Wpp[o] = a.Wpproj[i]; s.Wkv[o] = a.Wkv[i]; s.Wkv[r * RP + o] = a.Wkv[r * r + i];
     }
     if (tid < r) s.bpp[tid] = a.bpproj[tid];
 #pragma unroll 4
-    for (int i = tid; i < C * r; i += 256) s.Wup[(i / r) * RP + i % r] = a.Wup[i];
+    for (int i = tid; i < C * r; i += 256) { const int q = byR.div(i); s.Wup[q * RP + i - q * r] = a.Wup[i]; }
     if (tid < 32) s.Wup[C * RP + tid] = 0.f;                    // the slack behind the last row (column fragments overrun by < 32)
     if (KEEP_AT && a.stage_wdn)
         for (int i = tid; i < r * C; i += 256) s.Wdn[i] = a.Wdown[i];
@@ -206,8 +214,9 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
         lw[lane + 64] = e1 / tot;
     }
     // kv = Wkv d  (one thread per (window, row))
+    const FastDiv by2R(2 * r);
     for (int i = tid; i < PG_NWIN * 2 * r; i += 256) {
-        const int w = i / (2 * r), m = i % (2 * r);
+        const int w = by2R.div(i), m = i - w * 2 * r;
         const float* d = s.sm + w * PG_SMW + PG_D;
         float acc = 0.f;
         for (int j = 0; j < r; ++j) acc += s.Wkv[m * RP + j] * d[j];
@@ -217,7 +226,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     PG_MARK(3);
     // s = w^T P
     for (int i = tid; i < PG_NWIN * r; i += 256) {
-        const int w = i / r, j = i % r;
+        const int w = byR.div(i), j = i - w * r;
         const float* lw = s.w + w * s.LDW;
         float acc = 0.f;
         for (int p = 0; p < 128; ++p) acc += lw[p] * s.P[p * RP + j];
@@ -227,7 +236,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     PG_MARK(4);
     // q = Wq s
     for (int i = tid; i < PG_NWIN * r; i += 256) {
-        const int w = i / r, m = i % r;
+        const int w = byR.div(i), m = i - w * r;
         const float* sv = s.sm + w * PG_SMW + PG_S;
         float acc = 0.f;
         for (int j = 0; j < r; ++j) acc += s.Wq[m * RP + j] * sv[j];
@@ -238,7 +247,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     // o_i = sum_j softmax_j(q_i k_j / sqrt r) v_j
     const float sc = rsqrtf((float)r);
     for (int i = tid; i < PG_NWIN * r; i += 256) {
-        const int w = i / r, m = i % r;
+        const int w = byR.div(i), m = i - w * r;
         const float* kv = s.sm + w * PG_SMW + PG_KV;
         const float qs = s.sm[w * PG_SMW + PG_Q + m] * sc;
         float mx = -3.0e38f;
@@ -258,7 +267,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     PG_MARK(6);
     // o2 = Wproj o + b
     for (int i = tid; i < PG_NWIN * r; i += 256) {
-        const int w = i / r, m = i % r;
+        const int w = byR.div(i), m = i - w * r;
         const float* o = s.sm + w * PG_SMW + PG_O;
         float acc = s.bpp[m];
         for (int j = 0; j < r; ++j) acc += s.Wpp[m * RP + j] * o[j];
@@ -274,8 +283,9 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
     pg_forward_chain<false>(a, s, win0);
     PG_MARK(7);
     // g = Wup o2: one thread per (window, channel), coalesced along c
+    const FastDiv byC(C);
     for (int i = tid; i < PG_NWIN * C; i += 256) {
-        const int w = i / C, c = i % C;
+        const int w = byC.div(i), c = i - w * C;
         if (win0 + w >= a.nW) continue;
         const float* o2 = s.sm + w * PG_SMW + PG_O2;
         float acc = 0.f;
@@ -296,9 +306,10 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     f32x4 wfa[8][1], wfb[8][1];
     if (wv < nct) pg_load_chunk<1, true>(wfa, a.Wprompt, C, C, 128, colA, 0, 128);
     if (wv + 4 < nct) pg_load_chunk<1, true>(wfb, a.Wprompt, C, C, 128, colB, 0, 128);
+    const FastDiv byC(C), byR(r);
 #pragma unroll 4
     for (int i = tid; i < PG_NWIN * C; i += 256) {
-        const int w = i / C, c = i % C;
+        const int w = byC.div(i), c = i - w * C;
         s.dg[w * s.LDC + c] = win0 + w < a.nW ? a.dgate[(long)(win0 + w) * C + c] : 0.f;
     }
     pg_forward_chain<true>(a, s, win0);           // its first barrier also covers the dg tile
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     __syncthreads();
     PG_MARK(8);
     for (int i = tid; i < PG_NWIN * r; i += 256) {          // do = Wproj^T do2
-        const int w = i / r, m = i % r;
+        const int w = byR.div(i), m = i - w * r;
         const float* do2 = s.sm + w * PG_SMW + PG_DO2;
         float acc = 0.f;
         for (int j = 0; j < r; ++j) acc += s.Wpp[j * s.RP + m] * do2[j];
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     PG_MARK(9);
     // row i: rs_i = sum_j A_ij do_i v_j;  dS_ij = A_ij (do_i v_j - rs_i);  dq_i = sc sum_j dS_ij k_j
     for (int i = tid; i < PG_NWIN * r; i += 256) {
-        const int w = i / r, m = i % r;
+        const int w = byR.div(i), m = i - w * r;
         const float* A = s.At + w * s.LDA + m * s.RP;
         const float* kv = s.sm + w * PG_SMW + PG_KV;
         const float dov = s.sm[w * PG_SMW + PG_DO + m];
@@ -341,7 +352,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     PG_MARK(10);
     // column j: dk_j = sc sum_i dS_ij q_i ; dv_j = sum_i A_ij do_i   (dS re-formed from A and the row sums rs_i)
     for (int i = tid; i < PG_NWIN * r; i += 256) {
-        const int w = i / r, j = i % r;
+        const int w = byR.div(i), j = i - w * r;
         const float* sm = s.sm + w * PG_SMW;
         const float vj = sm[PG_KV + r + j];
         float dk = 0.f, dv = 0.f;
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     __syncthreads();
     PG_MARK(11);
     for (int i = tid; i < PG_NWIN * r; i += 256) {          // dd = Wkv^T dkv ; ds = Wq^T dq
-        const int w = i / r, j = i % r;
+        const int w = byR.div(i), j = i - w * r;
         const float* dkv = s.sm + w * PG_SMW + PG_DKV;
         const float* dq = s.sm + w * PG_SMW + PG_DQ;
         float acc = 0.f, acc2 = 0.f;
@@ -409,40 +420,32 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     PG_MARK(15);
     // ---- factor rows: L = [dg(C) | do2(r) | dkv(2r) | dq(r) | w(128) | dlogit(128) | dd(r) | 0..],
     //                   R = [o2(r) | o(r) | 1 | d(r) | s(r) | ds(r) | mu(C) | 0..]
-    // one flat loop per row kind over (window, column): the element's source is selected by a short ladder on the column
-    const int nwin = a.nW - win0 < PG_NWIN ? a.nW - win0 : PG_NWIN;
+    // wave wv writes windows wv, wv+4, ...; one short loop per segment (no per-element ladder: the divergent ladder with an
+    // LDS read in every arm cost 16 us per launch)
     auto put = [&](void* base, long idx, float v) __attribute__((always_inline)) {
         if (a.lr_bf16 == MPHSIR_BF16) reinterpret_cast<bf16_t*>(base)[idx] = (bf16_t)v;
         else if (a.lr_bf16 == MPHSIR_F16) reinterpret_cast<f16_t*>(base)[idx] = (f16_t)v;
         else reinterpret_cast<float*>(base)[idx] = v;
     };
-    for (int i = tid; i < nwin * a.KL; i += 256) {
-        const int w = i / a.KL, c = i % a.KL;
+    for (int w = wv; w < PG_NWIN && win0 + w < a.nW; w += 4) {
         const float* sm = s.sm + w * PG_SMW;
-        float v = 0.f;
-        int o = c;
-        if (o < C) v = s.dg[w * s.LDC + o];
-        else if ((o -= C) < r) v = sm[PG_DO2 + o];
-        else if ((o -= r) < 2 * r) v = sm[PG_DKV + o];
-        else if ((o -= 2 * r) < r) v = sm[PG_DQ + o];
-        else if ((o -= r) < 128) v = s.w[w * s.LDW + o];
-        else if ((o -= 128) < 128) v = s.dl[w * s.LDW + o];
-        else if ((o -= 128) < r) v = sm[PG_DD + o];
-        put(a.L, (long)(win0 + w) * a.KL + c, v);
-    }
-    for (int i = tid; i < nwin * a.KR; i += 256) {
-        const int w = i / a.KR, c = i % a.KR;
-        const float* sm = s.sm + w * PG_SMW;
-        float v = 0.f;
-        int o = c;
-        if (o < r) v = sm[PG_O2 + o];
-        else if ((o -= r) < r) v = sm[PG_O + o];
-        else if ((o -= r) < 1) v = 1.f;
-        else if ((o -= 1) < r) v = sm[PG_D + o];
-        else if ((o -= r) < r) v = sm[PG_S + o];
-        else if ((o -= r) < r) v = sm[PG_DS + o];
-        else if ((o -= r) < C) v = s.mu[w * s.LDC + o];
-        put(a.R, (long)(win0 + w) * a.KR + c, v);
+        const long L0 = (long)(win0 + w) * a.KL, R0 = (long)(win0 + w) * a.KR;
+        for (int c = lane; c < C; c += 64) { put(a.L, L0 + c, s.dg[w * s.LDC + c]); put(a.R, R0 + 5 * r + 1 + c, s.mu[w * s.LDC + c]); }
+        for (int c = lane; c < 128; c += 64) { put(a.L, L0 + C + 4 * r + c, s.w[w * s.LDW + c]); put(a.L, L0 + C + 4 * r + 128 + c, s.dl[w * s.LDW + c]); }
+        if (lane < r) {
+            put(a.L, L0 + C + lane, sm[PG_DO2 + lane]);
+            put(a.L, L0 + C + 3 * r + lane, sm[PG_DQ + lane]);
+            put(a.L, L0 + C + 4 * r + 256 + lane, sm[PG_DD + lane]);
+            put(a.R, R0 + lane, sm[PG_O2 + lane]);
+            put(a.R, R0 + r + lane, sm[PG_O + lane]);
+            put(a.R, R0 + 2 * r + 1 + lane, sm[PG_D + lane]);
+            put(a.R, R0 + 3 * r + 1 + lane, sm[PG_S + lane]);
+            put(a.R, R0 + 4 * r + 1 + lane, sm[PG_DS + lane]);
+        }
+        if (lane < 2 * r) put(a.L, L0 + C + r + lane, sm[PG_DKV + lane]);
+        if (lane == 0) put(a.R, R0 + 2 * r, 1.f);
+        for (int c = C + 5 * r + 256 + lane; c < a.KL; c += 64) put(a.L, L0 + c, 0.f);      // zero padding of the row tails
+        for (int c = 5 * r + 1 + C + lane; c < a.KR; c += 64) put(a.R, R0 + c, 0.f);
     }
     PG_MARK(16);
 }
