@@ -189,7 +189,9 @@ class DataParallelEngine:
         # arena-wide reduction after the replay: 58 MB over xGMI is <1 ms next to a ~45 ms step).
         self.use_graph, self.graph_warmup, self._graph, self._graph_key = use_graph, graph_warmup, None, None
         self.use_pack_plan, self.plan = use_pack_plan, None
-        self.graph_overlap = True       # graph mode, world > 1: bucket all-reduces start while the replay is still running
+        import os
+        # graph mode, world > 1: bucket all-reduces start while the replay is still running (MPHSIR_GRAPH_OVERLAP=0: off)
+        self.graph_overlap = os.environ.get("MPHSIR_GRAPH_OVERLAP", "1") != "0"
         self.force_eager = False        # diagnostics: run a graph-mode engine's step with eager launches (same data flow)
         # fp16 compute (the reference's precision="16-mixed", train.py:118) needs dynamic loss scaling: the loss is
         # multiplied by a device-resident scale before backward, the optimizer kernel divides it out again and skips
@@ -394,15 +396,28 @@ class DataParallelEngine:
         self._graph.replay()
         if self.world > 1:
             if getattr(self, "_overlap", False) and len(self._bucket_order) == len(self.buckets):
-                handles = []
-                for bi in self._bucket_order:           # completion order of the captured backward
-                    self._comm.wait_event(self._bucket_events[bi])
-                    st, en, _ = self.buckets[bi]
-                    with torch.cuda.stream(self._comm):
-                        handles.append(dist.all_reduce(self.flat_g[st:en], group=self.pg, async_op=True))
-                for h in handles:
-                    h.wait()
-                torch.cuda.current_stream(dev).wait_stream(self._comm)
+                handles, issued = [], set()
+                try:
+                    for bi in self._bucket_order:           # completion order of the captured backward
+                        self._comm.wait_event(self._bucket_events[bi])
+                        st, en, _ = self.buckets[bi]
+                        with torch.cuda.stream(self._comm):
+                            handles.append(dist.all_reduce(self.flat_g[st:en], group=self.pg, async_op=True))
+                        issued.add(bi)
+                    for h in handles:
+                        h.wait()
+                    torch.cuda.current_stream(dev).wait_stream(self._comm)
+                except Exception as e:      # a stack that cannot do this: finish the step the plain way and stop trying
+                    import warnings
+                    warnings.warn("graph-mode all-reduce overlap disabled (%s: %s)" % (type(e).__name__, e))
+                    self._overlap = False
+                    for h in handles:
+                        h.wait()
+                    torch.cuda.synchronize(dev)
+                    for bi in range(len(self.buckets)):
+                        if bi not in issued:
+                            st, en, _ = self.buckets[bi]
+                            dist.all_reduce(self.flat_g[st:en], group=self.pg)
             else:
                 dist.all_reduce(self.flat_g, group=self.pg)     # no external events on this stack: one message after the replay
             self._optimizer_step(None, hyper=self._hyper)
