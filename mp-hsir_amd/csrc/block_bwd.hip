@@ -11,6 +11,8 @@
 //   ln_bwd_win    d_x = d_res + LayerNorm_backward(d_xn) with d_xn in window-token order (un-shift /
 //                 un-window by address arithmetic), plus per-window partials of d(norm1 weight/bias).
 // All reductions are ordered (no atomics): results are bitwise reproducible.
+#include <stdlib.h>
+
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
 
@@ -427,15 +429,30 @@ __global__ __launch_bounds__(256) void ln_bwd_win_kernel(LnBwdDev a) {
     }
 }
 
-template <class T, int C, int HD>
-static int launch_win_bwd(const WinBwdDev& d, hipStream_t s) {
-    constexpr bool XL = WinBwdPick<T, C, HD>::XL;
+template <class T, int C, int HD, bool XL>
+static int launch_win_bwd_xl(const WinBwdDev& d, hipStream_t s) {
     typedef WinBwdCfg<T, C, HD, XL> CF;
     static_assert(CF::FITS, "win_attn_bwd tiles do not fit LDS");
     allow_big_lds(win_attn_bwd_kernel<T, C, HD, XL>, CF::BYTES);
     const int nblk = d.g.B * (d.g.H / 8) * (d.g.W / 8);
     MPHSIR_LAUNCH(MPHSIR_K_WIN_ATTN_BWD, (win_attn_bwd_kernel<T, C, HD, XL>), dim3(nblk), dim3(256), CF::BYTES, s, d);
     return MPHSIR_OK;
+}
+
+// MPHSIR_WINB_XL = 0 / 1 forces the X-tile placement (tuning aid); unset: WinBwdPick
+static int winb_xl_override() {
+    static const int v = [] { const char* e = getenv("MPHSIR_WINB_XL"); return e ? atoi(e) : -1; }();
+    return v;
+}
+
+template <class T, int C, int HD>
+static int launch_win_bwd(const WinBwdDev& d, hipStream_t s) {
+    constexpr bool PICK = WinBwdPick<T, C, HD>::XL;
+    const int ov = winb_xl_override();
+    if constexpr (WinBwdCfg<T, C, HD, true>::FITS) {
+        if (ov == 1 || (ov < 0 && PICK)) return launch_win_bwd_xl<T, C, HD, true>(d, s);
+    }
+    return launch_win_bwd_xl<T, C, HD, false>(d, s);
 }
 
 #define MPHSIR_WINB_SHAPES(X) X(32, 32) X(64, 32) X(64, 64) X(128, 32) X(128, 64) X(256, 32) X(96, 48) X(192, 48) X(192, 96) X(384, 48)

@@ -12,10 +12,17 @@ def t_us(fn, n=20):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-for (B, H, C, heads, cr) in [(32, 64, 128, 2, 8), (32, 64, 64, 2, 8)]:
+for (B, H, C, heads, cr) in [(32, 64, 128, 2, 8), (32, 64, 64, 2, 8), (32, 32, 128, 4, 16), (32, 16, 256, 8, 32)]:
     blk = PGSSTB(C, heads, [64, 64], 8, 4, 0.0, 2.66, cr, 128).to(dev)
     pk = blk.packed(dt)
     x = torch.randn(B, H, H, C, device=dev, dtype=dt)
     for shift in (0, 4):
         f = lambda: ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"], pk["bproj"], pk["pg"], heads, shift, save=True)
         print("C=%d shift=%d win_attn_fwd %.1f us" % (C, shift, t_us(f)))
+
+    # backward core (set MPHSIR_WINB_XL=0/1 to force the X-tile placement)
+    M = B * H * H
+    dsa = torch.randn(B, H, H, C, device=dev, dtype=dt)
+    dmu = torch.randn(M // 64, C, device=dev)
+    fb = lambda: ops.win_attn_bwd(x, dsa, dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wprojT"], heads, 4)
+    print("C=%d win_attn_bwd %.1f us" % (C, t_us(fb)))
