@@ -277,6 +277,7 @@ class DataParallelEngine:
     def _gather_bucket(self, bi):
         """autograd hands every gradient over as a fresh tensor (p.grad was None): move the bucket's gradients into
         the arena with one multi-tensor copy instead of one accumulate kernel per parameter."""
+        ops.join_wgrad_stream()
         ps, views = self._bucket_members[bi]
         # _foreach_copy_ takes its multi-tensor kernel only when EVERY pair has identical dense strides; one transposed /
         # strided gradient view in the list silently turns the whole bucket into one copy launch per parameter (measured:
