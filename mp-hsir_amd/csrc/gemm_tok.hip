@@ -8,6 +8,8 @@
 // from L2 as MFMA fragments (weights are tiny and shared by every workgroup).  The accumulators hold
 // the transposed tile (channels x tokens), so a lane owns 4 consecutive channels of a token and the
 // epilogue (bias / residual / branch sum) is a direct 8- or 16-byte load-modify-store.
+#include <stdlib.h>
+
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
 
@@ -180,6 +182,9 @@ template <class T, int EPI, bool LN>
 static int launch_gemm(const GemmDev& d, hipStream_t s) {
     // enough workgroups to fill the chip first, then as many output channels per staged token tile as possible
     const long mt = d.M / GT_BM;
+    static const int nw_override = [] { const char* e = getenv("MPHSIR_GEMM_NW"); return e ? atoi(e) : 0; }();    // tuning aid
+    if (nw_override == 6 && d.N > 256 && mt >= 1024) return launch_gemm_nw<T, EPI, LN, 6>(d, s);
+    if (nw_override == 3 && d.N > 128 && mt >= 1024) return launch_gemm_nw<T, EPI, LN, 3>(d, s);
     if (d.N > 128 && mt >= 1024) return launch_gemm_nw<T, EPI, LN, 4>(d, s);
     if (d.N > 64 && mt >= 512) return launch_gemm_nw<T, EPI, LN, 2>(d, s);
     return launch_gemm_nw<T, EPI, LN, 1>(d, s);
