@@ -143,29 +143,58 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
         if (k0 + GT_KC < K) step(xb, k0 + GT_KC, As + 64 * LDA);
     }
 
-    T* Y = reinterpret_cast<T*>(a.Y);
-    const T* R = reinterpret_cast<const T*>(a.R);
-    const T* SA = reinterpret_cast<const T*>(a.SA);
-    const int hw = EPI == 2 ? a.H * a.Wimg : 1;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        const int n = ntile + w * 64 + (lane >> 4) * 4;        // 4 consecutive output channels of this lane
-        if (ntile + w * 64 >= a.N) continue;
-        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const long m = m0 + mt * 16 + (lane & 15);
-            f32x4 v = acc[w][mt] + bias4;
-            if (EPI == 1) v += load4<T>(R + m * a.ldr + n);
-            if (EPI == 2) {
-                const int b = (int)(m / hw), p = (int)(m % hw), y = p / a.Wimg, x = p % a.Wimg;
-                const int ys = (y - a.shift + a.H) % a.H, xs = (x - a.shift + a.Wimg) % a.Wimg;   // shifted-frame coords
-                const f32x4 g = *reinterpret_cast<const f32x4*>(a.gate + ((long)b * (hw / 64) + (ys >> 3) * (a.Wimg >> 3) + (xs >> 3)) * a.N + n);
-                const float kf = a.keep ? a.keep[b] : 1.f;
-                v = load4<T>(R + m * a.ldr + n) + kf * (load4<T>(SA + m * a.ldsa + n) * g + v);
+    if constexpr (EPI == 0) {
+        // ---- epilogue: accumulators -> LDS (as [token][channel], reusing the staging tiles) -> whole 16-byte chunks of output
+        // rows.  Storing straight from the transposed accumulators wrote 32-byte pieces of 16 different rows per instruction;
+        // the write-heavy shapes (N = 3C from K = C) ran at 2.5 TB/s against 3.2-3.7 TB/s for the read-heavy ones.  Plain
+        // stores only (EPI 0): the residual epilogues keep the one-rounding fp32 path below and are read-heavy anyway.
+        constexpr int LDCS = GT_BN * NW + PAD;
+        T* Cs = reinterpret_cast<T*>(smem);                                   // [64][LDCS]
+        __syncthreads();                                                      // every wave is done with the staging tiles
+    #pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            if (ntile + w * 64 >= a.N) continue;
+            const int nl = wv * 16 + w * 64 + (lane >> 4) * 4;                // column inside the workgroup's tile
+            f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n0 + nl);
+    #pragma unroll
+            for (int mt = 0; mt < 4; ++mt) store4<T>(Cs + (mt * 16 + (lane & 15)) * LDCS + nl, acc[w][mt] + bias4);
+        }
+        __syncthreads();
+        T* Y = reinterpret_cast<T*>(a.Y);
+        const int ncols = (a.N - n0) < GT_BN * NW ? (a.N - n0) : GT_BN * NW, cpr = ncols / VEC;      // 16-byte chunks per row
+        for (int idx = tid; idx < 64 * cpr; idx += 256) {
+            const int tok = idx / cpr, c = (idx % cpr) * VEC;
+            const long m = m0 + tok;
+            const int n = n0 + c;
+            Vec16<T> v = load16<T>(Cs + tok * LDCS + c);
+            store16<T>(Y + m * a.ldy + n, v);
+        }
+    } else {
+        T* Y = reinterpret_cast<T*>(a.Y);
+        const T* R = reinterpret_cast<const T*>(a.R);
+        const T* SA = reinterpret_cast<const T*>(a.SA);
+        const int hw = EPI == 2 ? a.H * a.Wimg : 1;
+    #pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int n = ntile + w * 64 + (lane >> 4) * 4;        // 4 consecutive output channels of this lane
+            if (ntile + w * 64 >= a.N) continue;
+            f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+    #pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const long m = m0 + mt * 16 + (lane & 15);
+                f32x4 v = acc[w][mt] + bias4;
+                if (EPI == 1) v += load4<T>(R + m * a.ldr + n);
+                if (EPI == 2) {
+                    const int b = (int)(m / hw), p = (int)(m % hw), y = p / a.Wimg, x = p % a.Wimg;
+                    const int ys = (y - a.shift + a.H) % a.H, xs = (x - a.shift + a.Wimg) % a.Wimg;   // shifted-frame coords
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(a.gate + ((long)b * (hw / 64) + (ys >> 3) * (a.Wimg >> 3) + (xs >> 3)) * a.N + n);
+                    const float kf = a.keep ? a.keep[b] : 1.f;
+                    v = load4<T>(R + m * a.ldr + n) + kf * (load4<T>(SA + m * a.ldsa + n) * g + v);
+                }
+                store4<T>(Y + m * a.ldy + n, v);
             }
-            store4<T>(Y + m * a.ldy + n, v);
         }
     }
 }
@@ -173,7 +202,10 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
 template <class T, int EPI, bool LN, int NW>
 static int launch_gemm_nw(const GemmDev& d, hipStream_t s) {
     dim3 grid(d.M / GT_BM, (d.N + GT_BN * NW - 1) / (GT_BN * NW));
-    const size_t shmem = 2 * 64 * (size_t)(GT_KC + LDS_PAD_BYTES / sizeof(T)) * sizeof(T) + 128 * sizeof(float);
+    const size_t stage = 2 * 64 * (size_t)(GT_KC + LDS_PAD_BYTES / sizeof(T)) * sizeof(T) + 128 * sizeof(float);
+    const size_t epil = 64 * (size_t)(GT_BN * NW + LDS_PAD_BYTES / sizeof(T)) * sizeof(T);
+    const size_t shmem = stage > epil ? stage : epil;
+    allow_big_lds(gemm_tok_kernel<T, EPI, LN, NW>, shmem);
     MPHSIR_LAUNCH(MPHSIR_K_GEMM_TOK, (gemm_tok_kernel<T, EPI, LN, NW>), grid, dim3(256), shmem, s, d);
     return MPHSIR_OK;
 }
