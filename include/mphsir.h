@@ -310,6 +310,15 @@ int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY, int64_t l
  * given dU [M][HP] writes U (recomputed, for d project_out) and dT [M][2*HP].                          */
 int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void* dT, int64_t M, int32_t HP, int dtype, void* stream);
 
+/* ---- sizes of the caller-allocated partial / workspace buffers (bytes) ----------------------------------------------------------
+ * The library never allocates: split partials and factor rows are outputs the caller provides.  These helpers return
+ * the byte sizes the entry points expect (what mp-hsir_amd/ops.py allocates), so that a binding in another language
+ * does not have to re-derive them from the layouts documented above.                                                     */
+int64_t mphsir_gemm_tn_workspace_bytes(int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int32_t with_colsum);
+int64_t mphsir_dwconv_gram_workspace_bytes(int32_t B, int32_t nsplit, int32_t C, int32_t heads);   /* Gpart + Spart */
+int64_t mphsir_pg_gate_bwd_workspace_bytes(int32_t nW, int32_t C, int32_t r, int dtype, int32_t* KL, int32_t* KR); /* L + R; widths out */
+int64_t mphsir_win_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads, int dtype); /* dQKV+XNw+dSAt+drpb */
+
 /* ---- the resamplers of TVSP.forward (net/MP_HSIR.py:572-583), channels-last ----------------------------------------------
  * mphsir_tvsp_text_map: text [B][ps][ps][D] fp32 = L[b][d] * clip[floor(i*B/ps)][floor(j*512/ps)] -- the reference's broadcast
  *   of (B,D,1,1) x (B,512) followed by F.interpolate(nearest) to (ps,ps) (:575-577; the batch axis lands on image rows).

@@ -113,6 +113,10 @@ _SYMBOLS = {
     "mphsir_last_error": (ctypes.c_char_p, []),
     "mphsir_device_arch": (c_int, [ctypes.c_char_p, c_int]),
     "mphsir_kernel_name": (ctypes.c_char_p, [c_int]),
+    "mphsir_gemm_tn_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mphsir_dwconv_gram_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    "mphsir_pg_gate_bwd_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int, ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]),
+    "mphsir_win_attn_bwd_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     "mphsir_prof_enable": (c_int, [c_int]),
     "mphsir_prof_read": (c_int, [ctypes.POINTER(c_int), c_float_p]),
     "mphsir_gemm_tok": (c_int, [ctypes.POINTER(GemmArgs), c_int, c_void_p]),

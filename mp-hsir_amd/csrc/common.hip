@@ -77,6 +77,28 @@ const char* mphsir_kernel_name(int kid) {
     return (kid >= 0 && kid < (int)(sizeof(names) / sizeof(names[0]))) ? names[kid] : "?";
 }
 
+int64_t mphsir_gemm_tn_workspace_bytes(int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int32_t with_colsum) {
+    if (N1 <= 0 || N2 <= 0 || nsplit <= 0 || batch <= 0) return MPHSIR_EINVAL;
+    return (int64_t)batch * nsplit * ((int64_t)N1 * N2 + (with_colsum ? N1 : 0)) * 4;
+}
+int64_t mphsir_dwconv_gram_workspace_bytes(int32_t B, int32_t nsplit, int32_t C, int32_t heads) {
+    if (B <= 0 || nsplit <= 0 || heads <= 0 || C % heads != 0) return MPHSIR_EINVAL;
+    const int64_t hd = C / heads;
+    return (int64_t)B * nsplit * ((int64_t)heads * hd * hd + 2 * (int64_t)C) * 4;
+}
+int64_t mphsir_pg_gate_bwd_workspace_bytes(int32_t nW, int32_t C, int32_t r, int dtype, int32_t* KL, int32_t* KR) {
+    if (nW <= 0 || C <= 0 || r <= 0) return MPHSIR_EINVAL;
+    const int kl = (C + 5 * r + 256 + 7) / 8 * 8, kr = (5 * r + 1 + C + 7) / 8 * 8;
+    if (KL) *KL = kl;
+    if (KR) *KR = kr;
+    return (int64_t)nW * (kl + kr) * (dtype == MPHSIR_F32 ? 4 : 2);
+}
+int64_t mphsir_win_attn_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t heads, int dtype) {
+    if (B <= 0 || H % 8 || W % 8 || heads <= 0) return MPHSIR_EINVAL;
+    const int64_t M = (int64_t)B * H * W, esz = dtype == MPHSIR_F32 ? 4 : 2;
+    return M * 5 * C * esz + (M / 64) * 225 * heads * 4;
+}
+
 int mphsir_prof_enable(int kid) {
     mphsir::g_prof.kid = kid;
     mphsir::g_prof.used = 0;

@@ -460,6 +460,7 @@ class MP_HSIR_Net(nn.Module):                                                   
             cache = self.__dict__["_dp_keep"] = torch.tensor([1.0 - m.drop_prob for m in blks], dtype=torch.float32, device=device)
         keep = cache.reshape(-1, 1, 1).expand(len(blks), 2, B)
         f = torch.bernoulli(keep) / keep
+        self.__dict__["_dp_last"] = f          # the factors of the latest forward ((blocks, 2, B); under hipGraph replay: the static buffer)
         for i, m in enumerate(blks):
             m.__dict__["_dp_factors"] = f[i]
 

@@ -19,6 +19,9 @@ TINY_CASES = {
     "t128_b1": dict(shape=(1, 8, 128, 128), task=[5]),
     "t64_b2_T7": dict(shape=(2, 8, 64, 64), task=[5, 6], task_classes=7),
     "t64_b1_T1": dict(shape=(1, 8, 64, 64), task=[0], task_classes=1),
+    # the benchmark's batch size: TVSP's text map depends on B (clip[floor(i*B/ps)]).  Stored: samples `keep`
+    # in full + the per-sample norms of all 32 outputs.
+    "t32_b32": dict(shape=(32, 8, 32, 32), task=[i % 6 for i in range(32)], keep=[0, 13, 31]),
 }
 
 # One PGSSTB per shape class of both shipped configurations (SURVEY §8d stage table), plus the

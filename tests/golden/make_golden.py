@@ -65,7 +65,11 @@ def gen_tiny():
         x = seeded_input(name, case["shape"]).double()
         with torch.no_grad():
             y = net(x, task_tensor(case["task"]))
-        out[name + "/out"] = to_np(y)
+        if "keep" in case:
+            out[name + "/out"] = to_np(y[case["keep"]])
+            out[name + "/norms"] = y.flatten(1).norm(dim=1).numpy()
+        else:
+            out[name + "/out"] = to_np(y)
         print("tiny", name, tuple(y.shape), float(y.abs().mean()))
     np.savez_compressed(os.path.join(HERE, "tiny_fwd.npz"), **out)
 

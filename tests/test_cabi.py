@@ -65,3 +65,19 @@ def test_ops_refuse_cpu_tensors_without_fallback(lib):
             L.load("/nonexistent/libmphsir.so")
     finally:
         L._lib, L._is_emu = saved
+
+
+def test_workspace_size_queries_match_the_python_allocations(lib):
+    """mphsir_*_workspace_bytes (the caller owns every buffer and asks the library for its size) agree with what
+    mp-hsir_amd/ops.py allocates for the same shapes (pure host arithmetic: no GPU needed)."""
+    for f in ("mphsir_gemm_tn_workspace_bytes", "mphsir_dwconv_gram_workspace_bytes", "mphsir_pg_gate_bwd_workspace_bytes",
+              "mphsir_win_attn_bwd_workspace_bytes"):
+        getattr(lib, f).restype = ctypes.c_int64
+    assert lib.mphsir_gemm_tn_workspace_bytes(704, 128, 42, 1, 1) == 42 * (704 * 128 + 704) * 4
+    assert lib.mphsir_dwconv_gram_workspace_bytes(32, 16, 128, 2) == 32 * 16 * (2 * 64 * 64 + 256) * 4
+    kl, kr = ctypes.c_int32(0), ctypes.c_int32(0)
+    n = lib.mphsir_pg_gate_bwd_workspace_bytes(2048, 128, 16, 1, ctypes.byref(kl), ctypes.byref(kr))
+    assert (kl.value, kr.value) == (464, 216) and n == 2048 * (464 + 216) * 2          # ops.pg_gate_bwd: round_up(C+5r+256, 8), round_up(5r+1+C, 8)
+    M = 32 * 64 * 64
+    assert lib.mphsir_win_attn_bwd_workspace_bytes(32, 64, 64, 128, 2, 1) == M * 5 * 128 * 2 + (M // 64) * 225 * 2 * 4
+    assert lib.mphsir_gemm_tn_workspace_bytes(0, 1, 1, 1, 0) < 0

@@ -306,6 +306,60 @@ def test_graph_replay_matches_eager_training():
         assert float(d.max()) < 5 * 2 * 2e-4 and float(d.mean()) < 1e-5, (float(d.max()), float(d.mean()))
 
 
+def test_drop_path_factors_under_graph_replay():
+    """train mode under hipGraph capture.  The per-sample DropPath factors are drawn inside the captured step
+    (torch's graph-safe philox state): they must change from replay to replay, and -- same seed -- equal what the eager
+    engine draws at the same step, so the captured training run follows the eager one."""
+    from mp_hsir_amd.data import SyntheticPatchSource
+    from mp_hsir_amd.engine import DataParallelEngine
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    from golden.cases import TINY_CFG
+    from golden.detfill import surrogate_clip_prompt
+    runs = []
+    for use_graph in (False, True):
+        torch.manual_seed(11)
+        net = MP_HSIR_Net(**TINY_CFG, clip_prompt=surrogate_clip_prompt(6), compute_dtype=torch.float32).cuda().train()
+        eng = DataParallelEngine(net, lr=2e-4, use_graph=use_graph, graph_warmup=2)
+        src = SyntheticPatchSource(8, 32, 16, 6, "cuda", 2024, 0)
+        torch.manual_seed(5)                       # the DropPath stream
+        fac, losses = [], []
+        for _ in range(6):
+            _, x, c, p = src.next()
+            losses.append(float(eng.train_step(x, c, p)))
+            fac.append(net.__dict__["_dp_last"].detach().clone().cpu())
+        eng.finish()
+        runs.append((fac, losses))
+    (fe, le), (fg, lg) = runs
+    assert fg[0].shape[1:] == (2, 16) and float((fg[0] != 1).sum()) >= 0
+    assert any(not torch.equal(fg[i], fg[i + 1]) for i in range(2, 5)), "the replayed graph re-used one set of DropPath factors"
+    for i in range(6):
+        assert torch.equal(fe[i], fg[i]), "step %d: graph-mode DropPath factors differ from the eager engine's" % i
+    assert torch.allclose(torch.tensor(le), torch.tensor(lg), rtol=1e-4), (le, lg)
+
+
+def test_natural_training_batch32_bf16_graph():
+    """BASELINE configs[2] at its real batch size (32 per GPU; TVSP's text map depends on B): three captured bf16 steps are
+    finite, and the first loss agrees with the fp32 path on the same weights and batch (bf16 forward deviation only)."""
+    from mp_hsir_amd.data import SyntheticPatchSource
+    from mp_hsir_amd.engine import DataParallelEngine
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    torch.manual_seed(0)
+    net = MP_HSIR_Net(compute_dtype=torch.bfloat16, clip_prompt="surrogate").cuda().train()
+    src = SyntheticPatchSource(31, 64, 32, 6, "cuda", 2024, 0)
+    _, x, c, p = src.next()
+    net.eval()
+    with torch.no_grad():
+        l16 = float((net(x, p).clamp(0, 1) - c).abs().mean())
+        net.set_compute_dtype(torch.float32)
+        l32 = float((net(x, p).clamp(0, 1) - c).abs().mean())
+    assert abs(l16 - l32) < 2e-2 * l32, (l16, l32)
+    net.set_compute_dtype(torch.bfloat16).train()
+    eng = DataParallelEngine(net, lr=2e-4, use_graph=True, graph_warmup=1)
+    losses = [float(eng.train_step(x, c, p)) for _ in range(4)]
+    eng.finish()
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+
+
 def test_pack_plan_matches_per_module_packers():
     M.check_pack_plan("cuda")
     M.check_pack_plan("cuda", torch.bfloat16)
