@@ -170,8 +170,13 @@ __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
     constexpr int NSQ = (2 * C + 255) / 256;             // rows of [q;k] per thread for the final sums of squares
     constexpr int NITEM = (3 * CV * 8 + 255) / 256;      // (q|k|v, channel vector, 8-pixel strip) items per thread: fixed per thread
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    T* qT = reinterpret_cast<T*>(smem_v);                // [C][LDT]
-    T* kT = qT + C * LDT;                                // [C][LDT]
+    // q and k tiles as [pixel][channel] (pitch LDP): a thread's 8 channels of one pixel are one 16-byte store and the lanes of
+    // a wave cover consecutive chunks of a pixel row -- conflict-free.  (The first form kept the tiles transposed,
+    // [channel][pixel]: its 16-byte stores landed 8 rows = 1280 B apart, all on the same banks: 0.8 conflict cycles per
+    // LDS cycle, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.)  The Gram's operands are K-strided now: load_frag_tr.
+    constexpr int LDP = C + PAD;
+    T* qT = reinterpret_cast<T*>(smem_v);                // [64][LDP]
+    T* kT = qT + 64 * LDP;                               // [64][LDP]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
@@ -236,20 +241,18 @@ __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
                 for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
             }
             if (which < 2) {
-                T* dst = (which == 0 ? qT : kT) + c0 * LDT + st * 8;
+                T* dst = (which == 0 ? qT : kT) + (st * 8) * LDP + c0;
+                T* QK = a.QK ? reinterpret_cast<T*>(a.QK) + img * a.ldqk + which * C + c0 : nullptr;      // training: q | k kept for the backward
                 for (int e = 0; e < VEC; ++e) {
-                    store8<T>(dst + e * LDT, out[e]);
                     float s2 = 0.f;
                     for (int i = 0; i < 8; ++i) { const float r = to_f32(from_f32<T>(out[e][i])); s2 += r * r; }     // the values the Gram sees
                     ssq[slot][e] += s2;
                 }
-                if (a.QK) {                      // training: q | k are kept for the backward pass
-                    T* QK = reinterpret_cast<T*>(a.QK) + img * a.ldqk + which * C + c0;
-                    for (int i = 0; i < 8; ++i) {
-                        Vec16<T> o;
-                        for (int e = 0; e < VEC; ++e) o.set(e, out[e][i]);
-                        store16<T>(QK + (long)(p0 + i) * a.ldqk, o);
-                    }
+                for (int i = 0; i < 8; ++i) {
+                    Vec16<T> o;
+                    for (int e = 0; e < VEC; ++e) o.set(e, out[e][i]);
+                    store16<T>(dst + i * LDP, o);
+                    if (QK) store16<T>(QK + (long)(p0 + i) * a.ldqk, o);
                 }
             } else {
                 for (int i = 0; i < 8; ++i) {
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
                     const int ti = t / NT, tj = t % NT;
 #pragma unroll
                     for (int kk = 0; kk < 64; kk += TR::KCHUNK)
-                        mma(g[h][s], load_frag<T>(qT + h * HD * LDT, LDT, ti * 16, kk), load_frag<T>(kT + h * HD * LDT, LDT, tj * 16, kk));
+                        mma(g[h][s], load_frag_tr<T>(qT, LDP, h * HD + ti * 16, kk), load_frag_tr<T>(kT, LDP, h * HD + tj * 16, kk));
                 }
             }
         __syncthreads();
@@ -449,7 +452,8 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(GateDev a) {
 template <class T, int C, int HD>
 static int launch_gram(const GramDev& d, hipStream_t s) {
     constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
-    constexpr size_t shmem2 = 2 * (size_t)C * (64 + PAD) * sizeof(T);
+    constexpr size_t gram_tiles = 2 * 64 * (size_t)(C + PAD) * sizeof(T), gram_red = 2 * (size_t)C * 8 * sizeof(float);
+    constexpr size_t shmem2 = gram_tiles > gram_red ? gram_tiles : gram_red;      // the strip partials of the sums of squares reuse the tiles
     if constexpr (shmem2 <= 160 * 1024) {
         if (d.W % 8 == 0) {
             allow_big_lds(dwconv_gram2_kernel<T, C, HD>, shmem2);
@@ -499,9 +503,9 @@ extern "C" int mphsir_dwconv_gram(const mphsir_gram_args* a, int dtype, void* st
 }
 
 extern "C" int mphsir_dwconv_gram_keeps_qk(int32_t C, int32_t W, int dtype) {
-    // the sliding-window form (the one that can also emit q | k) needs both transposed tiles of all heads in LDS
+    // the sliding-window form (the one that can also emit q | k) needs the q and k tiles of all heads in LDS
     const size_t esz = dtype == MPHSIR_F32 ? 4 : 2;
-    return (W % 8 == 0 && 2 * (size_t)C * (64 + mphsir::LDS_PAD_BYTES / esz) * esz <= 160 * 1024) ? 1 : 0;
+    return (W % 8 == 0 && 2 * 64 * ((size_t)C + mphsir::LDS_PAD_BYTES / esz) * esz <= 160 * 1024) ? 1 : 0;
 }
 
 extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* stream) {
