@@ -7,6 +7,8 @@
 //  * pack_gather: all kernel-layout weights (cast to the compute dtype, padded, transposed, split, gathered) are one
 //    gather from the flat fp32 parameter arena through a static int32 index map built once from the packers
 //    (host: engine.PackPlan); index < 0 = zero padding.  Runs right after flat_adamw inside the captured step.
+#include <stdlib.h>
+
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
 
@@ -95,7 +97,8 @@ extern "C" int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, 
                          g.src_batch_stride % 4 == 0 && g.dst_batch_stride % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0;
         const long nitems = (long)g.nbatch * rows * ((g.n + 3) / 4);
         int lg = 0;                        // lanes per item: keep <= 32 splits per lane, and small segments still fill waves
-        while (lg < 6 && (g.nsplit >> lg) > 32) ++lg;
+        static const int max_chain = [] { const char* e = getenv("MPHSIR_REDUCE_CHAIN"); return e ? atoi(e) : 32; }();   // tuning aid
+        while (lg < 6 && (g.nsplit >> lg) > max_chain) ++lg;
         while (lg < 6 && (nitems << lg) < 8192 && (g.nsplit >> lg) > 4) ++lg;
         d.s[k] = RedSegDev{g.src, g.dst, (long)g.n, (long)g.stride, (long)g.src_batch_stride, (long)g.dst_batch_stride, threads, nitems,
                            src_ld, dst_ld, g.nsplit, vec ? 1 : 0, lg, rows, dcs};
