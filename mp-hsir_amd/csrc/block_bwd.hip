@@ -363,7 +363,7 @@ struct LnBwdDev {
     int linear;                    // 1: dXNw rows are plain token order (no window gather)
 };
 
-template <class T>
+template <class T, int MAXV>          // MAXV: 16-byte vectors of the row per lane (4 lanes per token): C <= 4 * MAXV * VEC
 __global__ __launch_bounds__(256) void ln_bwd_win_kernel(LnBwdDev a) {
     constexpr int VEC = Vec16<T>::N;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
@@ -379,40 +379,66 @@ __global__ __launch_bounds__(256) void ln_bwd_win_kernel(LnBwdDev a) {
     const int nv = C / VEC;
     const int t = tid >> 2, q = tid & 3;
     const long pix = a.linear ? (long)blockIdx.x * 64 + t : win_pixel(a.g, blockIdx.x, t);
-    // pass 1: statistics of x, and the two LN-backward row sums
-    float s = 0.f;
-    for (int i = q; i < nv; i += 4) {
-        const Vec16<T> xv = load16<T>(X + pix * C + i * VEC);
-        for (int e = 0; e < VEC; ++e) s += xv.get(e);
+    // the lane's share of the token row (x, d_xn, d_res) is loaded ONCE and lives in registers through all phases
+    // (the first form re-read x four times and ran three dependent global phases)
+    Vec16<T> xv[MAXV], gv[MAXV], dr[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = q + 4 * k;
+        if (i < nv) {
+            xv[k] = load16<T>(X + pix * C + i * VEC);
+            gv[k] = load16<T>(dXN + (long)t * C + i * VEC);
+            dr[k] = load16<T>(dRes + pix * C + i * VEC);
+        }
     }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+        if (q + 4 * k < nv)
+            for (int e = 0; e < VEC; ++e) s += xv[k].get(e);
     s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
     const float mean = s / (float)C;
     float d2 = 0.f;
-    for (int i = q; i < nv; i += 4) {
-        const Vec16<T> xv = load16<T>(X + pix * C + i * VEC);
-        for (int e = 0; e < VEC; ++e) { const float d = xv.get(e) - mean; d2 += d * d; }
-    }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+        if (q + 4 * k < nv)
+            for (int e = 0; e < VEC; ++e) { const float d = xv[k].get(e) - mean; d2 += d * d; }
     d2 += __shfl_xor(d2, 1); d2 += __shfl_xor(d2, 2);
     const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
     float s1 = 0.f, s2 = 0.f;
-    for (int i = q; i < nv; i += 4) {
-        const Vec16<T> xv = load16<T>(X + pix * C + i * VEC);
-        const Vec16<T> g = load16<T>(dXN + (long)t * C + i * VEC);
-        for (int e = 0; e < VEC; ++e) {
-            const int c = i * VEC + e;
-            const float gw = g.get(e) * a.ln_w[c], xh = (xv.get(e) - mean) * rstd;
-            s1 += gw; s2 += gw * xh;
-            Fs[t * LDF + c] = g.get(e);
-        }
-        if (a.XN) {
-            Vec16<T> o;
-            for (int e = 0; e < VEC; ++e) o.set(e, (xv.get(e) - mean) * rstd * a.ln_w[i * VEC + e] + a.ln_b[i * VEC + e]);
-            store16<T>(reinterpret_cast<T*>(a.XN) + ((long)blockIdx.x * 64 + t) * C + i * VEC, o);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = q + 4 * k;
+        if (i < nv) {
+            for (int e = 0; e < VEC; ++e) {
+                const int c = i * VEC + e;
+                const float gw = gv[k].get(e) * a.ln_w[c], xh = (xv[k].get(e) - mean) * rstd;
+                s1 += gw; s2 += gw * xh;
+                Fs[t * LDF + c] = gv[k].get(e);
+            }
+            if (a.XN) {
+                Vec16<T> o;
+                for (int e = 0; e < VEC; ++e) o.set(e, (xv[k].get(e) - mean) * rstd * a.ln_w[i * VEC + e] + a.ln_b[i * VEC + e]);
+                store16<T>(reinterpret_cast<T*>(a.XN) + ((long)blockIdx.x * 64 + t) * C + i * VEC, o);
+            }
         }
     }
     s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
     s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
     s1 *= 1.0f / (float)C; s2 *= 1.0f / (float)C;
+    // d_x needs nothing from other lanes any more: out it goes, before the column sums
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = q + 4 * k;
+        if (i < nv) {
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) {
+                const float dxn = gv[k].get(e), xh = (xv[k].get(e) - mean) * rstd;
+                o.set(e, dr[k].get(e) + rstd * (dxn * a.ln_w[i * VEC + e] - s1 - xh * s2));
+            }
+            store16<T>(dX + pix * C + i * VEC, o);
+        }
+    }
     __syncthreads();
     float* part = a.part + (long)blockIdx.x * 2 * C;
     for (int c = tid; c < C; c += 256) {
@@ -421,17 +447,11 @@ __global__ __launch_bounds__(256) void ln_bwd_win_kernel(LnBwdDev a) {
         part[C + c] = acc;
     }
     __syncthreads();
-    for (int i = q; i < nv; i += 4) {
-        const Vec16<T> xv = load16<T>(X + pix * C + i * VEC);
-        const Vec16<T> dr = load16<T>(dRes + pix * C + i * VEC);
-        Vec16<T> o;
-        for (int e = 0; e < VEC; ++e) {
-            const int c = i * VEC + e;
-            const float dxn = Fs[t * LDF + c], xh = (xv.get(e) - mean) * rstd;
-            o.set(e, dr.get(e) + rstd * (dxn * a.ln_w[c] - s1 - xh * s2));
-            Fs[t * LDF + c] = dxn * xh;
-        }
-        store16<T>(dX + pix * C + i * VEC, o);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = q + 4 * k;
+        if (i < nv)
+            for (int e = 0; e < VEC; ++e) Fs[t * LDF + i * VEC + e] = gv[k].get(e) * ((xv[k].get(e) - mean) * rstd);
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -541,15 +561,18 @@ extern "C" int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dR
     const size_t shmem = (64 * (size_t)(C + 1) + 256 + 3) * sizeof(float);
     const int nblk = B * (H / 8) * (W / 8);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MPHSIR_F32) {
-        allow_big_lds(ln_bwd_win_kernel<float>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_kernel<float>), dim3(nblk), dim3(256), shmem, s, d);
-    } else if (dtype == MPHSIR_BF16) {
-        allow_big_lds(ln_bwd_win_kernel<bf16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_kernel<bf16_t>), dim3(nblk), dim3(256), shmem, s, d);
-    } else {
-        allow_big_lds(ln_bwd_win_kernel<f16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_kernel<f16_t>), dim3(nblk), dim3(256), shmem, s, d);
-    }
-    return MPHSIR_OK;
+    const int vec = 16 / dtype_size(dtype), vpt = (C / vec + 3) / 4;
+#define MPHSIR_LNB(MV)                                                                                                   \
+    return MPHSIR_DISPATCH_T(dtype, ([&]() -> int {                                                                      \
+        allow_big_lds(ln_bwd_win_kernel<T_, MV>, shmem);                                                                 \
+        MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_kernel<T_, MV>), dim3(nblk), dim3(256), shmem, s, d);             \
+        return MPHSIR_OK;                                                                                                \
+    }()))
+    if (vpt <= 4) { MPHSIR_LNB(4); }
+    if (vpt <= 8) { MPHSIR_LNB(8); }
+    if (vpt <= 12) { MPHSIR_LNB(12); }
+    if (vpt <= 32) { MPHSIR_LNB(32); }
+#undef MPHSIR_LNB
+    set_error("ln_bwd_win: C=%d too wide", C);
+    return MPHSIR_EINVAL;
 }
