@@ -137,6 +137,30 @@ typedef struct mphsir_gram_args {
 } mphsir_gram_args;
 int mphsir_dwconv_gram(const mphsir_gram_args* a, int dtype, void* stream);
 int mphsir_dwconv_gram_keeps_qk(int32_t C, int32_t W, int dtype);     /* 1 if QK can be requested for this shape */
+
+/* ---- fused pass A (inference): LayerNorm (optional) + 1x1 qkv conv + depthwise 3x3 + Gram / norms ------------
+ * The same results as mphsir_gemm_tok (X -> t = [q|k|v] sources, 3C per pixel) followed by mphsir_dwconv_gram, with t
+ * kept on-chip (Spectral_Attention.forward net/MP_HSIR.py:96-107, Attention.forward :301-313 incl. its norm1 :476):
+ * one workgroup = one 8x16-pixel tile + one-pixel halo.  X [B*H*W][ldx]; Wqkv [3C][C] compute dtype; w9 fp32
+ * [9][ldw >= 3C] taps of the q | k | v channels; V [B*H*W][ldvo]; Gpart [B][nsplit][heads][hd][hd], Spart
+ * [B][nsplit][2][C] fp32 exactly as mphsir_dwconv_gram writes them (nsplit divides (H/8)*(W/16)), so
+ * mphsir_spectral_fold and pass B follow unchanged.  Training keeps the two-kernel path (its backward needs t, q, k).
+ * mphsir_qkv_dwconv_gram_fits: 1 if (C, heads, H, W, dtype) is covered (H % 8 == 0, W % 16 == 0, instantiated width). */
+typedef struct mphsir_fused_gram_args {
+    const void* X; int64_t ldx;
+    const float* ln_w; const float* ln_b;   /* both or neither: LayerNorm over C (eps 1e-5) applied to X first */
+    const void* Wqkv;
+    const float* w9; int64_t ldw;
+    void* V; int64_t ldvo;
+    float* Gpart; float* Spart;
+    int32_t B, H, W, C, heads, nsplit;
+    int32_t head_groups;                    /* 0/1: one workgroup runs all heads of its tiles; g > 1 (divides heads): g workgroups
+                                               per tile set, heads/g heads each (small images: more workgroups)          */
+} mphsir_fused_gram_args;
+int mphsir_qkv_dwconv_gram(const mphsir_fused_gram_args* a, int dtype, void* stream);
+int mphsir_qkv_dwconv_gram_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype);
+int mphsir_fused_debug(void* stamps);   /* diagnostics: device buffer of >= 9 uint64 that workgroup 0 fills with shader-clock stamps
+                                           at its phase boundaries (NULL = off); tools/bench_fused.py */
 typedef struct mphsir_fold_args {
     const float* Gpart; const float* Spart;
     const float* temperature;   /* [heads] */
@@ -406,6 +430,7 @@ int mphsir_pack_gather(const float* arena, const int32_t* index, void* dst, int6
 #define MPHSIR_K_LAYERNORM 21
 #define MPHSIR_K_PG_GATE 22
 #define MPHSIR_K_RESAMPLE 23
+#define MPHSIR_K_QKV_DWCONV_GRAM 24
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

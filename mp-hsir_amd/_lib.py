@@ -51,6 +51,13 @@ class GramArgs(ctypes.Structure):
                [("QK", c_void_p), ("ldqk", c_int64)]
 
 
+class FusedGramArgs(ctypes.Structure):
+    """mirror of struct mphsir_fused_gram_args"""
+    _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("Wqkv", c_void_p), ("w9", c_void_p),
+                ("ldw", c_int64), ("V", c_void_p), ("ldvo", c_int64), ("Gpart", c_void_p), ("Spart", c_void_p)] + \
+               [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nsplit", "head_groups")]
+
+
 class FoldArgs(ctypes.Structure):
     """mirror of struct mphsir_fold_args"""
     _fields_ = [("Gpart", c_void_p), ("Spart", c_void_p), ("temperature", c_void_p), ("Wo", c_void_p), ("M", c_void_p),
@@ -130,6 +137,9 @@ _SYMBOLS = {
     "mphsir_pg_debug": (c_int, [c_void_p]),
     "mphsir_dwconv_gram": (c_int, [ctypes.POINTER(GramArgs), c_int, c_void_p]),
     "mphsir_dwconv_gram_keeps_qk": (c_int, [c_int32, c_int32, c_int]),
+    "mphsir_qkv_dwconv_gram": (c_int, [ctypes.POINTER(FusedGramArgs), c_int, c_void_p]),
+    "mphsir_qkv_dwconv_gram_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int]),
+    "mphsir_fused_debug": (c_int, [c_void_p]),
     "mphsir_spectral_fold": (c_int, [ctypes.POINTER(FoldArgs), c_int, c_void_p]),
     "mphsir_dwconv_gate": (c_int, [ctypes.POINTER(GateArgs), c_int, c_void_p]),
     "mphsir_dwconv3x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,

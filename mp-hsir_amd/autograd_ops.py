@@ -98,6 +98,42 @@ _PG_KEYS = ("linear_down.weight", "linear_up.weight", "linear_prompt.weight", "p
             "proj.weight", "proj.bias")
 
 
+def _pass_a_infer(x2, wqkv, w9, B, H, W, C, heads, ln=None):
+    """pass A of the channel attention without a backward: (v, Gram partials, sum-of-squares partials).  One fused launch
+    (csrc/spectral_fused.hip) where the shape is covered, else the two-kernel path without its training outputs."""
+    if ops.qkv_dwconv_gram_fits(C, heads, H, W, x2.dtype):
+        v, gp, sp, _ = ops.qkv_dwconv_gram(x2, wqkv, w9, B, H, W, C, heads, ln=ln)
+    else:
+        t = ops.gemm_tok(x2, wqkv, ln=ln)
+        v, gp, sp, _ = ops.dwconv_gram(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], w9[:, :C], w9[:, C:2 * C], w9[:, 2 * C:], 3 * C, B, H, W, C, heads)
+    return v, gp, sp
+
+
+def _pgsstb_attn_infer(blk, k1, x):
+    """First residual branch of a PGSSTB block under no_grad: nothing is kept for a backward, and the 1x1 qkv conv, the
+    depthwise conv and the Gram of the global spectral branch run as ONE launch (t = qkv(sa) never reaches HBM)."""
+    B, H, W, Cc = x.shape
+    dt = x.dtype
+    pk = blk.packed(dt)
+    sp = blk.gobal_spectral_attn.packed(dt)
+    heads, shift = blk.num_heads, blk.shift_size
+    sa, gate = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"], pk["bproj"],
+                                pk["pg"], heads, shift)
+    sa2 = sa.reshape(-1, Cc)
+    v, gp, spart = _pass_a_infer(sa2, sp["wqkv"], sp["w9"], B, H, W, Cc, heads)
+    Mb = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt)
+    y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
+    return y.reshape(B, H, W, Cc)
+
+
+def _self_channel_attn_infer(attn, ln, geom, t2):
+    """a = t + M_b v (ref Attention :289-322 inside :476) under no_grad: fused pass A with the LayerNorm prologue."""
+    B, H, W = geom
+    pa = attn.packed(t2.dtype)
+    v, gp, sp = _pass_a_infer(t2, pa["wqkv"], pa["w9"], B, H, W, t2.shape[1], attn.num_heads, ln=ln.pair())
+    return ops.gemm_tok(v, ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], t2.dtype), epi=1, res=t2)
+
+
 class _PgsstbAttn(torch.autograd.Function):
     """First residual branch of a PGSSTB block: HIP forward (5 launches) and HIP backward."""
 
@@ -108,11 +144,11 @@ class _PgsstbAttn(torch.autograd.Function):
         pk = blk.packed(dt)
         sp = blk.gobal_spectral_attn.packed(dt)
         heads, shift = blk.num_heads, blk.shift_size
+        w9 = sp["w9"]
         sa, gate, mu, oattn = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"],
                                                pk["bproj"], pk["pg"], heads, shift, save=True)
         sa2 = sa.reshape(-1, Cc)
         t = ops.gemm_tok(sa2, sp["wqkv"])
-        w9 = sp["w9"]
         # q | k after the depthwise conv are kept for the backward (2C values per token: cheaper than recomputing them)
         v, gp, spart, _, qk = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
                                               3 * Cc, B, H, W, Cc, heads, keep_qk=True)
@@ -194,9 +230,12 @@ def getattr_path(mod, dotted):
 def pgsstb(blk, x, k1, k2):
     """One PGSSTB block (ref :662-723): attention-side residual branch, then the gated-MLP residual branch."""
     a, sp, pgm = blk.attn, blk.gobal_spectral_attn, blk.local_spectral_attn
-    y = _PgsstbAttn.apply(blk, k1, x, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
-                          a.relative_position_bias_table, sp.temperature, sp.qkv.weight, sp.qkv_dwconv.weight,
-                          sp.project_out.weight, *[getattr_path(pgm, k) for k in _PG_KEYS])
+    if not torch.is_grad_enabled():
+        y = _pgsstb_attn_infer(blk, k1, x)
+    else:
+        y = _PgsstbAttn.apply(blk, k1, x, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                              a.relative_position_bias_table, sp.temperature, sp.qkv.weight, sp.qkv_dwconv.weight,
+                              sp.project_out.weight, *[getattr_path(pgm, k) for k in _PG_KEYS])
     m = blk.mlp
     return _GatedMlp.apply(blk, k2, y, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
 
@@ -256,8 +295,8 @@ class _SelfChannelAttnRes(torch.autograd.Function):
         D = t2.shape[1]
         dt = t2.dtype
         pa = attn.packed(dt)
-        q = ops.gemm_tok(t2, pa["wqkv"], ln=ln.pair())
         w9 = pa["w9"]
+        q = ops.gemm_tok(t2, pa["wqkv"], ln=ln.pair())
         v, gp, sp, _ = ops.dwconv_gram(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
                                        B, H, W, D, attn.num_heads)
         Mb, MbT, gp, sp = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
@@ -399,8 +438,11 @@ def prompt_fusion(mod, x, prompt):
     B, H, W, D = t.shape
     tb = mod.transformer
     at = tb.attn
-    a = _SelfChannelAttnRes.apply(at, tb.norm1, (B, H, W), t.reshape(-1, D), tb.norm1.body.weight, tb.norm1.body.bias,
-                                  at.qkv.weight, at.qkv_dwconv.weight, at.project_out.weight, at.temperature)
+    if not torch.is_grad_enabled():
+        a = _self_channel_attn_infer(at, tb.norm1, (B, H, W), t.reshape(-1, D))
+    else:
+        a = _SelfChannelAttnRes.apply(at, tb.norm1, (B, H, W), t.reshape(-1, D), tb.norm1.body.weight, tb.norm1.body.bias,
+                                      at.qkv.weight, at.qkv_dwconv.weight, at.project_out.weight, at.temperature)
     y = _gdfn_res_ag(tb.ffn, tb.norm2, a, B, H, W).reshape(B, H, W, D)
     return conv1x1(y, mod.conv)
 

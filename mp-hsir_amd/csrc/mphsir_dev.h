@@ -61,6 +61,10 @@ template <class T> __device__ __forceinline__ constexpr int round_up_k(int k) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// The wave index as a SCALAR.  threadIdx-derived values live in VGPRs, so the compiler cannot know that `wave_id() < n` is
+// the same for all 64 lanes: every such `if` becomes s_and_saveexec + s_cbranch_execz around the statements it guards (seen
+// around every MFMA of a wave-uniform tile test).  readfirstlane moves the value to an SGPR: plain scalar branches.
+__device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // 16-byte fragment of a K-contiguous row-major operand (LDS or global): row0 + (lane&15), k0 + EPL*(lane>>4).
 template <class T>

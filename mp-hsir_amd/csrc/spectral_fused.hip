@@ -1,0 +1,431 @@
+// qkv_dwconv_gram: the FUSED pass A of the global spectral (channel) attention, inference form.
+//
+// Reference: Spectral_Attention.forward net/MP_HSIR.py:96-107 (== Attention :301-313):
+//     qkv = qkv_dwconv(qkv(x));  q,k,v = chunk(3);  q,k -> F.normalize over pixels;  attn = q @ k^T
+// The unfused path (gemm_tok -> dwconv_gram) writes the 1x1-conv output t (3C values per pixel) to HBM and reads it back
+// with a 3-row halo.  Here t never leaves the chip: one workgroup owns an 8x16-pixel tile, computes t for the tile plus
+// its one-pixel halo (10x18 pixels, padded to 12 MFMA row blocks) by MFMA straight into LDS, runs the depthwise 3x3 on
+// that LDS tile, writes v, and reduces q,k of the 128 interior pixels into its Gram / sum-of-squares partials.
+// HBM traffic per pixel: C in (plus the halo, mostly L2 hits) and C out, against 8-9 C for the two-kernel path.
+//
+// Work split inside the workgroup (8 waves):
+//   * x fragments: each wave keeps the (optionally LayerNorm-ed) 16-byte MFMA fragments of ITS 16 or 32 halo pixels in
+//     registers for the whole tile -- they are the B operand of every head's 1x1 conv.
+//   * per head: the 3*HD weight rows (q_h | k_h | v_h) go through LDS once per workgroup; accumulators hold the
+//     transposed tile (channels x pixels) so a lane owns 4 consecutive channels of one pixel -> 16-byte stores into
+//     the fp32 t tile [pixel][channel]; rows of pixels outside the image are stored as zeros (the depthwise conv zero-pads
+//     t, not x).
+//   * depthwise 3x3: one thread = (q|k|v, 4 channels, strip of 8 pixels), sliding window over LDS.
+//   * Gram: q_h, k_h tiles [128 pixel][HD] read pixel-strided (load_frag_tr), K = 128 pixels.
+// The per-head Gram / sum-of-squares partials of the workgroup live in ITS slot of Gpart / Spart (L2-resident
+// read-modify-write by the same lanes, no atomics, fixed order -> deterministic), so the head loop is a runtime loop
+// and the register budget does not grow with the number of heads.
+//
+// Training keeps the two-kernel path: its backward needs t (depthwise weight gradient) and q,k.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "mphsir_dev.h"
+#include "mphsir_host.h"
+
+namespace mphsir {
+
+constexpr int FG_TH = 8, FG_TW = 16, FG_HH = FG_TH + 2, FG_HW = FG_TW + 2;
+constexpr int FG_ROWS = FG_HH * FG_HW;          // 180 halo pixels
+constexpr int FG_MB = 12;                       // 16-row MFMA blocks (192 rows, 12 of them padding)
+constexpr int FG_PIX = FG_TH * FG_TW;           // 128 interior pixels
+constexpr int FG_STRIPS = FG_PIX / 8;           // 16 strips of 8 pixels
+
+struct FusedGramDev {
+    const void* X; long ldx;
+    const float* ln_w; const float* ln_b;
+    const void* Wqkv;                            // [3C][C]
+    const float* w9; long ldw;                   // [9][ldw]: taps of q | k | v channels
+    void* V; long ldvo;
+    float* Gpart; float* Spart;
+    int B, H, W, nsplit, hgroups;
+    unsigned long long* dbg;                     // diagnostics (mphsir_fused_debug): shader-clock stamps of workgroup 0
+};
+static unsigned long long* g_fg_dbg = nullptr;
+#define FG_MARK(k) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && first && step == 0) a.dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
+
+template <int C> struct FgStage { static constexpr int KS = C <= 128 ? C : (C % 128 == 0 ? 128 : 96); };
+// The 1x1 conv and the depthwise conv do not care about heads: they run on channel SLABS (q_s | k_s | v_s, SLAB channels
+// each) so that the fp32 t tile of one slab fits LDS at any head width; only the Gram waits for the head's last slab.
+template <int HD> struct FgSlab { static constexpr int W = HD % 32 == 0 ? 32 : (HD % 48 == 0 ? 48 : HD); };
+
+constexpr int FG_THREADS = 512, FG_WAVES = 8;   // 2 waves per SIMD per workgroup: every phase is latency-bound per wave
+constexpr int FG_MBW = (FG_MB + FG_WAVES - 1) / FG_WAVES;     // row blocks per wave: wave w owns blocks w and w+8 (< 12)
+
+template <class T, int C, int HD> struct FgLds {
+    static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
+    static constexpr int KS = FgStage<C>::KS, SLAB = FgSlab<HD>::W, NSL = HD / SLAB;
+    // the t tile is fp32: the MFMA accumulators go in as they are and the depthwise pass reads whole f32x4 without
+    // unpacking (unpacking 16-bit pairs was a third of that pass's VALU work, and it is VALU-bound).  Pitch = 3*SLAB + 4
+    // floats: strips that differ by 8 pixels land 32 banks apart, 16 lanes of a ds_read_b128 cover all 64 banks once.
+    static constexpr int LDW = KS + PAD, LDT = 3 * SLAB + 4, LDQ = HD + PAD;
+    static constexpr size_t w_elems = (size_t)3 * SLAB * LDW, qk_elems = (size_t)2 * FG_PIX * LDQ;
+    // one slab per head: the q|k tiles reuse the weight stage (dead once t is complete); several: both stay live
+    static constexpr size_t a_elems = NSL == 1 ? (w_elems > qk_elems ? w_elems : qk_elems) : w_elems + qk_elems;
+    static constexpr size_t qk_off = NSL == 1 ? 0 : w_elems;
+    static constexpr size_t t_floats = (size_t)FG_MB * 16 * LDT;
+    static constexpr size_t bytes = a_elems * sizeof(T) + (t_floats + (size_t)27 * SLAB) * sizeof(float);
+};
+
+// OCC = workgroups per CU the register allocation is held to (2 only where the LDS footprint allows two as well); the
+// second launch-bound is waves per SIMD, and one workgroup already puts two there
+template <class T, int C, int HD, bool LN, int OCC>
+__global__ __launch_bounds__(FG_THREADS, 2 * OCC) void qkv_dwconv_gram_kernel(FusedGramDev a) {
+    typedef ElemTraits<T> TR;
+    typedef FgLds<T, C, HD> L;
+    constexpr int VEC = Vec16<T>::N, KCH = TR::KCHUNK, EPL = TR::EPL;
+    constexpr int SLAB = L::SLAB, NSL = L::NSL;
+    constexpr int HEADS = C / HD, NKC = C / KCH, NB = 3 * SLAB / 16;
+    constexpr int KS = L::KS, NST = C / KS, KPS = KS / KCH;
+    constexpr int LDW = L::LDW, LDT = L::LDT, LDQ = L::LDQ;
+    constexpr int NT = HD / 16, SLOTS = (NT * NT + FG_WAVES - 1) / FG_WAVES;
+    constexpr int QPS = SLAB / 4;                                // 4-channel groups per slab and q/k/v
+    constexpr int NITEM_TOT = 3 * QPS * FG_STRIPS, NITEM = (NITEM_TOT + FG_THREADS - 1) / FG_THREADS;
+    constexpr int NSG = 2 * HD / 16, SGW = (NSG + FG_WAVES - 1) / FG_WAVES;   // 16-channel groups of [q_h | k_h] (sums of squares), per wave
+    static_assert(C % KCH == 0 && C % KS == 0 && KS % KCH == 0 && HD % 16 == 0 && SLAB % 16 == 0 && HD % SLAB == 0, "shape");
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    T* Ws = reinterpret_cast<T*>(smem_v);                       // [3 SLAB][LDW]   1x1 weights of this slab, one K stage
+    T* Qs = Ws + L::qk_off;                                     // [128][LDQ]      q_h of the interior pixels (all slabs of the head)
+    T* Ks = Qs + FG_PIX * LDQ;                                  // [128][LDQ]
+    float* Ts = reinterpret_cast<float*>(Ws + L::a_elems);     // [192][LDT] fp32 t = conv1x1(x) of the halo tile, this slab
+    float* tapsS = Ts + L::t_floats;                            // [9][3][SLAB]    depthwise taps of this slab (q | k | v)
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
+    const int blk = (gridDim.x & 7) == 0 ? (int)xcd_contiguous_block() : (int)blockIdx.x;   // neighbours share halo rows
+    // (sample, pixel split, head group): the head groups of one pixel tile are neighbours (they read the same x rows)
+    const int hg = blk % a.hgroups, bs = blk / a.hgroups, b = bs / a.nsplit, sp = bs % a.nsplit;
+    const int hpg = HEADS / a.hgroups, h0 = hg * hpg, nstep = hpg * NSL;
+    const int tilesx = a.W / FG_TW, tiles = (a.H / FG_TH) * tilesx, tpw = tiles / a.nsplit;
+    const long img = (long)b * a.H * a.W;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* Wg = reinterpret_cast<const T*>(a.Wqkv);
+    T* V = reinterpret_cast<T*>(a.V);
+    float* Gp = a.Gpart + (long)bs * HEADS * HD * HD;
+    float* Sp = a.Spart + (long)bs * 2 * C;
+
+    // Software pipeline over (tile, head, slab, K stage): the weight rows and taps of the NEXT step are requested from L2
+    // into registers while the current step computes, and go to LDS once its readers are past their barrier -- no global
+    // latency sits between two phases of the steady state.  c0 = first channel of the slab inside q (k, v: + C, + 2C).
+    constexpr int WVT = 3 * SLAB * (KS / VEC), NWV = (WVT + FG_THREADS - 1) / FG_THREADS;    // 16-byte weight vectors of one stage
+    constexpr int NTP = (27 * SLAB + FG_THREADS - 1) / FG_THREADS;                            // tap values per thread
+    Vec16<T> wpre[NWV];
+    float tpre[NTP];
+    auto wload = [&](int c0, int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + FG_THREADS * i;
+            if (idx < WVT) {
+                const int n = idx / (KS / VEC), cv = idx % (KS / VEC);
+                wpre[i] = load16<T>(Wg + ((long)(n / SLAB) * C + c0 + n % SLAB) * C + st * KS + cv * VEC);
+            }
+        }
+    };
+    auto wstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + FG_THREADS * i;
+            if (idx < WVT) store16<T>(Ws + (idx / (KS / VEC)) * LDW + (idx % (KS / VEC)) * VEC, wpre[i]);
+        }
+    };
+    auto tload = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NTP; ++i) {
+            const int idx = tid + FG_THREADS * i;
+            if (idx < 27 * SLAB) tpre[i] = a.w9[(idx / (3 * SLAB)) * a.ldw + ((idx % (3 * SLAB)) / SLAB) * C + c0 + idx % SLAB];
+        }
+    };
+    auto tstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NTP; ++i) {
+            const int idx = tid + FG_THREADS * i;
+            if (idx < 27 * SLAB) tapsS[idx] = tpre[i];
+        }
+    };
+    wload(h0 * HD, 0);
+    tload(h0 * HD);
+
+    for (int tile = sp * tpw; tile < (sp + 1) * tpw; ++tile) {
+        const bool first = tile == sp * tpw;
+        { const int step = 0; FG_MARK(0); }
+        const int ty0 = (tile / tilesx) * FG_TH, tx0 = (tile % tilesx) * FG_TW;
+
+        // ---- this wave's halo pixels (row blocks wv and wv+8) as MFMA fragments: the B operand of every slab
+        typename TR::frag_t xf[FG_MBW][NKC];
+        bool valid[FG_MBW];
+#pragma unroll
+        for (int mb = 0; mb < FG_MBW; ++mb) {
+            const int r = (wv + FG_WAVES * mb) * 16 + (lane & 15);
+            const int y = ty0 - 1 + r / FG_HW, x = tx0 - 1 + r % FG_HW;
+            valid[mb] = r < FG_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const T* src = X + (img + (long)y * a.W + x) * a.ldx + EPL * (lane >> 4);
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) {
+                if (valid[mb]) xf[mb][kc] = *reinterpret_cast<const typename TR::frag_t*>(src + kc * KCH);
+                else for (int e = 0; e < EPL; ++e) xf[mb][kc][e] = from_f32<T>(0.f);
+            }
+            if (LN) {   // a row is spread over the 4 lanes l, l^16, l^32, l^48
+                float s = 0.f;
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc)
+                    for (int e = 0; e < EPL; ++e) s += to_f32(xf[mb][kc][e]);
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                const float mean = s / (float)C;
+                float d2 = 0.f;
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc)
+                    for (int e = 0; e < EPL; ++e) { const float d = to_f32(xf[mb][kc][e]) - mean; d2 += d * d; }
+                d2 += __shfl_xor(d2, 16);
+                d2 += __shfl_xor(d2, 32);
+                const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+#pragma unroll
+                for (int kc = 0; kc < NKC; ++kc)
+                    for (int e = 0; e < EPL; ++e) {
+                        const int k = kc * KCH + EPL * (lane >> 4) + e;
+                        xf[mb][kc][e] = from_f32<T>((to_f32(xf[mb][kc][e]) - mean) * rstd * a.ln_w[k] + a.ln_b[k]);
+                    }
+            }
+        }
+
+        f32x4 gprev[SLOTS];        // the running partials of the current head (this workgroup's slot; the same lanes wrote them)
+        float sprev[SGW];
+#pragma unroll 1
+        for (int step = 0; step < nstep; ++step) {
+            const int h = h0 + step / NSL, sl = step % NSL, c0 = h * HD + sl * SLAB;
+            FG_MARK(1);
+            if (sl == 0) {         // requested at the head's first slab, used after the Gram of its last
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    gprev[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int t = wv + FG_WAVES * s;
+                    if (!first && t < NT * NT) {
+                        const int ti = t / NT, tj = t % NT;
+                        for (int r = 0; r < 4; ++r)
+                            gprev[s][r] = Gp[(h * HD + ti * 16 + (lane >> 4) * 4 + r) * HD + tj * 16 + (lane & 15)];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < SGW; ++j) {      // 16-channel groups of [q_h | k_h], dealt from the top wave down (the low waves
+                    const int sg = FG_WAVES - 1 - wv + FG_WAVES * j, sc = sg * 16 + (lane & 15);   // carry the first Gram tiles)
+                    sprev[j] = (!first && sg < NSG && lane < 16) ? Sp[(sc / HD) * C + h * HD + sc % HD] : 0.f;
+                }
+            }
+
+            // ---- t_s = W_s x^T  (transposed accumulators: rows = channels q_s|k_s|v_s, columns = pixels)
+            f32x4 acc[FG_MBW][NB];
+#pragma unroll
+            for (int mb = 0; mb < FG_MBW; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                __syncthreads();          // Ws (with one slab per head also the q|k tiles of the previous head) and the taps are free
+                wstore();
+                if (st == 0) tstore();
+                if (st + 1 < NST) wload(c0, st + 1);
+                else if (step + 1 < nstep) { const int cn = (h0 + (step + 1) / NSL) * HD + ((step + 1) % NSL) * SLAB; wload(cn, 0); tload(cn); }
+                else if (tile + 1 < (sp + 1) * tpw) { wload(h0 * HD, 0); tload(h0 * HD); }
+                __syncthreads();
+                if (st == 0) FG_MARK(2);
+                // the weight fragments of the next K-chunk are requested before this chunk's MFMAs are issued.  Waves 0-3 own two
+                // row blocks, waves 4-7 one: ONE scalar branch selects the loop body (a per-MFMA test, even a uniform one, puts a
+                // branch around every MFMA)
+                auto stage = [&](auto nmb_c) __attribute__((always_inline)) {
+                    constexpr int NMB = decltype(nmb_c)::value;
+                    typename TR::frag_t wf[2][NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) wf[0][nb] = load_frag<T>(Ws, LDW, nb * 16, 0);
+#pragma unroll
+                    for (int kk = 0; kk < KPS; ++kk) {
+                        if (kk + 1 < KPS) {
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) wf[(kk + 1) & 1][nb] = load_frag<T>(Ws, LDW, nb * 16, (kk + 1) * KCH);
+                        }
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int mb = 0; mb < NMB; ++mb) mma(acc[mb][nb], wf[kk & 1][nb], xf[mb][st * KPS + kk]);
+                    }
+                };
+                if (wv + FG_WAVES < FG_MB) stage(std::integral_constant<int, FG_MBW>{});
+                else stage(std::integral_constant<int, FG_MBW - 1>{});
+            }
+            FG_MARK(3);
+#pragma unroll
+            for (int mb = 0; mb < FG_MBW; ++mb) {
+                if (wv + FG_WAVES * mb >= FG_MB) continue;
+                float* trow = Ts + ((wv + FG_WAVES * mb) * 16 + (lane & 15)) * LDT + (lane >> 4) * 4;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    *reinterpret_cast<f32x4*>(trow + nb * 16) = valid[mb] ? acc[mb][nb] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();              // t tile complete; every wave is done reading Ws
+            FG_MARK(4);
+
+            // ---- depthwise 3x3 on the LDS tile: q_s, k_s -> LDS tiles, v_s -> HBM.  One thread = (q|k|v, 4 channels, strip
+            // of 8 pixels): 16-byte LDS reads, a sliding 3x3 window, 36 taps + 4 accumulators in registers.
+#pragma unroll
+            for (int slot = 0; slot < NITEM; ++slot) {
+                const int it = tid + FG_THREADS * slot;
+                if (it >= NITEM_TOT) break;
+                const int which = it / (QPS * FG_STRIPS), rem = it % (QPS * FG_STRIPS), c4 = rem % QPS, st = rem / QPS;
+                const int iy = st >> 1, ix0 = (st & 1) * 8;
+                const float* tsrc = Ts + (iy * FG_HW + ix0) * LDT + which * SLAB + c4 * 4;
+                const float* wsrc = tapsS + which * SLAB + c4 * 4;
+                f32x4 w[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const f32x4*>(wsrc + t * 3 * SLAB);
+                auto tvec = [&](int r, int col) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(tsrc + (r * FG_HW + col) * LDT); };
+                f32x4 cl[3], cm[3], cr[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { cl[r] = tvec(r, 0); cm[r] = tvec(r, 1); }
+                const int pi0 = iy * FG_TW + ix0;
+                T* qdst = (which == 0 ? Qs : Ks) + pi0 * LDQ + sl * SLAB + c4 * 4;
+                T* vdst = V + (img + (long)(ty0 + iy) * a.W + tx0 + ix0) * a.ldvo + c0 + c4 * 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) cr[r] = tvec(r, i + 2);
+                    f32x4 o = cl[0] * w[0];                            // nine taps = one multiply + eight fused multiply-adds
+                    o = __builtin_elementwise_fma(cm[0], w[1], o);
+                    o = __builtin_elementwise_fma(cr[0], w[2], o);
+#pragma unroll
+                    for (int r = 1; r < 3; ++r) {
+                        o = __builtin_elementwise_fma(cl[r], w[r * 3], o);
+                        o = __builtin_elementwise_fma(cm[r], w[r * 3 + 1], o);
+                        o = __builtin_elementwise_fma(cr[r], w[r * 3 + 2], o);
+                    }
+                    if (which < 2) store4<T>(qdst + i * LDQ, o);
+                    else store4<T>(vdst + (long)i * a.ldvo, o);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
+                }
+            }
+            FG_MARK(5);
+            __syncthreads();
+            FG_MARK(6);
+            if (sl != NSL - 1) continue;
+
+            // ---- Gram of the 128 interior pixels (tiles dealt from wave 0 up), sums of squares of the rounded q / k values
+            // (groups dealt from wave 7 down: lane = (channel, pixel phase) -> conflict-free 2-byte column reads, fixed-order
+            // shuffle sums), both added to the workgroup's partials
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int t = wv + FG_WAVES * s;              // wave-uniform
+                if (t < NT * NT) {
+                    const int ti = t / NT, tj = t % NT;
+                    f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < FG_PIX; kk += KCH)
+                        mma(g, load_frag_tr<T>(Qs, LDQ, ti * 16, kk), load_frag_tr<T>(Ks, LDQ, tj * 16, kk));
+                    g += gprev[s];
+                    for (int r = 0; r < 4; ++r)
+                        Gp[(h * HD + ti * 16 + (lane >> 4) * 4 + r) * HD + tj * 16 + (lane & 15)] = g[r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SGW; ++j) {
+                const int sg = FG_WAVES - 1 - wv + FG_WAVES * j, sc = sg * 16 + (lane & 15);
+                if (sg < NSG) {
+                    const T* col = (sc < HD ? Qs + sc : Ks + (sc - HD)) + (lane >> 4) * LDQ;
+                    float s2 = 0.f;
+#pragma unroll 8
+                    for (int i = 0; i < FG_PIX / 4; ++i) { const float v = to_f32(col[i * 4 * LDQ]); s2 += v * v; }
+                    s2 += __shfl_xor(s2, 16);
+                    s2 += __shfl_xor(s2, 32);
+                    if (lane < 16) Sp[(sc / HD) * C + h * HD + sc % HD] = sprev[j] + s2;
+                }
+            }
+            FG_MARK(7);
+        }
+    }
+    if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[8] = __builtin_amdgcn_s_memtime();
+}
+
+template <class T, int C, int HD, bool LN, int OCC>
+static int launch_fused_occ(const FusedGramDev& d, hipStream_t s) {
+    const size_t shmem = FgLds<T, C, HD>::bytes;
+    allow_big_lds(qkv_dwconv_gram_kernel<T, C, HD, LN, OCC>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_QKV_DWCONV_GRAM, (qkv_dwconv_gram_kernel<T, C, HD, LN, OCC>), dim3(d.B * d.nsplit * d.hgroups), dim3(FG_THREADS), shmem, s, d);
+    return MPHSIR_OK;
+}
+
+template <class T, int C, int HD>
+static int launch_fused(const FusedGramDev& d, hipStream_t s) {
+    static const int occ_env = [] { const char* e = getenv("MPHSIR_FUSED_OCC"); return e ? atoi(e) : 0; }();     // tuning aid
+    if constexpr (FgLds<T, C, HD>::bytes <= 80 * 1024) {
+        // two workgroups per CU halve the register budget (128 per wave): taken where that costs few spills
+        if (occ_env == 2 || (occ_env == 0 && C <= 64)) return d.ln_w ? launch_fused_occ<T, C, HD, true, 2>(d, s) : launch_fused_occ<T, C, HD, false, 2>(d, s);
+    }
+    return d.ln_w ? launch_fused_occ<T, C, HD, true, 1>(d, s) : launch_fused_occ<T, C, HD, false, 1>(d, s);
+}
+
+// shapes: the 16-bit types at every width / head width of both configurations (+ the small test nets); fp32 (the
+// parity path keeps 4-byte fragments of all K in registers) for the narrow widths only
+template <class T> struct FusedShapes {
+    static bool has(int C, int HD) {
+        return (HD == 32 && (C == 32 || C == 64 || C == 128 || C == 256)) || (HD == 16 && (C == 32 || C == 64)) ||
+               (HD == 48 && (C == 96 || C == 192 || C == 384)) || (HD == 64 && (C == 64 || C == 128)) || (HD == 96 && C == 192);
+    }
+    static int run(const FusedGramDev& d, int C, int HD, hipStream_t s) {
+#define MPHSIR_FG_CASE(c, hd) if (C == c && HD == hd) return launch_fused<T, c, hd>(d, s);
+        MPHSIR_FG_CASE(32, 16) MPHSIR_FG_CASE(64, 16) MPHSIR_FG_CASE(32, 32) MPHSIR_FG_CASE(64, 32) MPHSIR_FG_CASE(128, 32)
+        MPHSIR_FG_CASE(256, 32) MPHSIR_FG_CASE(96, 48) MPHSIR_FG_CASE(192, 48) MPHSIR_FG_CASE(384, 48)
+        MPHSIR_FG_CASE(64, 64) MPHSIR_FG_CASE(128, 64) MPHSIR_FG_CASE(192, 96)
+#undef MPHSIR_FG_CASE
+        return MPHSIR_EINVAL;
+    }
+};
+template <> struct FusedShapes<float> {
+    static bool has(int C, int HD) { return (HD == 32 && (C == 32 || C == 64)) || (HD == 16 && (C == 32 || C == 64)); }
+    static int run(const FusedGramDev& d, int C, int HD, hipStream_t s) {
+#define MPHSIR_FG_CASE(c, hd) if (C == c && HD == hd) return launch_fused<float, c, hd>(d, s);
+        MPHSIR_FG_CASE(32, 16) MPHSIR_FG_CASE(64, 16) MPHSIR_FG_CASE(32, 32) MPHSIR_FG_CASE(64, 32)
+#undef MPHSIR_FG_CASE
+        return MPHSIR_EINVAL;
+    }
+};
+
+}  // namespace mphsir
+
+extern "C" int mphsir_fused_debug(void* stamps) {      // diagnostics: device buffer of >= 9 uint64 (NULL = off)
+    mphsir::g_fg_dbg = reinterpret_cast<unsigned long long*>(stamps);
+    return MPHSIR_OK;
+}
+
+extern "C" int mphsir_qkv_dwconv_gram_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype) {
+    using namespace mphsir;
+    if (!MPHSIR_DTYPE_OK(dtype) || heads <= 0 || C % heads != 0 || H <= 0 || W <= 0 || H % FG_TH != 0 || W % FG_TW != 0) return 0;
+    const int HD = C / heads;
+    return MPHSIR_DISPATCH_T(dtype, (FusedShapes<T_>::has(C, HD) ? 1 : 0));
+}
+
+extern "C" int mphsir_qkv_dwconv_gram(const mphsir_fused_gram_args* a, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(a && a->X && a->Wqkv && a->w9 && a->V && a->Gpart && a->Spart, "qkv_dwconv_gram: null pointer");
+    MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "qkv_dwconv_gram: dtype %d unsupported", dtype);
+    MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C > 0 && a->C % a->heads == 0, "qkv_dwconv_gram: bad shape");
+    MPHSIR_REQUIRE(mphsir_qkv_dwconv_gram_fits(a->C, a->heads, a->H, a->W, dtype),
+                   "qkv_dwconv_gram: (C=%d, heads=%d, H=%d, W=%d) not covered (ask mphsir_qkv_dwconv_gram_fits; H %% 8 == 0, W %% 16 == 0)",
+                   a->C, a->heads, a->H, a->W);
+    const int esz = dtype == MPHSIR_F32 ? 4 : 2;
+    const int tiles = (a->H / FG_TH) * (a->W / FG_TW);
+    MPHSIR_REQUIRE(a->nsplit > 0 && tiles % a->nsplit == 0, "qkv_dwconv_gram: nsplit=%d must divide the %d pixel tiles", a->nsplit, tiles);
+    MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->Wqkv) && aligned16(a->V) && (a->ldx * esz) % 16 == 0 && (a->ldvo * esz) % 16 == 0 &&
+                       a->ldx >= a->C && a->ldvo >= a->C && a->ldw >= 3 * a->C,
+                   "qkv_dwconv_gram: 16-byte alignment / row pitch");
+    MPHSIR_REQUIRE((a->ln_w == nullptr) == (a->ln_b == nullptr), "qkv_dwconv_gram: ln_w and ln_b go together");
+    const int hgroups = a->head_groups > 0 ? a->head_groups : 1;
+    MPHSIR_REQUIRE(a->heads % hgroups == 0, "qkv_dwconv_gram: head_groups=%d must divide heads=%d", hgroups, a->heads);
+    FusedGramDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->Wqkv, a->w9, (long)a->ldw, a->V, (long)a->ldvo, a->Gpart, a->Spart,
+                   a->B, a->H, a->W, a->nsplit, hgroups, g_fg_dbg};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return MPHSIR_DISPATCH_T(dtype, (FusedShapes<T_>::run(d, a->C, a->C / a->heads, s)));
+}

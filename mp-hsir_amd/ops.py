@@ -496,6 +496,53 @@ def dwconv_gram(tq, tk, tv, wq, wk, wv, ldw, B, H, W, C, heads, nsplit=None, kee
     return v, gp, sp, nsplit
 
 
+def qkv_dwconv_gram_fits(C, heads, H, W, dtype):
+    return bool(_lib.load().mphsir_qkv_dwconv_gram_fits(C, heads, H, W, _DT[dtype]))
+
+
+def choose_nsplit_fused(B, H, W):
+    """workgroups per sample for the fused pass A (8x16-pixel tiles): up to ~1024 workgroups in flight."""
+    n = (H // 8) * (W // 16)
+    while n > 1 and B * n > 1024 and n % 2 == 0:
+        n //= 2
+    return n
+
+
+def choose_head_groups(B, nsplit, heads):
+    """workgroups per tile set for the fused pass A: split the heads while that still adds workgroups below ~1024"""
+    g = 1
+    while g < heads and heads % (2 * g) == 0 and B * nsplit * 2 * g <= 1024:
+        g *= 2
+    return g
+
+
+def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_groups=None):
+    """Fused inference pass A: x (M, >=C) row-major view, wqkv (3C, C) in x.dtype, w9 fp32 (9, >=3C) taps of q|k|v,
+    ln = (weight, bias) fp32 or None.  Returns (v (M,C), Gpart, Spart, nsplit) like dwconv_gram(gemm_tok(x, wqkv))."""
+    lib = _lib.load()
+    _check(x, wqkv, w9)
+    M, ldx = _rows(x)
+    assert M == B * H * W and wqkv.shape == (3 * C, C) and wqkv.is_contiguous() and wqkv.dtype == x.dtype
+    nsplit = nsplit or choose_nsplit_fused(B, H, W)
+    hd = C // heads
+    v = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    gp = torch.empty((B, nsplit, heads, hd, hd), dtype=torch.float32, device=x.device)
+    sp = torch.empty((B, nsplit, 2, C), dtype=torch.float32, device=x.device)
+    a = _lib.FusedGramArgs()
+    a.X, a.ldx, a.Wqkv, a.w9, a.ldw = _p(x), ldx, _p(wqkv), _p(w9), w9.stride(0)
+    if ln is not None:
+        a.ln_w, a.ln_b = _p(ln[0]), _p(ln[1])
+    a.V, a.ldvo, a.Gpart, a.Spart = _p(v), C, _p(gp), _p(sp)
+    a.B, a.H, a.W, a.C, a.heads, a.nsplit = B, H, W, C, heads, nsplit
+    a.head_groups = head_groups or choose_head_groups(B, nsplit, heads)
+    _lib.check(lib.mphsir_qkv_dwconv_gram(ctypes.byref(a), _DT[x.dtype], _stream(x)), "qkv_dwconv_gram")
+    # the 1x1 conv is counted on the pixels it is useful for (the halo recompute is overhead, not work)
+    _acct("qkv_dwconv_gram", M * (6.0 * C * C + 54.0 * C + 2.0 * C * hd), 2.0 * M * C * x.element_size() + wqkv.numel() * x.element_size()
+          + gp.numel() * 4 + sp.numel() * 4)
+    _acct("dwconv_gram:qk", 2.0 * M * C * hd, 0.0)
+    return v, gp, sp, nsplit
+
+
 def spectral_fold(gp, sp, temperature, Wo, dtype, transposed=False):
     """-> per-sample folded matrix M (B, C, C) in `dtype`; with transposed=True (training) -> (M, M^T, gsum, ssum):
     gsum (B,1,heads,hd,hd) / ssum (B,1,2,C) are the reduced partials, the form spectral_fold_bwd wants."""

@@ -301,6 +301,7 @@ inline bf16x4_t ds_read_tr16_b64(const void* p) {
 }
 }  // namespace hipemu
 #define __builtin_amdgcn_s_memtime() 0ull
+#define __builtin_amdgcn_readfirstlane(x) (x)      /* wave-uniform by contract: any lane's value */
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p) hipemu::ds_read_tr16_b64((const void*)(p))

@@ -149,6 +149,47 @@ def check_spectral_attention_chain(dev, dtype, C, heads, shape, nsplit):
     assert rel_l2(y.reshape(B, H, W, C), ref) < TOL[dtype] * (2 if dtype != torch.float32 else 1)
 
 
+FUSED_CASES = [(32, 1, (1, 8, 16), 1, False), (32, 2, (2, 16, 32), 2, True), (64, 2, (1, 24, 32), 3, False), (64, 4, (1, 16, 16), 1, True)]
+# (…, head_groups): 1 = all heads in one workgroup, g > 1 = heads split over g workgroups per tile set
+# heads wider than one channel slab (two slabs of 32 per head): 16-bit only
+FUSED_SLAB_CASES = [(64, 1, (1, 16, 32), 2, False), (64, 1, (1, 8, 16), 1, True)]
+FUSED_HG_CASES = [(64, 4, (1, 16, 32), 2, False, 1), (64, 4, (1, 16, 32), 2, True, 2), (64, 4, (1, 8, 16), 1, False, 4)]
+
+
+def check_fused_pass_a(dev, dtype, C, heads, shape, nsplit, ln, hgroups=None):
+    """qkv_dwconv_gram (LN + 1x1 qkv + depthwise 3x3 + Gram / norms in one launch) == gemm_tok -> dwconv_gram, and the
+    chain through spectral_fold / pass B == oracle spectral_attention (ref :96-114; with ln: norm1 of :476 first)."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    assert ops.qkv_dwconv_gram_fits(C, heads, H, W, dtype)
+    x = rnd((B, H, W, C), 61, dtype)
+    P = {"qkv.weight": rnd((3 * C, C, 1, 1), 62, scale=C ** -0.5), "qkv_dwconv.weight": rnd((3 * C, 1, 3, 3), 63, scale=1 / 3),
+         "project_out.weight": rnd((C, C, 1, 1), 64, scale=C ** -0.5), "temperature": 1 + 0.3 * rnd((heads, 1, 1), 65)}
+    lnp = (1 + 0.2 * rnd((C,), 66), 0.1 * rnd((C,), 67)) if ln else None
+    wqkv = P["qkv.weight"].reshape(3 * C, C).to(dtype).contiguous()
+    w9 = ops.pack_dw(P["qkv_dwconv.weight"])
+    x2 = x.reshape(-1, C)
+    v, gp, sp, ns = ops.qkv_dwconv_gram(x2, wqkv, w9, B, H, W, C, heads, ln=lnp, nsplit=nsplit, head_groups=hgroups)
+    assert gp.shape == (B, nsplit, heads, C // heads, C // heads) and sp.shape == (B, nsplit, 2, C)
+    # the two-kernel path on the same inputs: same rounding points (t and q,k,v in the compute dtype), different
+    # accumulation order in the 1x1 conv only
+    t = ops.gemm_tok(x2, wqkv, ln=lnp)
+    v0, gp0, sp0, _ = ops.dwconv_gram(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], w9[:, :C], w9[:, C:2 * C], w9[:, 2 * C:], 3 * C, B, H, W, C, heads)
+    tol = TOL[dtype]
+    assert rel_l2(v, v0) < tol
+    assert rel_l2(gp.double().sum(1), gp0.double().sum(1)) < tol and rel_l2(sp.double().sum(1), sp0.double().sum(1)) < tol
+    temp, wo = P["temperature"].reshape(heads).contiguous(), P["project_out.weight"].reshape(C, C).contiguous()
+    y = ops.gemm_tok(v, ops.spectral_fold(gp, sp, temp, wo, dtype))
+    Pd = {k: v_.double().cpu() for k, v_ in P.items()}
+    Pd["qkv.weight"] = wqkv.double().cpu().reshape(3 * C, C, 1, 1)
+    xin = x.double().cpu()
+    if ln:
+        xin = torch.nn.functional.layer_norm(xin, (C,), lnp[0].double().cpu(), lnp[1].double().cpu(), 1e-5)
+    ref = O.spectral_attention(Pd, "", xin, heads)
+    assert rel_l2(y.reshape(B, H, W, C), ref) < tol * (2 if dtype != torch.float32 else 1)
+
+
 def check_gdfn_chain(dev, dtype):
     """gemm_tok(LN + project_in) -> dwconv_gate -> gemm_tok(project_out + residual) == x + gdfn(LN(x))"""
     _use(dev)

@@ -44,6 +44,22 @@ def test_spectral_attention_chain(dtype, C, heads, shape, nsplit):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,heads,shape,nsplit,ln", K.FUSED_CASES)
+def test_fused_pass_a(dtype, C, heads, shape, nsplit, ln):
+    K.check_fused_pass_a("cpu", dtype, C, heads, shape, nsplit, ln)
+
+
+@pytest.mark.parametrize("C,heads,shape,nsplit,ln", K.FUSED_SLAB_CASES)
+def test_fused_pass_a_slabs(C, heads, shape, nsplit, ln):
+    K.check_fused_pass_a("cpu", torch.bfloat16, C, heads, shape, nsplit, ln)
+
+
+@pytest.mark.parametrize("C,heads,shape,nsplit,ln,hg", K.FUSED_HG_CASES)
+def test_fused_pass_a_head_groups(C, heads, shape, nsplit, ln, hg):
+    K.check_fused_pass_a("cpu", torch.bfloat16, C, heads, shape, nsplit, ln, hgroups=hg)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
 def test_gdfn_chain(dtype):
     K.check_gdfn_chain("cpu", dtype)
 

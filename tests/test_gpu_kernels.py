@@ -74,6 +74,52 @@ def test_spectral_attention_chain(dtype, C, heads, shape, nsplit):
     K.check_spectral_attention_chain("cuda", dtype, C, heads, shape, nsplit)
 
 
+GPU_FUSED_CASES = [(64, 2, (2, 64, 64), 8, False), (128, 4, (1, 32, 32), 2, False), (256, 8, (2, 16, 16), 1, False),
+                   (128, 4, (1, 64, 64), 32, True), (256, 8, (1, 32, 32), 4, True), (96, 2, (1, 32, 32), 2, False),
+                   (192, 4, (1, 16, 32), 1, True), (384, 8, (1, 16, 16), 2, False), (64, 2, (1, 128, 128), 16, False),
+                   (128, 2, (1, 64, 64), 8, False), (128, 2, (2, 32, 32), 2, True), (192, 2, (1, 32, 32), 4, False)] + K.FUSED_SLAB_CASES
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,heads,shape,nsplit,ln", K.FUSED_CASES + GPU_FUSED_CASES)
+def test_fused_pass_a(dtype, C, heads, shape, nsplit, ln):
+    K.check_fused_pass_a("cuda", dtype, C, heads, shape, nsplit, ln)
+
+
+@pytest.mark.parametrize("C,heads,shape,nsplit,ln,hg", K.FUSED_HG_CASES + [(256, 8, (1, 32, 32), 2, False, 8), (256, 8, (1, 32, 32), 2, True, 1),
+                                                                   (384, 8, (1, 16, 16), 1, False, 4), (128, 4, (2, 64, 64), 4, False, 2)])
+def test_fused_pass_a_head_groups(C, heads, shape, nsplit, ln, hg):
+    K.check_fused_pass_a("cuda", torch.bfloat16, C, heads, shape, nsplit, ln, hgroups=hg)
+
+
+@pytest.mark.parametrize("C,heads,shape,nsplit,ln", K.FUSED_CASES)
+def test_fused_pass_a_fp32(C, heads, shape, nsplit, ln):
+    K.check_fused_pass_a("cuda", torch.float32, C, heads, shape, nsplit, ln)
+
+
+def test_fused_pass_a_is_deterministic_and_used_by_inference():
+    """bitwise equal repeats (fixed-order partials, no atomics), and the no-grad forward of a block goes through it"""
+    from mp_hsir_amd import ops
+    x = torch.randn(2 * 64 * 64, 128, device="cuda", dtype=torch.bfloat16)
+    w = (torch.randn(384, 128, device="cuda") * 128 ** -0.5).to(torch.bfloat16)
+    w9 = torch.randn(9, 384, device="cuda") / 3
+    a = ops.qkv_dwconv_gram(x, w, w9, 2, 64, 64, 128, 4, nsplit=8)
+    b = ops.qkv_dwconv_gram(x, w, w9, 2, 64, 64, 128, 4, nsplit=8)
+    assert all(torch.equal(p, q) for p, q in zip(a[:3], b[:3]))
+    from mp_hsir_amd.net.MP_HSIR import PGSSTB
+    from mp_hsir_amd import autograd_ops
+    blk = PGSSTB(64, 2, [64, 64], 8, 0, 0.0, 2.66, 8, 128).cuda().eval()
+    xin = torch.randn(1, 64, 64, 64, device="cuda", dtype=torch.bfloat16)
+    ops.ACCOUNT = {}
+    try:
+        with torch.no_grad():
+            autograd_ops.pgsstb(blk, xin, None, None)
+        st = dict(ops.ACCOUNT)
+    finally:
+        ops.ACCOUNT = None
+    assert "qkv_dwconv_gram" in st and "dwconv_gram" not in st, sorted(st)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 def test_gdfn_chain(dtype):
     K.check_gdfn_chain("cuda", dtype)
