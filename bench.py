@@ -134,8 +134,10 @@ def spectral_roofline(net, dev, lib, steps=5):
     """What north_star names: the spectral attention at 512x512x31 bf16 (forward, batch 1 = one test cube of test.py).
     Times the forward (eager warm-up, then the replayed hipGraph) and, with HIP events on the launch stream, the kernels
     of the global spectral branch; reports them against the roof that bounds each:
-      dwconv_gram   depthwise 3x3 + Gram + norms, q and k never in HBM -> HBM-bound: algorithmic bytes / time vs 8 TB/s
-      qk_gram       the QK^T FLOPs inside it (2*C*hd per pixel) / the same time vs the dense bf16 MFMA peak"""
+      qkv_dwconv_gram   fused pass A (1x1 qkv + depthwise 3x3 + Gram + norms; t, q, k never in HBM): algorithmic bytes
+                        (x in, v out) / time vs 8 TB/s, and its useful FLOPs / time vs the dense bf16 MFMA peak
+      dwconv_gram       the two-kernel form's depthwise + Gram kernel where it still runs (cross attention)
+      qk_*              the QK^T FLOPs inside either (2*C*hd per pixel) / the same time vs the MFMA peak"""
     from mp_hsir_amd import ops
     from mp_hsir_amd.engine import GraphedForward
     net.eval()
@@ -172,7 +174,11 @@ def spectral_roofline(net, dev, lib, steps=5):
            "cubes_per_s": round(1.0 / t_fwd, 2), "ms_per_cube": round(t_fwd * 1e3, 3),
            "kernel_table": {k: [int(v[0]), round(v[1], 3), round(acct[k][2] / 1e9, 3), round(acct[k][2] / v[1] / 1e9, 2),
                                 round(acct[k][1] / v[1] / 1e9, 1)] for k, v in sorted(per.items())}}
-    for kname in ("dwconv_gram", "spectral_passA"):
+    # pass A of the global spectral attention: the fused kernel (LN + 1x1 qkv + depthwise 3x3 + Gram, t on-chip) on the no-grad
+    # path, the depthwise+Gram kernel wherever the two-kernel path still runs (cross attention).  AI of the fused pass =
+    # (6 C^2 + ...) FLOP per 4 C bytes ~ 1.5 C FLOP/B: HBM side of the ridge (312 FLOP/B) at C <= 128 -> priced against HBM,
+    # with the MFMA fraction of its useful FLOPs beside it.
+    for kname in ("qkv_dwconv_gram", "dwconv_gram"):
         if kname in per:
             n, ms = per[kname]
             nbytes, flops = acct[kname][2], acct[kname][1]
@@ -180,7 +186,8 @@ def spectral_roofline(net, dev, lib, steps=5):
             out[kname] = {"bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4), "launches": int(n), "avg_launch_us": round(ms * 1e3 / n, 2),
                           "algorithmic_bytes_per_launch": round(nbytes / n),
-                          "tflops": round(flops / ms / 1e9, 1), "qk_tflops": round(qk / ms / 1e9, 1),
+                          "tflops": round(flops / ms / 1e9, 1), "mfma_frac": round(flops / ms / 1e9 / PEAK_MFMA_TF["bf16"], 4),
+                          "qk_tflops": round(qk / ms / 1e9, 1),
                           "qk_mfma_frac": round(qk / ms / 1e9 / PEAK_MFMA_TF["bf16"], 4),
                           "qk_ceiling_at_hbm_peak_tflops": round(qk / (nbytes / (PEAK_HBM_GBS * 1e9)) / 1e12, 1)}
     return out

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
     float* rpbs = reinterpret_cast<float*>(Xs + CF::T_ELEMS);
     int* reg = reinterpret_cast<int*>(rpbs + 225);
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const T* X = reinterpret_cast<const T*>(a.X);
     const T* dSA = reinterpret_cast<const T*>(a.dSA);
     const long row0 = (long)blockIdx.x * 64;

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void conv3x3_tok_kernel(ConvDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     T* As = reinterpret_cast<T*>(smem_v);          // [64][LDA]
     float* Cs = reinterpret_cast<float*>(smem_v);  // [64][LDC] (aliases As after the K loop)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
     const int HW = a.H * a.Wd, K = 9 * a.Cin;
     const T* X = reinterpret_cast<const T*>(a.X);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(DwWgDev a) {
     constexpr int VEC = Vec16<T>::N;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     float* red = reinterpret_cast<float*>(smem_v);        // [64][9*VEC]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = wave_id_uniform();
     const int cvec = blockIdx.y * 64 + lane, c0 = cvec * VEC;
     const bool live = c0 < a.C;
     const int HW = a.H * a.W;

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void gated_mlp_kernel(MlpDev a) {
     T* Xs = reinterpret_cast<T*>(smem_v);               // [64][LDX]  LN(x); later the output stage
     T* Hs = Xs + 64 * LDX;                              // [4][16][LDH] per-wave hidden chunk
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int m0 = blockIdx.x * 64;
     const T* X = reinterpret_cast<const T*>(a.X);
 
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
     T* W2s = W1s + 64 * LDX;                            // [C][LDH]
     T* Hs = W2s + C * LDH;                              // [4][16*TT][LDH]
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int m0 = blockIdx.x * BM;
     const T* X = reinterpret_cast<const T*>(a.X);
 

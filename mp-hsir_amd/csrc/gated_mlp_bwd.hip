@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
     static_assert(GX || 64 * LDF * 4 <= 2 * 64 * LDX * sizeof(T), "fp32 dxn stage must fit in the two token tiles");
     static_assert(!(GX && STAGE), "the global-operand form streams its weights");
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int m0 = blockIdx.x * 64;
     const T* X = reinterpret_cast<const T*>(a.X);
     const T* DM = reinterpret_cast<const T*>(a.DM);
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
     float* Fs = reinterpret_cast<float*>(smem);          // end:  [TOK][LDF] fp32 dxn
     float* stat = reinterpret_cast<float*>(smem + REG);  // mean[TOK], rstd[TOK]
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const long m0 = (long)blockIdx.x * TOK;
     const T* X = reinterpret_cast<const T*>(a.X);
     const T* DM = reinterpret_cast<const T*>(a.DM);

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     T* At = reinterpret_cast<T*>(smem_v);        // [TN1][LDT]
     T* Bt = At + TN1 * LDT;                      // [TN2][LDT]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int t2n = (a.N2 + TN2 - 1) / TN2, ntiles = ((a.N1 + TN1 - 1) / TN1) * t2n;
     // XCD-aware block -> (token split, output tile) map: workgroups are dealt round-robin over the 8 XCDs (blocks L and
     // L+8 share an L2), so tile = (L/8) % ntiles, split = L%8 + 8*(L/(8*ntiles)) puts all tiles of one token range on
@@ -177,7 +177,7 @@ template <class T, int W1, int W2>          // T: a 16-bit element type (bf16_t 
 __device__ __forceinline__ void tn_tr_body(const TnDev& a, char* smem, int L, int bz) {
     constexpr int KT = 64, RW = W1 / 64, NT = W2 / 16;
     constexpr int IMG_A = KT * W1 * 2, IMG_B = KT * W2 * 2, STAGE = IMG_A + IMG_B;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int t2n = (a.N2 + W2 - 1) / W2, ntiles = ((a.N1 + W1 - 1) / W1) * t2n;
     // L: block index inside this problem; XCD-aware map, as in gemm_tn_kernel
     const int tile = (L >> 3) % ntiles, sp = (L & 7) + 8 * (L / (8 * ntiles));

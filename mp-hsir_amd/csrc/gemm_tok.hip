@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
     constexpr size_t TILE_B = 2 * 64 * LDA * sizeof(T);
     float* stat = reinterpret_cast<float*>(smem + TILE_B);               // mean[64], rstd[64]
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int m0 = blockIdx.x * GT_BM, n0 = blockIdx.y * GT_BN * NW;
     const T* X = reinterpret_cast<const T*>(a.X);
     const T* W = reinterpret_cast<const T*>(a.W) + (a.wbs ? (long)(m0 / a.rpb) * a.wbs : 0);

@@ -153,7 +153,7 @@ __device__ __forceinline__ void pg_mfma_rows(f32x4 (&acc)[NT], f32x4 (&wf)[8][NT
 // ---- the forward chain for the workgroup's 16 windows (shared by both kernels); ends with o2 in sm[.][PG_O2] --------------
 template <bool KEEP_AT>
 __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s, int win0) {
-    const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     // the weight fragments of the two C-sized products are requested first ...
     const int rows[2] = {wv * 32, wv * 32 + 16}, rowd[1] = {wv * 16};
     const bool has_d = wv * 16 < r;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
 __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), a.C, a.r, true, a.stage_wdn != 0);
-    const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, win0 = blockIdx.x * PG_NWIN;
+    const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), win0 = blockIdx.x * PG_NWIN;
     // Wprompt column fragments of this wave's first two d-mu tiles (used at the very end): requested now, they cost no
     // round trip later
     const int nct = C / 16;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
     float* sq = rn + 2 * HD;                          // [2*HD] raw sums of squares
     float* dn = sq + 2 * HD;                          // [2*HD] d nq | d nk
     float* red = dn + 2 * HD;                         // [HD] per-row d temperature terms
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
     const float temp = a.temperature[h];
 
     for (int i = tid; i < HD * HD; i += FB_THREADS) {        // ordered sum over the splits (1 when the forward saved the sums)

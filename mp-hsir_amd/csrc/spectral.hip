@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void dwconv_gram_kernel(GramDev a) {
     T* qT = reinterpret_cast<T*>(smem_v);                // [HD][LDT]  q_h^T : channel-major, pixel-contiguous
     T* kT = qT + HD * LDT;                               // [HD][LDT]
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int b = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
     const int HW = a.H * a.W, tiles = HW / 64, tpw = tiles / a.nsplit;
     const long img = (long)b * HW;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void dwconv_gram2_kernel(GramDev a) {
     T* qT = reinterpret_cast<T*>(smem_v);                // [64][LDP]
     T* kT = qT + 64 * LDP;                               // [64][LDP]
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int b = blockIdx.x / a.nsplit, sp = blockIdx.x % a.nsplit;
     const int HW = a.H * a.W, tiles = HW / 64, tpw = tiles / a.nsplit;
     const long img = (long)b * HW;

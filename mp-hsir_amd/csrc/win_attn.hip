@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
     float* rpbs = reinterpret_cast<float*>(Ps + CF::PS);
     int* reg = reinterpret_cast<int*>(rpbs + 225);
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int nwx = a.W >> 3, nW = (a.H >> 3) * nwx;
     const int b = blockIdx.x / nW, wi = blockIdx.x % nW, wy = wi / nwx, wx = wi % nwx;
     const T* X = reinterpret_cast<const T*>(a.X);

@@ -539,7 +539,7 @@ def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_g
     # the 1x1 conv is counted on the pixels it is useful for (the halo recompute is overhead, not work)
     _acct("qkv_dwconv_gram", M * (6.0 * C * C + 54.0 * C + 2.0 * C * hd), 2.0 * M * C * x.element_size() + wqkv.numel() * x.element_size()
           + gp.numel() * 4 + sp.numel() * 4)
-    _acct("dwconv_gram:qk", 2.0 * M * C * hd, 0.0)
+    _acct("qkv_dwconv_gram:qk", 2.0 * M * C * hd, 0.0)
     return v, gp, sp, nsplit
 
 
