@@ -117,8 +117,11 @@ def _pgsstb_attn_infer(blk, k1, x):
     pk = blk.packed(dt)
     sp = blk.gobal_spectral_attn.packed(dt)
     heads, shift = blk.num_heads, blk.shift_size
-    sa, gate = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"], pk["bproj"],
-                                pk["pg"], heads, shift)
+    sa, mu, _ = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"], pk["bproj"],
+                                 pk["pg"], heads, shift, gate=False)
+    # (no side branch for the gate here: beside the fused pass A, whose workgroups fill the LDS of every CU, it costs 2 % of the
+    # 512x512 forward instead of saving time)
+    gate = ops.pg_gate_fwd(mu, pk["pg"])
     sa2 = sa.reshape(-1, Cc)
     v, gp, spart = _pass_a_infer(sa2, sp["wqkv"], sp["w9"], B, H, W, Cc, heads)
     Mb = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt)
@@ -145,14 +148,17 @@ class _PgsstbAttn(torch.autograd.Function):
         sp = blk.gobal_spectral_attn.packed(dt)
         heads, shift = blk.num_heads, blk.shift_size
         w9 = sp["w9"]
-        sa, gate, mu, oattn = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"],
-                                               pk["bproj"], pk["pg"], heads, shift, save=True)
+        sa, mu, oattn = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"],
+                                         pk["bproj"], pk["pg"], heads, shift, save=True, gate=False)
+        with ops.side_stream(sa, ops.SIDE_BRANCH) as br:      # the prompt gate (few workgroups, latency-bound) runs beside pass A
+            gate = ops.pg_gate_fwd(mu, pk["pg"])
         sa2 = sa.reshape(-1, Cc)
         t = ops.gemm_tok(sa2, sp["wqkv"])
         # q | k after the depthwise conv are kept for the backward (2C values per token: cheaper than recomputing them)
         v, gp, spart, _, qk = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
                                               3 * Cc, B, H, W, Cc, heads, keep_qk=True)
         Mb, MbT, gp, spart = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt, transposed=True)   # keep the sums, drop the partials
+        br.join()
         y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
         ctx.blk, ctx.k1 = blk, k1
         ctx.has_qk = qk is not None
@@ -174,6 +180,11 @@ class _PgsstbAttn(torch.autograd.Function):
         with ops.reduce_scope():      # every split partial of this backward is summed by ONE launch when the scope exits
             # (1) branch sum  y = x + keep*(sa*gate + out)
             d_out, d_sa, dgate = ops.combine_bwd(dy, sa, gate, k1, shift)
+            # (3, issued first on a side branch) local spectral-prompt gate: one launch per block + one token-reduction GEMM
+            # over the windows.  Factor rows in the compute dtype ride in the grouped 16-bit GEMM launch; fp16's narrow exponent
+            # would flush the gate's tiny d-logits (w ~ 1/128 of an already small gradient), so that path keeps them in fp32
+            with ops.side_stream(dy, ops.SIDE_BRANCH) as br:
+                dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=torch.float32 if dt == torch.float16 else dt)
             # (2) global spectral attention
             t4 = t.reshape(B, H, W, 3 * Cc)
             w9 = sp["w9"]
@@ -187,11 +198,8 @@ class _PgsstbAttn(torch.autograd.Function):
                 dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
             d_sa = ops.gemm_tok(dt3, sp["wqkvT"], epi=1, res=d_sa.reshape(M, Cc))    # + dt Wqkv  (1x1 conv backward)
             d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
-            # (3) local spectral-prompt gate: one launch per block + one token-reduction GEMM over the windows
-            # factor rows in the compute dtype ride in the grouped 16-bit GEMM launch; fp16's narrow exponent would flush the
-            # gate's tiny d-logits (w ~ 1/128 of an already small gradient), so that path keeps them in fp32
-            dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=torch.float32 if dt == torch.float16 else dt)
             dpg = tuple(gpg[k].reshape(getattr_path(blk.local_spectral_attn, k).shape) for k in _PG_KEYS)
+            br.join()
             # (4) window attention core
             dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
                                                      pk["rpb"], pk["wprojT"], heads, shift)

@@ -46,10 +46,18 @@ def _check(*tensors):
 
 # ---- side stream: small latency-bound kernels (64-256 workgroups) run beside the big streaming ones ------------------
 _SIDE = {}
-# Off by default: measured on MI355X (tools/bench_fork.py, graph-replay trace) the fold backward does overlap the
-# depthwise recompute (71 % of its time), but the cross-queue edges of the forked graph cost as much as that saves
-# (whole step 34.12 ms either way).  MPHSIR_SIDE_STREAM=1 enables it.
+# Two users, measured separately on MI355X (graph replay, bench.py):
+#  * the prompt gate (MPHSIR_SIDE_BRANCH, default ON): pg_gate_fwd / pg_gate_bwd run 128..2048 windows in 16-window
+#    workgroups -- a few dozen to 128 workgroups for 20-45 us, most of the chip idle -- and nothing needs their output until
+#    the branch sum / the window-attention backward.  Forked beside pass A (forward) / the channel-attention backward:
+#    1159.5 -> 1182.4 patches/s.
+#  * the fold backward (MPHSIR_SIDE_STREAM, default off): it does overlap the dv GEMM, but there is too little independent
+#    work before its consumer; whole step unchanged (tools/bench_fork.py, round 1).
+# Allocation stays stream-safe without record_stream on the inputs: tensors created inside the branch belong to the side
+# stream's pool, every branch starts by waiting for the launch stream (a reused block is ordered after its last consumer
+# there), and the caller holds the inputs until the join.
 USE_SIDE_STREAM = os.environ.get("MPHSIR_SIDE_STREAM", "0") == "1"
+SIDE_BRANCH = os.environ.get("MPHSIR_SIDE_BRANCH", "1") == "1"
 
 
 class side_stream:
@@ -58,8 +66,8 @@ class side_stream:
     (record_stream).  Works under hipGraph capture (fork/join from the capturing stream = parallel graph branches).
     No-op on CPU tensors (emulator) or when disabled."""
 
-    def __init__(self, like):
-        self.on = USE_SIDE_STREAM and like.is_cuda
+    def __init__(self, like, enabled=None):
+        self.on = (USE_SIDE_STREAM if enabled is None else enabled) and like.is_cuda
         self.ctx = None
         if self.on:
             dev = like.device
@@ -406,10 +414,11 @@ def pack_win_proj(proj_w, heads, dtype):
     return out.reshape(C, heads * hdp)
 
 
-def win_attn_fwd(x, ln_w, ln_b, Wqkv, bqkv, rpb, Wproj, bproj, pg, heads, shift, save=False):
+def win_attn_fwd(x, ln_w, ln_b, Wqkv, bqkv, rpb, Wproj, bproj, pg, heads, shift, save=False, gate=True):
     """x (B,H,W,C) contiguous.  pg = dict of the fp32 local_spectral_attn parameters.
     Returns (sa (B,H,W,C), gate (B*nW, C) fp32) and, with save=True, also (mu (B*nW,C) fp32, o_attn [B*nW*64][C] in
-    window-token order).  Two launches: the window attention (which also emits the window means) and the gate."""
+    window-token order).  Two launches: the window attention (which also emits the window means) and the gate.
+    gate=False: only the first launch -> (sa, mu, o_attn or None); the caller runs pg_gate_fwd(mu, pg) itself (side branch)."""
     lib = _lib.load()
     _check(x, Wqkv, Wproj, *pg.values())
     B, H, W, C = x.shape
@@ -428,6 +437,8 @@ def win_attn_fwd(x, ln_w, ln_b, Wqkv, bqkv, rpb, Wproj, bproj, pg, heads, shift,
     _lib.check(lib.mphsir_win_attn_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "win_attn_fwd")
     M = B * H * W
     _acct("win_attn", M * (8.0 * C * C + 4.0 * 64 * C), 2.0 * M * C * x.element_size() + mu.numel() * 4 + 4.0 * C * C * x.element_size())
+    if not gate:
+        return sa, mu, oattn
     gate = pg_gate_fwd(mu, pg)
     if save:
         return sa, gate, mu, oattn
