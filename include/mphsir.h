@@ -144,7 +144,7 @@ int mphsir_dwconv_gram_keeps_qk(int32_t C, int32_t W, int dtype);     /* 1 if QK
  * one workgroup = one 8x16-pixel tile + one-pixel halo.  X [B*H*W][ldx]; Wqkv [3C][C] compute dtype; w9 fp32
  * [9][ldw >= 3C] taps of the q | k | v channels; V [B*H*W][ldvo]; Gpart [B][nsplit][heads][hd][hd], Spart
  * [B][nsplit][2][C] fp32 exactly as mphsir_dwconv_gram writes them (nsplit divides (H/8)*(W/16)), so
- * mphsir_spectral_fold and pass B follow unchanged.  Training keeps the two-kernel path (its backward needs t, q, k).
+ * mphsir_spectral_fold and pass B follow unchanged.  Training passes T and QK to keep what its backward needs.
  * mphsir_qkv_dwconv_gram_fits: 1 if (C, heads, H, W, dtype) is covered (H % 8 == 0, W % 16 == 0, instantiated width). */
 typedef struct mphsir_fused_gram_args {
     const void* X; int64_t ldx;
@@ -156,6 +156,8 @@ typedef struct mphsir_fused_gram_args {
     int32_t B, H, W, C, heads, nsplit;
     int32_t head_groups;                    /* 0/1: one workgroup runs all heads of its tiles; g > 1 (divides heads): g workgroups
                                                per tile set, heads/g heads each (small images: more workgroups)          */
+    void* T; int64_t ldt;                   /* optional, both or neither (training): t = qkv(LN(x)) [B*H*W][ldt >= 3C] and    */
+    void* QK; int64_t ldqk;                 /* q | k after the depthwise conv [B*H*W][ldqk >= 2C], kept for the backward      */
 } mphsir_fused_gram_args;
 int mphsir_qkv_dwconv_gram(const mphsir_fused_gram_args* a, int dtype, void* stream);
 int mphsir_qkv_dwconv_gram_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype);

@@ -55,7 +55,8 @@ class FusedGramArgs(ctypes.Structure):
     """mirror of struct mphsir_fused_gram_args"""
     _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("Wqkv", c_void_p), ("w9", c_void_p),
                 ("ldw", c_int64), ("V", c_void_p), ("ldvo", c_int64), ("Gpart", c_void_p), ("Spart", c_void_p)] + \
-               [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nsplit", "head_groups")]
+               [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nsplit", "head_groups")] + \
+               [("T", c_void_p), ("ldt", c_int64), ("QK", c_void_p), ("ldqk", c_int64)]
 
 
 class FoldArgs(ctypes.Structure):

@@ -153,10 +153,14 @@ class _PgsstbAttn(torch.autograd.Function):
         with ops.side_stream(sa, ops.SIDE_BRANCH) as br:      # the prompt gate (few workgroups, latency-bound) runs beside pass A
             gate = ops.pg_gate_fwd(mu, pk["pg"])
         sa2 = sa.reshape(-1, Cc)
-        t = ops.gemm_tok(sa2, sp["wqkv"])
-        # q | k after the depthwise conv are kept for the backward (2C values per token: cheaper than recomputing them)
-        v, gp, spart, _, qk = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
-                                              3 * Cc, B, H, W, Cc, heads, keep_qk=True)
+        # pass A; t and q | k after the depthwise conv are kept for the backward (q|k: 2C values per token, cheaper than
+        # recomputing them).  One fused launch where the kernel covers the shape, else 1x1 GEMM + depthwise/Gram kernel.
+        if ops.FUSED_TRAIN and ops.qkv_dwconv_gram_fits(Cc, heads, H, W, dt):
+            v, gp, spart, _, t, qk = ops.qkv_dwconv_gram(sa2, sp["wqkv"], w9, B, H, W, Cc, heads, keep=True)
+        else:
+            t = ops.gemm_tok(sa2, sp["wqkv"])
+            v, gp, spart, _, qk = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
+                                                  3 * Cc, B, H, W, Cc, heads, keep_qk=True)
         Mb, MbT, gp, spart = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt, transposed=True)   # keep the sums, drop the partials
         br.join()
         y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
@@ -304,18 +308,23 @@ class _SelfChannelAttnRes(torch.autograd.Function):
         dt = t2.dtype
         pa = attn.packed(dt)
         w9 = pa["w9"]
-        q = ops.gemm_tok(t2, pa["wqkv"], ln=ln.pair())
-        v, gp, sp, _ = ops.dwconv_gram(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
-                                       B, H, W, D, attn.num_heads)
+        if ops.FUSED_TRAIN and ops.qkv_dwconv_gram_fits(D, attn.num_heads, H, W, dt):
+            v, gp, sp, _, q, qk = ops.qkv_dwconv_gram(t2, pa["wqkv"], w9, B, H, W, D, attn.num_heads, ln=ln.pair(), keep=True)
+        else:
+            q = ops.gemm_tok(t2, pa["wqkv"], ln=ln.pair())
+            v, gp, sp, _, qk = ops.dwconv_gram(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
+                                               B, H, W, D, attn.num_heads, keep_qk=True)
         Mb, MbT, gp, sp = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
         a = ops.gemm_tok(v, Mb, epi=1, res=t2)
         ctx.attn, ctx.ln, ctx.geom = attn, ln, geom
-        ctx.save_for_backward(t2, q, v, gp, sp, Mb, MbT)
+        ctx.has_qk = qk is not None
+        ctx.save_for_backward(t2, q, v, gp, sp, Mb, MbT, *([qk] if qk is not None else []))
         return a
 
     @staticmethod
     def backward(ctx, da):
-        t2, q, v, gp, sp, Mb, MbT = ctx.saved_tensors
+        t2, q, v, gp, sp, Mb, MbT = ctx.saved_tensors[:7]
+        qk = ctx.saved_tensors[7] if ctx.has_qk else None
         attn, ln, (B, H, W) = ctx.attn, ctx.ln, ctx.geom
         D = t2.shape[1]
         M = t2.shape[0]
@@ -326,7 +335,7 @@ class _SelfChannelAttnRes(torch.autograd.Function):
         with ops.reduce_scope():      # every split partial of this backward is summed by ONE launch when the scope exits
             dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
                 da, q4[..., :D], q4[..., D:2 * D], q4[..., 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
-                attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
+                attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W, qk=qk)
             if dtq.data_ptr() + D * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * D:
                 dt3 = torch.as_strided(dtq, (M, 3 * D), (3 * D, 1))
             else:

@@ -21,7 +21,8 @@
 // read-modify-write by the same lanes, no atomics, fixed order -> deterministic), so the head loop is a runtime loop
 // and the register budget does not grow with the number of heads.
 //
-// Training keeps the two-kernel path: its backward needs t (depthwise weight gradient) and q,k.
+// Training runs the same kernel with two more outputs, t and q|k (its backward needs t for the depthwise weight gradient
+// and q,k for the Gram backward): x is read once instead of t being written, re-read with its halo and q,k recomputed.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -45,6 +46,8 @@ struct FusedGramDev {
     void* V; long ldvo;
     float* Gpart; float* Spart;
     int B, H, W, nsplit, hgroups;
+    void* Tout; long ldt;                        // training: t = qkv(x) [B*H*W][ldt >= 3C] and q|k after the depthwise conv
+    void* QKout; long ldqk;                      // [B*H*W][ldqk >= 2C], kept for the backward
     unsigned long long* dbg;                     // diagnostics (mphsir_fused_debug): shader-clock stamps of workgroup 0
 };
 static unsigned long long* g_fg_dbg = nullptr;
@@ -75,7 +78,7 @@ template <class T, int C, int HD> struct FgLds {
 
 // OCC = workgroups per CU the register allocation is held to (2 only where the LDS footprint allows two as well); the
 // second launch-bound is waves per SIMD, and one workgroup already puts two there
-template <class T, int C, int HD, bool LN, int OCC>
+template <class T, int C, int HD, bool LN, int OCC, bool KEEP>
 __global__ __launch_bounds__(FG_THREADS, 2 * OCC) void qkv_dwconv_gram_kernel(FusedGramDev a) {
     typedef ElemTraits<T> TR;
     typedef FgLds<T, C, HD> L;
@@ -287,7 +290,10 @@ __global__ __launch_bounds__(FG_THREADS, 2 * OCC) void qkv_dwconv_gram_kernel(Fu
                 for (int r = 0; r < 3; ++r) { cl[r] = tvec(r, 0); cm[r] = tvec(r, 1); }
                 const int pi0 = iy * FG_TW + ix0;
                 T* qdst = (which == 0 ? Qs : Ks) + pi0 * LDQ + sl * SLAB + c4 * 4;
-                T* vdst = V + (img + (long)(ty0 + iy) * a.W + tx0 + ix0) * a.ldvo + c0 + c4 * 4;
+                const long pix0 = img + (long)(ty0 + iy) * a.W + tx0 + ix0;
+                T* vdst = V + pix0 * a.ldvo + c0 + c4 * 4;
+                T* tdst = KEEP ? reinterpret_cast<T*>(a.Tout) + pix0 * a.ldt + which * C + c0 + c4 * 4 : nullptr;
+                T* kdst = KEEP ? reinterpret_cast<T*>(a.QKout) + pix0 * a.ldqk + which * C + c0 + c4 * 4 : nullptr;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -303,6 +309,10 @@ __global__ __launch_bounds__(FG_THREADS, 2 * OCC) void qkv_dwconv_gram_kernel(Fu
                     }
                     if (which < 2) store4<T>(qdst + i * LDQ, o);
                     else store4<T>(vdst + (long)i * a.ldvo, o);
+                    if (KEEP) {                                        // training: the centre tap's t value and q / k go to HBM too
+                        store4<T>(tdst + (long)i * a.ldt, cm[1]);
+                        if (which < 2) store4<T>(kdst + (long)i * a.ldqk, o);
+                    }
 #pragma unroll
                     for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
                 }
@@ -348,22 +358,19 @@ __global__ __launch_bounds__(FG_THREADS, 2 * OCC) void qkv_dwconv_gram_kernel(Fu
     if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[8] = __builtin_amdgcn_s_memtime();
 }
 
-template <class T, int C, int HD, bool LN, int OCC>
+template <class T, int C, int HD, bool LN, int OCC, bool KEEP>
 static int launch_fused_occ(const FusedGramDev& d, hipStream_t s) {
     const size_t shmem = FgLds<T, C, HD>::bytes;
-    allow_big_lds(qkv_dwconv_gram_kernel<T, C, HD, LN, OCC>, shmem);
-    MPHSIR_LAUNCH(MPHSIR_K_QKV_DWCONV_GRAM, (qkv_dwconv_gram_kernel<T, C, HD, LN, OCC>), dim3(d.B * d.nsplit * d.hgroups), dim3(FG_THREADS), shmem, s, d);
+    allow_big_lds(qkv_dwconv_gram_kernel<T, C, HD, LN, OCC, KEEP>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_QKV_DWCONV_GRAM, (qkv_dwconv_gram_kernel<T, C, HD, LN, OCC, KEEP>), dim3(d.B * d.nsplit * d.hgroups), dim3(FG_THREADS), shmem, s, d);
     return MPHSIR_OK;
 }
 
 template <class T, int C, int HD>
 static int launch_fused(const FusedGramDev& d, hipStream_t s) {
-    static const int occ_env = [] { const char* e = getenv("MPHSIR_FUSED_OCC"); return e ? atoi(e) : 0; }();     // tuning aid
-    if constexpr (FgLds<T, C, HD>::bytes <= 80 * 1024) {
-        // two workgroups per CU halve the register budget (128 per wave): taken where that costs few spills
-        if (occ_env == 2 || (occ_env == 0 && C <= 64)) return d.ln_w ? launch_fused_occ<T, C, HD, true, 2>(d, s) : launch_fused_occ<T, C, HD, false, 2>(d, s);
-    }
-    return d.ln_w ? launch_fused_occ<T, C, HD, true, 1>(d, s) : launch_fused_occ<T, C, HD, false, 1>(d, s);
+    // (the t tile alone takes half of LDS: one workgroup of eight waves per CU everywhere)
+    if (d.Tout) return d.ln_w ? launch_fused_occ<T, C, HD, true, 1, true>(d, s) : launch_fused_occ<T, C, HD, false, 1, true>(d, s);
+    return d.ln_w ? launch_fused_occ<T, C, HD, true, 1, false>(d, s) : launch_fused_occ<T, C, HD, false, 1, false>(d, s);
 }
 
 // shapes: the 16-bit types at every width / head width of both configurations (+ the small test nets); fp32 (the
@@ -424,8 +431,12 @@ extern "C" int mphsir_qkv_dwconv_gram(const mphsir_fused_gram_args* a, int dtype
     MPHSIR_REQUIRE((a->ln_w == nullptr) == (a->ln_b == nullptr), "qkv_dwconv_gram: ln_w and ln_b go together");
     const int hgroups = a->head_groups > 0 ? a->head_groups : 1;
     MPHSIR_REQUIRE(a->heads % hgroups == 0, "qkv_dwconv_gram: head_groups=%d must divide heads=%d", hgroups, a->heads);
+    MPHSIR_REQUIRE((a->T == nullptr) == (a->QK == nullptr), "qkv_dwconv_gram: T and QK (the training outputs) go together");
+    if (a->T)
+        MPHSIR_REQUIRE(aligned16(a->T) && aligned16(a->QK) && (a->ldt * esz) % 16 == 0 && (a->ldqk * esz) % 16 == 0 && a->ldt >= 3 * a->C &&
+                           a->ldqk >= 2 * a->C, "qkv_dwconv_gram: T / QK must be 16-byte aligned with ldt >= 3C, ldqk >= 2C");
     FusedGramDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->Wqkv, a->w9, (long)a->ldw, a->V, (long)a->ldvo, a->Gpart, a->Spart,
-                   a->B, a->H, a->W, a->nsplit, hgroups, g_fg_dbg};
+                   a->B, a->H, a->W, a->nsplit, hgroups, a->T, (long)a->ldt, a->QK, (long)a->ldqk, g_fg_dbg};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return MPHSIR_DISPATCH_T(dtype, (FusedShapes<T_>::run(d, a->C, a->C / a->heads, s)));
 }

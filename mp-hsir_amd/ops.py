@@ -507,6 +507,10 @@ def dwconv_gram(tq, tk, tv, wq, wk, wv, ldw, B, H, W, C, heads, nsplit=None, kee
     return v, gp, sp, nsplit
 
 
+# training forward through the fused pass A (t and q|k as extra outputs); MPHSIR_FUSED_TRAIN=0 = 1x1 GEMM + depthwise/Gram kernel
+FUSED_TRAIN = os.environ.get("MPHSIR_FUSED_TRAIN", "1") == "1"
+
+
 def qkv_dwconv_gram_fits(C, heads, H, W, dtype):
     return bool(_lib.load().mphsir_qkv_dwconv_gram_fits(C, heads, H, W, _DT[dtype]))
 
@@ -527,9 +531,10 @@ def choose_head_groups(B, nsplit, heads):
     return g
 
 
-def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_groups=None):
-    """Fused inference pass A: x (M, >=C) row-major view, wqkv (3C, C) in x.dtype, w9 fp32 (9, >=3C) taps of q|k|v,
-    ln = (weight, bias) fp32 or None.  Returns (v (M,C), Gpart, Spart, nsplit) like dwconv_gram(gemm_tok(x, wqkv))."""
+def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_groups=None, keep=False):
+    """Fused pass A: x (M, >=C) row-major view, wqkv (3C, C) in x.dtype, w9 fp32 (9, >=3C) taps of q|k|v,
+    ln = (weight, bias) fp32 or None.  Returns (v (M,C), Gpart, Spart, nsplit) like dwconv_gram(gemm_tok(x, wqkv));
+    keep=True (training) appends t = qkv(LN(x)) (M,3C) and q|k after the depthwise conv (M,2C)."""
     lib = _lib.load()
     _check(x, wqkv, w9)
     M, ldx = _rows(x)
@@ -546,11 +551,18 @@ def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_g
     a.V, a.ldvo, a.Gpart, a.Spart = _p(v), C, _p(gp), _p(sp)
     a.B, a.H, a.W, a.C, a.heads, a.nsplit = B, H, W, C, heads, nsplit
     a.head_groups = head_groups or choose_head_groups(B, nsplit, heads)
+    t = qk = None
+    if keep:
+        t = torch.empty((M, 3 * C), dtype=x.dtype, device=x.device)
+        qk = torch.empty((M, 2 * C), dtype=x.dtype, device=x.device)
+        a.T, a.ldt, a.QK, a.ldqk = _p(t), 3 * C, _p(qk), 2 * C
     _lib.check(lib.mphsir_qkv_dwconv_gram(ctypes.byref(a), _DT[x.dtype], _stream(x)), "qkv_dwconv_gram")
     # the 1x1 conv is counted on the pixels it is useful for (the halo recompute is overhead, not work)
-    _acct("qkv_dwconv_gram", M * (6.0 * C * C + 54.0 * C + 2.0 * C * hd), 2.0 * M * C * x.element_size() + wqkv.numel() * x.element_size()
-          + gp.numel() * 4 + sp.numel() * 4)
+    _acct("qkv_dwconv_gram", M * (6.0 * C * C + 54.0 * C + 2.0 * C * hd), (7.0 if keep else 2.0) * M * C * x.element_size()
+          + wqkv.numel() * x.element_size() + gp.numel() * 4 + sp.numel() * 4)
     _acct("qkv_dwconv_gram:qk", 2.0 * M * C * hd, 0.0)
+    if keep:
+        return v, gp, sp, nsplit, t, qk
     return v, gp, sp, nsplit
 
 

@@ -179,6 +179,14 @@ def check_fused_pass_a(dev, dtype, C, heads, shape, nsplit, ln, hgroups=None):
     tol = TOL[dtype]
     assert rel_l2(v, v0) < tol
     assert rel_l2(gp.double().sum(1), gp0.double().sum(1)) < tol and rel_l2(sp.double().sum(1), sp0.double().sum(1)) < tol
+    # training form: the same launch also keeps t and q|k; v and the partials must not change (bitwise)
+    v2, gp2, sp2, _, tk, qk = ops.qkv_dwconv_gram(x2, wqkv, w9, B, H, W, C, heads, ln=lnp, nsplit=nsplit, head_groups=hgroups, keep=True)
+    assert torch.equal(v2.cpu(), v.cpu()) and torch.equal(gp2.cpu(), gp.cpu()) and torch.equal(sp2.cpu(), sp.cpu())
+    assert rel_l2(tk, t) < tol
+    _, _, _, _, qk0 = ops.dwconv_gram(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], w9[:, :C], w9[:, C:2 * C], w9[:, 2 * C:], 3 * C, B, H, W, C, heads,
+                                      keep_qk=True)
+    if qk0 is not None:
+        assert rel_l2(qk, qk0) < tol
     temp, wo = P["temperature"].reshape(heads).contiguous(), P["project_out.weight"].reshape(C, C).contiguous()
     y = ops.gemm_tok(v, ops.spectral_fold(gp, sp, temp, wo, dtype))
     Pd = {k: v_.double().cpu() for k, v_ in P.items()}
