@@ -69,11 +69,18 @@ template <class T, int C, int HD> struct FgLds {
     // floats: strips that differ by 8 pixels land 32 banks apart, 16 lanes of a ds_read_b128 cover all 64 banks once.
     static constexpr int LDW = KS + PAD, LDT = 3 * SLAB + 4, LDQ = HD + PAD;
     static constexpr size_t w_elems = (size_t)3 * SLAB * LDW, qk_elems = (size_t)2 * FG_PIX * LDQ;
-    // one slab per head: the q|k tiles reuse the weight stage (dead once t is complete); several: both stay live
-    static constexpr size_t a_elems = NSL == 1 ? (w_elems > qk_elems ? w_elems : qk_elems) : w_elems + qk_elems;
-    static constexpr size_t qk_off = NSL == 1 ? 0 : w_elems;
     static constexpr size_t t_floats = (size_t)FG_MB * 16 * LDT;
-    static constexpr size_t bytes = a_elems * sizeof(T) + (t_floats + (size_t)27 * SLAB) * sizeof(float);
+    // EARLY (one K stage, and LDS has room for weights AND q|k tiles side by side): the next slab's weights and taps go to LDS
+    // during the depthwise pass of the current one -- the weight stage is dead once t is complete -- so a step has two
+    // barriers instead of four and no store-then-wait phase in front of its MFMAs.  Needs the q|k tiles out of the weight
+    // stage's way and a second tap buffer.
+    static constexpr size_t bytes_early = (w_elems + qk_elems) * sizeof(T) + (t_floats + (size_t)2 * 27 * SLAB) * sizeof(float);
+    static constexpr bool EARLY = (C / KS == 1) && bytes_early <= 160 * 1024;
+    // otherwise, one slab per head: the q|k tiles reuse the weight stage; several slabs: both stay live
+    static constexpr bool SPLIT = EARLY || NSL > 1;
+    static constexpr size_t a_elems = SPLIT ? w_elems + qk_elems : (w_elems > qk_elems ? w_elems : qk_elems);
+    static constexpr size_t qk_off = SPLIT ? w_elems : 0;
+    static constexpr size_t bytes = a_elems * sizeof(T) + (t_floats + (size_t)(EARLY ? 2 : 1) * 27 * SLAB) * sizeof(float);
 };
 
 // OCC = workgroups per CU the register allocation is held to (2 only where the LDS footprint allows two as well); the
@@ -143,15 +150,26 @@ __global__ __launch_bounds__(FG_THREADS, 2 * OCC) void qkv_dwconv_gram_kernel(Fu
             if (idx < 27 * SLAB) tpre[i] = a.w9[(idx / (3 * SLAB)) * a.ldw + ((idx % (3 * SLAB)) / SLAB) * C + c0 + idx % SLAB];
         }
     };
-    auto tstore = [&]() __attribute__((always_inline)) {
+    auto tstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NTP; ++i) {
             const int idx = tid + FG_THREADS * i;
-            if (idx < 27 * SLAB) tapsS[idx] = tpre[i];
+            if (idx < 27 * SLAB) tapsS[buf * 27 * SLAB + idx] = tpre[i];
         }
     };
+    constexpr bool EARLY = L::EARLY;
+    // c0 of flattened step g = (tile - first tile) * nstep + step of this workgroup
+    const int gsteps = tpw * nstep;
+    auto c0_of = [&](int g) { const int st_ = g % nstep; return (h0 + st_ / NSL) * HD + (st_ % NSL) * SLAB; };
     wload(h0 * HD, 0);
     tload(h0 * HD);
+    int tapbuf = 0;                 // EARLY: the tap buffer of the current step
+    if (EARLY) {                    // step 0's weights and taps to LDS now, step 1's into the registers
+        wstore();
+        tstore(0);
+        if (gsteps > 1) { wload(c0_of(1), 0); tload(c0_of(1)); }
+        __syncthreads();
+    }
 
     for (int tile = sp * tpw; tile < (sp + 1) * tpw; ++tile) {
         const bool first = tile == sp * tpw;
@@ -228,13 +246,15 @@ __global__ __launch_bounds__(FG_THREADS, 2 * OCC) void qkv_dwconv_gram_kernel(Fu
                 for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
-                __syncthreads();          // Ws (with one slab per head also the q|k tiles of the previous head) and the taps are free
-                wstore();
-                if (st == 0) tstore();
-                if (st + 1 < NST) wload(c0, st + 1);
-                else if (step + 1 < nstep) { const int cn = (h0 + (step + 1) / NSL) * HD + ((step + 1) % NSL) * SLAB; wload(cn, 0); tload(cn); }
-                else if (tile + 1 < (sp + 1) * tpw) { wload(h0 * HD, 0); tload(h0 * HD); }
-                __syncthreads();
+                if (!EARLY) {
+                    __syncthreads();      // Ws (with one slab per head also the q|k tiles of the previous head) and the taps are free
+                    wstore();
+                    if (st == 0) tstore(0);
+                    if (st + 1 < NST) wload(c0, st + 1);
+                    else if (step + 1 < nstep) { const int cn = c0_of(step + 1); wload(cn, 0); tload(cn); }
+                    else if (tile + 1 < (sp + 1) * tpw) { wload(h0 * HD, 0); tload(h0 * HD); }
+                    __syncthreads();
+                }
                 if (st == 0) FG_MARK(2);
                 // the weight fragments of the next K-chunk are requested before this chunk's MFMAs are issued.  Waves 0-3 own two
                 // row blocks, waves 4-7 one: ONE scalar branch selects the loop body (a per-MFMA test, even a uniform one, puts a
@@ -272,7 +292,9 @@ __global__ __launch_bounds__(FG_THREADS, 2 * OCC) void qkv_dwconv_gram_kernel(Fu
             FG_MARK(4);
 
             // ---- depthwise 3x3 on the LDS tile: q_s, k_s -> LDS tiles, v_s -> HBM.  One thread = (q|k|v, 4 channels, strip
-            // of 8 pixels): 16-byte LDS reads, a sliding 3x3 window, 36 taps + 4 accumulators in registers.
+            // of 8 pixels): 16-byte LDS reads, a sliding 3x3 window, 36 taps + 4 accumulators in registers.  (Two output rows per
+            // thread -- 2.5 instead of 3.75 LDS reads per output -- on half as many waves was measured slower: 3800 against 3000
+            // cycles; with one wave per SIMD the longer per-thread chains are latency-bound.)
 #pragma unroll
             for (int slot = 0; slot < NITEM; ++slot) {
                 const int it = tid + FG_THREADS * slot;
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(FG_THREADS, 2 * OCC) void qkv_dwconv_gram_kernel(Fu
                 const int which = it / (QPS * FG_STRIPS), rem = it % (QPS * FG_STRIPS), c4 = rem % QPS, st = rem / QPS;
                 const int iy = st >> 1, ix0 = (st & 1) * 8;
                 const float* tsrc = Ts + (iy * FG_HW + ix0) * LDT + which * SLAB + c4 * 4;
-                const float* wsrc = tapsS + which * SLAB + c4 * 4;
+                const float* wsrc = tapsS + tapbuf * 27 * SLAB + which * SLAB + c4 * 4;
                 f32x4 w[9];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const f32x4*>(wsrc + t * 3 * SLAB);
@@ -316,6 +338,15 @@ __global__ __launch_bounds__(FG_THREADS, 2 * OCC) void qkv_dwconv_gram_kernel(Fu
 #pragma unroll
                     for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
                 }
+            }
+            if (EARLY) {      // the weight stage is dead (t complete): next step's weights / taps to LDS, the step after into registers
+                const int g = (tile - sp * tpw) * nstep + step;
+                if (g + 1 < gsteps) {
+                    wstore();
+                    tstore(tapbuf ^ 1);
+                    if (g + 2 < gsteps) { wload(c0_of(g + 2), 0); tload(c0_of(g + 2)); }
+                }
+                tapbuf ^= 1;
             }
             FG_MARK(5);
             __syncthreads();
