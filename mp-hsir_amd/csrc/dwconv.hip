@@ -5,6 +5,8 @@
 // net/MP_HSIR.py:92,227,230,257,382): d/dx of a depthwise correlation is the depthwise correlation of
 // dy with the spatially flipped taps; d/dw[tap][c] = sum over pixels of x[pixel+tap][c] * dy[pixel][c].
 // Pure HBM/L2 streaming: 16 B per lane along the channel axis, fp32 accumulation.
+#include <stdlib.h>
+
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
 
@@ -63,6 +65,99 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(DwDev a) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
     }
+}
+
+// ---- tile form (16-bit types, H % 8 == 0, W % 16 == 0, C % 32 == 0) ------------------------------------------------------
+// One workgroup (8 waves) = an 8x16-pixel tile + one-pixel halo x a slab of up to 96 channels.  The halo tile goes to LDS as
+// fp32 through coalesced 16-byte loads that are all in flight at once (the strip form above issues 30 dependent-use loads per
+// thread through L1), each element is unpacked ONCE (the strip form unpacks it 3.75 times), and the 3x3 window slides over
+// LDS (f32x4 reads, fma chains) exactly as in the fused spectral pass A (spectral_fused.hip).  Two workgroups per CU.
+constexpr int DT_TH = 8, DT_TW = 16, DT_HW = DT_TW + 2, DT_ROWS = (DT_TH + 2) * DT_HW, DT_CS = 96, DT_LD = DT_CS + 4;
+constexpr int DT_THREADS = 512;
+
+template <class T>
+__global__ __launch_bounds__(DT_THREADS, 4) void dwconv3x3_tile_kernel(DwDev a) {
+    constexpr int VEC = Vec16<T>::N;                       // 8
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    float* Ts = reinterpret_cast<float*>(smem_v);          // [180][DT_LD]
+    float* taps = Ts + DT_ROWS * DT_LD;                    // [9][DT_CS]
+    const int tid = threadIdx.x;
+    const int tilesx = a.W / DT_TW, tiles = (a.H / DT_TH) * tilesx, nslab = (a.C + DT_CS - 1) / DT_CS;
+    const long blk = (gridDim.x & 7) == 0 ? xcd_contiguous_block() : (long)blockIdx.x;
+    if (blk >= (long)a.B * tiles * nslab) return;
+    const int tile = (int)(blk % tiles), slab = (int)((blk / tiles) % nslab), b = (int)(blk / ((long)tiles * nslab));
+    const int ty0 = (tile / tilesx) * DT_TH, tx0 = (tile % tilesx) * DT_TW;
+    const int cs0 = slab * DT_CS, cw = (a.C - cs0) < DT_CS ? (a.C - cs0) : DT_CS, vpr = cw / VEC;
+    const T* X = reinterpret_cast<const T*>(a.X) + (long)b * a.H * a.W * a.ldx + cs0;
+    T* Y = reinterpret_cast<T*>(a.Y) + (long)b * a.H * a.W * a.ldy + cs0;
+
+    // ---- stage: halo pixels x channel vectors, every load requested before the first is used.  (A capped, persistent grid
+    // with the next tile-slab's loads in flight during the pass was measured no faster: with two workgroups per CU the stage
+    // of one already overlaps the pass of the other.)
+    constexpr int NV = (DT_ROWS * (DT_CS / VEC) + DT_THREADS - 1) / DT_THREADS;       // 5
+    Vec16<T> xv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + DT_THREADS * i, r = idx / vpr, v = idx % vpr;
+        const int y = ty0 - 1 + r / DT_HW, x = tx0 - 1 + r % DT_HW;
+        if (r < DT_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W) xv[i] = load16<T>(X + ((long)y * a.W + x) * a.ldx + v * VEC);
+        else xv[i] = Vec16<T>{};
+    }
+    for (int i = tid; i < 9 * cw; i += DT_THREADS) {
+        const int t = i / cw, c = i % cw;
+        taps[t * DT_CS + c] = a.w9[(a.flip ? 8 - t : t) * a.ldw + cs0 + c];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + DT_THREADS * i, r = idx / vpr, v = idx % vpr;
+        if (r < DT_ROWS) {
+            float* dst = Ts + r * DT_LD + v * VEC;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{xv[i].get(0), xv[i].get(1), xv[i].get(2), xv[i].get(3)};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{xv[i].get(4), xv[i].get(5), xv[i].get(6), xv[i].get(7)};
+        }
+    }
+    __syncthreads();
+
+    // ---- 3x3 window over the LDS tile: one thread = 4 channels x a strip of 8 pixels
+    const int qpr = cw / 4, it = tid;
+    if (it < qpr * 16) {
+        const int c4 = it % qpr, st = it / qpr, iy = st >> 1, ix0 = (st & 1) * 8;
+        const float* tsrc = Ts + (iy * DT_HW + ix0) * DT_LD + c4 * 4;
+        f32x4 w[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const f32x4*>(taps + t * DT_CS + c4 * 4);
+        auto tvec = [&](int r, int col) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(tsrc + (r * DT_HW + col) * DT_LD); };
+        f32x4 cl[3], cm[3], cr[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { cl[r] = tvec(r, 0); cm[r] = tvec(r, 1); }
+        T* ydst = Y + ((long)(ty0 + iy) * a.W + tx0 + ix0) * a.ldy + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cr[r] = tvec(r, i + 2);
+            f32x4 o = cl[0] * w[0];
+            o = __builtin_elementwise_fma(cm[0], w[1], o);
+            o = __builtin_elementwise_fma(cr[0], w[2], o);
+#pragma unroll
+            for (int r = 1; r < 3; ++r) {
+                o = __builtin_elementwise_fma(cl[r], w[r * 3], o);
+                o = __builtin_elementwise_fma(cm[r], w[r * 3 + 1], o);
+                o = __builtin_elementwise_fma(cr[r], w[r * 3 + 2], o);
+            }
+            store4<T>(ydst + (long)i * a.ldy, o);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
+        }
+    }
+}
+
+template <class T> static int launch_dw_tile(const DwDev& d, hipStream_t s) {
+    const long nblk = (long)d.B * (d.H / DT_TH) * (d.W / DT_TW) * ((d.C + DT_CS - 1) / DT_CS);
+    const long blocks = (nblk + 7) / 8 * 8;              // multiple of 8: XCD-contiguous order
+    const size_t shmem = ((size_t)DT_ROWS * DT_LD + 9 * DT_CS) * sizeof(float);
+    allow_big_lds(dwconv3x3_tile_kernel<T>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_DWCONV, (dwconv3x3_tile_kernel<T>), dim3((unsigned)blocks), dim3(DT_THREADS), shmem, s, d);
+    return MPHSIR_OK;
 }
 
 struct DwWgDev {
@@ -213,6 +308,9 @@ extern "C" int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int
     MPHSIR_REQUIRE(W % DW_S == 0, "dwconv3x3: W must be a multiple of %d", DW_S);
     const long blocks = (((long)B * H * (W / DW_S) * (C / vec) + 255) / 256 + 7) / 8 * 8;      // multiple of 8: XCD-contiguous order
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const int tile_env = [] { const char* e = getenv("MPHSIR_DW_TILE"); return e ? atoi(e) : 1; }();      // tuning aid: 0 = strip form
+    if (tile_env && dtype != MPHSIR_F32 && H % DT_TH == 0 && W % DT_TW == 0 && C % 32 == 0)
+        return dtype == MPHSIR_BF16 ? launch_dw_tile<bf16_t>(d, s) : launch_dw_tile<f16_t>(d, s);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV, (dwconv3x3_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
     else if (dtype == MPHSIR_BF16)

@@ -14,6 +14,8 @@
 //   spectral_fold per (sample, head): ordered reduction of the partials, F.normalize (eps 1e-12)
 //                 scaling, temperature, row softmax, fold with project_out -> M_b (compute dtype).
 //   pass B        is mphsir_gemm_tok with the per-sample weight M_b (epi 2 adds the PGSSTB branch sum).
+#include <stdlib.h>
+
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
 
@@ -449,6 +451,116 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(GateDev a) {
     }
 }
 
+// Tile form of the GDFN middle (16-bit types, H % 8 == 0, W % 16 == 0): the scheme of dwconv3x3_tile_kernel (dwconv.hip) --
+// an 8x16-pixel tile + halo of 48 gelu-side and their 48 partner channels staged in LDS as fp32 through coalesced loads
+// that are all in flight at once, each element unpacked once, the 3x3 window sliding over LDS.  The strip form above
+// ran at 1.6 TB/s (30 dependent-use loads per thread and half through L1).
+constexpr int GT2_TH = 8, GT2_TW = 16, GT2_HW = GT2_TW + 2, GT2_ROWS = (GT2_TH + 2) * GT2_HW, GT2_CH = 48, GT2_LD = 2 * GT2_CH + 4;
+constexpr int GT2_THREADS = 512;
+
+template <class T>
+__global__ __launch_bounds__(GT2_THREADS, 4) void dwconv_gate_tile_kernel(GateDev a) {
+    constexpr int VEC = Vec16<T>::N;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    float* Ts = reinterpret_cast<float*>(smem_v);          // [180][GT2_LD]: 48 gelu-side channels | their 48 partners
+    float* taps = Ts + GT2_ROWS * GT2_LD;                  // [9][96]
+    const int tid = threadIdx.x;
+    const int tilesx = a.W / GT2_TW, tiles = (a.H / GT2_TH) * tilesx, nslab = (a.HP + GT2_CH - 1) / GT2_CH;
+    const long blk = (gridDim.x & 7) == 0 ? xcd_contiguous_block() : (long)blockIdx.x;
+    if (blk >= (long)a.B * tiles * nslab) return;
+    const int tile = (int)(blk % tiles), slab = (int)((blk / tiles) % nslab), b = (int)(blk / ((long)tiles * nslab));
+    const int ty0 = (tile / tilesx) * GT2_TH, tx0 = (tile % tilesx) * GT2_TW;
+    const int cs0 = slab * GT2_CH, cw = (a.HP - cs0) < GT2_CH ? (a.HP - cs0) : GT2_CH, vph = cw / VEC, vpr = 2 * vph;
+    const T* Tin = reinterpret_cast<const T*>(a.Tin) + (long)b * a.H * a.W * a.ldt;
+    T* U = reinterpret_cast<T*>(a.U) + (long)b * a.H * a.W * a.ldu + cs0;
+
+    constexpr int NV = (GT2_ROWS * (2 * GT2_CH / VEC) + GT2_THREADS - 1) / GT2_THREADS;      // 5
+    Vec16<T> xv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + GT2_THREADS * i, r = idx / vpr, v = idx % vpr;
+        const int y = ty0 - 1 + r / GT2_HW, x = tx0 - 1 + r % GT2_HW;
+        const int ch = v < vph ? cs0 + v * VEC : a.HP + cs0 + (v - vph) * VEC;
+        if (r < GT2_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W) xv[i] = load16<T>(Tin + ((long)y * a.W + x) * a.ldt + ch);
+        else xv[i] = Vec16<T>{};
+    }
+    for (int i = tid; i < 9 * 2 * cw; i += GT2_THREADS) {
+        const int t = i / (2 * cw), c = i % (2 * cw);
+        taps[t * 2 * GT2_CH + (c < cw ? c : GT2_CH + c - cw)] = a.w9[t * a.ldw + (c < cw ? cs0 + c : a.HP + cs0 + c - cw)];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + GT2_THREADS * i, r = idx / vpr, v = idx % vpr;
+        if (r < GT2_ROWS) {
+            float* dst = Ts + r * GT2_LD + (v < vph ? v * VEC : GT2_CH + (v - vph) * VEC);
+            *reinterpret_cast<f32x4*>(dst) = f32x4{xv[i].get(0), xv[i].get(1), xv[i].get(2), xv[i].get(3)};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{xv[i].get(4), xv[i].get(5), xv[i].get(6), xv[i].get(7)};
+        }
+    }
+    __syncthreads();
+
+    // one thread = (gelu side | partner side, 4 channels, strip of 8 pixels); the two sides of a channel group sit in
+    // adjacent lanes and meet through one shuffle per output
+    const int qpr = cw / 4;
+    const int it = tid >> 1, side = tid & 1;
+    const bool on = it < qpr * 16;
+    f32x4 res[8];
+    int c4 = 0, iy = 0, ix0 = 0;
+    if (on) {
+        c4 = it % qpr;
+        const int st = it / qpr;
+        iy = st >> 1; ix0 = (st & 1) * 8;
+        const float* tsrc = Ts + (iy * GT2_HW + ix0) * GT2_LD + side * GT2_CH + c4 * 4;
+        f32x4 w[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const f32x4*>(taps + t * 2 * GT2_CH + side * GT2_CH + c4 * 4);
+        auto tvec = [&](int r, int col) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(tsrc + (r * GT2_HW + col) * GT2_LD); };
+        f32x4 cl[3], cm[3], cr[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { cl[r] = tvec(r, 0); cm[r] = tvec(r, 1); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) cr[r] = tvec(r, i + 2);
+            f32x4 o = cl[0] * w[0];
+            o = __builtin_elementwise_fma(cm[0], w[1], o);
+            o = __builtin_elementwise_fma(cr[0], w[2], o);
+#pragma unroll
+            for (int r = 1; r < 3; ++r) {
+                o = __builtin_elementwise_fma(cl[r], w[r * 3], o);
+                o = __builtin_elementwise_fma(cm[r], w[r * 3 + 1], o);
+                o = __builtin_elementwise_fma(cr[r], w[r * 3 + 2], o);
+            }
+            res[i] = o;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) res[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // gelu side (even lane) keeps pixels 0-3 of the strip, the partner side (odd lane) pixels 4-7: each lane sends the other
+    // half of its results across and finishes 4 outputs
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 mine = side ? res[4 + i] : res[i], send = side ? res[i] : res[4 + i];
+        f32x4 other;
+        for (int e = 0; e < 4; ++e) other[e] = __shfl_xor(send[e], 1);
+        const f32x4 g = side ? other : mine, p = side ? mine : other;      // g: gelu-side value, p: partner
+        f32x4 o;
+        for (int e = 0; e < 4; ++e) o[e] = Math<T>::gelu(g[e]) * p[e];
+        if (on) store4<T>(U + ((long)(ty0 + iy) * a.W + tx0 + ix0 + (side ? 4 : 0) + i) * a.ldu + c4 * 4, o);
+    }
+}
+
+template <class T> static int launch_gate_tile(const GateDev& d, hipStream_t s) {
+    const long nblk = (long)d.B * (d.H / GT2_TH) * (d.W / GT2_TW) * ((d.HP + GT2_CH - 1) / GT2_CH);
+    const size_t shmem = ((size_t)GT2_ROWS * GT2_LD + 9 * 2 * GT2_CH) * sizeof(float);
+    allow_big_lds(dwconv_gate_tile_kernel<T>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_tile_kernel<T>), dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(GT2_THREADS), shmem, s, d);
+    return MPHSIR_OK;
+}
+
 template <class T, int C, int HD>
 static int launch_gram(const GramDev& d, hipStream_t s) {
     constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
@@ -547,6 +659,9 @@ extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* st
     const long total = (long)a->B * a->H * (a->W / 8) * (a->HP / (16 / esz));
     const long blocks = ((total + 255) / 256 + 7) / 8 * 8;            // multiple of 8: XCD-contiguous order
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const int tile_env = [] { const char* e = getenv("MPHSIR_DW_TILE"); return e ? atoi(e) : 1; }();      // tuning aid: 0 = strip form
+    if (tile_env && dtype != MPHSIR_F32 && a->H % GT2_TH == 0 && a->W % GT2_TW == 0)
+        return dtype == MPHSIR_BF16 ? launch_gate_tile<bf16_t>(d, s) : launch_gate_tile<f16_t>(d, s);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);
     else if (dtype == MPHSIR_BF16)

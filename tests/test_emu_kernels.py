@@ -65,7 +65,7 @@ def test_gdfn_chain(dtype):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
-@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 5, 8, 96)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 5, 8, 96), (2, 16, 32, 128), (1, 8, 16, 32)])      # the last two: the LDS-tile form (16-bit)
 def test_dwconv_plain(dtype, shape):
     K.check_dwconv_plain("cpu", dtype, shape)
 

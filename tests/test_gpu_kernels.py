@@ -126,7 +126,7 @@ def test_gdfn_chain(dtype):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
-@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 5, 8, 96), (4, 64, 64, 384), (2, 32, 32, 704)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 5, 8, 96), (4, 64, 64, 384), (2, 32, 32, 704), (2, 16, 32, 128), (1, 8, 16, 32)])
 def test_dwconv_plain(dtype, shape):
     K.check_dwconv_plain("cuda", dtype, shape)
 
