@@ -331,6 +331,10 @@ int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int64_t ldw, v
                      int32_t B, int32_t H, int32_t W, int32_t C, int32_t flip, int dtype, void* stream);
 int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY, int64_t lddy, float* partial, int32_t nblk,
                            int32_t B, int32_t H, int32_t W, int32_t C, int dtype, void* stream);
+/* 1 if mphsir_dwconv3x3_wgrad takes its LDS-tile form for this shape (16-bit, H % 8 == 0, W % 16 == 0, C % 32 == 0): workgroup
+ * (b, slab) of the grid (nblk, ceil(C/96)) then walks the 8x16-pixel tiles b, b + nblk, ... -- size nblk for about one workgroup
+ * per CU instead of one partial block per ~128 pixels. */
+int mphsir_dwconv3x3_wgrad_tiled(int32_t H, int32_t W, int32_t C, int dtype);
 
 /* backward of the GDFN gate u = gelu_erf(T[:, :HP]) * T[:, HP:] (FFN/FeedForward.forward :263, :389):
  * given dU [M][HP] writes U (recomputed, for d project_out) and dT [M][2*HP].                          */

@@ -272,6 +272,108 @@ __global__ __launch_bounds__(256) void gdfn_gate_bwd_kernel(GateBwdDev a) {
     }
 }
 
+// ---- tile form of the weight gradient (16-bit types, H % 8 == 0, W % 16 == 0, C % 32 == 0) -----------------------------
+// Workgroup (pblk, slab) walks the 8x16-pixel tiles pblk, pblk + nblk, ... of ALL images for its 96-channel slab: the x halo
+// tile goes through LDS as fp32 exactly as in dwconv3x3_tile_kernel (the next tile's loads are in flight during the pass), a
+// thread = 4 channels x a strip of 8 pixels keeps its 9 tap sums (f32x4 each) in registers across all its tiles, dy comes
+// straight from global (8 bytes per pixel, the lanes of a pixel are contiguous).  One ordered LDS reduction over the 16
+// strips at the end -> part[pblk][9][C]: fixed order, no atomics.
+// (the 9 tap sums, the window and the prefetched vectors want ~170 VGPRs: one workgroup of 8 waves per CU)
+template <class T>
+__global__ __launch_bounds__(DT_THREADS, 2) void dwconv3x3_wgrad_tile_kernel(DwWgDev a) {
+    constexpr int VEC = Vec16<T>::N;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    float* Ts = reinterpret_cast<float*>(smem_v);          // [180][DT_LD]; at the end: [16 strips][9][DT_CS] partial sums
+    const int tid = threadIdx.x;
+    const int tilesx = a.W / DT_TW, tiles = (a.H / DT_TH) * tilesx;
+    const long total = (long)a.B * tiles;
+    const int slab = blockIdx.y, cs0 = slab * DT_CS, cw = (a.C - cs0) < DT_CS ? (a.C - cs0) : DT_CS, vpr = cw / VEC, qpr = cw / 4;
+    const bool on = tid < qpr * 16;
+    const int c4 = tid % qpr, st = tid / qpr, iy = st >> 1, ix0 = (st & 1) * 8;
+    typedef typename ElemTraits<T>::vec4_t v4_t;
+
+    constexpr int NV = (DT_ROWS * (DT_CS / VEC) + DT_THREADS - 1) / DT_THREADS;       // 5
+    Vec16<T> xv[NV];
+    v4_t gy[8];
+    auto gload = [&](long t) __attribute__((always_inline)) {
+        const int b = (int)(t / tiles), tile = (int)(t % tiles);
+        const int ty0 = (tile / tilesx) * DT_TH, tx0 = (tile % tilesx) * DT_TW;
+        const T* X = reinterpret_cast<const T*>(a.X) + (long)b * a.H * a.W * a.ldx + cs0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + DT_THREADS * i, r = idx / vpr, v = idx % vpr;
+            const int y = ty0 - 1 + r / DT_HW, x = tx0 - 1 + r % DT_HW;
+            if (r < DT_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W) xv[i] = load16<T>(X + ((long)y * a.W + x) * a.ldx + v * VEC);
+            else xv[i] = Vec16<T>{};
+        }
+        if (on) {
+            const T* g = reinterpret_cast<const T*>(a.dY) + ((long)b * a.H * a.W + (long)(ty0 + iy) * a.W + tx0 + ix0) * a.lddy + cs0 + c4 * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gy[i] = *reinterpret_cast<const v4_t*>(g + (long)i * a.lddy);
+        }
+    };
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    long t = blockIdx.x;
+    if (t < total) gload(t);
+    for (; t < total; t += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + DT_THREADS * i, r = idx / vpr, v = idx % vpr;
+            if (r < DT_ROWS) {
+                float* dst = Ts + r * DT_LD + v * VEC;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{xv[i].get(0), xv[i].get(1), xv[i].get(2), xv[i].get(3)};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{xv[i].get(4), xv[i].get(5), xv[i].get(6), xv[i].get(7)};
+            }
+        }
+        f32x4 g[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = f32x4{to_f32(gy[i][0]), to_f32(gy[i][1]), to_f32(gy[i][2]), to_f32(gy[i][3])};
+        __syncthreads();
+        if (t + gridDim.x < total) gload(t + gridDim.x);
+        if (on) {
+            const float* tsrc = Ts + (iy * DT_HW + ix0) * DT_LD + c4 * 4;
+            auto tvec = [&](int r, int col) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(tsrc + (r * DT_HW + col) * DT_LD); };
+            f32x4 cl[3], cm[3], cr[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { cl[r] = tvec(r, 0); cm[r] = tvec(r, 1); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) cr[r] = tvec(r, i + 2);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    acc[r * 3] = __builtin_elementwise_fma(cl[r], g[i], acc[r * 3]);
+                    acc[r * 3 + 1] = __builtin_elementwise_fma(cm[r], g[i], acc[r * 3 + 1]);
+                    acc[r * 3 + 2] = __builtin_elementwise_fma(cr[r], g[i], acc[r * 3 + 2]);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
+            }
+        }
+        __syncthreads();           // the tile is free for the next stage (and, after the last tile, for the strip sums)
+    }
+    float* red = Ts;                                       // [16][9][DT_CS]
+    if (on)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) *reinterpret_cast<f32x4*>(red + (st * 9 + tp) * DT_CS + c4 * 4) = acc[tp];
+    __syncthreads();
+    for (int i = tid; i < 9 * cw; i += DT_THREADS) {
+        const int tp = i / cw, c = i % cw;
+        float s = 0.f;
+        for (int k = 0; k < 16; ++k) s += red[(k * 9 + tp) * DT_CS + c];
+        a.part[((long)blockIdx.x * 9 + tp) * a.C + cs0 + c] = s;
+    }
+}
+
+template <class T> static int launch_dw_wgrad_tile(const DwWgDev& d, hipStream_t s) {
+    const size_t shmem = (size_t)DT_ROWS * DT_LD * sizeof(float);       // >= 16 * 9 * DT_CS floats
+    allow_big_lds(dwconv3x3_wgrad_tile_kernel<T>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_DWCONV_WGRAD, (dwconv3x3_wgrad_tile_kernel<T>), dim3(d.nblk, (d.C + DT_CS - 1) / DT_CS), dim3(DT_THREADS), shmem, s, d);
+    return MPHSIR_OK;
+}
+
 }  // namespace mphsir
 
 extern "C" int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void* dT, int64_t M, int32_t HP, int dtype, void* stream) {
@@ -293,6 +395,14 @@ extern "C" int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void
     else
         MPHSIR_LAUNCH(MPHSIR_K_GDFN_GATE_BWD, (gdfn_gate_bwd_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
     return MPHSIR_OK;
+}
+
+extern "C" int mphsir_dwconv3x3_wgrad_tiled(int32_t H, int32_t W, int32_t C, int dtype) {
+    // 1 if mphsir_dwconv3x3_wgrad takes the tile form for this shape: the caller then sizes nblk for one workgroup per CU
+    // over (nblk, ceil(C/96)) instead of one partial block per 128 pixels
+    static const int tile_env = [] { const char* e = getenv("MPHSIR_DW_TILE"); return e ? atoi(e) : 1; }();
+    return (tile_env && (dtype == MPHSIR_BF16 || dtype == MPHSIR_F16) && H > 0 && W > 0 && H % mphsir::DT_TH == 0 && W % mphsir::DT_TW == 0 &&
+            C % 32 == 0) ? 1 : 0;
 }
 
 extern "C" int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int64_t ldw, void* Y, int64_t ldy,
@@ -333,6 +443,8 @@ extern "C" int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY
     const size_t shmem = 64 * 9 * vec * sizeof(float);
     dim3 grid(nblk, (C / vec + 63) / 64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (mphsir_dwconv3x3_wgrad_tiled(H, W, C, dtype))
+        return dtype == MPHSIR_BF16 ? launch_dw_wgrad_tile<bf16_t>(d, s) : launch_dw_wgrad_tile<f16_t>(d, s);
     if (dtype == MPHSIR_F32) {
         allow_big_lds(dwconv3x3_wgrad_kernel<float>, shmem);
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_WGRAD, (dwconv3x3_wgrad_kernel<float>), grid, dim3(256), shmem, s, d);

@@ -718,7 +718,11 @@ def dwconv3x3_wgrad(x, dy, nblk=None, col_ranges=None):
     _check(x, dy)
     B, H, W, C = x.shape
     assert x.stride(3) == 1 and dy.stride(3) == 1 and dy.shape == x.shape
-    nblk = nblk or max(1, min(1024, B * H * W // 128))
+    if nblk is None:
+        if lib.mphsir_dwconv3x3_wgrad_tiled(H, W, C, _DT[x.dtype]):      # LDS-tile form: one workgroup per CU walks the tiles
+            nblk = max(1, min(B * (H // 8) * (W // 16), 256 // ((C + 95) // 96)))
+        else:
+            nblk = max(1, min(1024, B * H * W // 128))
     part = torch.empty((nblk, 9, C), dtype=torch.float32, device=x.device)
     _lib.check(lib.mphsir_dwconv3x3_wgrad(_p(x), x.stride(2), _p(dy), dy.stride(2), _p(part), nblk, B, H, W, C,
                                           _DT[x.dtype], _stream(x)), "dwconv3x3_wgrad")
