@@ -161,6 +161,7 @@ typedef struct mphsir_fused_gram_args {
 } mphsir_fused_gram_args;
 int mphsir_qkv_dwconv_gram(const mphsir_fused_gram_args* a, int dtype, void* stream);
 int mphsir_qkv_dwconv_gram_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype);
+int mphsir_win_debug(void* stamps);     /* the same for mphsir_win_attn_fwd: >= 8 uint64 (tools/bench_win.py) */
 int mphsir_fused_debug(void* stamps);   /* diagnostics: device buffer of >= 9 uint64 that workgroup 0 fills with shader-clock stamps
                                            at its phase boundaries (NULL = off); tools/bench_fused.py */
 typedef struct mphsir_fold_args {

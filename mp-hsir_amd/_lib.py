@@ -141,6 +141,7 @@ _SYMBOLS = {
     "mphsir_qkv_dwconv_gram": (c_int, [ctypes.POINTER(FusedGramArgs), c_int, c_void_p]),
     "mphsir_qkv_dwconv_gram_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int]),
     "mphsir_fused_debug": (c_int, [c_void_p]),
+    "mphsir_win_debug": (c_int, [c_void_p]),
     "mphsir_dwconv3x3_wgrad_tiled": (c_int, [c_int32, c_int32, c_int32, c_int]),
     "mphsir_spectral_fold": (c_int, [ctypes.POINTER(FoldArgs), c_int, c_void_p]),
     "mphsir_dwconv_gate": (c_int, [ctypes.POINTER(GateArgs), c_int, c_void_p]),

@@ -43,8 +43,17 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(RedDev a) {
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (live) {
         if (s.vec) {
-#pragma unroll 4
-            for (int sp = g; sp < s.nsplit; sp += G) acc += *reinterpret_cast<const f32x4*>(src + (long)sp * s.stride);
+            // 8 independent 16-byte loads in flight per lane (the kernel is a latency chain of strided L2 reads), summed in
+            // split order
+            int sp = g;
+            for (; sp + 7 * G < s.nsplit; sp += 8 * G) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (long)(sp + u * G) * s.stride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; sp < s.nsplit; sp += G) acc += *reinterpret_cast<const f32x4*>(src + (long)sp * s.stride);
         } else {
             for (int sp = g; sp < s.nsplit; sp += G)
                 for (int e = 0; e < ne; ++e) acc[e] += src[(long)sp * s.stride + e];

@@ -29,7 +29,10 @@ struct WinAttnDev {
     float* mu;      // [B*nW][C]: window mean of SA = the input of the spectral-prompt gate (mphsir_pg_gate_fwd)
     void* Oattn;    // optional [B*nW*64][C]: attention output before proj, window-token order (training: dWproj)
     int B, H, W, shift;
+    unsigned long long* dbg;    // diagnostics (mphsir_win_debug): shader-clock stamps of workgroup 0 at its phase boundaries
 };
+static unsigned long long* g_win_dbg = nullptr;
+#define WIN_MARK(k) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <class T, int C, int HD> struct WinAttnCfg {
     static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
@@ -75,6 +78,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         return ((long)b * a.H + y) * a.W + x;
     };
 
+    WIN_MARK(0);
     // ---- LayerNorm(norm1) of the 64 tokens into LDS; 4 adjacent lanes per token -----------------
     {
         constexpr int NV = C / VEC, VPT = NV / 4;
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
 
     for (int h = 0; h < CF::HEADS; ++h) {
         __syncthreads();   // Xs ready (h=0) / previous head's K, V^T, bias column no longer read
+        if (h == 0) WIN_MARK(1);
         if (tid < 225) rpbs[tid] = a.rpb[tid * CF::HEADS + h];
         // ---- (a) q, k, v^T for head h ---------------------------------------------------------
         // unit u = (16-channel tile of q|k|v, half of the 64 tokens); a wave walks units u = wv, wv+4, ...  The weight
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
             }
         }
         __syncthreads();
+        if (h == 0) WIN_MARK(2);
 
         // ---- (b) S^T = K Q^T for this wave's 16 queries, + bias + mask, softmax over keys --------
         // the proj fragments of phase (d) (straight from L2, one MFMA each) are requested now: their latency hides
@@ -231,6 +237,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
             store4<T>(Ps + qi * CF::LDP + kt * 16 + (lane >> 4) * 4, p);
         }
         __syncthreads();
+        if (h == 0) WIN_MARK(3);
 
         // ---- (c) O^T = V^T P^T -> O [tok][hd] (over the q tile rows of this wave) ---------------
 #pragma unroll
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
             store4<T>(Qs + qi * CF::LDQ + ct * 16 + (lane >> 4) * 4, o);
         }
         __syncthreads();
+        if (h == 0) WIN_MARK(4);
         if (a.Oattn) {   // training: keep softmax(QK^T)V (before proj) for the proj weight gradient
             constexpr int VPH = HD / VEC;
             T* Oa = reinterpret_cast<T*>(a.Oattn);
@@ -258,8 +266,10 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) mma(out[ct], wpf[kd][ct], of);
         }
+        if (h == 0) WIN_MARK(5);
     }
     __syncthreads();
+    WIN_MARK(6);
 
     // ---- proj bias, stage the 64 x C output tile in LDS (reusing the X tile) --------------------
     {
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         for (int t = 0; t < 64; ++t) acc += to_f32(Xs[t * CF::LDX + c]);
         a.mu[(long)blockIdx.x * C + c] = acc * (1.0f / 64.0f);
     }
+    WIN_MARK(7);
 }
 
 template <class T, int C, int HD>
@@ -316,6 +327,11 @@ extern "C" int mphsir_win_attn_hdp(int head_dim, int dtype) {
     return (head_dim + kc - 1) / kc * kc;
 }
 
+extern "C" int mphsir_win_debug(void* stamps) {      // diagnostics: device buffer of >= 8 uint64 (NULL = off); tools/bench_win.py
+    mphsir::g_win_dbg = reinterpret_cast<unsigned long long*>(stamps);
+    return MPHSIR_OK;
+}
+
 extern "C" int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
@@ -326,7 +342,7 @@ extern "C" int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, voi
     MPHSIR_REQUIRE(a->shift == 0 || a->shift == 4, "win_attn: shift must be 0 or 4");
     MPHSIR_REQUIRE(a->heads > 0 && a->C % a->heads == 0, "win_attn: C %% heads != 0");
     MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->SA) && aligned16(a->Wqkv) && aligned16(a->Wproj), "win_attn: 16-byte alignment required");
-    WinAttnDev d{a->X, a->ln_w, a->ln_b, a->Wqkv, a->bqkv, a->rpb, a->Wproj, a->bproj, a->SA, a->mu, a->Oattn, a->B, a->H, a->W, a->shift};
+    WinAttnDev d{a->X, a->ln_w, a->ln_b, a->Wqkv, a->bqkv, a->rpb, a->Wproj, a->bproj, a->SA, a->mu, a->Oattn, a->B, a->H, a->W, a->shift, g_win_dbg};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return MPHSIR_DISPATCH_T(dtype, (dispatch_win<T_>(d, a->C, a->C / a->heads, s)));
 }
