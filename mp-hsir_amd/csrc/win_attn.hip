@@ -42,7 +42,15 @@ template <class T, int C, int HD> struct WinAttnCfg {
     static constexpr int LDQ = HDP + PAD;
     static constexpr int LDV = 64 + PAD;
     static constexpr int LDP = 64 + PAD;
-    static constexpr size_t XS = 64 * LDX, QS = 64 * LDQ, VS = HD * LDV, PS = 64 * LDP;
+    // the P tile's region doubles as the stage of one part (q, k or v rows of the head) of the qkv weights: P is only live
+    // between the softmax and P V, the weights only while q, k, v are computed
+    static constexpr int LDWS = C + PAD;
+    // rows per weight stage: a whole part (HD rows) where LDS has room for it, else one 16-channel tile at a time
+    static constexpr size_t REST = (64 * LDX + 2 * 64 * LDQ + HD * LDV) * sizeof(T) + (225 + 64) * 4;
+    static constexpr int SR = (REST + (size_t)HD * LDWS * sizeof(T) <= 160 * 1024) ? HD : 16;
+    static constexpr bool STAGE = REST + (size_t)SR * LDWS * sizeof(T) <= 160 * 1024;
+    static constexpr size_t XS = 64 * LDX, QS = 64 * LDQ, VS = HD * LDV,
+                            PS = (!STAGE || 64 * LDP > SR * LDWS) ? 64 * LDP : SR * LDWS;
     static constexpr size_t T_ELEMS = XS + 2 * QS + VS + PS;
     static constexpr size_t F_WORDS = 225 + 64;                      // bias column of one head, region ids
     static constexpr size_t BYTES = T_ELEMS * sizeof(T) + F_WORDS * 4;
@@ -127,15 +135,92 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
 #pragma unroll
     for (int i = 0; i < NCT; ++i) out[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // weight stage: SR rows x C (one part q/k/v of the head, or one 16-channel tile of it where LDS is tight), 16-byte vectors
+    // over all 256 threads, register prefetch one stage ahead
+    constexpr int WVT = CF::SR * (C / VEC), NWV = (WVT + 255) / 256;
+    Vec16<T> wpre[NWV];
+    auto wload = [&](int h, int sub) __attribute__((always_inline)) {       // stage `sub` of head h: rows (sub % (HD/SR)) * SR .. of part sub / (HD/SR)
+        const int row0 = (sub / (HD / CF::SR)) * C + h * HD + (sub % (HD / CF::SR)) * CF::SR;
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < WVT) wpre[i] = load16<T>(Wqkv + (long)(row0 + idx / (C / VEC)) * C + (idx % (C / VEC)) * VEC);
+        }
+    };
+    auto wstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < WVT) store16<T>(Ps + (idx / (C / VEC)) * CF::LDWS + (idx % (C / VEC)) * VEC, wpre[i]);
+        }
+    };
+    if (CF::STAGE) wload(0, 0);
+
     for (int h = 0; h < CF::HEADS; ++h) {
-        __syncthreads();   // Xs ready (h=0) / previous head's K, V^T, bias column no longer read
+        __syncthreads();   // Xs ready (h=0) / previous head's K, V^T, bias column and P tile (= the weight stage) no longer read
         if (h == 0) WIN_MARK(1);
         if (tid < 225) rpbs[tid] = a.rpb[tid * CF::HEADS + h];
+        constexpr int TPW = HD / 16;                 // channel tiles per q/k/v
+        if constexpr (CF::STAGE) {
+        // ---- (a) q, k, v^T for head h ---------------------------------------------------------
+        // The weight rows go through LDS one part (q, k, v) at a time: all 256 threads fetch the NEXT part's HD x C rows from
+        // L2 (coalesced, all in flight) while the current part is multiplied, and store them once its readers are past a
+        // barrier.  (First version: every 4-MFMA unit fetched its own fragments from L2 with a one-unit prefetch -- 5.0 k of the
+        // 8.6 k cycles of a head at C=64, 13.8 k of 23 k at C=128/hd=64, shader-clock stamps of mphsir_win_debug.)
+        // unit u = (16-channel tile of the part, half of the 64 tokens); a wave walks units u = wv, wv+4, ...
+        constexpr int NKC = C / TR::KCHUNK;
+        T* Wst = Ps;                                 // [SR][LDWS]
+        constexpr int SR = CF::SR, NSUB = 3 * HD / SR, TPS = SR / 16;      // stages per head, channel tiles per stage
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int part = sub / (HD / SR), r0 = (sub % (HD / SR)) * SR;   // rows r0.. of q_h / k_h / v_h
+            if (sub > 0) __syncthreads();            // the previous stage's fragments are read
+            wstore();
+            if (sub + 1 < NSUB) wload(h, sub + 1);
+            else if (h + 1 < CF::HEADS) wload(h + 1, 0);
+            __syncthreads();
+            for (int u = wv; u < 2 * TPS; u += 4) {
+                const int ctl = u >> 1, cti = r0 / 16 + ctl, th = u & 1;    // tile inside the stage / inside the head
+                const int wrow = part * C + h * HD + cti * 16;
+                f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+                if (part < 2) {
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        const frag_t w = load_frag<T>(Wst, CF::LDWS, ctl * 16, kc * TR::KCHUNK);
+                        mma(c0, w, load_frag<T>(Xs, CF::LDX, th * 32, kc * TR::KCHUNK));
+                        mma(c1, w, load_frag<T>(Xs, CF::LDX, th * 32 + 16, kc * TR::KCHUNK));
+                    }
+                    const int cr = cti * 16 + (lane >> 4) * 4;        // 4 consecutive channels of the head
+                    const float sc = part == 0 ? scale : 1.f;
+                    for (int r = 0; r < 4; ++r) {
+                        const float bb = a.bqkv[wrow + (lane >> 4) * 4 + r];
+                        c0[r] = (c0[r] + bb) * sc;
+                        c1[r] = (c1[r] + bb) * sc;
+                    }
+                    T* dst = part == 0 ? Qs : Ks;
+                    store4<T>(dst + (th * 32 + (lane & 15)) * CF::LDQ + cr, c0);
+                    store4<T>(dst + (th * 32 + 16 + (lane & 15)) * CF::LDQ + cr, c1);
+                } else {
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        const frag_t w = load_frag<T>(Wst, CF::LDWS, ctl * 16, kc * TR::KCHUNK);
+                        mma(c0, load_frag<T>(Xs, CF::LDX, th * 32, kc * TR::KCHUNK), w);
+                        mma(c1, load_frag<T>(Xs, CF::LDX, th * 32 + 16, kc * TR::KCHUNK), w);
+                    }
+                    const float bb = a.bqkv[wrow + (lane & 15)];
+                    for (int r = 0; r < 4; ++r) { c0[r] += bb; c1[r] += bb; }
+                    T* vrow = Vt + (cti * 16 + (lane & 15)) * CF::LDV + (lane >> 4) * 4;   // 4 consecutive tokens
+                    store4<T>(vrow + th * 32, c0);
+                    store4<T>(vrow + th * 32 + 16, c1);
+                }
+            }
+        }
+        __syncthreads();
+        } else {      // LDS too tight even for a 16-row stage (fp32 at C=384): weight fragments straight from L2
         // ---- (a) q, k, v^T for head h ---------------------------------------------------------
         // unit u = (16-channel tile of q|k|v, half of the 64 tokens); a wave walks units u = wv, wv+4, ...  The weight
         // fragments come straight from L2 and each feeds only two MFMAs, so their latency is the cost of this phase:
         // the next unit's fragments are loaded (second register set) while the current unit runs.
-        constexpr int TPW = HD / 16;                 // channel tiles per q/k/v
         constexpr int NUNITS = 3 * TPW * 2, NKC = C / TR::KCHUNK;
         auto loadw = [&](frag_t (&w)[NKC], int u) __attribute__((always_inline)) {
             if (u < NUNITS) {
@@ -189,6 +274,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
             }
         }
         __syncthreads();
+        }
         if (h == 0) WIN_MARK(2);
 
         // ---- (b) S^T = K Q^T for this wave's 16 queries, + bias + mask, softmax over keys --------
