@@ -115,6 +115,11 @@ template <class T, int C, int HD, bool XL> struct WinBwdCfg {
     static constexpr size_t T_ELEMS = XS + 4 * QS + (ALIAS ? 1 : 2) * SS;
     static constexpr size_t BYTES = T_ELEMS * sizeof(T) + (225 + 64) * 4;
     static constexpr bool FITS = BYTES <= 160 * 1024;
+    // weight stage of phase (a): SR rows x C of q_h / k_h / v_h / proj rows, placed in the dS tile (free until the softmax
+    // backward) -- no LDS growth.  SR = the largest of HD, 32, 16 that divides HD and fits; none: fragments straight from L2.
+    static constexpr int LDWS = C + PAD;
+    static constexpr int SR = (size_t)HD * LDWS <= SS ? HD : (HD % 32 == 0 && (size_t)32 * LDWS <= SS) ? 32 : ((size_t)16 * LDWS <= SS ? 16 : 0);
+    static constexpr bool STAGE = SR > 0;
 };
 
 // X tile in LDS whenever the whole footprint then still allows two workgroups per CU (80 KB each); beyond that the
@@ -203,6 +208,28 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
     T* dQKV = reinterpret_cast<T*>(a.dQKV);
     const float scale = rsqrtf((float)HD);
 
+    // weight stage of phase (a): SR rows x C, 16-byte vectors over all 256 threads, register prefetch one stage ahead
+    constexpr int WSR = CF::STAGE ? CF::SR : 16;
+    constexpr int WVT = WSR * (C / VEC), NWV = (WVT + 255) / 256;
+    Vec16<T> wpre[NWV];
+    auto wload = [&](int h, int sub) __attribute__((always_inline)) {
+        const int which = sub / (HD / WSR), r0 = (sub % (HD / WSR)) * WSR;
+        const T* Wsrc = (which < 3 ? Wqkv + (long)(which * C) * C : WpT) + (long)(h * HD + r0) * C;
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < WVT) wpre[i] = load16<T>(Wsrc + (long)(idx / (C / VEC)) * C + (idx % (C / VEC)) * VEC);
+        }
+    };
+    auto wstore = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < WVT) store16<T>(dS + (idx / (C / VEC)) * CF::LDWS + (idx % (C / VEC)) * VEC, wpre[i]);
+        }
+    };
+    if (CF::STAGE) wload(0, 0);
+
     for (int h = 0; h < CF::HEADS; ++h) {
         __syncthreads();      // h = 0: the side outputs / X tile are visible to the whole workgroup; h > 0: tiles free
         if (CF::ALIAS && CF::HDP != HD)   // P overwrote the zero padding of v
@@ -211,6 +238,64 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
                 Vr[rr * CF::LDQ + cc] = from_f32<T>(0.f);
             }
         if (tid < 225) rpbs[tid] = a.rpb[tid * CF::HEADS + h];
+        if constexpr (CF::STAGE) {
+        // ---- (a) recompute q,k,v and dO_h = d_sa W_proj[:, head] (row-major [tok][hd]) -------------------------------
+        // The weight rows go through LDS (the dS tile, free in this phase) SR rows at a time: all 256 threads fetch the NEXT
+        // stage from L2 (coalesced, all in flight) while the current one is multiplied -- as in win_attn.hip, where per-unit
+        // fragment fetches from L2 were 58 % of a head's time.  unit u = (16-channel tile of the stage, half of the tokens).
+        constexpr int NKC = C / TR::KCHUNK, SR = CF::SR, SPP = HD / SR, NSUB = 4 * SPP, TPS = SR / 16;
+        T* Wst = dS;                                 // [SR][LDWS]
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int which = sub / SPP, r0 = (sub % SPP) * SR;     // 0..2: q, k, v rows of Wqkv; 3: rows of WprojT
+            if (sub > 0) __syncthreads();            // the previous stage's fragments are read
+            wstore();
+            if (sub + 1 < NSUB) wload(h, sub + 1);
+            else if (h + 1 < CF::HEADS) wload(h + 1, 0);
+            __syncthreads();
+            for (int u = wv; u < 2 * TPS; u += 4) {
+                const int ctl = u >> 1, cti = r0 / 16 + ctl, th = u & 1;
+                f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+                const int wrow = (which < 3 ? which * C : 0) + h * HD + cti * 16;
+                if (XL && which < 3) {                   // wave-uniform: LDS operand
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        const frag_t w = load_frag<T>(Wst, CF::LDWS, ctl * 16, kc * TR::KCHUNK);
+                        mma(c0, w, load_frag<T>(Xs, CF::LDX, th * 32, kc * TR::KCHUNK));
+                        mma(c1, w, load_frag<T>(Xs, CF::LDX, th * 32 + 16, kc * TR::KCHUNK));
+                    }
+                } else {                                 // global operand (rows written above by this workgroup)
+                    const T* Bsrc = which < 3 ? Xg : Dg;
+                    frag_t b0[NKC], b1[NKC];
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        b0[kc] = load_frag<T>(Bsrc, C, th * 32, kc * TR::KCHUNK);
+                        b1[kc] = load_frag<T>(Bsrc, C, th * 32 + 16, kc * TR::KCHUNK);
+                    }
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        const frag_t w = load_frag<T>(Wst, CF::LDWS, ctl * 16, kc * TR::KCHUNK);
+                        mma(c0, w, b0[kc]);
+                        mma(c1, w, b1[kc]);
+                    }
+                }
+                const int cr = cti * 16 + (lane >> 4) * 4;
+                if (which < 3) {
+                    const float sc = which == 0 ? scale : 1.f;
+                    for (int r = 0; r < 4; ++r) {
+                        const float bb = a.bqkv[wrow + (lane >> 4) * 4 + r];
+                        c0[r] = (c0[r] + bb) * sc;
+                        c1[r] = (c1[r] + bb) * sc;
+                    }
+                }
+                T* rowm = which == 0 ? Qr : which == 1 ? Kr : which == 2 ? Vr : Or;
+                store4<T>(rowm + (th * 32 + (lane & 15)) * CF::LDQ + cr, c0);
+                store4<T>(rowm + (th * 32 + 16 + (lane & 15)) * CF::LDQ + cr, c1);
+            }
+        }
+        __syncthreads();
+
+        } else {
         // ---- (a) recompute q,k,v and dO_h = d_sa W_proj[:, head] (row-major [tok][hd]) -------------------------------
         // unit u = (16-channel tile of q|k|v|dO, half of the 64 tokens).  The weight fragments come straight from L2 and
         // feed two MFMAs each: the next unit's fragments are loaded into a second register set during the current unit.
@@ -273,6 +358,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
         }
         __syncthreads();
 
+        }
         // ---- (b) P^T (recomputed softmax) and dP^T = V dO^T for this wave's 16 queries -------------------
         f32x4 s[4], dp[4];
 #pragma unroll
