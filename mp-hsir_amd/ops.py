@@ -515,10 +515,15 @@ def qkv_dwconv_gram_fits(C, heads, H, W, dtype):
     return bool(_lib.load().mphsir_qkv_dwconv_gram_fits(C, heads, H, W, _DT[dtype]))
 
 
+# workgroups of the fused pass A: 512 = two per CU-slot of work; measured 1.57 -> 1.45 ms/step against 1024 (each workgroup
+# then walks two tiles with the next slab's weights already in flight), 256 no better
+FUSED_WGS = int(os.environ.get("MPHSIR_FUSED_WGS", "512"))
+
+
 def choose_nsplit_fused(B, H, W):
-    """workgroups per sample for the fused pass A (8x16-pixel tiles): up to ~1024 workgroups in flight."""
+    """workgroups per sample for the fused pass A (8x16-pixel tiles): up to ~FUSED_WGS workgroups in all."""
     n = (H // 8) * (W // 16)
-    while n > 1 and B * n > 1024 and n % 2 == 0:
+    while n > 1 and B * n > FUSED_WGS and n % 2 == 0:
         n //= 2
     return n
 
@@ -526,7 +531,7 @@ def choose_nsplit_fused(B, H, W):
 def choose_head_groups(B, nsplit, heads):
     """workgroups per tile set for the fused pass A: split the heads while that still adds workgroups below ~1024"""
     g = 1
-    while g < heads and heads % (2 * g) == 0 and B * nsplit * 2 * g <= 1024:
+    while g < heads and heads % (2 * g) == 0 and B * nsplit * 2 * g <= FUSED_WGS:
         g *= 2
     return g
 
