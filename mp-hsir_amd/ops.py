@@ -582,8 +582,10 @@ def spectral_fold(gp, sp, temperature, Wo, dtype, transposed=False):
     if nsplit > 64:
         # few samples, large images (a 512x512 test cube: B = 1, 1024 partials): the fold kernel has only B*heads*C/32
         # workgroups, so the long ordered sum is done by the wide reduction kernel first
-        gp = reduce_parts(gp, batched=True, immediate=True).unsqueeze(1)
-        sp = reduce_parts(sp, batched=True, immediate=True).unsqueeze(1)
+        with reduce_scope():            # both sums in ONE launch (its own scope: they are read right below)
+            gp = reduce_parts(gp, batched=True)
+            sp = reduce_parts(sp, batched=True)
+        gp, sp = gp.unsqueeze(1), sp.unsqueeze(1)
         nsplit = 1
     Mo = torch.empty((B, C, C), dtype=dtype, device=gp.device)
     a = _lib.FoldArgs()
