@@ -150,7 +150,7 @@ class _PgsstbAttn(torch.autograd.Function):
         w9 = sp["w9"]
         sa, mu, oattn = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"],
                                          pk["bproj"], pk["pg"], heads, shift, save=True, gate=False)
-        with ops.side_stream(sa, ops.SIDE_BRANCH) as br:      # the prompt gate (few workgroups, latency-bound) runs beside pass A
+        with ops.side_stream(sa, ops.SIDE_BRANCH_FWD) as br:      # the prompt gate (few workgroups, latency-bound) runs beside pass A
             gate = ops.pg_gate_fwd(mu, pk["pg"])
         sa2 = sa.reshape(-1, Cc)
         # pass A; t and q | k after the depthwise conv are kept for the backward (q|k: 2C values per token, cheaper than

@@ -81,14 +81,28 @@ struct PgLds {
     float* At;      // [16][LDA]   (backward) attention probabilities, LDA = r*r + 4
     int LDC, LDW, LDA, RP;      // RP = r + 1: the pitch of every r-wide LDS matrix (odd: lanes striding rows or columns never collide)
 };
-// offsets of the small vectors inside a window's sm row (r <= 32)
-// (row pitch 484 = 4 mod 32: the windows of one wave start 4 banks apart, so the per-window broadcast reads of the r-sized
-// links do not collide)
-enum { PG_S = 0, PG_D = 32, PG_KV = 64, PG_Q = 128, PG_O = 160, PG_O2 = 192, PG_DO2 = 224, PG_DO = 256, PG_DQ = 288, PG_DKV = 320,
-       PG_DD = 384, PG_DS = 416, PG_RS = 448, PG_SMW = 484 };
+// offsets of the small vectors inside a window's sm row: 15 slots of `pgw` = r floats (kv / dkv take two), + 4 floats so that the
+// windows of one wave start a few banks apart (15 r + 4 is never a multiple of 32 for r <= 32) and the per-window broadcast
+// reads of the r-sized links do not collide.  (Slots were a fixed 32 floats wide: 31 KB of the kernel's LDS for r = 8, which
+// kept it from sharing a CU with the kernels it runs beside on the side stream.)
+#define PG_S (0 * pgw)
+#define PG_D (1 * pgw)
+#define PG_KV (2 * pgw)
+#define PG_Q (4 * pgw)
+#define PG_O (5 * pgw)
+#define PG_O2 (6 * pgw)
+#define PG_DO2 (7 * pgw)
+#define PG_DO (8 * pgw)
+#define PG_DQ (9 * pgw)
+#define PG_DKV (10 * pgw)
+#define PG_DD (12 * pgw)
+#define PG_DS (13 * pgw)
+#define PG_RS (14 * pgw)
+#define PG_SMW (15 * pgw + 4)
 
 __device__ __forceinline__ PgLds pg_lds(float* base, int C, int r, bool bwd, bool wdn = false) {
     PgLds s;
+    const int pgw = r;
     s.LDC = C + 8;                 // 32-byte row padding: conflict-free ds_read_b128 fragments (mphsir_dev.h)
     s.LDW = 128 + 8;
     s.RP = r + 1;
@@ -110,6 +124,7 @@ __device__ __forceinline__ PgLds pg_lds(float* base, int C, int r, bool bwd, boo
 }
 static size_t pg_lds_bytes(int C, int r, bool bwd, bool wdn = false) {
     const size_t rp = r + 1;
+    const int pgw = r;
     size_t n = (size_t)PG_NWIN * (C + 8) * (bwd ? 2 : 1) + (size_t)PG_NWIN * 136 * (bwd ? 2 : 1) + 132 * rp + 3 + 4 * (size_t)r * rp +
                ((r + 3) & ~3) + (size_t)C * rp + 32 + 3 + (size_t)PG_NWIN * PG_SMW;
     if (bwd) n += (size_t)PG_NWIN * (r * rp + 4) + (wdn ? (size_t)r * C : 0);
@@ -153,7 +168,7 @@ __device__ __forceinline__ void pg_mfma_rows(f32x4 (&acc)[NT], f32x4 (&wf)[8][NT
 // ---- the forward chain for the workgroup's 16 windows (shared by both kernels); ends with o2 in sm[.][PG_O2] --------------
 template <bool KEEP_AT>
 __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s, int win0) {
-    const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
+    const int C = a.C, r = a.r, pgw = r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     // the weight fragments of the two C-sized products are requested first ...
     const int rows[2] = {wv * 32, wv * 32 + 16}, rowd[1] = {wv * 16};
     const bool has_d = wv * 16 < r;
@@ -279,7 +294,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
 __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), a.C, a.r, false);
-    const int C = a.C, r = a.r, tid = threadIdx.x, win0 = blockIdx.x * PG_NWIN;
+    const int C = a.C, r = a.r, pgw = r, tid = threadIdx.x, win0 = blockIdx.x * PG_NWIN;
     pg_forward_chain<false>(a, s, win0);
     PG_MARK(7);
     // g = Wup o2: one thread per (window, channel), coalesced along c
@@ -298,7 +313,7 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
 __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), a.C, a.r, true, a.stage_wdn != 0);
-    const int C = a.C, r = a.r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), win0 = blockIdx.x * PG_NWIN;
+    const int C = a.C, r = a.r, pgw = r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), win0 = blockIdx.x * PG_NWIN;
     // Wprompt column fragments of this wave's first two d-mu tiles (used at the very end): requested now, they cost no
     // round trip later
     const int nct = C / 16;

@@ -58,6 +58,7 @@ _SIDE = {}
 # there), and the caller holds the inputs until the join.
 USE_SIDE_STREAM = os.environ.get("MPHSIR_SIDE_STREAM", "0") == "1"
 SIDE_BRANCH = os.environ.get("MPHSIR_SIDE_BRANCH", "1") == "1"
+SIDE_BRANCH_FWD = os.environ.get("MPHSIR_SIDE_BRANCH_FWD", "1" if SIDE_BRANCH else "0") == "1"      # the forward gate alone
 
 
 class side_stream:
