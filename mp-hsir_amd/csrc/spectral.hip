@@ -323,11 +323,13 @@ struct FoldDev {
     void* MTout;                // optional [B][C][C]: M^T (training: dv = d_out M is a token GEMM with weight M^T)
     int B, C, HD;
     float* Gsum; float* Ssum;   // optional: reduced Gram [B][HEADS][HD][HD] and sums of squares [B][2][C]
+    int co;                     // output rows of project_out per workgroup
 };
 
-// grid = (B*HEADS, C/FOLD_CO): every workgroup redoes the (tiny) reduction + softmax of its head and
-// folds FOLD_CO output rows of project_out, whose head slice is staged through LDS.
-constexpr int FOLD_CO = 32, FOLD_THREADS = 1024;      // few workgroups (B*heads*C/32): make each one wide
+// grid = (B*HEADS, C/co): every workgroup redoes the (tiny) reduction + softmax of its head and folds `co` output rows of
+// project_out, whose head slice is staged through LDS.  co = 32 while that keeps the grid small, up to 128 for wide nets (at
+// C=256 / 8 heads co=32 meant 2048 workgroups of 1024 threads, 8 of them redoing each softmax: 33 us a launch).
+constexpr int FOLD_CO = 32, FOLD_THREADS = 1024;      // few workgroups: make each one wide
 
 template <class T>
 __global__ __launch_bounds__(FOLD_THREADS) void spectral_fold_kernel(FoldDev a) {
@@ -337,8 +339,9 @@ __global__ __launch_bounds__(FOLD_THREADS) void spectral_fold_kernel(FoldDev a) 
     const int LDG = HD + 1;
     float* nq = G + HD * LDG;                         // [HD]
     float* nk = nq + HD;                              // [HD]
-    float* Ws = nk + HD;                              // [FOLD_CO][HD+1] project_out rows of this workgroup
-    const int tid = threadIdx.x, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS, co0 = blockIdx.y * FOLD_CO;
+    float* Ws = nk + HD;                              // [co][HD+1] project_out rows of this workgroup
+    const int CO = a.co;
+    const int tid = threadIdx.x, b = blockIdx.x / HEADS, h = blockIdx.x % HEADS, co0 = blockIdx.y * CO;
 
     for (int i = tid; i < HD * HD; i += FOLD_THREADS) {        // ordered (deterministic) reduction over the splits
         // ordered sum over the splits; 8 independent loads in flight per step (the loads, not the adds, are the latency)
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void spectral_fold_kernel(FoldDev a) 
         nq[tid] = fmaxf(sqrtf(s), 1e-12f);            // F.normalize eps (nk follows nq in memory)
         if (a.Ssum && blockIdx.y == 0) a.Ssum[(long)b * 2 * C + (tid / HD) * C + h * HD + tid % HD] = s;
     }
-    for (int i = tid; i < FOLD_CO * HD; i += FOLD_THREADS)
+    for (int i = tid; i < CO * HD; i += FOLD_THREADS)
         Ws[(i / HD) * LDG + i % HD] = a.Wo[(long)(co0 + i / HD) * C + h * HD + i % HD];
     __syncthreads();
     for (int row = tid >> 2; row < (HD + FOLD_THREADS / 4 - 1) / (FOLD_THREADS / 4) * (FOLD_THREADS / 4); row += FOLD_THREADS / 4) {
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(FOLD_THREADS) void spectral_fold_kernel(FoldDev a) 
     }
     __syncthreads();
     T* M = reinterpret_cast<T*>(a.Mout) + (long)b * C * C;
-    for (int o = tid; o < FOLD_CO * HD; o += FOLD_THREADS) {   // M[co][h*HD+j] = sum_i Wo[co][h*HD+i] A[i][j]
+    for (int o = tid; o < CO * HD; o += FOLD_THREADS) {   // M[co][h*HD+j] = sum_i Wo[co][h*HD+i] A[i][j]
         const int cl = o / HD, j = o % HD;
         float s = 0.f;
         for (int i = 0; i < HD; ++i) s += Ws[cl * LDG + i] * G[i * LDG + j];
@@ -629,19 +632,22 @@ extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* 
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 128, "spectral_fold: head_dim %d > 128", HD);
     MPHSIR_REQUIRE((a->Gsum == nullptr) == (a->Ssum == nullptr), "spectral_fold: Gsum and Ssum go together");
-    FoldDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->M, a->MT, a->B, a->C, HD, a->Gsum, a->Ssum};
     MPHSIR_REQUIRE(a->C % FOLD_CO == 0, "spectral_fold: C must be a multiple of %d", FOLD_CO);
-    const size_t shmem = ((size_t)HD * (HD + 1) + 2 * HD + (size_t)FOLD_CO * (HD + 1)) * sizeof(float);
+    int co = FOLD_CO;                                  // rows per workgroup: grow while the grid stays >= 256 workgroups
+    while (co < 128 && a->C % (2 * co) == 0 && (long)a->B * a->heads * (a->C / (2 * co)) >= 256) co *= 2;
+    FoldDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->M, a->MT, a->B, a->C, HD, a->Gsum, a->Ssum, co};
+    const size_t shmem = ((size_t)HD * (HD + 1) + 2 * HD + (size_t)co * (HD + 1)) * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(a->B * a->heads, a->C / co);
     if (dtype == MPHSIR_F32) {
         allow_big_lds(spectral_fold_kernel<float>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<float>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(FOLD_THREADS), shmem, s, d);
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<float>), grid, dim3(FOLD_THREADS), shmem, s, d);
     } else if (dtype == MPHSIR_BF16) {
         allow_big_lds(spectral_fold_kernel<bf16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<bf16_t>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(FOLD_THREADS), shmem, s, d);
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<bf16_t>), grid, dim3(FOLD_THREADS), shmem, s, d);
     } else {
         allow_big_lds(spectral_fold_kernel<f16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<f16_t>), dim3(a->B * a->heads, a->C / FOLD_CO), dim3(FOLD_THREADS), shmem, s, d);
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<f16_t>), grid, dim3(FOLD_THREADS), shmem, s, d);
     }
     return MPHSIR_OK;
 }
