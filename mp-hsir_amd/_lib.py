@@ -56,7 +56,7 @@ class FusedGramArgs(ctypes.Structure):
     _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("Wqkv", c_void_p), ("w9", c_void_p),
                 ("ldw", c_int64), ("V", c_void_p), ("ldvo", c_int64), ("Gpart", c_void_p), ("Spart", c_void_p)] + \
                [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nsplit", "head_groups")] + \
-               [("T", c_void_p), ("ldt", c_int64), ("QK", c_void_p), ("ldqk", c_int64)]
+               [("T", c_void_p), ("ldt", c_int64), ("QK", c_void_p), ("ldqk", c_int64), ("row_segments", c_int32)]
 
 
 class FoldArgs(ctypes.Structure):
@@ -140,6 +140,7 @@ _SYMBOLS = {
     "mphsir_dwconv_gram_keeps_qk": (c_int, [c_int32, c_int32, c_int]),
     "mphsir_qkv_dwconv_gram": (c_int, [ctypes.POINTER(FusedGramArgs), c_int, c_void_p]),
     "mphsir_qkv_dwconv_gram_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int]),
+    "mphsir_qkv_dwconv_gram_rows_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int]),
     "mphsir_fused_debug": (c_int, [c_void_p]),
     "mphsir_win_debug": (c_int, [c_void_p]),
     "mphsir_dwconv3x3_wgrad_tiled": (c_int, [c_int32, c_int32, c_int32, c_int]),

@@ -430,6 +430,11 @@ template <> struct FusedShapes<float> {
     }
 };
 
+unsigned long long* fused_debug_buffer() { return g_fg_dbg; }
+// row-walking form (spectral_rows.hip)
+int rows_form_fits(int C, int heads, int H, int W, int dtype);
+int rows_form_launch(const mphsir_fused_gram_args* a, int dtype, hipStream_t s);
+
 }  // namespace mphsir
 
 extern "C" int mphsir_fused_debug(void* stamps) {      // diagnostics: device buffer of >= 9 uint64 (NULL = off)
@@ -450,6 +455,22 @@ extern "C" int mphsir_qkv_dwconv_gram(const mphsir_fused_gram_args* a, int dtype
     MPHSIR_REQUIRE(a && a->X && a->Wqkv && a->w9 && a->V && a->Gpart && a->Spart, "qkv_dwconv_gram: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "qkv_dwconv_gram: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C > 0 && a->C % a->heads == 0, "qkv_dwconv_gram: bad shape");
+    if (a->row_segments > 0) {
+        const int esz_ = 2;
+        MPHSIR_REQUIRE(rows_form_fits(a->C, a->heads, a->H, a->W, dtype),
+                       "qkv_dwconv_gram: (C=%d, heads=%d, H=%d, W=%d, dtype=%d) not covered by the row-walking form (ask mphsir_qkv_dwconv_gram_rows_fits)",
+                       a->C, a->heads, a->H, a->W, dtype);
+        MPHSIR_REQUIRE(a->H % a->row_segments == 0 && a->nsplit == (a->W / 32) * a->row_segments,
+                       "qkv_dwconv_gram: row_segments=%d must divide H=%d and nsplit=%d must be (W/32)*row_segments", a->row_segments, a->H, a->nsplit);
+        MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->Wqkv) && aligned16(a->V) && (a->ldx * esz_) % 16 == 0 && (a->ldvo * esz_) % 16 == 0 &&
+                           a->ldx >= a->C && a->ldvo >= a->C && a->ldw >= 3 * a->C, "qkv_dwconv_gram: 16-byte alignment / row pitch");
+        MPHSIR_REQUIRE((a->ln_w == nullptr) == (a->ln_b == nullptr), "qkv_dwconv_gram: ln_w and ln_b go together");
+        MPHSIR_REQUIRE((a->T == nullptr) == (a->QK == nullptr), "qkv_dwconv_gram: T and QK (the training outputs) go together");
+        if (a->T)
+            MPHSIR_REQUIRE(aligned16(a->T) && aligned16(a->QK) && (a->ldt * esz_) % 16 == 0 && (a->ldqk * esz_) % 16 == 0 && a->ldt >= 3 * a->C &&
+                               a->ldqk >= 2 * a->C, "qkv_dwconv_gram: T / QK must be 16-byte aligned with ldt >= 3C, ldqk >= 2C");
+        return rows_form_launch(a, dtype, reinterpret_cast<hipStream_t>(stream));
+    }
     MPHSIR_REQUIRE(mphsir_qkv_dwconv_gram_fits(a->C, a->heads, a->H, a->W, dtype),
                    "qkv_dwconv_gram: (C=%d, heads=%d, H=%d, W=%d) not covered (ask mphsir_qkv_dwconv_gram_fits; H %% 8 == 0, W %% 16 == 0)",
                    a->C, a->heads, a->H, a->W);

@@ -537,14 +537,42 @@ def choose_head_groups(B, nsplit, heads):
     return g
 
 
-def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_groups=None, keep=False):
+def qkv_dwconv_gram_rows_fits(C, heads, H, W, dtype):
+    """the row-walking form of the fused pass A (spectral_rows.hip): 16-bit dtypes, W % 32 == 0, C <= 192"""
+    return bool(_lib.load().mphsir_qkv_dwconv_gram_rows_fits(C, heads, H, W, _DT[dtype]))
+
+
+# the row-walking form: MPHSIR_ROWS_FORM=0 keeps every shape on the tile form
+ROWS_FORM = os.environ.get("MPHSIR_ROWS_FORM", "1") == "1"
+
+
+def choose_row_segments(B, H, W, C, heads):
+    """row segments per 32-pixel strip: the most rows per workgroup (least halo recompute: 2 rows per segment) that still
+    gives every CU a workgroup"""
+    hd = C // heads
+    hgroups = max(1, heads // ((96 if hd % 48 == 0 else 64) // hd))
+    s = 1
+    while B * (W // 32) * s * hgroups < 256 and H % (2 * s) == 0 and H // (2 * s) >= 4:
+        s *= 2
+    return s
+
+
+def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_groups=None, keep=False, row_segments=None):
     """Fused pass A: x (M, >=C) row-major view, wqkv (3C, C) in x.dtype, w9 fp32 (9, >=3C) taps of q|k|v,
     ln = (weight, bias) fp32 or None.  Returns (v (M,C), Gpart, Spart, nsplit) like dwconv_gram(gemm_tok(x, wqkv));
-    keep=True (training) appends t = qkv(LN(x)) (M,3C) and q|k after the depthwise conv (M,2C)."""
+    keep=True (training) appends t = qkv(LN(x)) (M,3C) and q|k after the depthwise conv (M,2C).
+    row_segments: None = the row-walking form where it applies (unless nsplit / head_groups ask for the tile form), 0 = tile
+    form, s > 0 = row-walking form with s segments per strip (nsplit = (W/32)*s partial slots per sample)."""
     lib = _lib.load()
     _check(x, wqkv, w9)
     M, ldx = _rows(x)
     assert M == B * H * W and wqkv.shape == (3 * C, C) and wqkv.is_contiguous() and wqkv.dtype == x.dtype
+    if row_segments is None:
+        row_segments = 0
+        if ROWS_FORM and nsplit is None and head_groups is None and qkv_dwconv_gram_rows_fits(C, heads, H, W, x.dtype):
+            row_segments = choose_row_segments(B, H, W, C, heads)
+    if row_segments:
+        nsplit = (W // 32) * row_segments
     nsplit = nsplit or choose_nsplit_fused(B, H, W)
     hd = C // heads
     v = torch.empty((M, C), dtype=x.dtype, device=x.device)
@@ -556,7 +584,8 @@ def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_g
         a.ln_w, a.ln_b = _p(ln[0]), _p(ln[1])
     a.V, a.ldvo, a.Gpart, a.Spart = _p(v), C, _p(gp), _p(sp)
     a.B, a.H, a.W, a.C, a.heads, a.nsplit = B, H, W, C, heads, nsplit
-    a.head_groups = head_groups or choose_head_groups(B, nsplit, heads)
+    a.head_groups = 1 if row_segments else (head_groups or choose_head_groups(B, nsplit, heads))
+    a.row_segments = row_segments
     t = qk = None
     if keep:
         t = torch.empty((M, 3 * C), dtype=x.dtype, device=x.device)

@@ -300,6 +300,22 @@ inline bf16x4_t ds_read_tr16_b64(const void* p) {
     return r;
 }
 }  // namespace hipemu
+// DPP row shifts (v_mov_b32_dpp row_shl:n = 0x100+n: lane i <- lane i+n; row_shr:n = 0x110+n: lane i <- lane i-n, inside the
+// 16-lane row; a lane whose source falls outside its row keeps `old` (bound_ctrl = 0) or gets 0) and ds_bpermute_b32.
+namespace hipemu {
+inline int update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
+    const int l = lane_id(), row = l & ~15, i = l & 15;
+    int sl = -1;
+    if (ctrl >= 0x101 && ctrl <= 0x10f) sl = i + (ctrl - 0x100) < 16 ? row + i + (ctrl - 0x100) : -1;
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) sl = i - (ctrl - 0x110) >= 0 ? row + i - (ctrl - 0x110) : -1;
+    else { fprintf(stderr, "hipemu: dpp_ctrl 0x%x not emulated\n", ctrl); abort(); }
+    const int v = wave_xchg(src, sl < 0 ? l : sl);
+    return sl < 0 ? (bound_ctrl ? 0 : old) : v;
+}
+inline int ds_bpermute(int addr, int src) { return wave_xchg(src, (addr >> 2) & (kWave - 1)); }
+}  // namespace hipemu
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu::update_dpp(old, src, ctrl, rm, bm, bc)
+#define __builtin_amdgcn_ds_bpermute(addr, src) hipemu::ds_bpermute(addr, src)
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_readfirstlane(x) (x)      /* wave-uniform by contract: any lane's value */
 #define __builtin_amdgcn_wave_barrier() hipemu::wave_sync()

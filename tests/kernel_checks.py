@@ -156,13 +156,27 @@ FUSED_SLAB_CASES = [(64, 1, (1, 16, 32), 2, False), (64, 1, (1, 8, 16), 1, True)
 FUSED_HG_CASES = [(64, 4, (1, 16, 32), 2, False, 1), (64, 4, (1, 16, 32), 2, True, 2), (64, 4, (1, 8, 16), 1, False, 4)]
 
 
-def check_fused_pass_a(dev, dtype, C, heads, shape, nsplit, ln, hgroups=None):
+# the row-walking form (spectral_rows.hip): (C, heads, (B, H, W), row segments per strip, ln); W % 32 == 0, 16-bit
+ROWS_CASES = [(64, 2, (1, 8, 32), 1, False), (64, 2, (2, 16, 64), 2, True), (128, 4, (1, 8, 32), 2, False), (128, 2, (1, 12, 32), 1, True),
+              (64, 1, (1, 8, 64), 2, False), (96, 2, (1, 8, 32), 1, False), (192, 2, (1, 6, 32), 1, True), (192, 4, (1, 4, 32), 1, False)]
+
+
+# larger ones for the GPU only: the widths / resolutions of both nets' levels 1-2 at 64x64 and 128x128 inputs
+ROWS_CASES_GPU = [(64, 2, (2, 64, 64), 4, False), (128, 4, (2, 32, 32), 2, False), (128, 2, (2, 64, 64), 8, True), (128, 4, (1, 64, 64), 1, True),
+                  (96, 2, (2, 64, 64), 2, False), (192, 4, (2, 32, 32), 4, False), (192, 2, (1, 64, 64), 16, False), (64, 2, (1, 128, 128), 8, False)]
+
+
+def check_fused_pass_a(dev, dtype, C, heads, shape, nsplit, ln, hgroups=None, row_segments=0):
     """qkv_dwconv_gram (LN + 1x1 qkv + depthwise 3x3 + Gram / norms in one launch) == gemm_tok -> dwconv_gram, and the
     chain through spectral_fold / pass B == oracle spectral_attention (ref :96-114; with ln: norm1 of :476 first)."""
     _use(dev)
     from mp_hsir_amd import ops
     B, H, W = shape
-    assert ops.qkv_dwconv_gram_fits(C, heads, H, W, dtype)
+    if row_segments:
+        assert ops.qkv_dwconv_gram_rows_fits(C, heads, H, W, dtype)
+        nsplit = (W // 32) * row_segments
+    else:
+        assert ops.qkv_dwconv_gram_fits(C, heads, H, W, dtype)
     x = rnd((B, H, W, C), 61, dtype)
     P = {"qkv.weight": rnd((3 * C, C, 1, 1), 62, scale=C ** -0.5), "qkv_dwconv.weight": rnd((3 * C, 1, 3, 3), 63, scale=1 / 3),
          "project_out.weight": rnd((C, C, 1, 1), 64, scale=C ** -0.5), "temperature": 1 + 0.3 * rnd((heads, 1, 1), 65)}
@@ -170,7 +184,7 @@ def check_fused_pass_a(dev, dtype, C, heads, shape, nsplit, ln, hgroups=None):
     wqkv = P["qkv.weight"].reshape(3 * C, C).to(dtype).contiguous()
     w9 = ops.pack_dw(P["qkv_dwconv.weight"])
     x2 = x.reshape(-1, C)
-    v, gp, sp, ns = ops.qkv_dwconv_gram(x2, wqkv, w9, B, H, W, C, heads, ln=lnp, nsplit=nsplit, head_groups=hgroups)
+    v, gp, sp, ns = ops.qkv_dwconv_gram(x2, wqkv, w9, B, H, W, C, heads, ln=lnp, nsplit=nsplit, head_groups=hgroups, row_segments=row_segments)
     assert gp.shape == (B, nsplit, heads, C // heads, C // heads) and sp.shape == (B, nsplit, 2, C)
     # the two-kernel path on the same inputs: same rounding points (t and q,k,v in the compute dtype), different
     # accumulation order in the 1x1 conv only
@@ -180,7 +194,8 @@ def check_fused_pass_a(dev, dtype, C, heads, shape, nsplit, ln, hgroups=None):
     assert rel_l2(v, v0) < tol
     assert rel_l2(gp.double().sum(1), gp0.double().sum(1)) < tol and rel_l2(sp.double().sum(1), sp0.double().sum(1)) < tol
     # training form: the same launch also keeps t and q|k; v and the partials must not change (bitwise)
-    v2, gp2, sp2, _, tk, qk = ops.qkv_dwconv_gram(x2, wqkv, w9, B, H, W, C, heads, ln=lnp, nsplit=nsplit, head_groups=hgroups, keep=True)
+    v2, gp2, sp2, _, tk, qk = ops.qkv_dwconv_gram(x2, wqkv, w9, B, H, W, C, heads, ln=lnp, nsplit=nsplit, head_groups=hgroups, keep=True,
+                                                  row_segments=row_segments)
     assert torch.equal(v2.cpu(), v.cpu()) and torch.equal(gp2.cpu(), gp.cpu()) and torch.equal(sp2.cpu(), sp.cpu())
     assert rel_l2(tk, t) < tol
     _, _, _, _, qk0 = ops.dwconv_gram(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], w9[:, :C], w9[:, C:2 * C], w9[:, 2 * C:], 3 * C, B, H, W, C, heads,

@@ -59,6 +59,12 @@ def test_fused_pass_a_head_groups(C, heads, shape, nsplit, ln, hg):
     K.check_fused_pass_a("cpu", torch.bfloat16, C, heads, shape, nsplit, ln, hgroups=hg)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,heads,shape,rs,ln", K.ROWS_CASES)
+def test_fused_pass_a_rows(dtype, C, heads, shape, rs, ln):
+    K.check_fused_pass_a("cpu", dtype, C, heads, shape, None, ln, row_segments=rs)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 def test_gdfn_chain(dtype):
     K.check_gdfn_chain("cpu", dtype)

@@ -98,6 +98,13 @@ def test_fused_pass_a_fp32(C, heads, shape, nsplit, ln):
     K.check_fused_pass_a("cuda", torch.float32, C, heads, shape, nsplit, ln)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,heads,shape,rs,ln", K.ROWS_CASES + K.ROWS_CASES_GPU)
+def test_fused_pass_a_rows(dtype, C, heads, shape, rs, ln):
+    """the row-walking form of the fused pass A == two-kernel path and oracle, every shipped (C, head width)"""
+    K.check_fused_pass_a("cuda", dtype, C, heads, shape, None, ln, row_segments=rs)
+
+
 def test_fused_pass_a_is_deterministic_and_used_by_inference():
     """bitwise equal repeats (fixed-order partials, no atomics), and the no-grad forward of a block goes through it"""
     from mp_hsir_amd import ops
