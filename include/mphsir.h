@@ -159,14 +159,15 @@ typedef struct mphsir_fused_gram_args {
     void* T; int64_t ldt;                   /* optional, both or neither (training): t = qkv(LN(x)) [B*H*W][ldt >= 3C] and    */
     void* QK; int64_t ldqk;                 /* q | k after the depthwise conv [B*H*W][ldqk >= 2C], kept for the backward      */
     int32_t row_segments;                   /* 0: tile form (8x16-pixel tiles, nsplit divides the tile count).  s > 0: ROW-WALKING
-                                               form (mphsir_qkv_dwconv_gram_rows_fits): a workgroup walks H/s rows of a 32-pixel
+                                               form (mphsir_qkv_dwconv_gram_rows_fits): a workgroup walks H/s >= 4 rows of a 32-pixel
                                                column strip, t stays in registers; needs H % s == 0 and nsplit == (W/32)*s;
                                                head_groups is ignored (the form fixes its own head split)                   */
 } mphsir_fused_gram_args;
 int mphsir_qkv_dwconv_gram(const mphsir_fused_gram_args* a, int dtype, void* stream);
 int mphsir_qkv_dwconv_gram_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype);
-int mphsir_qkv_dwconv_gram_rows_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype);   /* row-walking form: 16-bit
-                                           dtypes, W % 32 == 0, (C, head width) in {64,128}x{32,64}, {96,192}x{48,96} */
+int mphsir_qkv_dwconv_gram_rows_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype, int32_t with_ln);   /* row-walking
+                                           form: 16-bit dtypes, no LayerNorm prologue, W % 32 == 0, H >= 4, (C, head width) in
+                                           {64,128}x{32,64}, {96,192}x{48,96} */
 int mphsir_win_debug(void* stamps);     /* the same for mphsir_win_attn_fwd: >= 8 uint64 (tools/bench_win.py) */
 int mphsir_fused_debug(void* stamps);   /* diagnostics: device buffer of >= 9 uint64 that workgroup 0 fills with shader-clock stamps
                                            at its phase boundaries (NULL = off); tools/bench_fused.py */

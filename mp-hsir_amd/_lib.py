@@ -140,7 +140,7 @@ _SYMBOLS = {
     "mphsir_dwconv_gram_keeps_qk": (c_int, [c_int32, c_int32, c_int]),
     "mphsir_qkv_dwconv_gram": (c_int, [ctypes.POINTER(FusedGramArgs), c_int, c_void_p]),
     "mphsir_qkv_dwconv_gram_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int]),
-    "mphsir_qkv_dwconv_gram_rows_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int]),
+    "mphsir_qkv_dwconv_gram_rows_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int, c_int32]),
     "mphsir_fused_debug": (c_int, [c_void_p]),
     "mphsir_win_debug": (c_int, [c_void_p]),
     "mphsir_dwconv3x3_wgrad_tiled": (c_int, [c_int32, c_int32, c_int32, c_int]),

@@ -211,6 +211,19 @@ __device__ __forceinline__ void wave_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// LDS-DMA: lane l copies 16 bytes from (scalar base pointer) + (ITS unsigned byte offset) to (wave-uniform LDS address) + 16 l -- no destination
+// registers, completion counted by vmcnt.  Written as inline assembly on purpose: hipcc models the builtin form
+// (__builtin_amdgcn_global_load_lds) as a pending LDS write and then drains vmcnt(0) in front of every ds_read_b64_tr_b16 and
+// every fence, which turns a ring of rows in flight into one synchronous load per step (seen in the ISA of spectral_rows.hip).
+// As assembly the transfer is invisible to that bookkeeping; the code that issues it retires it with a counted
+// s_waitcnt vmcnt(N) before the barrier that publishes the row.  (MPHSIR_LDS_DMA16 is the one customisation point of this
+// header: the CPU emulation of the test suite supplies a memcpy.)
+#ifndef MPHSIR_LDS_DMA16
+#define MPHSIR_LDS_DMA16(gbase, byte_off, lds_wave_base)                                                                \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                        \
+                 :: "v"(byte_off), "s"(gbase), "s"((unsigned)(unsigned long long)(lds_wave_base)) : "memory")
+#endif
+
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx b runs on XCD b % 8, each XCD has its own L2).  For
 // streaming kernels whose neighbouring workgroups share input rows (3x3 stencils) this maps XCD x to one contiguous
 // eighth of the logical block range, so the shared rows are fetched from HBM once and re-read from that XCD's L2

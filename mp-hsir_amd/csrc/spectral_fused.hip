@@ -432,7 +432,7 @@ template <> struct FusedShapes<float> {
 
 unsigned long long* fused_debug_buffer() { return g_fg_dbg; }
 // row-walking form (spectral_rows.hip)
-int rows_form_fits(int C, int heads, int H, int W, int dtype);
+int rows_form_fits(int C, int heads, int H, int W, int dtype, int ln);
 int rows_form_launch(const mphsir_fused_gram_args* a, int dtype, hipStream_t s);
 
 }  // namespace mphsir
@@ -457,11 +457,12 @@ extern "C" int mphsir_qkv_dwconv_gram(const mphsir_fused_gram_args* a, int dtype
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C > 0 && a->C % a->heads == 0, "qkv_dwconv_gram: bad shape");
     if (a->row_segments > 0) {
         const int esz_ = 2;
-        MPHSIR_REQUIRE(rows_form_fits(a->C, a->heads, a->H, a->W, dtype),
-                       "qkv_dwconv_gram: (C=%d, heads=%d, H=%d, W=%d, dtype=%d) not covered by the row-walking form (ask mphsir_qkv_dwconv_gram_rows_fits)",
-                       a->C, a->heads, a->H, a->W, dtype);
-        MPHSIR_REQUIRE(a->H % a->row_segments == 0 && a->nsplit == (a->W / 32) * a->row_segments,
-                       "qkv_dwconv_gram: row_segments=%d must divide H=%d and nsplit=%d must be (W/32)*row_segments", a->row_segments, a->H, a->nsplit);
+        MPHSIR_REQUIRE(rows_form_fits(a->C, a->heads, a->H, a->W, dtype, a->ln_w != nullptr),
+                       "qkv_dwconv_gram: (C=%d, heads=%d, H=%d, W=%d, dtype=%d, ln=%d) not covered by the row-walking form (ask mphsir_qkv_dwconv_gram_rows_fits)",
+                       a->C, a->heads, a->H, a->W, dtype, (int)(a->ln_w != nullptr));
+        MPHSIR_REQUIRE(a->H % a->row_segments == 0 && a->H / a->row_segments >= 4 && a->nsplit == (a->W / 32) * a->row_segments,
+                       "qkv_dwconv_gram: row_segments=%d must divide H=%d into segments of >= 4 rows and nsplit=%d must be (W/32)*row_segments",
+                       a->row_segments, a->H, a->nsplit);
         MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->Wqkv) && aligned16(a->V) && (a->ldx * esz_) % 16 == 0 && (a->ldvo * esz_) % 16 == 0 &&
                            a->ldx >= a->C && a->ldvo >= a->C && a->ldw >= 3 * a->C, "qkv_dwconv_gram: 16-byte alignment / row pitch");
         MPHSIR_REQUIRE((a->ln_w == nullptr) == (a->ln_b == nullptr), "qkv_dwconv_gram: ln_w and ln_b go together");

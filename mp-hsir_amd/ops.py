@@ -537,9 +537,9 @@ def choose_head_groups(B, nsplit, heads):
     return g
 
 
-def qkv_dwconv_gram_rows_fits(C, heads, H, W, dtype):
-    """the row-walking form of the fused pass A (spectral_rows.hip): 16-bit dtypes, W % 32 == 0, C <= 192"""
-    return bool(_lib.load().mphsir_qkv_dwconv_gram_rows_fits(C, heads, H, W, _DT[dtype]))
+def qkv_dwconv_gram_rows_fits(C, heads, H, W, dtype, ln=False):
+    """the row-walking form of the fused pass A (spectral_rows.hip): 16-bit dtypes, no LayerNorm, W % 32 == 0, C <= 192"""
+    return bool(_lib.load().mphsir_qkv_dwconv_gram_rows_fits(C, heads, H, W, _DT[dtype], int(bool(ln))))
 
 
 # the row-walking form: MPHSIR_ROWS_FORM=0 keeps every shape on the tile form
@@ -549,8 +549,7 @@ ROWS_FORM = os.environ.get("MPHSIR_ROWS_FORM", "1") == "1"
 def choose_row_segments(B, H, W, C, heads):
     """row segments per 32-pixel strip: the most rows per workgroup (least halo recompute: 2 rows per segment) that still
     gives every CU a workgroup"""
-    hd = C // heads
-    hgroups = max(1, heads // ((96 if hd % 48 == 0 else 64) // hd))
+    hgroups = max(1, heads // (2 if C // heads == 32 else 1))
     s = 1
     while B * (W // 32) * s * hgroups < 256 and H % (2 * s) == 0 and H // (2 * s) >= 4:
         s *= 2
@@ -569,7 +568,10 @@ def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_g
     assert M == B * H * W and wqkv.shape == (3 * C, C) and wqkv.is_contiguous() and wqkv.dtype == x.dtype
     if row_segments is None:
         row_segments = 0
-        if ROWS_FORM and nsplit is None and head_groups is None and qkv_dwconv_gram_rows_fits(C, heads, H, W, x.dtype):
+        # (training outputs at C = 128 / 64-wide heads and at C = 192: the row form's registers spill there -- measured 129 us
+        # against 86 for the tile form at batch 32, 64x64 -- so those keep the tile form)
+        spills = keep and ((C == 128 and C // heads == 64) or C >= 192)
+        if ROWS_FORM and nsplit is None and head_groups is None and not spills and qkv_dwconv_gram_rows_fits(C, heads, H, W, x.dtype, ln is not None):
             row_segments = choose_row_segments(B, H, W, C, heads)
     if row_segments:
         nsplit = (W // 32) * row_segments

@@ -314,6 +314,17 @@ inline int update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
 }
 inline int ds_bpermute(int addr, int src) { return wave_xchg(src, (addr >> 2) & (kWave - 1)); }
 }  // namespace hipemu
+// LDS-DMA (global_load_lds): lane l copies `size` bytes from its own source address to the wave's LDS base + l * size
+// (synchronous here); the raw barrier, the counted waits and address-space qualifiers mean nothing on the CPU.
+namespace hipemu {
+inline void global_load_lds(const void* src, void* dst, int size) { memcpy((char*)dst + (size_t)lane_id() * size, src, size); }
+}  // namespace hipemu
+#define address_space(n)
+#define __builtin_amdgcn_global_load_lds(src, dst, size, off, aux) hipemu::global_load_lds((const void*)(src), (void*)(dst), size)
+#define MPHSIR_LDS_DMA16(gbase, byte_off, lds_wave_base) hipemu::global_load_lds((const char*)(gbase) + (byte_off), (void*)(lds_wave_base), 16)
+#define __builtin_amdgcn_s_barrier() hipemu::block_sync()
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu::update_dpp(old, src, ctrl, rm, bm, bc)
 #define __builtin_amdgcn_ds_bpermute(addr, src) hipemu::ds_bpermute(addr, src)
 #define __builtin_amdgcn_s_memtime() 0ull
