@@ -59,11 +59,8 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     M = B * N
     dt = v.dtype
     dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), immediate=True)      # (B,C,C) fp32, read right below
-    # the fold backward is a latency-bound 64..256-workgroup kernel: it runs on the side stream while this one
-    # recomputes q,k (depthwise) and does the dv GEMM, which do not need its result
-    with ops.side_stream(dM) as fork:
-        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temperature.detach().reshape(heads).float().contiguous(),
-                                                   wo.detach().reshape(C, C).float().contiguous(), dM, dt, reduce=False)
+    W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temperature.detach().reshape(heads).float().contiguous(),
+                                               wo.detach().reshape(C, C).float().contiguous(), dM, dt, reduce=False)
     # q, k of the forward: either kept by it (qk) or recomputed by the depthwise kernel; when q|k|v are adjacent channel
     # slices of one tensor (self-attention) every depthwise pass runs once over the joint channel range.
     joint = (t_q.data_ptr() + C * t_q.element_size() == t_k.data_ptr() and t_k.data_ptr() + C * t_k.element_size() == t_v.data_ptr()
@@ -77,7 +74,6 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     else:
         qk = torch.cat([ops.dwconv3x3(t_q, w9q), ops.dwconv3x3(t_k, w9k)], dim=-1)
     ops.gemm_tok(d_out, MbT, out=dall[:, 2 * C:])                                     # dv = d_out M_b
-    fork.join(W2, dwo_p, dtemp_p)
     dwo, dtemp = ops.reduce_parts(dwo_p), ops.reduce_parts(dtemp_p)
     ops.gemm_tok(qk.reshape(M, 2 * C), W2, out=dall[:, :2 * C])                       # [dq | dk]
     dall4 = dall.reshape(B, H, W, 3 * C)
@@ -150,7 +146,7 @@ class _PgsstbAttn(torch.autograd.Function):
         w9 = sp["w9"]
         sa, mu, oattn = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"],
                                          pk["bproj"], pk["pg"], heads, shift, save=True, gate=False)
-        with ops.side_stream(sa, ops.SIDE_BRANCH_FWD) as br:      # the prompt gate (few workgroups, latency-bound) runs beside pass A
+        with ops.side_stream(sa, ops.SIDE_BRANCH) as br:      # the prompt gate (few workgroups, latency-bound) runs beside pass A
             gate = ops.pg_gate_fwd(mu, pk["pg"])
         sa2 = sa.reshape(-1, Cc)
         # pass A; t and q | k after the depthwise conv are kept for the backward (q|k: 2C values per token, cheaper than

@@ -16,8 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmphsir.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-# per-file additions (MPHSIR_EXTRA_<stem> in the environment appends more, for experiments)
-FILE_FLAGS = {}
+FILE_FLAGS = {}      # per-file additions
 
 
 def sources():
@@ -35,7 +34,7 @@ def _compile(src, objdir, hdr_mtime, verbose):
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_mtime):
         return obj
     stem = os.path.basename(src)[:-4]
-    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(stem, []) + os.environ.get("MPHSIR_EXTRA_" + stem, "").split() + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(stem, []) + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

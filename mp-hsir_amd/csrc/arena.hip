@@ -106,8 +106,7 @@ extern "C" int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, 
                          g.src_batch_stride % 4 == 0 && g.dst_batch_stride % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0;
         const long nitems = (long)g.nbatch * rows * ((g.n + 3) / 4);
         int lg = 0;                        // lanes per item: keep <= 32 splits per lane, and small segments still fill waves
-        static const int max_chain = [] { const char* e = getenv("MPHSIR_REDUCE_CHAIN"); return e ? atoi(e) : 32; }();   // tuning aid
-        while (lg < 6 && (g.nsplit >> lg) > max_chain) ++lg;
+        while (lg < 6 && (g.nsplit >> lg) > 32) ++lg;
         while (lg < 6 && (nitems << lg) < 8192 && (g.nsplit >> lg) > 4) ++lg;
         d.s[k] = RedSegDev{g.src, g.dst, (long)g.n, (long)g.stride, (long)g.src_batch_stride, (long)g.dst_batch_stride, threads, nitems,
                            src_ld, dst_ld, g.nsplit, vec ? 1 : 0, lg, rows, dcs};

@@ -557,16 +557,10 @@ static int launch_win_bwd_xl(const WinBwdDev& d, hipStream_t s) {
     return MPHSIR_OK;
 }
 
-// MPHSIR_WINB_XL = 0 / 1 forces the X-tile placement (tuning aid); unset: WinBwdPick
-static int winb_xl_override() {
-    static const int v = [] { const char* e = getenv("MPHSIR_WINB_XL"); return e ? atoi(e) : -1; }();
-    return v;
-}
-
 template <class T, int C, int HD>
 static int launch_win_bwd(const WinBwdDev& d, hipStream_t s) {
     constexpr bool PICK = WinBwdPick<T, C, HD>::XL;
-    const int ov = winb_xl_override();
+    constexpr int ov = -1;                      // (the X-tile placement is WinBwdPick's: measured both ways)
     if constexpr (WinBwdCfg<T, C, HD, true>::FITS) {
         if (ov == 1 || (ov < 0 && PICK)) return launch_win_bwd_xl<T, C, HD, true>(d, s);
     }

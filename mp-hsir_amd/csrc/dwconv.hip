@@ -400,8 +400,7 @@ extern "C" int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void
 extern "C" int mphsir_dwconv3x3_wgrad_tiled(int32_t H, int32_t W, int32_t C, int dtype) {
     // 1 if mphsir_dwconv3x3_wgrad takes the tile form for this shape: the caller then sizes nblk for one workgroup per CU
     // over (nblk, ceil(C/96)) instead of one partial block per 128 pixels
-    static const int tile_env = [] { const char* e = getenv("MPHSIR_DW_TILE"); return e ? atoi(e) : 1; }();
-    return (tile_env && (dtype == MPHSIR_BF16 || dtype == MPHSIR_F16) && H > 0 && W > 0 && H % mphsir::DT_TH == 0 && W % mphsir::DT_TW == 0 &&
+    return ((dtype == MPHSIR_BF16 || dtype == MPHSIR_F16) && H > 0 && W > 0 && H % mphsir::DT_TH == 0 && W % mphsir::DT_TW == 0 &&
             C % 32 == 0) ? 1 : 0;
 }
 
@@ -418,8 +417,7 @@ extern "C" int mphsir_dwconv3x3(const void* X, int64_t ldx, const float* w9, int
     MPHSIR_REQUIRE(W % DW_S == 0, "dwconv3x3: W must be a multiple of %d", DW_S);
     const long blocks = (((long)B * H * (W / DW_S) * (C / vec) + 255) / 256 + 7) / 8 * 8;      // multiple of 8: XCD-contiguous order
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const int tile_env = [] { const char* e = getenv("MPHSIR_DW_TILE"); return e ? atoi(e) : 1; }();      // tuning aid: 0 = strip form
-    if (tile_env && dtype != MPHSIR_F32 && H % DT_TH == 0 && W % DT_TW == 0 && C % 32 == 0)
+    if (dtype != MPHSIR_F32 && H % DT_TH == 0 && W % DT_TW == 0 && C % 32 == 0)
         return dtype == MPHSIR_BF16 ? launch_dw_tile<bf16_t>(d, s) : launch_dw_tile<f16_t>(d, s);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV, (dwconv3x3_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);

@@ -214,11 +214,8 @@ template <class T, int EPI, bool LN>
 static int launch_gemm(const GemmDev& d, hipStream_t s) {
     // enough workgroups to fill the chip first, then as many output channels per staged token tile as possible
     const long mt = d.M / GT_BM;
-    static const int nw_override = [] { const char* e = getenv("MPHSIR_GEMM_NW"); return e ? atoi(e) : 0; }();    // tuning aid
-    if (nw_override == 6 && d.N > 256 && mt >= 1024) return launch_gemm_nw<T, EPI, LN, 6>(d, s);
-    if (nw_override == 3 && d.N > 128 && mt >= 1024) return launch_gemm_nw<T, EPI, LN, 3>(d, s);
     // the widest tile (token tile staged / LayerNorm-ed once per 64*NW outputs) that still leaves >= ~1024 workgroups
-    static const int wg_min = [] { const char* e = getenv("MPHSIR_GEMM_WGMIN"); return e ? atoi(e) : 1024; }();     // tuning aid
+    constexpr long wg_min = 1024;
     auto wgs = [&](int nw) { return mt * ((d.N + 64 * nw - 1) / (64 * nw)); };
     if (d.N > 128 && (mt >= 1024 || wgs(4) >= wg_min)) return launch_gemm_nw<T, EPI, LN, 4>(d, s);
     if (d.N > 64 && (mt >= 512 || wgs(2) >= wg_min)) return launch_gemm_nw<T, EPI, LN, 2>(d, s);

@@ -85,18 +85,22 @@ __global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(ResizeDev a) {
     const long n = (long)a.B * a.h * a.w * cv;
     const T* dY = reinterpret_cast<const T*>(a.X);
     T* dX = reinterpret_cast<T*>(a.Y);
-    const int ry = (a.H + a.h - 1) / a.h + 1, rx = (a.W + a.w - 1) / a.w + 1;      // output pixels per input pixel, plus slack
+    const float sy = (float)a.H / (float)a.h, sx = (float)a.W / (float)a.w;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % cv) * VEC;
         const long p = i / cv;
         const int ix = (int)(p % a.w), iy = (int)((p / a.w) % a.h), b = (int)(p / ((long)a.w * a.h));
         float acc[VEC];
         for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-        int ylo = (int)(((long)(iy - 1) * a.H) / a.h) - 1, xlo = (int)(((long)(ix - 1) * a.W) / a.w) - 1;
+        // output pixel y reads input rows floor(s) and floor(s) + 1 with s = (y + 0.5) h / H - 0.5: it touches iy for s in
+        // (iy - 1, iy + 1), i.e. y in ((iy - 0.5) H / h - 0.5, (iy + 1.5) H / h - 0.5) -- any ratio (one pixel of slack each
+        // side for the rounding of the bounds; the weights decide)
+        int ylo = (int)floorf(((float)iy - 0.5f) * sy - 0.5f) - 1, xlo = (int)floorf(((float)ix - 0.5f) * sx - 0.5f) - 1;
+        int yhi = (int)ceilf(((float)iy + 1.5f) * sy - 0.5f) + 1, xhi = (int)ceilf(((float)ix + 1.5f) * sx - 0.5f) + 1;
         ylo = ylo < 0 ? 0 : ylo;
         xlo = xlo < 0 ? 0 : xlo;
-        const int yhi = ylo + 2 * ry + 2 < a.H - 1 ? ylo + 2 * ry + 2 : a.H - 1;
-        const int xhi = xlo + 2 * rx + 2 < a.W - 1 ? xlo + 2 * rx + 2 : a.W - 1;
+        yhi = yhi > a.H - 1 ? a.H - 1 : yhi;
+        xhi = xhi > a.W - 1 ? a.W - 1 : xhi;
         for (int y = ylo; y <= yhi; ++y) {
             int y0, y1;
             float ly;

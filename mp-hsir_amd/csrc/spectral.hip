@@ -665,8 +665,7 @@ extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* st
     const long total = (long)a->B * a->H * (a->W / 8) * (a->HP / (16 / esz));
     const long blocks = ((total + 255) / 256 + 7) / 8 * 8;            // multiple of 8: XCD-contiguous order
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const int tile_env = [] { const char* e = getenv("MPHSIR_DW_TILE"); return e ? atoi(e) : 1; }();      // tuning aid: 0 = strip form
-    if (tile_env && dtype != MPHSIR_F32 && a->H % GT2_TH == 0 && a->W % GT2_TW == 0)
+    if (dtype != MPHSIR_F32 && a->H % GT2_TH == 0 && a->W % GT2_TW == 0)
         return dtype == MPHSIR_BF16 ? launch_gate_tile<bf16_t>(d, s) : launch_gate_tile<f16_t>(d, s);
     if (dtype == MPHSIR_F32)
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, d);

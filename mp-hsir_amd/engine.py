@@ -150,21 +150,25 @@ def _external_events_work(dev):
         side = torch.cuda.Stream(dev)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
+        stale = torch.zeros(8, device=dev)
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            torch.cuda._sleep(20_000_000)       # ~10 ms in front of the record node: a wait that is NOT honoured reads the old value
             for _ in range(8):
-                src.add_(1.0)                   # something that takes a while
+                src.add_(1.0)
             val.copy_(src[0])
             ev.record()
             src.mul_(1.0)
         ok = True
-        for i in range(4):
+        for i in range(6):
             g.replay()
+            with torch.cuda.stream(side):
+                stale[i].copy_(val)             # unsynchronised: must still see the previous replay's value (the probe can tell)
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 out[i].copy_(val)
             torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        ok = out[:4].tolist() == [8.0, 16.0, 24.0, 32.0]
+        ok = out[:6].tolist() == [8.0 * (i + 1) for i in range(6)] and stale[:6].tolist() == [8.0 * i for i in range(6)]
     except Exception:
         ok = False
     _EXT_EVENTS[key] = ok
@@ -277,13 +281,12 @@ class DataParallelEngine:
     def _gather_bucket(self, bi):
         """autograd hands every gradient over as a fresh tensor (p.grad was None): move the bucket's gradients into
         the arena with one multi-tensor copy instead of one accumulate kernel per parameter."""
-        ops.join_wgrad_stream()
         ps, views = self._bucket_members[bi]
         # _foreach_copy_ takes its multi-tensor kernel only when EVERY pair has identical dense strides; one transposed /
         # strided gradient view in the list silently turns the whole bucket into one copy launch per parameter (measured:
         # ~530 tiny copies, 1.6 ms of a 28.8 ms step).  So the list is split: contiguous gradients (all but a handful) go
-        # through the multi-tensor kernel, the rest are copied one by one; gradients a backward function already wrote
-        # into the arena view (ops.grad_sink) need no copy at all.
+        # through the multi-tensor kernel, the rest are copied one by one; a gradient that already is the arena view
+        # needs no copy at all.
         fv, fg = [], []
         for p, v in zip(ps, views):
             g = p.grad
@@ -428,8 +431,8 @@ class DataParallelEngine:
 
     # ---- optimizer state for checkpoints (the reference's Lightning checkpoints carry AdamW's moments and step) ----------
     def optimizer_state(self):
-        """{'step', 'exp_avg': {param name: tensor}, 'exp_avg_sq': {...}} -- per parameter NAME, so it survives a different
-        arena layout; parameters without gradient have no entry."""
+        """{'step', 'exp_avg': {param name: tensor}, 'exp_avg_sq': {...}, 'loss_scaler'} -- per parameter NAME, so it survives a
+        different arena layout; parameters without gradient have no entry."""
         if self.arena is None:
             return {"step": self.step_count, "exp_avg": {}, "exp_avg_sq": {}}
         names = {id(p): n for n, p in self.net.named_parameters()}
@@ -444,8 +447,16 @@ class DataParallelEngine:
         as the arenas exist)."""
         self._resume = state
         self.step_count = int(state["step"])
-        if state.get("loss_scaler") is not None:
-            self.scaler = state["loss_scaler"].to(next(self.net.parameters()).device).float()
+        dev = next(self.net.parameters()).device
+        if self._use_scaler(dev):
+            # the fp16 path counts its optimizer steps in scaler[3] (skipped steps do not advance the bias correction): adopt
+            # the saved scaler, or -- a bf16 / fp32 checkpoint resumed in fp16 -- start a fresh one at the saved step count
+            if state.get("loss_scaler") is not None:
+                self.scaler = state["loss_scaler"].to(dev).float()
+            else:
+                self.scaler[3] = float(self.step_count)
+        elif state.get("loss_scaler") is not None:
+            self.step_count = int(state["loss_scaler"][3])       # an fp16 checkpoint resumed in bf16 / fp32: no scaler there
         if self.arena is not None:
             self._apply_resume()
 

@@ -51,14 +51,11 @@ _SIDE = {}
 #    workgroups -- a few dozen to 128 workgroups for 20-45 us, most of the chip idle -- and nothing needs their output until
 #    the branch sum / the window-attention backward.  Forked beside pass A (forward) / the channel-attention backward:
 #    1159.5 -> 1182.4 patches/s.
-#  * the fold backward (MPHSIR_SIDE_STREAM, default off): it does overlap the dv GEMM, but there is too little independent
-#    work before its consumer; whole step unchanged (tools/bench_fork.py, round 1).
+#    (Tried and dropped: the fold backward and the weight-gradient GEMMs on side streams -- whole step unchanged, DESIGN.md.)
 # Allocation stays stream-safe without record_stream on the inputs: tensors created inside the branch belong to the side
 # stream's pool, every branch starts by waiting for the launch stream (a reused block is ordered after its last consumer
 # there), and the caller holds the inputs until the join.
-USE_SIDE_STREAM = os.environ.get("MPHSIR_SIDE_STREAM", "0") == "1"
 SIDE_BRANCH = os.environ.get("MPHSIR_SIDE_BRANCH", "1") == "1"
-SIDE_BRANCH_FWD = os.environ.get("MPHSIR_SIDE_BRANCH_FWD", "1" if SIDE_BRANCH else "0") == "1"      # the forward gate alone
 
 
 class side_stream:
@@ -67,8 +64,8 @@ class side_stream:
     (record_stream).  Works under hipGraph capture (fork/join from the capturing stream = parallel graph branches).
     No-op on CPU tensors (emulator) or when disabled."""
 
-    def __init__(self, like, enabled=None):
-        self.on = (USE_SIDE_STREAM if enabled is None else enabled) and like.is_cuda
+    def __init__(self, like, enabled=True):
+        self.on = enabled and like.is_cuda
         self.ctx = None
         if self.on:
             dev = like.device
@@ -116,65 +113,10 @@ class reduce_scope:
         global _SCOPE
         _SCOPE = self.prev
         if exc[0] is None:
-            dev_t = next((t for g in self.gemms for t in g["keep"] if t is not None), None)
-            if dev_t is None:
-                dev_t = next((t for g in self.segs for t in g["keep"] if t is not None), None)
-            with _wgrad_stream(dev_t, self.segs, self.gemms):
-                _flush_gemms(self.gemms)        # the deferred weight-gradient GEMMs, grouped ...
-                _flush(self.segs)               # ... then the ordered sums of everything they (and others) wrote
+            _flush_gemms(self.gemms)            # the deferred weight-gradient GEMMs, grouped ...
+            _flush(self.segs)                   # ... then the ordered sums of everything they (and others) wrote
         self.segs, self.gemms = [], []
         return False
-
-
-# ---- weight-gradient stream -----------------------------------------------------------------------------------------------
-# Nothing inside a backward pass reads a parameter gradient: the deferred token-reduction GEMMs and the ordered partial sums
-# of a backward function only feed the optimizer.  With MPHSIR_WGRAD_STREAM=1 they are issued on a second stream that forks
-# from the launch stream at the end of the function (so its inputs are complete) and is joined once, before the gradients
-# are handed to the arena (engine) -- under hipGraph capture the fork/join become parallel graph branches, and the
-# latency-bound kernels of the next backward functions run beside them.  Every tensor the side stream touches is kept
-# alive until the join, so the caching allocator cannot hand its memory to a later main-stream allocation.
-WGRAD_STREAM = os.environ.get("MPHSIR_WGRAD_STREAM", "0") == "1"
-_WG = {"stream": {}, "keep": [], "dirty": False}
-
-
-class _wgrad_stream:
-    def __init__(self, like, segs, gemms):
-        self.on = WGRAD_STREAM and like is not None and like.is_cuda
-        if self.on:
-            dev = like.device
-            self.main = torch.cuda.current_stream(dev)
-            self.side = _WG["stream"].get(dev)
-            if self.side is None:
-                self.side = _WG["stream"][dev] = torch.cuda.Stream(dev)
-            _WG["keep"].append([g["keep"] for g in segs] + [g["keep"] for g in gemms])
-
-    def __enter__(self):
-        if self.on:
-            self.side.wait_stream(self.main)
-            self.ctx = torch.cuda.stream(self.side)
-            self.ctx.__enter__()
-            if not _WG["dirty"]:        # first fork of this backward pass: join automatically when the pass ends
-                try:
-                    torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
-                except RuntimeError:    # not inside a backward pass (kernel-level tests call the scope directly)
-                    pass
-            _WG["dirty"] = True
-        return self
-
-    def __exit__(self, *exc):
-        if self.on:
-            self.ctx.__exit__(*exc)
-        return False
-
-
-def join_wgrad_stream():
-    """make the current stream wait for every weight-gradient launch issued so far (call before reading parameter
-    gradients: the engine does, before the hand-over to the arena)"""
-    if _WG["dirty"]:
-        for dev, side in _WG["stream"].items():
-            torch.cuda.current_stream(dev).wait_stream(side)
-        _WG["keep"].clear()
-        _WG["dirty"] = False
 
 
 def _flush_gemms(gemms):
@@ -518,7 +460,7 @@ def qkv_dwconv_gram_fits(C, heads, H, W, dtype):
 
 # workgroups of the fused pass A: 512 = two per CU-slot of work; measured 1.57 -> 1.45 ms/step against 1024 (each workgroup
 # then walks two tiles with the next slab's weights already in flight), 256 no better
-FUSED_WGS = int(os.environ.get("MPHSIR_FUSED_WGS", "512"))
+FUSED_WGS = 512
 
 
 def choose_nsplit_fused(B, H, W):

@@ -6,7 +6,7 @@ options.py (options.py:6-37), so its command lines (README.md:36,38) work unchan
 Like the reference, the namespace is built at import time (`from options import options as opt`);
 unknown flags are tolerated so that importing this module under pytest/torchrun does not abort.
 Additions (not present in the reference, all optional): --model, --precision, --steps_per_epoch, --graph,
---synthetic, --log_every, --allow_surrogate_clip, --all_sources.  Reference hazards kept on purpose: `--num_gpus type=list` turns "01"
+--synthetic, --log_every, --allow_surrogate_clip, --all_sources, --resume.  Reference hazards kept on purpose: `--num_gpus type=list` turns "01"
 into ['0','1'] (options.py:36) and `--classifier type=bool` treats any non-empty string as True.
 """
 import argparse
@@ -47,6 +47,8 @@ _FLAGS = [
     ("--synthetic", dict(type=int, default=1, help="1: GPU-side synthetic patch source (no datasets offline)")),
     ("--log_every", dict(type=int, default=10)),
     ("--graph", dict(type=int, default=1, help="1: capture the training step in a hipGraph after two eager steps and replay it")),
+    ("--resume", dict(type=int, default=0, help="1: --ckpt_path also restores the optimizer state and continues at the saved "
+                      "epoch + 1 (a checkpoint written by this script); 0 (default) = the reference's warm start: weights only, epoch 0")),
 ]
 
 

@@ -12,7 +12,8 @@ checkpoint every 50 epochs (:104).  Data: --synthetic 1 (default; datasets are n
 data.SyntheticPatchSource; --synthetic 0 --db_path <dir> reads the reference's patch records (data.PatchDB, the LMDB
 record format in a flat file).  Either way the per-task degradations of --*_single_de_type are synthesised on the GPU
 (degrade.DegradationSynthesizer).  Checkpoints carry, besides the `net.`-prefixed state_dict, AdamW's moments and step
-count (resumable, like the reference's Lightning checkpoints) and the CLIP text-embedding table the model was built with.
+count and the CLIP text-embedding table the model was built with.  --ckpt_path is the reference's warm start (weights whose
+key and shape match, epoch 0); --resume 1 additionally restores the optimizer state and continues at the saved epoch + 1.
 """
 import os
 import random
@@ -40,21 +41,33 @@ def set_seed(seed):
     torch.cuda.manual_seed_all(seed)
 
 
-def load_warm_start(net, path, device, engine=None):
-    """keep checkpoint entries whose key AND shape match (train.py:109-116); keys carry the `net.` prefix.  A checkpoint
-    written by save_checkpoint also restores the optimizer state into `engine` and is checked against the model's CLIP
-    table (a model built on other text embeddings would silently mis-evaluate)."""
+def saved_clip_table(path, task_classes):
+    """the CLIP text-embedding table a checkpoint of this script carries, if it fits a model with `task_classes` tasks
+    (a natural-scene checkpoint, 6 x 512, warm-starting the remote-sensing model, 7 x 512, brings no table)"""
+    table = torch.load(path, map_location="cpu").get("mphsir_clip_prompt")
+    return table if table is not None and tuple(table.shape) == (task_classes, 512) else None
+
+
+def load_warm_start(net, path, device, engine=None, resume=False):
+    """The reference's warm start (train.py:109-116): keep checkpoint entries whose key AND shape match (keys carry the
+    `net.` prefix), nothing else -- training starts at epoch 0 whatever wrote the checkpoint.  resume=True (--resume 1, a
+    checkpoint written by save_checkpoint) also restores the optimizer state into `engine` and returns the epoch to
+    continue at.  A saved CLIP table of the model's own shape must match the model's (a model built on other text
+    embeddings would silently mis-evaluate); a table of another shape belongs to the other configuration and is ignored."""
     ckpt = torch.load(path, map_location=device)
     state = ckpt["state_dict"]
     own = {"net." + k: v for k, v in net.state_dict().items()}
     kept = {k[4:]: v for k, v in state.items() if k in own and own[k].shape == v.shape}
     net.load_state_dict(kept, strict=False)
     table = ckpt.get("mphsir_clip_prompt")
-    if table is not None and not torch.allclose(table.float().cpu(), net.clip_prompts.float().cpu(), atol=1e-5):
+    if table is not None and tuple(table.shape) == tuple(net.clip_prompts.shape) and \
+            not torch.allclose(table.float().cpu(), net.clip_prompts.float().cpu(), atol=1e-5):
         raise RuntimeError("%s was trained with other CLIP text embeddings than this model was built with; build the model "
                            "with clip_prompt=ckpt['mphsir_clip_prompt']" % path)
     resume_epoch = 0
-    if engine is not None and "mphsir_optimizer" in ckpt:
+    if resume:
+        if engine is None or "mphsir_optimizer" not in ckpt:
+            raise RuntimeError("--resume 1 needs a checkpoint written by this script (optimizer state); %s has none" % path)
         engine.load_optimizer_state(ckpt["mphsir_optimizer"])
         resume_epoch = int(ckpt.get("epoch", -1)) + 1
     return len(kept), resume_epoch
@@ -79,16 +92,18 @@ def main():
     cfg = MODELS[opt.model or opt.data_type]
     clip_prompt = "surrogate" if opt.allow_surrogate_clip else None      # None: encode with OpenAI clip, or raise
     if opt.ckpt_path is not None:
-        saved = torch.load(opt.ckpt_path, map_location="cpu").get("mphsir_clip_prompt")
+        saved = saved_clip_table(opt.ckpt_path, cfg["task_classes"])
         clip_prompt = saved if saved is not None else clip_prompt
     dtypes = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}
     net = MP_HSIR_Net(**cfg, clip_prompt=clip_prompt, compute_dtype=dtypes[opt.precision]).to(dev).train()
     eng = DataParallelEngine(net, lr=opt.lr, use_graph=bool(opt.graph))
     start_epoch = 0
     if opt.ckpt_path is not None:
-        n, start_epoch = load_warm_start(net, opt.ckpt_path, dev, eng)
+        n, start_epoch = load_warm_start(net, opt.ckpt_path, dev, eng, resume=bool(opt.resume))
         if rank == 0:
-            print("warm start: %d tensors from %s, continuing at epoch %d" % (n, opt.ckpt_path, start_epoch))
+            print("warm start: %d tensors from %s, %s at epoch %d" % (n, opt.ckpt_path, "resuming" if opt.resume else "starting", start_epoch))
+        if start_epoch >= opt.epochs:
+            raise SystemExit("--resume 1: %s already holds epoch %d of --epochs %d: nothing left to train" % (opt.ckpt_path, start_epoch - 1, opt.epochs))
     data_type = opt.model or opt.data_type
     de_types = opt.natural_scene_single_de_type if data_type == "natural_scene" else opt.remote_sensing_single_de_type
     if opt.synthetic:

@@ -100,39 +100,25 @@ def test_tiny_adamw_two_steps_vs_reference(use_graph):
     print("tiny AdamW worst relative error", M.check_tiny_adamw("cuda", use_graph=use_graph))
 
 
-def _spawn_ranks(mode, steps, out, world=2, port=29541):
+def _spawn_ranks(mode, steps, out, world=2, port=29541, backend="gloo"):
     import os
     import subprocess
     import sys
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_graph_worker.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, worker, out, mode, str(steps)], env=dict(env, RANK=str(r))) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, worker, out, mode, str(steps), backend], env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     return [torch.load(out + str(r)) for r in range(world)]
 
 
-@pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["graph", "eager"])
-def test_data_parallel_world2_on_one_gpu(mode, tmp_path):
-    """e / a19: two ranks (fresh child processes, gloo, both on cuda:0) x micro-batch 2 through the engine -- graph mode:
-    captured step + arena-wide all-reduce + AdamW/repack after the replay (what bench.py --gpus N runs); eager mode:
-    bucketed all-reduces from the gradient hooks -- against ONE process that runs both micro-batches, averages the
-    gradients (DDP semantics; TVSP's batch coupling is per micro-batch, SURVEY Q1) and steps torch.optim.AdamW."""
+def _check_world2(res, mode, steps):
+    """both ranks' final parameters are bitwise equal and equal ONE process that runs both micro-batches, averages the
+    gradients (DDP semantics; TVSP's batch coupling is per micro-batch) and steps torch.optim.AdamW"""
     from golden.cases import TINY_CFG
     from golden.detfill import seeded_input
-    steps = 5
-    res = _spawn_ranks(mode, steps, str(tmp_path / "res"), port=29541 if mode == "graph" else 29543)
     for k in res[0]["state"]:
         assert torch.equal(res[0]["state"][k], res[1]["state"][k]), "ranks diverged: " + k
-    print("world-2 %s mode: %d buckets, all-reduce overlapped with the replay: %s (bucket order %s)"
-          % (mode, res[0]["nbuckets"], res[0]["overlap"], res[0]["bucket_order"]))
-    assert res[0]["nbuckets"] >= 2
-    if mode == "graph":
-        from mp_hsir_amd.engine import _external_events_work
-        assert res[0]["overlap"] == _external_events_work(torch.device("cuda", 0))
-        if res[0]["overlap"]:
-            assert sorted(res[0]["bucket_order"]) == list(range(res[0]["nbuckets"]))
     net = M.build_net(TINY_CFG, "cuda", torch.float32)
     p0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
     opt = torch.optim.AdamW([p for p in net.parameters()], lr=2e-3)
@@ -156,6 +142,97 @@ def test_data_parallel_world2_on_one_gpu(mode, tmp_path):
             assert float(d_got.norm()) == 0.0, k
             continue
         assert float((d_got - d_ref).norm() / d_ref.norm()) < 2e-2, (k, float((d_got - d_ref).norm() / d_ref.norm()))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_data_parallel_world2_rccl(mode, tmp_path):
+    """e / a19 on real hardware: two ranks, one GPU each, backend nccl (= RCCL) -- broadcast at start, bucketed gradient
+    all-reduce (graph mode: started from external event nodes inside the replay, or one arena-wide message if the stack has
+    none), AdamW -- against the one-process reference.  Runs wherever >= 2 GPUs are visible; the children are started
+    before this process touches a GPU (device_count() does not initialise HIP)."""
+    steps = 5
+    res = _spawn_ranks(mode, steps, str(tmp_path / "res"), port=29551 if mode == "graph" else 29553, backend="nccl")
+    print("world-2 RCCL %s mode: %d buckets, all-reduce overlapped with the replay: %s (bucket order %s)"
+          % (mode, res[0]["nbuckets"], res[0]["overlap"], res[0]["bucket_order"]))
+    assert res[0]["nbuckets"] >= 2
+    _check_world2(res, mode, steps)
+
+
+def test_checkpoint_resume_continues_bitwise(tmp_path):
+    """f3: save_checkpoint after 2 steps -> a NEW model + engine, load_warm_start(resume=True) -> 2 more steps == 4 steps
+    straight through, bitwise (parameters, AdamW moments, step count); without resume the same file is the reference's warm
+    start: weights only, epoch 0, fresh optimizer (train.py:109-116)."""
+    import importlib
+    from golden.cases import TINY_CFG
+    from golden.detfill import seeded_input
+    from mp_hsir_amd.engine import DataParallelEngine
+    T = importlib.import_module("mp_hsir_amd.train")
+
+    def batch(step):
+        return (seeded_input("ck_x%d" % step, (2, 8, 32, 32)).cuda(), seeded_input("ck_c%d" % step, (2, 8, 32, 32)).cuda(),
+                torch.tensor([[1], [3]]).cuda())
+
+    def run(net, eng, steps):
+        for s in steps:
+            torch.manual_seed(100 + s)           # DropPath draws: the same per step whatever ran before
+            eng.train_step(*batch(s), lr=2e-3)
+        torch.cuda.synchronize()
+
+    net_a = M.build_net(TINY_CFG, "cuda", torch.float32).train()
+    eng_a = DataParallelEngine(net_a, lr=2e-3)
+    run(net_a, eng_a, range(4))
+    net_b = M.build_net(TINY_CFG, "cuda", torch.float32).train()
+    eng_b = DataParallelEngine(net_b, lr=2e-3)
+    run(net_b, eng_b, range(2))
+    path = str(tmp_path / "epoch=7.ckpt")
+    T.save_checkpoint(path, net_b, eng_b, epoch=7)
+    net_c = M.build_net(TINY_CFG, "cuda", torch.float32).train()
+    with torch.no_grad():
+        for p in net_c.parameters():
+            p.mul_(0.5)                       # everything must come from the file
+    eng_c = DataParallelEngine(net_c, lr=2e-3)
+    n, start = T.load_warm_start(net_c, path, torch.device("cuda"), eng_c, resume=True)
+    assert start == 8 and n == len(net_c.state_dict())
+    run(net_c, eng_c, range(2, 4))
+    for (k, va), vc in zip(net_a.state_dict().items(), net_c.state_dict().values()):
+        assert torch.equal(va, vc), k
+    sa, sc = eng_a.optimizer_state(), eng_c.optimizer_state()
+    assert sa["step"] == sc["step"] == 4
+    for k in sa["exp_avg"]:
+        assert torch.equal(sa["exp_avg"][k], sc["exp_avg"][k]) and torch.equal(sa["exp_avg_sq"][k], sc["exp_avg_sq"][k]), k
+    # the same file as a warm start: weights only
+    net_d = M.build_net(TINY_CFG, "cuda", torch.float32).train()
+    eng_d = DataParallelEngine(net_d, lr=2e-3)
+    n, start = T.load_warm_start(net_d, path, torch.device("cuda"), eng_d)
+    assert start == 0 and eng_d.step_count == 0
+    for (k, vb), vd in zip(net_b.state_dict().items(), net_d.state_dict().values()):
+        assert torch.equal(vb, vd), k
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_data_parallel_world2_on_one_gpu(mode, tmp_path):
+    """e / a19: two ranks (fresh child processes, gloo, both on cuda:0) x micro-batch 2 through the engine -- graph mode:
+    captured step + arena-wide all-reduce + AdamW/repack after the replay (what bench.py --gpus N runs); eager mode:
+    bucketed all-reduces from the gradient hooks -- against ONE process that runs both micro-batches, averages the
+    gradients (DDP semantics; TVSP's batch coupling is per micro-batch, SURVEY Q1) and steps torch.optim.AdamW."""
+    from golden.cases import TINY_CFG
+    from golden.detfill import seeded_input
+    steps = 5
+    res = _spawn_ranks(mode, steps, str(tmp_path / "res"), port=29541 if mode == "graph" else 29543)
+    for k in res[0]["state"]:
+        assert torch.equal(res[0]["state"][k], res[1]["state"][k]), "ranks diverged: " + k
+    print("world-2 %s mode: %d buckets, all-reduce overlapped with the replay: %s (bucket order %s)"
+          % (mode, res[0]["nbuckets"], res[0]["overlap"], res[0]["bucket_order"]))
+    assert res[0]["nbuckets"] >= 2
+    if mode == "graph":
+        from mp_hsir_amd.engine import _external_events_work
+        assert res[0]["overlap"] == _external_events_work(torch.device("cuda", 0))
+        if res[0]["overlap"]:
+            assert sorted(res[0]["bucket_order"]) == list(range(res[0]["nbuckets"]))
+    _check_world2(res, mode, steps)
 
 
 @pytest.mark.timeout(900)
