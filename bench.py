@@ -35,7 +35,11 @@ sys.path.insert(0, ROOT)
 warnings.filterwarnings("ignore")
 
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PEAK_MFMA_TF = {"bf16": 2500.0, "f32": 157.3}
+PEAK_MFMA_TF = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}
+MODELS = {"natural_scene": dict(in_channel=31, out_channel=31, dim=64, task_classes=6),      # test.py:39
+          "remote_sensing": dict(in_channel=100, out_channel=100, dim=96, task_classes=7),   # train.py:45
+          "rs172": dict(in_channel=172, out_channel=172, dim=96, task_classes=7)}            # BASELINE configs[3]
+DTYPES = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}
 RIDGE = 312.0                  # FLOP/B, bf16 dense MFMA peak / HBM peak
 
 def kernel_ids(lib):
@@ -56,13 +60,32 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
     ap.add_argument("--patch", type=int, default=64, help="patch height = width (diagnostic: 512 = the test cubes of test.py)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"], help="f16 = the reference's 16-mixed (dynamic loss scaling)")
+    ap.add_argument("--model", default="natural_scene", choices=sorted(MODELS), help="headline = natural_scene; the others are BASELINE configs[3]/[4]")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra BASELINE configurations of the N=1 line")
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: time inference only (not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-spectral", action="store_true", help="skip the 512x512 spectral-attention roofline leg")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured step (hipGraph)")
     return ap.parse_args()
+
+
+def cube_forward_worker(out_path, threads):
+    """child process: ONE 512x512x31 forward of the CPU oracle (SURVEY 8d's fourth shape; ~2 min on 32 threads), started at
+    the beginning of the run so that it overlaps the GPU legs; writes seconds to out_path"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(threads)
+    from oracle import mp_hsir_oracle as O
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    torch.manual_seed(2024)
+    net = MP_HSIR_Net(clip_prompt="surrogate")
+    P = {k: v.detach().clone() for k, v in net.state_dict().items() if not k.endswith("attn_mask")}
+    x = torch.rand(1, 31, 512, 512)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.mp_hsir_forward(P, O.make_cfg(), x, torch.tensor([[0]]), net.clip_prompts)
+    json.dump({"seconds": time.perf_counter() - t0, "threads": threads}, open(out_path, "w"))
 
 
 def cpu_baseline(budget_s=30.0):
@@ -118,14 +141,20 @@ def cpu_baseline(budget_s=30.0):
         if best is None or 4 / t > best[0]:
             best = (4 / t, nt)
     torch.set_num_threads(best[1])
+    dropped = []
     detail["fwd_b1_threads%d" % best[1]] = round(1 / timed(fwd(1)), 4)
     if time.perf_counter() - t_start < budget_s:
         detail["fwd_b16_threads%d" % best[1]] = round(16 / timed(fwd(16), iters=1), 4)
+    else:
+        dropped.append("fwd_b16")
     if time.perf_counter() - t_start < budget_s:
         torch.set_num_threads(1)
         detail["fwd_b1_threads1"] = round(1 / timed(fwd(1), iters=1), 4)
+    else:
+        dropped.append("fwd_b1_threads1")
     torch.set_num_threads(prev)
     return {"value": round(best[0], 4), "unit": "patches/s", "cores": best[1], "kind": "port", "host_cpus": ncpu, "detail": detail,
+            "dropped_legs": dropped,
             "sample": "natural 64x64x31 fp32, torch CPU oracle: fwd+bwd of batch 4, median of <=3 after 1 warm-up, best of the thread "
                       "counts in detail (patches/s each); bounded to ~%ds" % int(budget_s)}
 
@@ -193,13 +222,85 @@ def spectral_roofline(net, dev, lib, steps=5):
     return out
 
 
+def timed_leg(step, steps, warmup, fence):
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_configs(dev):
+    """The other BASELINE.json configurations on the same code (N = 1 line only; the headline stays configs[2]):
+    configs[1] natural net forward batch 16 bf16, configs[3] RS-width 172-band 512x512 cube forward bf16, configs[4]
+    remote-sensing training batch 16 fp16 + dynamic loss scaling.  Each: hipGraph replay, a few steps after the capture."""
+    from mp_hsir_amd.data import SyntheticPatchSource
+    from mp_hsir_amd.engine import DataParallelEngine, GraphedForward
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    out = {}
+
+    def sync():
+        torch.cuda.synchronize()
+
+    def fwd_leg(model, dtype, batch, patch, steps):
+        cfg = MODELS[model]
+        torch.manual_seed(2024)
+        net = MP_HSIR_Net(**cfg, compute_dtype=DTYPES[dtype], clip_prompt="surrogate").to(dev).eval()
+        src = SyntheticPatchSource(cfg["in_channel"], patch, batch, cfg["task_classes"], dev, 2024, 0)
+        run = GraphedForward(net)
+        def step():
+            _, x, c, p = src.next()
+            with torch.no_grad():
+                return run(x, p)
+        t = timed_leg(step, steps, 3, sync)
+        del run, net
+        torch.cuda.empty_cache()
+        return t
+
+    def train_leg(model, dtype, batch, steps):
+        cfg = MODELS[model]
+        torch.manual_seed(2024)
+        net = MP_HSIR_Net(**cfg, compute_dtype=DTYPES[dtype], clip_prompt="surrogate").to(dev).train()
+        src = SyntheticPatchSource(cfg["in_channel"], 64, batch, cfg["task_classes"], dev, 2024, 0)
+        eng = DataParallelEngine(net, lr=2e-4, use_graph=True)
+        def step():
+            _, x, c, p = src.next()
+            return eng.train_step(x, c, p)
+        t = timed_leg(step, steps, 4, sync)
+        scale = None if eng.scaler is None else float(eng.scaler[0])
+        del eng, net
+        torch.cuda.empty_cache()
+        return t, scale
+
+    t = fwd_leg("natural_scene", "bf16", 16, 64, 20)
+    out["configs[1] natural forward b16 bf16"] = {"patches_per_s": round(16 / t, 1), "ms_per_step": round(t * 1e3, 3)}
+    t = fwd_leg("rs172", "bf16", 1, 512, 5)
+    out["configs[3] rs172 512x512x172 forward b1 bf16"] = {"cubes_per_s": round(1 / t, 2), "ms_per_cube": round(t * 1e3, 3)}
+    t, scale = train_leg("remote_sensing", "f16", 16, 10)
+    out["configs[4] remote_sensing training b16 fp16+loss scaling"] = {"patches_per_s": round(16 / t, 1), "ms_per_step": round(t * 1e3, 3),
+                                                                        "loss_scale_after": scale}
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    cube_proc, cube_out = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "natural_scene" and not args.forward_only:
+        # the oracle's 512x512 forward (about two minutes of CPU) runs beside the GPU legs, before this process touches the GPU
+        import subprocess
+        import tempfile
+        cube_out = os.path.join(tempfile.gettempdir(), "mphsir_cpu_cube_%d.json" % os.getpid())
+        cube_proc = subprocess.Popen([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; bench.cube_forward_worker(%r, %d)"
+                                      % (ROOT, cube_out, min(32, os.cpu_count() or 1))], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
+    backend = None
     if world > 1:
         # RCCL over xGMI.  MPHSIR_DIST_BACKEND=gloo is a TEST hook: it lets the whole N>1 path (broadcast, gradient
         # all-reduce outside the captured step, AdamW + repack after it) run with several ranks sharing one GPU box.
@@ -213,10 +314,12 @@ def main():
     from mp_hsir_amd.engine import DataParallelEngine
     from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
     lib = _lib.load()
-    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dt = DTYPES[args.dtype]
+    cfg = MODELS[args.model]
+    bands = cfg["in_channel"]
     torch.manual_seed(2024)
-    net = MP_HSIR_Net(compute_dtype=dt, clip_prompt="surrogate").to(dev)      # no CLIP weights offline: seeded stand-in (timing only)
-    src = SyntheticPatchSource(31, args.patch, args.batch, 6, dev, 2024, rank)
+    net = MP_HSIR_Net(**cfg, compute_dtype=dt, clip_prompt="surrogate").to(dev)      # no CLIP weights offline: seeded stand-in (timing only)
+    src = SyntheticPatchSource(bands, args.patch, args.batch, cfg["task_classes"], dev, 2024, rank)
     if args.forward_only:
         net.eval()
         from mp_hsir_amd.engine import GraphedForward
@@ -250,6 +353,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t)
     value = world * args.batch * args.steps / dt_s
+
+    comm = None
+    if world > 1 and not args.forward_only:
+        # what the collective costs on its own: the gradient arena reduced bucket by bucket, as in a step, nothing else running
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            for st, en, _ in eng.buckets:
+                dist.all_reduce(eng.flat_g[st:en], group=eng.pg)
+        fence()
+        comm = {"backend": "rccl" if backend == "nccl" else backend, "ranks": world, "gradient_bytes": int(eng.flat_g.numel() * 4),
+                "buckets": len(eng.buckets), "allreduce_ms_per_step_alone": round((time.perf_counter() - t0) / 5 * 1e3, 3),
+                "overlap": ("graph: bucket all-reduces start from external event nodes inside the replay" if getattr(eng, "_overlap", False)
+                            else ("graph: one arena-wide all-reduce after the replay" if not args.no_graph else "eager: bucketed all-reduces from gradient hooks"))}
 
     roofline = None
     if not args.no_roofline:
@@ -302,14 +419,39 @@ def main():
                                          round(acct[k][1] / v[1] / 1e9, 1)] for k, v in sorted(per.items()) if k in acct}}
 
     spectral = None
-    if rank == 0 and world == 1 and not args.no_roofline and not args.forward_only and args.dtype == "bf16" and not args.no_spectral:
+    if rank == 0 and world == 1 and not args.no_roofline and not args.forward_only and args.dtype == "bf16" and not args.no_spectral \
+            and args.model == "natural_scene":
         eng.finish()
         torch.cuda.empty_cache()
         spectral = spectral_roofline(net, dev, lib)
 
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra and not args.forward_only and args.model == "natural_scene" and args.dtype == "bf16":
+        if spectral is None:
+            eng.finish()
+        del eng
+        torch.cuda.empty_cache()
+        extra = extra_configs(dev)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cube_done = False
+        if cube_proc is not None:                 # let it finish first: the timed legs below get the host to themselves
+            try:
+                cube_proc.wait(timeout=150)
+                cube_done = True
+            except Exception:
+                cube_proc.kill()
         cpu = cpu_baseline()
+        if cube_proc is not None:
+            try:
+                if not cube_done:
+                    raise RuntimeError("timeout")
+                r = json.load(open(cube_out))
+                cpu["detail"]["fwd_512x512_b1_threads%d_cubes_per_s" % r["threads"]] = round(1.0 / r["seconds"], 5)
+                cpu["detail"]["fwd_512x512_b1_seconds"] = round(r["seconds"], 1)
+            except Exception:
+                cpu["dropped_legs"].append("fwd_512x512_b1 (not finished 150 s after the GPU legs)")
 
     if rank == 0:
         line = {
@@ -317,12 +459,13 @@ def main():
             "value": round(value, 2), "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_s / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "natural-scene MP_HSIR_Net(31,31,64,T=6) %s, %dx%dx31 patches, batch %d/GPU, %s"
-                                   % ("forward" if args.forward_only else "training step fwd+bwd+allreduce+AdamW",
-                                      args.patch, args.patch, args.batch, "dp%d" % world),
-                       "global_batch": world * args.batch, "patch": "%dx%dx31" % (args.patch, args.patch), "parallelism": "dp%d" % world, "launch": "eager" if args.no_graph else "hipGraph replay",
+            "config": {"workload": "%s MP_HSIR_Net(%d,%d,%d,T=%d) %s, %dx%dx%d patches, batch %d/GPU, %s"
+                                   % (args.model.replace("_", "-"), bands, bands, cfg["dim"], cfg["task_classes"],
+                                      "forward" if args.forward_only else "training step fwd+bwd+allreduce+AdamW",
+                                      args.patch, args.patch, bands, args.batch, "dp%d" % world),
+                       "global_batch": world * args.batch, "patch": "%dx%dx%d" % (args.patch, args.patch, bands), "parallelism": "dp%d" % world, "launch": "eager" if args.no_graph else "hipGraph replay",
                        "backward": "HIP kernels for every module (fused block / prompt-module backward, token-reduction GEMMs, gemm_tok data gradients); no library GEMM on the step"},
-            "roofline": roofline, "roofline_spectral": spectral, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_spectral": spectral, "cpu_baseline": cpu, "extra_configs": extra, "comm": comm,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
