@@ -13,8 +13,9 @@
 //     accumulators (lane = 4 channels x 1 pixel) ARE the depthwise input: the row above / below is another register
 //     (two partial output rows are kept: every t row is multiplied into the three rows it touches and then dropped, so no
 //     row is ever computed twice), the pixel to the left / right is either the other block's register of the SAME lane
-//     or one DPP row shift away.  The strip's outer columns (x0-1, x0+32) travel with the row in the ring; their t values
-//     come from an "edge" MFMA block per 4 rows (16 columns = 4 rows x 2 sides, twice) and reach lanes 0 / 15 by ds_bpermute;
+//     or one DPP row shift away.  The strip's outer columns (x0-1, x0+32) travel with the row in the ring; their t comes from
+//     a third ("edge") MFMA block per row whose lanes 0..7 / 8..15 carry the left / right column, so it sits in lanes 0 / 15
+//     where the DPP moves of the taps pick it up as the value a lane without a source keeps;
 //   * the x rows arrive by LDS-DMA (global_load_lds, no registers) in an 8-slot ring, issued 8 rows ahead and retired with a
 //     counted vmcnt; q,k,v (training: t too) leave through a two-slot LDS row image [pixel][channel]: the Gram reads it
 //     pixel-strided (ds_read_b64_tr_b16) and the global stores are 16-byte chunks of >= 96 contiguous bytes per pixel;
@@ -35,7 +36,7 @@ namespace mphsir {
 constexpr int RW_SW = 32;                         // strip width in pixels
 constexpr int RW_RPX = RW_SW + 2;                 // ring row: left outer column | 32 pixels | right outer column
 constexpr int RW_RING = 8;                        // ring slots (rows)
-constexpr int RW_LEAD = 5;                        // a row is needed (by the edge block) up to 4 steps before its own MFMAs
+constexpr int RW_LEAD = 2;                        // a row is first read one step before the taps run on it
 constexpr int RW_UNR = 1;                         // steady steps come in groups of RW_UNR with the low bits of the ring position static
 
 struct RowGramDev {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
     // ---- running state
     f32x4 acc[2][NBW];                     // t of the walk row the depthwise taps run on in the next step
     f32x4 Pa[2][NBW], Pb[2][NBW];          // partial outputs of image rows ty-1 (taps 0..5 done) and ty (taps 0..2 done)
-    f32x4 eacc[NBW];                       // t of the strip's outer columns for 4 rows: lane j = (row (j >> 1) & 3, side j & 1)
+    f32x4 eacc[NBW];                       // t of the strip's outer columns for the row in acc: lanes 0..7 left, 8..15 right column
     f32x4 gacc[TPW];                       // this wave's Gram tiles (head, 16 q channels ti, 16 k channels tj)
     f32x4 sqacc[TPW], skacc[TPW];          // q_ti q_ti^T (tiles with tj == 0) and k_tj k_tj^T (ti == 0): their diagonals are the sums
                                            // of squares of F.normalize -- on the matrix cores, which idle, instead of 12 VALU per step
@@ -193,10 +194,9 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
     for (int s = 0; s < TPW; ++s) gacc[s] = sqacc[s] = skacc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const T* xlane = ring + (2 * j + 1) * XPE + 8 * g;      // pixel 2j of the strip = ring pixel 2j+1
-    const int eside = j & 1, erow = (j >> 1) & 3;
-    const bool ex_ok = eside ? (x0 + RW_SW < a.W) : (x0 > 0);
+    const int eside = j >> 3;                                // edge block: lanes 0..7 carry the left outer column, 8..15 the right
+    const bool ex_ok = eside ? (x0 + RW_SW < a.W) : (x0 > 0);      // one (zero padding of t at the image border otherwise)
     const T* elane = ring + (eside ? (RW_RPX - 1) * XPE : 0) + 8 * g;
-    const int esrc0 = ((lane & 48) | (j == 15 ? 1 : 0)) << 2;
     T* wlane = outs + cl0 + 4 * g + j * OPE;                 // this lane's 4 channels of pixel 2j in the row image (block 1: + 16 rows)
     constexpr int CPR = CT / 8;                              // 16-byte chunks per pixel and q | k | v
 
@@ -251,17 +251,6 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
         RW_MARK(0);
         if (STEADY || i >= 0) dma_next(u);                  // slot i % 8 is free: row i was last read in step i-1
 
-        // ---- the outer-column values of walk row i for lanes 0 / 15 (ds_bpermute: an LDS-pipe operation, first in the queue:
-        // the taps wait for nothing younger).  One fetch with a per-lane source; a second one instead of the register copy
-        // the two DPP moves need was slower (the LDS pipe is the busier unit: 42 % against 35 % for the VALU).
-        float ed[NBW][4];
-        {
-            const int esrc = esrc0 + 8 * (u & 3);           // lanes 0..14 fetch the left column's value, lane 15 the right one's
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ed[nb][r] = lane_fetch(esrc, eacc[nb][r]);
-        }
         // ---- LDS reads whose results the end of the step needs, issued first so that their latency hides behind the taps:
         // the Gram operands and the store chunks of output row i-3 (row image written in step i-1), training: the chunks of
         // t row i-1.  (The x fragments of walk row i+1 are read after the taps: 8 registers per K chunk held across them is
@@ -298,7 +287,8 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
 
         // ---- depthwise 3x3 of walk row i in registers.  Neighbours of pixel 2j (block 0): left = block 1 of lane j-1, right =
         // block 1 of this lane; of pixel 2j+1 (block 1): left = block 0 of this lane, right = block 0 of lane j+1.  Lane 0's
-        // left and lane 15's right neighbour are the strip's outer columns, fetched above from the edge block.
+        // left and lane 15's right neighbour are the strip's outer columns: the edge block of the previous step left their t
+        // in exactly those lanes (the `old` operand of the DPP move: what a lane without a source keeps).
         if (do_dw) {
             f32x4 fin[2][NBW];
 #pragma unroll
@@ -306,8 +296,8 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
                 f32x4 L0, R1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    L0[r] = dpp_row_shr1(ed[nb][r], acc[1][nb][r]);
-                    R1[r] = dpp_row_shl1(ed[nb][r], acc[0][nb][r]);
+                    L0[r] = dpp_row_shr1(eacc[nb][r], acc[1][nb][r]);
+                    R1[r] = dpp_row_shl1(eacc[nb][r], acc[0][nb][r]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -347,15 +337,6 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
         // ---- the matrix work of the step: the Gram of output row i-3 (one K chunk of 32 pixels per tile) and the sums of
         // squares (diagonals of q q^T / k k^T) on operands that arrived long ago, the stores, then t of walk row i+1 (used in
         // the NEXT step: nothing waits for it here)
-        frag_t xa[NKC], xb[NKC];
-        if (do_mma) {
-            const T* xrow = xlane + ((u + 1) & (RW_RING - 1)) * SLOTE;
-#pragma unroll
-            for (int kc = 0; kc < NKC; ++kc) {
-                xa[kc] = *reinterpret_cast<const frag_t*>(xrow + 32 * kc);
-                xb[kc] = *reinterpret_cast<const frag_t*>(xrow + XPE + 32 * kc);
-            }
-        }
         if (do_gram) {
 #pragma unroll
             for (int s = 0; s < TPW; ++s)
@@ -382,41 +363,45 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
         }
         vrow += vstep;
         if (KEEP) { qrow += qstep; trow_g += tstep; }
-        f32x4 nacc[2][NBW];
+        f32x4 nacc[2][NBW], neacc[NBW];
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) nacc[bb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NBW; ++nb) nacc[0][nb] = nacc[1][nb] = neacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (do_mma) {
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            const T* xrow = xlane + ((u + 1) & (RW_RING - 1)) * SLOTE;
+            const T* erow = elane + ((u + 1) & (RW_RING - 1)) * SLOTE;
+            const int emask = ex_ok ? -1 : 0;                // the outer column lies outside the image: t = 0 there
+            // two K chunks (6 fragments, 24 registers) at a time: all of a wide row's fragments in flight at once is what tips
+            // C = 128 over the 168 registers three waves per SIMD leave
 #pragma unroll
-            for (int kc = 0; kc < NKC; ++kc)
+            for (int k2 = 0; k2 < NKC; k2 += 2) {
+                frag_t xa[2], xb[2], xe[2];
 #pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) {
-                    mma(nacc[0][nb], Wf[nb][kc], xa[kc]);
-                    mma(nacc[1][nb], Wf[nb][kc], xb[kc]);
-                }
-        }
-
-        // ---- every 4 steps: t at the strip's outer columns for walk rows i+1 .. i+4 (zero outside the image)
-        if ((u & 3) == 3) {
-            const int ey = y0 + i + erow;                    // image row of walk row i + 1 + erow
-            const bool ev = ex_ok && ey >= 0 && ey < a.H;
-            const T* src = elane + ((u + 1 + erow) & (RW_RING - 1)) * SLOTE;
+                for (int q = 0; q < 2; ++q)
+                    if (k2 + q < NKC) {
+                        xa[q] = *reinterpret_cast<const frag_t*>(xrow + 32 * (k2 + q));
+                        xb[q] = *reinterpret_cast<const frag_t*>(xrow + XPE + 32 * (k2 + q));
+                        xe[q] = __builtin_bit_cast(frag_t, *reinterpret_cast<const i32x4*>(erow + 32 * (k2 + q)) & emask);
+                    }
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) eacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 2; ++q)
+                    if (k2 + q < NKC) {
 #pragma unroll
-            for (int kc = 0; kc < NKC; ++kc) {
-                typedef __attribute__((ext_vector_type(4))) int i32x4;
-                const i32x4 raw = *reinterpret_cast<const i32x4*>(src + 32 * kc) & (ev ? -1 : 0);
-                const frag_t ef = __builtin_bit_cast(frag_t, raw);
-#pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) mma(eacc[nb], Wf[nb][kc], ef);
+                        for (int nb = 0; nb < NBW; ++nb) {
+                            mma(nacc[0][nb], Wf[nb][k2 + q], xa[q]);
+                            mma(nacc[1][nb], Wf[nb][k2 + q], xb[q]);
+                            mma(neacc[nb], Wf[nb][k2 + q], xe[q]);    // the outer columns of the same row (a third of an MFMA block
+                        }                                             // used: the matrix cores are ~15 % busy, a ds_bpermute per value
+                    }                                                 // is not free)
+                if (k2 + 2 < NKC) asm volatile("" ::: "memory");      // the next pair's reads stay behind this pair's
             }
         }
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) acc[bb][nb] = nacc[bb][nb];
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) eacc[nb] = neacc[nb];
 
         // ---- the row DMA-ed RW_LEAD steps ago must have landed before the barrier: it is read from step i+1 on.  The DMAs of
         // the steps since are younger and stay in flight (vmcnt counts in issue order; this wave's stores only make the wait

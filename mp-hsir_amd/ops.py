@@ -510,10 +510,7 @@ def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_g
     assert M == B * H * W and wqkv.shape == (3 * C, C) and wqkv.is_contiguous() and wqkv.dtype == x.dtype
     if row_segments is None:
         row_segments = 0
-        # (training outputs at C = 128 / 64-wide heads and at C = 192: the row form's registers spill there -- measured 129 us
-        # against 86 for the tile form at batch 32, 64x64 -- so those keep the tile form)
-        spills = keep and ((C == 128 and C // heads == 64) or C >= 192)
-        if ROWS_FORM and nsplit is None and head_groups is None and not spills and qkv_dwconv_gram_rows_fits(C, heads, H, W, x.dtype, ln is not None):
+        if ROWS_FORM and nsplit is None and head_groups is None and qkv_dwconv_gram_rows_fits(C, heads, H, W, x.dtype, ln is not None):
             row_segments = choose_row_segments(B, H, W, C, heads)
     if row_segments:
         nsplit = (W // 32) * row_segments
