@@ -141,28 +141,32 @@ __global__ __launch_bounds__(256) void gated_mlp_kernel(MlpDev a) {
 // bound).  Here each 32-wide hidden chunk of fc1 (32 value + 32 gate rows, K = C) and of fc2 (C rows, K = 32)
 // is loaded once per workgroup with coalesced 16-byte loads, and each wave owns TT token tiles (BM = 64*TT)
 // so every weight fragment read from LDS feeds TT MFMAs.
-template <class T, int C, int TT> struct MlpLdsCfg {
+// WF = 1: four waves (one per SIMD); WF = 2: eight waves, two per SIMD -- per 32-wide hidden chunk a wave issues ~48 MFMAs
+// (768 cycles of its SIMD's matrix pipe) and then ~320 VALU instructions of GELU (1280 cycles): with one wave per SIMD the
+// two never overlap (MFMA-busy 9.6 %); with two, one wave's GELU runs beside the other's MFMAs, and each staged weight
+// chunk feeds twice the tokens.
+template <class T, int C, int TT, int WF = 1> struct MlpLdsCfg {
     static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
-    static constexpr int BM = 64 * TT;
+    static constexpr int BM = 64 * TT * WF, NTHR = 256 * WF;
     static constexpr int LDX = C + PAD, LDH = 32 + PAD;
-    static constexpr size_t ELEMS = (size_t)BM * LDX + 64 * LDX + (size_t)C * LDH + 4 * 16 * TT * LDH;
+    static constexpr size_t ELEMS = (size_t)BM * LDX + 64 * LDX + (size_t)C * LDH + 4 * WF * 16 * TT * LDH;
     static constexpr size_t BYTES = ELEMS * sizeof(T);
     static constexpr bool FITS = BYTES <= 160 * 1024;
 };
 
-template <class T, int C, int TT>
-__global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
+template <class T, int C, int TT, int WF>
+__global__ __launch_bounds__(256 * WF) void gated_mlp_lds_kernel(MlpDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
-    typedef MlpLdsCfg<T, C, TT> CF;
-    constexpr int LDX = CF::LDX, LDH = CF::LDH, BM = CF::BM;
+    typedef MlpLdsCfg<T, C, TT, WF> CF;
+    constexpr int LDX = CF::LDX, LDH = CF::LDH, BM = CF::BM, NTHR = CF::NTHR;
     constexpr int VEC = Vec16<T>::N;
     constexpr int NCT = C / 16;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     T* Xs = reinterpret_cast<T*>(smem_v);               // [BM][LDX]
     T* W1s = Xs + BM * LDX;                             // [64][LDX]  value rows 0..31, gate rows 32..63
     T* W2s = W1s + 64 * LDX;                            // [C][LDH]
-    T* Hs = W2s + C * LDH;                              // [4][16*TT][LDH]
+    T* Hs = W2s + C * LDH;                              // [4*WF][16*TT][LDH]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int m0 = blockIdx.x * BM;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
     // ---- LayerNorm into LDS: 4 adjacent lanes per token, TT passes ---------------------------------
     for (int pass = 0; pass < TT; ++pass) {
         constexpr int NV = C / VEC, VPT = NV / 4;
-        const int r = pass * 64 + (tid >> 2), q = tid & 3;
+        const int r = pass * 64 * WF + (tid >> 2), q = tid & 3;
         const T* row = X + (long)(m0 + r) * a.ldx;
         Vec16<T> xv[VPT];
         float s = 0.f;
@@ -214,12 +218,12 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
     const int HP = a.HP;
     // weight slices of one 32-wide hidden chunk: global -> registers (prefetched one chunk ahead) -> LDS
     constexpr int VPR = C / VEC, VPH = 32 / VEC;
-    constexpr int NW1 = 64 * VPR, NW2 = C * VPH, NVW = NW1 + NW2, NPT = (NVW + 255) / 256;
+    constexpr int NW1 = 64 * VPR, NW2 = C * VPH, NVW = NW1 + NW2, NPT = (NVW + NTHR - 1) / NTHR;
     Vec16<T> wreg[NPT];
     auto wload = [&](int j) {
 #pragma unroll
         for (int it = 0; it < NPT; ++it) {
-            const int v = tid + 256 * it;
+            const int v = tid + NTHR * it;
             if (v < NW1) {
                 const int r = v / VPR, c = (v % VPR) * VEC;
                 wreg[it] = load16<T>(W1 + (long)(r < 32 ? j + r : HP + j + (r - 32)) * C + c);
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
     auto wstore = [&]() {
 #pragma unroll
         for (int it = 0; it < NPT; ++it) {
-            const int v = tid + 256 * it;
+            const int v = tid + NTHR * it;
             if (v < NW1) {
                 const int r = v / VPR, c = (v % VPR) * VEC;
                 store16<T>(W1s + r * LDX + c, wreg[it]);
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
     __syncthreads();
     T* Y = reinterpret_cast<T*>(a.Y);
     constexpr int NV = C / VEC;
-    for (int idx = tid; idx < BM * NV; idx += 256) {
+    for (int idx = tid; idx < BM * NV; idx += NTHR) {
         const int r = idx / NV, c0 = (idx % NV) * VEC, m = m0 + r;
         const float kf = a.keep ? a.keep[m / a.rpb] : 1.f;
         const Vec16<T> x = load16<T>(X + (long)m * a.ldx + c0);
@@ -322,14 +326,14 @@ __global__ __launch_bounds__(256) void gated_mlp_lds_kernel(MlpDev a) {
     }
 }
 
-template <class T, int C, int TT>
+template <class T, int C, int TT, int WF = 1>
 static int launch_mlp_lds(const MlpDev& d, hipStream_t s) {
-    typedef MlpLdsCfg<T, C, TT> CF;
+    typedef MlpLdsCfg<T, C, TT, WF> CF;
     if constexpr (!CF::FITS) {
         return 1;   // caller falls back
     } else {
-        allow_big_lds(gated_mlp_lds_kernel<T, C, TT>, CF::BYTES);
-        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_lds_kernel<T, C, TT>), dim3(d.M / CF::BM), dim3(256), CF::BYTES, s, d);
+        allow_big_lds(gated_mlp_lds_kernel<T, C, TT, WF>, CF::BYTES);
+        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_lds_kernel<T, C, TT, WF>), dim3(d.M / CF::BM), dim3(CF::NTHR), CF::BYTES, s, d);
         return MPHSIR_OK;
     }
 }
@@ -338,7 +342,12 @@ template <class T, int C>
 static int launch_mlp(const MlpDev& d, hipStream_t s) {
     // preferred: LDS-staged weights; two token tiles per wave when there are enough tokens to fill the chip
     int rc = 1;
-    if (d.M % 128 == 0 && (d.tpw == 2 || (d.tpw == 0 && d.M / 128 >= 512))) rc = launch_mlp_lds<T, C, 2>(d, s);
+    // Eight waves with one 16-token tile each (two waves per SIMD) wherever that still leaves a workgroup per CU -- measured at
+    // M = 131072, C = 128: 68 us against 92 (four waves, one tile) and 112 (four waves, two tiles: the round-2 default);
+    // tpw 1 / 2 force the four-wave forms, 3 / 4 the eight-wave ones (tests, tools/bench_mlp_fwd.py)
+    if (sizeof(T) == 2 && d.M % 128 == 0 && (d.tpw == 3 || (d.tpw == 0 && d.M / 128 >= 256))) rc = launch_mlp_lds<T, C, 1, 2>(d, s);
+    if (rc == 1 && sizeof(T) == 2 && d.M % 256 == 0 && d.tpw == 4) rc = launch_mlp_lds<T, C, 2, 2>(d, s);
+    if (rc == 1 && d.M % 128 == 0 && d.tpw == 2) rc = launch_mlp_lds<T, C, 2>(d, s);
     if (rc == 1) rc = launch_mlp_lds<T, C, 1>(d, s);
     if (rc != 1) return rc;
     constexpr int PAD = LDS_PAD_BYTES / sizeof(T);

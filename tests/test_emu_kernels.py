@@ -29,6 +29,9 @@ def test_gemm_tok_per_sample_combine(dtype):
 def test_gated_mlp(dtype, C, hid):
     K.check_gated_mlp("cpu", dtype, C, hid)
     K.check_gated_mlp("cpu", dtype, C, hid, tpw=2, M=256)
+    if dtype != torch.float32:
+        K.check_gated_mlp("cpu", dtype, C, hid, tpw=3, M=256)          # eight waves, one / two tiles per wave
+        K.check_gated_mlp("cpu", dtype, C, hid, tpw=4, M=256)
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
@@ -83,7 +86,7 @@ def test_gated_mlp_bwd(dtype, C, hid):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
-@pytest.mark.parametrize("C,hid,variant", [(32, 85, 1), (32, 85, 3), (96, 255, 3)])
+@pytest.mark.parametrize("C,hid,variant", [(32, 85, 1), (32, 85, 3), (96, 255, 3), (32, 85, 4), (64, 170, 4)])
 def test_gated_mlp_bwd_kernel_forms(dtype, C, hid, variant):
     K.check_gated_mlp_bwd("cpu", dtype, C, hid, variant=variant)
 

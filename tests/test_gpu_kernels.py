@@ -41,6 +41,9 @@ def test_gemm_tok_per_sample_combine(dtype):
 def test_gated_mlp(dtype, C, hid):
     K.check_gated_mlp("cuda", dtype, C, hid)
     K.check_gated_mlp("cuda", dtype, C, hid, tpw=2, M=256)
+    if dtype != torch.float32:
+        K.check_gated_mlp("cuda", dtype, C, hid, tpw=3, M=256)         # eight waves, one / two tiles per wave
+        K.check_gated_mlp("cuda", dtype, C, hid, tpw=4, M=256)
 
 
 def test_gated_mlp_large_auto_tiles():
@@ -147,7 +150,7 @@ def test_gated_mlp_bwd(dtype, C, hid):
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("C,hid,variant", [(32, 85, 1), (32, 85, 3), (96, 255, 3), (128, 340, 1), (128, 340, 2), (128, 340, 3), (64, 170, 3),
-                                           (256, 680, 1), (256, 680, 2)])
+                                           (256, 680, 1), (256, 680, 2), (32, 85, 4), (64, 170, 4), (96, 255, 4), (128, 340, 4)])
 def test_gated_mlp_bwd_kernel_forms(dtype, C, hid, variant):
     K.check_gated_mlp_bwd("cuda", dtype, C, hid, variant=variant)
 

@@ -20,7 +20,7 @@ for M, C, hid in [(131072, 128, 340), (32768, 128, 340), (131072, 64, 170), (819
     HP = W2.shape[1]
     fl = 12.0 * M * C * HP
     res = []
-    for v in (1, 2, 3):
+    for v in (0, 1, 2, 3, 4):
         try:
             us = t_us(lambda: ops.gated_mlp_bwd(x, dy, dy, lnw, lnb, W1, b1, W1T, W2T, variant=v))
             res.append("v%d %7.1f us %6.1f TF/s" % (v, us, fl / us / 1e6))
