@@ -28,6 +28,7 @@ def short(name):
     m = re.search(r"mphsir\d*(\w+?)_kernel", name) or re.search(r"mphsir::(\w+?)_kernel", name)
     if m:
         n = re.sub(r"^\d+", "", m.group(1))
+        n = {"qkv_dwconv_gram_rows": "qkv_dwconv_gram"}.get(n, n)
         # kernel forms that share one C-ABI entry point / library kernel id
         return {"gemm_tn_tr": "gemm_tn", "gemm_tn_tr_group": "gemm_tn", "gated_mlp_bwd2": "gated_mlp_bwd", "gated_mlp_lds": "gated_mlp", "dwconv_gram2": "dwconv_gram",
                 "pg_gate_fwd": "pg_gate", "dwconv3x3_tile": "dwconv3x3", "dwconv3x3_wgrad_tile": "dwconv3x3_wgrad", "dwconv_gate_tile": "dwconv_gate", "tvsp_text_map": "resample", "tvsp_text_map_bwd": "resample", "resize_bilinear": "resample",
@@ -49,7 +50,7 @@ def counter_per_kernel(d, counter):
 
 def main():
     tag, trace = sys.argv[1], sys.argv[2]
-    out = os.path.join(ROOT, "profiles")
+    out = os.environ.get("MPHSIR_PROFILE_OUT", os.path.join(ROOT, "profiles"))      # (on the GPU box: a directory under gpurun_out/)
     os.makedirs(out, exist_ok=True)
     stats = glob.glob(os.path.join(trace, "*", "*_kernel_stats.csv"))[0]
     shutil.copy(stats, os.path.join(out, tag + "_kernel_stats.csv"))
