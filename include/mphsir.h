@@ -106,8 +106,6 @@ typedef struct mphsir_pg_fwd_args {
     int32_t nW, C, r;
 } mphsir_pg_fwd_args;
 int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream);
-int mphsir_pg_debug(void* stamps);   /* diagnostics: device uint64[17] receiving workgroup 0's shader-clock stamps at the phase
-                                        boundaries of the next pg_gate launches (NULL = off)                                  */
 int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream);
 int mphsir_win_attn_hdp(int head_dim, int dtype);
 
@@ -168,9 +166,11 @@ int mphsir_qkv_dwconv_gram_fits(int32_t C, int32_t heads, int32_t H, int32_t W, 
 int mphsir_qkv_dwconv_gram_rows_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype, int32_t with_ln);   /* row-walking
                                            form: 16-bit dtypes, no LayerNorm prologue, W % 32 == 0, H >= 4, (C, head width) in
                                            {64,128}x{32,64}, {96,192}x{48,96} */
-int mphsir_win_debug(void* stamps);     /* the same for mphsir_win_attn_fwd: >= 8 uint64 (tools/bench_win.py) */
-int mphsir_fused_debug(void* stamps);   /* diagnostics: device buffer of >= 9 uint64 that workgroup 0 fills with shader-clock stamps
-                                           at its phase boundaries (NULL = off); tools/bench_fused.py */
+/* Diagnostics, one entry point: arm (stamps = device buffer of >= 32 uint64) or disarm (NULL) the shader-clock phase stamps
+ * that workgroup 0 of the next launches of one kernel family writes (tools/bench_pg.py, bench_win.py, bench_fused.py,
+ * bench_rows.py).  The only mutable global state of the library besides the launch timer (mphsir_prof_*).               */
+enum { MPHSIR_DEBUG_PG_GATE = 0, MPHSIR_DEBUG_WIN_ATTN = 1, MPHSIR_DEBUG_FUSED_PASS_A = 2 };
+int mphsir_debug(int kind, void* stamps);
 typedef struct mphsir_fold_args {
     const float* Gpart; const float* Spart;
     const float* temperature;   /* [heads] */

@@ -135,14 +135,12 @@ _SYMBOLS = {
     "mphsir_win_attn_fwd": (c_int, [ctypes.POINTER(WinAttnArgs), c_int, c_void_p]),
     "mphsir_win_attn_hdp": (c_int, [c_int, c_int]),
     "mphsir_pg_gate_fwd": (c_int, [ctypes.POINTER(PgFwdArgs), c_void_p]),
-    "mphsir_pg_debug": (c_int, [c_void_p]),
     "mphsir_dwconv_gram": (c_int, [ctypes.POINTER(GramArgs), c_int, c_void_p]),
     "mphsir_dwconv_gram_keeps_qk": (c_int, [c_int32, c_int32, c_int]),
     "mphsir_qkv_dwconv_gram": (c_int, [ctypes.POINTER(FusedGramArgs), c_int, c_void_p]),
     "mphsir_qkv_dwconv_gram_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int]),
     "mphsir_qkv_dwconv_gram_rows_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int, c_int32]),
-    "mphsir_fused_debug": (c_int, [c_void_p]),
-    "mphsir_win_debug": (c_int, [c_void_p]),
+    "mphsir_debug": (c_int, [c_int, c_void_p]),
     "mphsir_dwconv3x3_wgrad_tiled": (c_int, [c_int32, c_int32, c_int32, c_int]),
     "mphsir_spectral_fold": (c_int, [ctypes.POINTER(FoldArgs), c_int, c_void_p]),
     "mphsir_dwconv_gate": (c_int, [ctypes.POINTER(GateArgs), c_int, c_void_p]),

@@ -27,7 +27,7 @@ struct PgDev {
     void* L; void* R;           // backward: [nW][KL], [nW][KR] factor rows (fp32 or bf16)
     int nW, C, r, KL, KR, lr_bf16;
     int stage_wdn;              // backward: linear_down also staged in LDS (when the budget allows)
-    unsigned long long* dbg;    // diagnostics (mphsir_pg_debug): shader-clock stamps of workgroup 0 at the phase boundaries
+    unsigned long long* dbg;    // diagnostics (mphsir_debug): shader-clock stamps of workgroup 0 at the phase boundaries
 };
 static unsigned long long* g_pg_dbg = nullptr;
 #define PG_MARK(k) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -467,10 +467,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
 
 }  // namespace mphsir
 
-extern "C" int mphsir_pg_debug(void* stamps) {      // diagnostics: device buffer of >= 17 uint64 (NULL = off)
-    mphsir::g_pg_dbg = reinterpret_cast<unsigned long long*>(stamps);
-    return MPHSIR_OK;
-}
+namespace mphsir { void pg_debug_buffer(unsigned long long* p) { g_pg_dbg = p; } }      // mphsir_debug(MPHSIR_DEBUG_PG_GATE, ...)
 
 extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
     using namespace mphsir;

@@ -48,7 +48,7 @@ struct FusedGramDev {
     int B, H, W, nsplit, hgroups;
     void* Tout; long ldt;                        // training: t = qkv(x) [B*H*W][ldt >= 3C] and q|k after the depthwise conv
     void* QKout; long ldqk;                      // [B*H*W][ldqk >= 2C], kept for the backward
-    unsigned long long* dbg;                     // diagnostics (mphsir_fused_debug): shader-clock stamps of workgroup 0
+    unsigned long long* dbg;                     // diagnostics (mphsir_debug): shader-clock stamps of workgroup 0
 };
 static unsigned long long* g_fg_dbg = nullptr;
 #define FG_MARK(k) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && first && step == 0) a.dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -437,9 +437,19 @@ int rows_form_launch(const mphsir_fused_gram_args* a, int dtype, hipStream_t s);
 
 }  // namespace mphsir
 
-extern "C" int mphsir_fused_debug(void* stamps) {      // diagnostics: device buffer of >= 9 uint64 (NULL = off)
-    mphsir::g_fg_dbg = reinterpret_cast<unsigned long long*>(stamps);
-    return MPHSIR_OK;
+namespace mphsir { void pg_debug_buffer(unsigned long long* p); void win_debug_buffer(unsigned long long* p); }
+
+// The one diagnostics switch of the library: arm (stamps != NULL) or disarm the shader-clock phase stamps of workgroup 0 of
+// one kernel family.  Diagnostic state only: no compute entry point reads anything else that is global.
+extern "C" int mphsir_debug(int kind, void* stamps) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(stamps);
+    switch (kind) {
+        case MPHSIR_DEBUG_PG_GATE: mphsir::pg_debug_buffer(p); return MPHSIR_OK;
+        case MPHSIR_DEBUG_WIN_ATTN: mphsir::win_debug_buffer(p); return MPHSIR_OK;
+        case MPHSIR_DEBUG_FUSED_PASS_A: mphsir::g_fg_dbg = p; return MPHSIR_OK;
+    }
+    mphsir::set_error("mphsir_debug: kind %d unknown", kind);
+    return MPHSIR_EINVAL;
 }
 
 extern "C" int mphsir_qkv_dwconv_gram_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype) {

@@ -48,7 +48,7 @@ struct RowGramDev {
     int B, H, W, nseg;                           // nseg row segments per strip: (W / 32) * nseg partial slots per sample
     void* Tout; long ldt;
     void* QKout; long ldqk;
-    unsigned long long* dbg;                     // diagnostics (mphsir_fused_debug): shader-clock stamps of workgroup 0, wave 0
+    unsigned long long* dbg;                     // diagnostics (mphsir_debug): shader-clock stamps of workgroup 0, wave 0
 };
 
 // waves per workgroup: 3 (q | k | v) x channels of each per workgroup / channels per wave (a function of the head width only)
@@ -74,7 +74,7 @@ template <class T, int C, int HD> struct RwCfg {
     static_assert(C % 32 == 0 && HD % 16 == 0 && CT % HD == 0 && CT % CW == 0 && NW <= 16, "shape");
 };
 
-unsigned long long* fused_debug_buffer();     // spectral_fused.hip (mphsir_fused_debug)
+unsigned long long* fused_debug_buffer();     // spectral_fused.hip (mphsir_debug)
 
 __device__ __forceinline__ float dpp_row_shr1(float old, float src) {     // lane i <- lane i-1 of its 16-lane row; lane 0 keeps old
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x111, 0xf, 0xf, false));
@@ -101,7 +101,7 @@ __device__ __forceinline__ float pick4(f32x4 v, int k) { return k == 0 ? v[0] : 
 // s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
 template <int N> __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14)); }
 
-// DBG builds only (mphsir_fused_debug armed): shader-clock stamps of workgroup 0 / wave 0 at walk step 9
+// DBG builds only (mphsir_debug armed): shader-clock stamps of workgroup 0 / wave 0 at walk step 9
 #define RW_MARK(k) do { if (DBG && blockIdx.x == 0 && tid == 0 && i == 9) a.dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <class T, int C, int HD, bool KEEP, bool DBG>

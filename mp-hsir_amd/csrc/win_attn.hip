@@ -29,7 +29,7 @@ struct WinAttnDev {
     float* mu;      // [B*nW][C]: window mean of SA = the input of the spectral-prompt gate (mphsir_pg_gate_fwd)
     void* Oattn;    // optional [B*nW*64][C]: attention output before proj, window-token order (training: dWproj)
     int B, H, W, shift;
-    unsigned long long* dbg;    // diagnostics (mphsir_win_debug): shader-clock stamps of workgroup 0 at its phase boundaries
+    unsigned long long* dbg;    // diagnostics (mphsir_debug): shader-clock stamps of workgroup 0 at its phase boundaries
 };
 static unsigned long long* g_win_dbg = nullptr;
 #define WIN_MARK(k) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         // The weight rows go through LDS one part (q, k, v) at a time: all 256 threads fetch the NEXT part's HD x C rows from
         // L2 (coalesced, all in flight) while the current part is multiplied, and store them once its readers are past a
         // barrier.  (First version: every 4-MFMA unit fetched its own fragments from L2 with a one-unit prefetch -- 5.0 k of the
-        // 8.6 k cycles of a head at C=64, 13.8 k of 23 k at C=128/hd=64, shader-clock stamps of mphsir_win_debug.)
+        // 8.6 k cycles of a head at C=64, 13.8 k of 23 k at C=128/hd=64, shader-clock stamps of mphsir_debug.)
         // unit u = (16-channel tile of the part, half of the 64 tokens); a wave walks units u = wv, wv+4, ...
         constexpr int NKC = C / TR::KCHUNK;
         T* Wst = Ps;                                 // [SR][LDWS]
@@ -413,10 +413,7 @@ extern "C" int mphsir_win_attn_hdp(int head_dim, int dtype) {
     return (head_dim + kc - 1) / kc * kc;
 }
 
-extern "C" int mphsir_win_debug(void* stamps) {      // diagnostics: device buffer of >= 8 uint64 (NULL = off); tools/bench_win.py
-    mphsir::g_win_dbg = reinterpret_cast<unsigned long long*>(stamps);
-    return MPHSIR_OK;
-}
+namespace mphsir { void win_debug_buffer(unsigned long long* p) { g_win_dbg = p; } }    // mphsir_debug(MPHSIR_DEBUG_WIN_ATTN, ...)
 
 extern "C" int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream) {
     using namespace mphsir;

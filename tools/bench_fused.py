@@ -38,7 +38,7 @@ for (B, H, C, heads, ln) in CASES:
     print("B=%d %dx%d C=%d heads=%d ln=%d: fused %.1f us (%.2f TB/s of x+v, %.0f TFLOP/s useful)   [1 head group: %.1f us]   two-kernel %.1f us (gemm_tok %.1f)  x%.2f" % (
         B, H, H, C, heads, ln, tf, byt / tf / 1e6, 6.0 * M * C * C / tf / 1e6, tf1, t2, tg, t2 / tf), flush=True)
 
-# per-phase shader-clock stamps (100 MHz) of workgroup 0, first tile, first head (mphsir_fused_debug)
+# per-phase shader-clock stamps (100 MHz) of workgroup 0, first tile, first head (mphsir_debug)
 import ctypes
 from mp_hsir_amd import _lib
 lib = _lib.load()
@@ -49,10 +49,10 @@ for (B, H, C, heads, ln) in [(1, 512, 64, 2, False), (1, 256, 128, 4, False), (1
     w = (torch.randn(3 * C, C, device=dev) * C ** -0.5).to(dt)
     w9 = torch.randn(9, 3 * C, device=dev) / 3
     stamps = torch.zeros(16, dtype=torch.int64, device=dev)
-    lib.mphsir_fused_debug(ctypes.c_void_p(stamps.data_ptr()))
+    lib.mphsir_debug(2, ctypes.c_void_p(stamps.data_ptr()))
     for hg in (1, None):
         f = lambda: ops.qkv_dwconv_gram(x, w, w9, B, H, H, C, heads, head_groups=hg)
         f(); f(); stamps.zero_(); f(); torch.cuda.synchronize()
         t = stamps.cpu().tolist()
         print("C=%d hg=%s phases (10 ns ticks):" % (C, hg), {n: t[i + 1] - t[i] for i, n in enumerate(names)}, "kernel of wg0:", t[8] - t[0], flush=True)
-    lib.mphsir_fused_debug(None)
+    lib.mphsir_debug(2, None)

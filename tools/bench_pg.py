@@ -26,7 +26,7 @@ for C, cr, nW in [(128, 8, 2048), (64, 8, 2048), (128, 16, 512), (256, 32, 128),
         torch.cuda.synchronize()
         print("C=%d r=%d nW=%d %s: %.1f us per call (back-to-back, bwd includes its gemm_tn)" % (C, r, nW, name, e0.elapsed_time(e1) * 1e3 / 50), flush=True)
 
-# per-phase shader-clock stamps of workgroup 0 (mphsir_pg_debug)
+# per-phase shader-clock stamps of workgroup 0 (mphsir_debug)
 import ctypes
 from mp_hsir_amd import _lib
 lib = _lib.load()
@@ -40,7 +40,7 @@ for C, cr, nW in [(128, 8, 2048), (256, 32, 128)]:
     pg = {k: v.to(dev).contiguous() for k, v in pg.items()}
     mu, dg = torch.randn(nW, C, device=dev), torch.randn(nW, C, device=dev)
     stamps = torch.zeros(32, dtype=torch.int64, device=dev)
-    lib.mphsir_pg_debug(ctypes.c_void_p(stamps.data_ptr()))
+    lib.mphsir_debug(0, ctypes.c_void_p(stamps.data_ptr()))
     for name, f, n in (("fwd", lambda: ops.pg_gate_fwd(mu, pg), 9), ("bwd", lambda: ops.pg_gate_bwd(mu, dg, pg, factor_dtype=torch.bfloat16), 17)):
         f(); f()
         stamps.zero_()
@@ -48,4 +48,4 @@ for C, cr, nW in [(128, 8, 2048), (256, 32, 128)]:
         torch.cuda.synchronize()
         t = stamps.cpu().tolist()[:n]
         print("C=%d r=%d %s phase cycles (100 MHz ticks?):" % (C, r, name), [t[i + 1] - t[i] for i in range(n - 1)], "total", t[n - 1] - t[0], flush=True)
-    lib.mphsir_pg_debug(None)
+    lib.mphsir_debug(0, None)

@@ -51,9 +51,9 @@ for (B, H, C, heads, ln) in [(1, 512, 64, 2, False), (1, 512, 128, 2, False), (1
     w9 = torch.randn(9, 3 * C, device=dev) / 3
     lnp = (torch.ones(C, device=dev), torch.zeros(C, device=dev)) if ln else None
     stamps = torch.zeros(64, dtype=torch.int64, device=dev)
-    lib.mphsir_fused_debug(ctypes.c_void_p(stamps.data_ptr()))
+    lib.mphsir_debug(2, ctypes.c_void_p(stamps.data_ptr()))
     f = lambda: ops.qkv_dwconv_gram(x, w, w9, B, H, H, C, heads, ln=lnp, keep=keep)
     f(); f(); stamps.zero_(); f(); torch.cuda.synchronize()
     t = stamps.cpu().tolist()
     print("C=%d heads=%d step 9 (shader clocks):" % (C, heads), {n: t[k + 1] - t[k] for k, n in enumerate(names)}, "whole walk of workgroup 0: %d" % (t[9] - t[0]), flush=True)
-    lib.mphsir_fused_debug(None)
+    lib.mphsir_debug(2, None)

@@ -27,7 +27,7 @@ for (B, H, C, heads, cr) in [(32, 64, 128, 2, 8), (32, 64, 64, 2, 8), (32, 32, 1
     fb = lambda: ops.win_attn_bwd(x, dsa, dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wprojT"], heads, 4)
     print("C=%d win_attn_bwd %.1f us" % (C, t_us(fb)))
 
-# per-phase shader-clock stamps of workgroup 0 of the forward kernel (mphsir_win_debug)
+# per-phase shader-clock stamps of workgroup 0 of the forward kernel (mphsir_debug)
 import ctypes
 from mp_hsir_amd import _lib
 lib = _lib.load()
@@ -37,9 +37,9 @@ for (B, H, C, heads, cr) in [(32, 64, 64, 2, 8), (32, 64, 128, 2, 8), (32, 32, 1
     pk = blk.packed(dt)
     x = torch.randn(B, H, H, C, device=dev, dtype=dt)
     stamps = torch.zeros(16, dtype=torch.int64, device=dev)
-    lib.mphsir_win_debug(ctypes.c_void_p(stamps.data_ptr()))
+    lib.mphsir_debug(1, ctypes.c_void_p(stamps.data_ptr()))
     f = lambda: ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"], pk["bproj"], pk["pg"], heads, 4, save=True)
     f(); f(); stamps.zero_(); f(); torch.cuda.synchronize()
     t = stamps.cpu().tolist()
     print("C=%d heads=%d phases (shader clocks):" % (C, heads), {n: t[i + 1] - t[i] for i, n in enumerate(names[:7])}, "workgroup 0 total:", t[7] - t[0], flush=True)
-    lib.mphsir_win_debug(None)
+    lib.mphsir_debug(1, None)
