@@ -196,6 +196,31 @@ typedef struct mphsir_gate_args {
 } mphsir_gate_args;
 int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* stream);
 
+/* ---- the whole GDFN feed-forward block in one launch (inference) -----------------------------------
+ * Y = X + project_out( gelu_erf(x1) * x2 ),  [x1|x2] = dwconv3x3(project_in(LayerNorm(X)))
+ * Replaces `x + self.ffn(self.norm2(x))` of CrossTransformer.forward (net/MP_HSIR.py:286) and
+ * TransformerBlock.forward (:477) with FFN / FeedForward.forward (:259-265 == :385-391): the 2*hid-wide
+ * project_in output and the hid-wide gate product stay on chip (the three-launch form
+ * mphsir_gemm_tok -> mphsir_dwconv_gate -> mphsir_gemm_tok moves 6.5x the bytes).
+ * X, Y [B*H*W][D] channels-last (ldx, ldy), Y must not alias X; ln_w, ln_b fp32 [D];
+ * Win [2*HP][D]: rows 0..hid-1 = project_in.weight[0:hid] (gelu side), rows HP..HP+hid-1 =
+ * project_in.weight[hid:2hid], everything else zero; w9 fp32 [9][ldw >= 2*HP] taps laid out the same
+ * way; Wout [D][HP] = project_out.weight zero-padded along K.  HP = hid rounded up to a multiple of 32.
+ * 16-bit types, D in {64,128,192,256}, H % 8 == 0, W % 16 == 0 (mphsir_gdfn_fused_fits); nsplit
+ * workgroups per sample walk (H/8)*(W/tw)/nsplit pixel tiles of 8 x tw pixels each,
+ * tw = mphsir_gdfn_fused_tile_width(D) (16 up to D = 128, 8 above).                                    */
+typedef struct mphsir_gdfn_args {
+    const void* X; int64_t ldx;
+    const float* ln_w; const float* ln_b;
+    const void* Win; const float* w9; int64_t ldw;
+    const void* Wout;
+    void* Y; int64_t ldy;
+    int32_t B, H, W, D, HP, nsplit;
+} mphsir_gdfn_args;
+int mphsir_gdfn_fused(const mphsir_gdfn_args* a, int dtype, void* stream);
+int mphsir_gdfn_fused_fits(int32_t D, int32_t HP, int32_t H, int32_t W, int dtype);
+int mphsir_gdfn_fused_tile_width(int32_t D);
+
 /* ---- fused LayerNorm + gated MLP + residual --------------------------------------------------
  * Y = X + keep[b] * ( fc2( value * gelu_erf(gate) ) + b2 ),  [value|gate] = fc1(LayerNorm(X)) + b1
  * Replaces PGSSTB's `x + drop_path(self.mlp(self.norm2(x)))` (net/MP_HSIR.py:719; GatedMlp :66-82:
@@ -446,6 +471,7 @@ int mphsir_pack_gather(const float* arena, const int32_t* index, void* dst, int6
 #define MPHSIR_K_PG_GATE 22
 #define MPHSIR_K_RESAMPLE 23
 #define MPHSIR_K_QKV_DWCONV_GRAM 24
+#define MPHSIR_K_GDFN_FUSED 25
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

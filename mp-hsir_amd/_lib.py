@@ -72,6 +72,13 @@ class GateArgs(ctypes.Structure):
                [(n, c_int32) for n in ("B", "H", "W", "HP")]
 
 
+class GdfnArgs(ctypes.Structure):
+    """mirror of struct mphsir_gdfn_args"""
+    _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("Win", c_void_p), ("w9", c_void_p),
+                ("ldw", c_int64), ("Wout", c_void_p), ("Y", c_void_p), ("ldy", c_int64)] + \
+               [(n, c_int32) for n in ("B", "H", "W", "D", "HP", "nsplit")]
+
+
 class MlpBwdArgs(ctypes.Structure):
     """mirror of struct mphsir_mlp_bwd_args"""
     _fields_ = [(n, c_void_p) for n in ("X", "dY", "DM", "ln_w", "ln_b", "W1", "b1", "W1T", "W2T", "dX", "XN", "H", "DPRE", "part")] + \
@@ -144,6 +151,9 @@ _SYMBOLS = {
     "mphsir_dwconv3x3_wgrad_tiled": (c_int, [c_int32, c_int32, c_int32, c_int]),
     "mphsir_spectral_fold": (c_int, [ctypes.POINTER(FoldArgs), c_int, c_void_p]),
     "mphsir_dwconv_gate": (c_int, [ctypes.POINTER(GateArgs), c_int, c_void_p]),
+    "mphsir_gdfn_fused": (c_int, [ctypes.POINTER(GdfnArgs), c_int, c_void_p]),
+    "mphsir_gdfn_fused_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int]),
+    "mphsir_gdfn_fused_tile_width": (c_int, [c_int32]),
     "mphsir_dwconv3x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                  c_int32, c_int, c_void_p]),
     "mphsir_dwconv3x3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,

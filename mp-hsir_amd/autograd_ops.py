@@ -290,6 +290,13 @@ class _GdfnRes(torch.autograd.Function):
 
 
 def _gdfn_res_ag(ffn, ln, a2, B, H, W):
+    if not torch.is_grad_enabled():
+        # no_grad: the whole block in one launch where the fused kernel covers the shape and the image is big enough to fill
+        # the chip with its pixel tiles (t = project_in(LN(a)) and the gate product never reach HBM)
+        pf = ffn.packed(a2.dtype)
+        D, HP = a2.shape[1], pf["w_out"].shape[1]
+        if B * H * W >= ops.GDFN_FUSED_MIN_PIXELS and ops.gdfn_fused_fits(D, HP, H, W, a2.dtype):
+            return ops.gdfn_fused(a2, ln.pair(), pf["w_in"], pf["w9"], pf["w_out"], B, H, W)
     return _GdfnRes.apply(ffn, ln, (B, H, W), a2, ln.body.weight, ln.body.bias, ffn.project_in.weight, ffn.dwconv.weight,
                           ffn.project_out.weight)
 

@@ -589,6 +589,36 @@ def dwconv_gate(t, w9, B, H, W):
     return u
 
 
+def gdfn_fused_fits(D, HP, H, W, dtype):
+    return bool(_lib.load().mphsir_gdfn_fused_fits(D, HP, H, W, _DT[dtype]))
+
+
+def gdfn_fused(x2, ln, w_in, w9, w_out, B, H, W, nsplit=None):
+    """x2 (M,D) -> x2 + project_out(gelu(x1) * x2'),  [x1|x2'] = dwconv3x3(project_in(LN(x2)))  in one launch (no_grad
+    path: nothing is kept for a backward).  w_in (2HP,D), w9 (9,2HP) fp32, w_out (D,HP)."""
+    lib = _lib.load()
+    _check(x2, w_in, w9, w_out, ln[0], ln[1])
+    M, ldx = _rows(x2)
+    D, HP = x2.shape[1], w_out.shape[1]
+    if nsplit is None:
+        nsplit = (H // 8) * (W // lib.mphsir_gdfn_fused_tile_width(D))
+        while nsplit > 1 and B * nsplit > GDFN_WGS and nsplit % 2 == 0:
+            nsplit //= 2
+    y = torch.empty((M, D), dtype=x2.dtype, device=x2.device)
+    a = _lib.GdfnArgs()
+    a.X, a.ldx, a.ln_w, a.ln_b, a.Win, a.w9, a.ldw, a.Wout = _p(x2), ldx, _p(ln[0]), _p(ln[1]), _p(w_in), _p(w9), w9.stride(0), _p(w_out)
+    a.Y, a.ldy, a.B, a.H, a.W, a.D, a.HP, a.nsplit = _p(y), D, B, H, W, D, HP, nsplit
+    _lib.check(lib.mphsir_gdfn_fused(ctypes.byref(a), _DT[x2.dtype], _stream(x2)), "gdfn_fused")
+    _acct("gdfn_fused", 2.0 * M * 3 * HP * D + M * HP * 40.0, 2.0 * M * D * x2.element_size())
+    return y
+
+
+# workgroups of the fused GDFN (one per CU: its tile takes ~100 KB of LDS)
+GDFN_WGS = 256
+# below this many pixels the three launches are as fast (a handful of tiles cannot fill the chip either way)
+GDFN_FUSED_MIN_PIXELS = 16384
+
+
 _WEIGHT_EPOCH = [0]
 
 

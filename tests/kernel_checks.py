@@ -241,6 +241,45 @@ def check_gdfn_chain(dev, dtype):
     assert rel_l2(y.reshape(B, H, W, C), ref) < TOL[dtype] * (2 if dtype != torch.float32 else 1)
 
 
+GDFN_FUSED_CASES = [(64, 170, (1, 8, 16), None), (64, 170, (2, 16, 32), 2), (128, 340, (1, 16, 16), 1), (192, 510, (1, 8, 16), None),
+                    (256, 680, (1, 16, 16), 2)]
+GDFN_FUSED_CASES_GPU = [(128, 340, (1, 64, 64), None), (256, 680, (2, 32, 32), None), (192, 510, (1, 32, 48), None), (64, 170, (2, 64, 64), None)]
+
+
+def check_gdfn_fused(dev, dtype, D, hid, shape, nsplit):
+    """mphsir_gdfn_fused == x + gdfn(LN(x)) (oracle, fp64) and == the three-launch chain gemm_tok -> dwconv_gate -> gemm_tok
+    (which rounds t to the storage type between the 1x1 and the depthwise conv; the fused kernel keeps it in fp32)."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    HP = ops.round_up(hid, 32)
+    assert ops.gdfn_fused_fits(D, HP, H, W, dtype)
+    x = rnd((B, H, W, D), 41, dtype)
+    P = {"project_in.weight": rnd((2 * hid, D, 1, 1), 42, scale=D ** -0.5), "dwconv.weight": rnd((2 * hid, 1, 3, 3), 43, scale=1 / 3),
+         "project_out.weight": rnd((D, hid, 1, 1), 44, scale=hid ** -0.5)}
+    lnw, lnb = 1 + 0.1 * rnd((D,), 45), 0.1 * rnd((D,), 46)
+    w_in = torch.zeros((2 * HP, D), dtype=dtype, device=dev)
+    wi = P["project_in.weight"].reshape(2 * hid, D)
+    w_in[:hid], w_in[HP:HP + hid] = wi[:hid].to(dtype), wi[hid:].to(dtype)
+    w9 = torch.zeros((9, 2 * HP), device=dev)
+    w9s = ops.pack_dw(P["dwconv.weight"])
+    w9[:, :hid], w9[:, HP:HP + hid] = w9s[:, :hid], w9s[:, hid:]
+    w_out = torch.zeros((D, HP), dtype=dtype, device=dev)
+    w_out[:, :hid] = P["project_out.weight"].reshape(D, hid).to(dtype)
+    x2 = x.reshape(-1, D)
+    y = ops.gdfn_fused(x2, (lnw, lnb), w_in, w9, w_out, B, H, W, nsplit=nsplit)
+    t = ops.gemm_tok(x2, w_in, ln=(lnw, lnb))
+    y3 = ops.gemm_tok(ops.dwconv_gate(t, w9, B, H, W), w_out, epi=1, res=x2)
+    Pd = {"project_in.weight": P["project_in.weight"].to(dtype).double().cpu(), "dwconv.weight": P["dwconv.weight"].double().cpu(),
+          "project_out.weight": P["project_out.weight"].to(dtype).double().cpu()}
+    ref = x.double().cpu() + O.gdfn(Pd, "", O.layer_norm_c(x.double().cpu(), lnw.double().cpu(), lnb.double().cpu()))
+    tol = TOL[dtype] * 2
+    assert rel_l2(y.reshape(B, H, W, D), ref) < tol, rel_l2(y.reshape(B, H, W, D), ref)
+    assert rel_l2(y, y3) < tol
+    # the fused form is the more accurate of the two (no rounding of t)
+    assert rel_l2(y.reshape(B, H, W, D), ref) <= rel_l2(y3.reshape(B, H, W, D), ref) * 1.05 + 1e-6
+
+
 def check_dwconv_plain(dev, dtype, shape):
     """forward, backward-data (flipped taps) and weight gradient of the depthwise 3x3 vs torch autograd (fp64)."""
     _use(dev)

@@ -73,6 +73,15 @@ def test_gdfn_chain(dtype):
     K.check_gdfn_chain("cpu", dtype)
 
 
+@pytest.mark.parametrize("D,hid,shape,nsplit", K.GDFN_FUSED_CASES)
+def test_gdfn_fused(D, hid, shape, nsplit):
+    K.check_gdfn_fused("cpu", torch.bfloat16, D, hid, shape, nsplit)
+
+
+def test_gdfn_fused_f16():
+    K.check_gdfn_fused("cpu", F16, 128, 340, (1, 8, 32), 2)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 5, 8, 96), (2, 16, 32, 128), (1, 8, 16, 32)])      # the last two: the LDS-tile form (16-bit)
 def test_dwconv_plain(dtype, shape):

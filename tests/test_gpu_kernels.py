@@ -136,6 +136,12 @@ def test_gdfn_chain(dtype):
     K.check_gdfn_chain("cuda", dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D,hid,shape,nsplit", K.GDFN_FUSED_CASES + K.GDFN_FUSED_CASES_GPU)
+def test_gdfn_fused(dtype, D, hid, shape, nsplit):
+    K.check_gdfn_fused("cuda", dtype, D, hid, shape, nsplit)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("shape", [(2, 8, 8, 32), (1, 5, 8, 96), (4, 64, 64, 384), (2, 32, 32, 704), (2, 16, 32, 128), (1, 8, 16, 32)])
 def test_dwconv_plain(dtype, shape):
