@@ -9,13 +9,15 @@
 // waves) owns an 8x16-pixel tile (8x8 for D > 128), keeps the LayerNorm-ed MFMA fragments of the tile + one-pixel halo
 // (180 pixels in 12 row blocks; 100 in 7) in registers, and walks the hidden dimension in slabs of 32 channel PAIRS (32 gelu-side channels + their 32
 // partners):
-//   (1) t_s = W_in[slab] LN(a)^T by MFMA (weights through LDS, register prefetch one slab ahead), transposed accumulators
+//   (1) t_s = W_in[slab] LN(a)^T by MFMA (weights through LDS: stored during the previous slab's depthwise pass, requested
+//       from L2 a slab before that), transposed accumulators
 //       -> fp32 t tile [halo pixel][64] in LDS; rows of pixels outside the image are zeros (the depthwise conv zero-pads t);
 //   (2) depthwise 3x3 from LDS: one thread = (side, 4 channels, 4 pixels of a row); the two sides of a channel group sit in
 //       adjacent lanes, swap half of their results through one shuffle each and finish gelu(x1)*x2 for 2 pixels;
 //       u_s -> LDS [128 pixel][32] in the storage type (the three-launch path rounds u the same way);
 //   (3) y += W_out[:, slab] u_s^T: a wave owns a 16-pixel block x all (8x8 tile: half of the) D output channels as
-//       persistent fp32 accumulator tiles over all slabs.
+//       persistent fp32 accumulator tiles over all slabs; issued together with the NEXT slab's project_in MFMAs (two
+//       barriers per slab).
 // After the last slab: y + a (residual, one rounding), staged through LDS, stored as whole 16-byte row chunks.
 // t is kept in fp32 between the 1x1 conv and the depthwise conv (the three-launch path rounds it to the storage type).
 #include <type_traits>
@@ -49,19 +51,17 @@ struct GdfnDev {
     int B, H, W, HP, nsplit;
 };
 
-template <int D> struct GfStage { static constexpr int KS = D <= 128 ? D : (D % 128 == 0 ? 128 : 96); };
-
 template <class T, int D> struct GfLds {
     typedef GfGeo<GfTile<D>::TW> G;
     static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
-    static constexpr int KS = GfStage<D>::KS;
     // t tile pitch 2*SLAB + 4 floats: a ds_read_b128 of 16 lanes that differ in the channel group covers all 64 banks once
-    static constexpr int LDW = KS + PAD, LDT = 2 * GF_SLAB + 4, LDU = GF_SLAB + PAD, LDO = GF_SLAB + PAD, LDY = D + PAD;
+    static constexpr int LDW = D + PAD, LDT = 2 * GF_SLAB + 4, LDU = GF_SLAB + PAD, LDO = GF_SLAB + PAD, LDY = D + PAD;
     static constexpr size_t w_elems = (size_t)2 * GF_SLAB * LDW, o_elems = (size_t)D * LDO, u_elems = (size_t)G::PIX * LDU;
     static constexpr size_t t_floats = (size_t)G::MB * 16 * LDT, tap_floats = 9 * 2 * GF_SLAB;
-    static constexpr size_t work = (w_elems + o_elems + u_elems) * sizeof(T) + (t_floats + tap_floats) * sizeof(float);
-    static constexpr size_t stage = (size_t)G::PIX * LDY * sizeof(T);          // the output tile reuses everything
-    static constexpr size_t bytes = work > stage ? work : stage;
+    // the output tile is staged over the u and t tiles (dead after the last slab); the weight stages stay live across tiles
+    static constexpr size_t ut_bytes_raw = u_elems * sizeof(T) + t_floats * sizeof(float), y_bytes = (size_t)G::PIX * LDY * sizeof(T);
+    static constexpr size_t ut_bytes = ut_bytes_raw > y_bytes ? ut_bytes_raw : y_bytes;
+    static constexpr size_t bytes = (w_elems + 2 * o_elems) * sizeof(T) + ut_bytes + 2 * tap_floats * sizeof(float);
     static_assert(bytes <= 160 * 1024, "fused GDFN tile does not fit LDS");
 };
 
@@ -74,16 +74,15 @@ __global__ __launch_bounds__(GF_THREADS, 2) void gdfn_fused_kernel(GdfnDev a) {
     constexpr int PXB = G::PXB, WPB = G::WPB, PPT = G::PPT, NOBW = D / 16 / WPB;
     constexpr int VEC = Vec16<T>::N, KCH = TR::KCHUNK, EPL = TR::EPL;
     constexpr int SLAB = GF_SLAB, NKC = D / KCH, NB = 2 * SLAB / 16, NOB = D / 16;
-    constexpr int KS = L::KS, NST = D / KS, KPS = KS / KCH;
     constexpr int LDW = L::LDW, LDT = L::LDT, LDU = L::LDU, LDO = L::LDO, LDY = L::LDY;
-    static_assert(D % KCH == 0 && D % KS == 0 && KS % KCH == 0 && SLAB == KCH && NOB % WPB == 0 && PPT % 2 == 0, "shape");
+    static_assert(D % KCH == 0 && SLAB == KCH && NOB % WPB == 0 && PPT % 2 == 0, "shape");
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    T* Ws = reinterpret_cast<T*>(smem_v);                       // [2 SLAB][LDW]  project_in rows of this slab, one K stage
-    T* Wos = Ws + L::w_elems;                                   // [D][LDO]       project_out columns of this slab
-    T* Us = Wos + L::o_elems;                                   // [PIX][LDU]     u = gelu(x1) * x2 of the interior pixels
-    float* Ts = reinterpret_cast<float*>(Us + L::u_elems);     // [16 MB][LDT]   fp32 t of the halo tile, this slab
-    float* tapsS = Ts + L::t_floats;                            // [9][2 SLAB]
-    T* Ys = reinterpret_cast<T*>(smem_v);                       // [PIX][LDY]     output tile (after the last slab)
+    T* Ws = reinterpret_cast<T*>(smem_v);                       // [2 SLAB][LDW]    project_in rows of the current slab
+    T* Wos = Ws + L::w_elems;                                   // [2][D][LDO]      project_out columns of the current / previous slab
+    T* Us = Wos + 2 * L::o_elems;                               // [PIX][LDU]       u = gelu(x1) * x2 of the interior pixels
+    float* Ts = reinterpret_cast<float*>(Us + L::u_elems);     // [16 MB][LDT]     fp32 t of the halo tile, this slab
+    T* Ys = Us;                                                 // [PIX][LDY]       output tile (after the last slab), over u | t
+    float* tapsS = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(Us) + L::ut_bytes);     // [2][9][2 SLAB]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int blk = (gridDim.x & 7) == 0 ? (int)xcd_contiguous_block() : (int)blockIdx.x;   // neighbours share halo rows
@@ -96,31 +95,25 @@ __global__ __launch_bounds__(GF_THREADS, 2) void gdfn_fused_kernel(GdfnDev a) {
     const T* Wo = reinterpret_cast<const T*>(a.Wout);
     T* Y = reinterpret_cast<T*>(a.Y);
 
-    // the weights and taps of the NEXT step (slab, K stage) are requested from L2 into registers while the current one computes
-    constexpr int WVT = 2 * SLAB * (KS / VEC), NWV = (WVT + GF_THREADS - 1) / GF_THREADS;
+    // Software pipeline over the flattened steps g = (tile, slab): the weights and taps of step g+1 go to LDS during the
+    // depthwise pass of step g (the project_in stage is dead once t is complete; project_out and the taps are double
+    // buffered), those of step g+2 are requested from L2 into registers at the same time -- two barriers per slab and no
+    // global latency between two phases of the steady state.
+    constexpr int WVT = 2 * SLAB * (D / VEC), NWV = (WVT + GF_THREADS - 1) / GF_THREADS;
     constexpr int OVT = D * (SLAB / VEC), NOV = (OVT + GF_THREADS - 1) / GF_THREADS;
     constexpr int NTP = (9 * 2 * SLAB + GF_THREADS - 1) / GF_THREADS;
     Vec16<T> wpre[NWV], opre[NOV];
     float tpre[NTP];
-    auto wload = [&](int s, int st) __attribute__((always_inline)) {
+    auto wload = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
             const int idx = tid + GF_THREADS * i;
             if (idx < WVT) {
-                const int n = idx / (KS / VEC), cv = idx % (KS / VEC);
+                const int n = idx / (D / VEC), cv = idx % (D / VEC);
                 const long row = n < SLAB ? s * SLAB + n : HP + s * SLAB + n - SLAB;
-                wpre[i] = load16<T>(Wi + row * D + st * KS + cv * VEC);
+                wpre[i] = load16<T>(Wi + row * D + cv * VEC);
             }
         }
-    };
-    auto wstore = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int idx = tid + GF_THREADS * i;
-            if (idx < WVT) store16<T>(Ws + (idx / (KS / VEC)) * LDW + (idx % (KS / VEC)) * VEC, wpre[i]);
-        }
-    };
-    auto oload = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NOV; ++i) {
             const int idx = tid + GF_THREADS * i;
@@ -135,25 +128,33 @@ __global__ __launch_bounds__(GF_THREADS, 2) void gdfn_fused_kernel(GdfnDev a) {
             }
         }
     };
-    auto ostore = [&]() __attribute__((always_inline)) {
+    auto wstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + GF_THREADS * i;
+            if (idx < WVT) store16<T>(Ws + (idx / (D / VEC)) * LDW + (idx % (D / VEC)) * VEC, wpre[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NOV; ++i) {
             const int idx = tid + GF_THREADS * i;
-            if (idx < OVT) store16<T>(Wos + (idx / (SLAB / VEC)) * LDO + (idx % (SLAB / VEC)) * VEC, opre[i]);
+            if (idx < OVT) store16<T>(Wos + buf * L::o_elems + (idx / (SLAB / VEC)) * LDO + (idx % (SLAB / VEC)) * VEC, opre[i]);
         }
 #pragma unroll
         for (int i = 0; i < NTP; ++i) {
             const int idx = tid + GF_THREADS * i;
-            if (idx < 9 * 2 * SLAB) tapsS[idx] = tpre[i];
+            if (idx < 9 * 2 * SLAB) tapsS[buf * 9 * 2 * SLAB + idx] = tpre[i];
         }
     };
-    wload(0, 0);
-    oload(0);
+    const int gsteps = tpw * nslab;
+    wload(0);
+    wstore(0);
+    if (gsteps > 1) wload(1 % nslab);
+    __syncthreads();
 
     for (int tile = sp * tpw; tile < (sp + 1) * tpw; ++tile) {
         const int ty0 = (tile / tilesx) * GF_TH, tx0 = (tile % tilesx) * GF_TW;
 
-        // ---- this wave's halo pixels (row blocks wv and wv+8), LayerNorm-ed, as MFMA fragments: the B operand of every slab
+        // ---- this wave's halo pixels (row blocks wv, wv+8, ..), LayerNorm-ed, as MFMA fragments: the B operand of every slab
         typename TR::frag_t xf[GF_MBW][NKC];
         bool valid[GF_MBW];
 #pragma unroll
@@ -195,40 +196,40 @@ __global__ __launch_bounds__(GF_THREADS, 2) void gdfn_fused_kernel(GdfnDev a) {
         f32x4 yacc[NOBW];
 #pragma unroll
         for (int ob = 0; ob < NOBW; ++ob) yacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // y[channels of this wave, pixel block pb] += W_out[:, slab] u^T with the u tile in LDS and the project_out stage `buf`
+        auto ymma = [&](int buf) __attribute__((always_inline)) {
+            const typename TR::frag_t uf = load_frag<T>(Us, LDU, pb * 16, 0);
+            const T* wo = Wos + buf * L::o_elems;
+#pragma unroll
+            for (int ob = 0; ob < NOBW; ++ob) mma(yacc[ob], load_frag<T>(wo, LDO, (och * NOBW + ob) * 16, 0), uf);
+        };
 
 #pragma unroll 1
         for (int s = 0; s < nslab; ++s) {
+            const int g = (tile - sp * tpw) * nslab + s, buf = g & 1;
             // ---- (1) t_s = W_s LN(a)^T  (transposed accumulators: rows = channels x1_s | x2_s, columns = pixels)
             f32x4 acc[GF_MBW][NB];
 #pragma unroll
             for (int mb = 0; mb < GF_MBW; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                __syncthreads();      // Ws free; at st == 0 also Wos, the taps and u (the previous slab's project_out is done) / Ys
-                wstore();
-                if (st == 0) ostore();
-                if (st + 1 < NST) wload(s, st + 1);
-                else if (s + 1 < nslab) { wload(s + 1, 0); oload(s + 1); }
-                else if (tile + 1 < (sp + 1) * tpw) { wload(0, 0); oload(0); }
-                __syncthreads();
-                // waves 0-3 own two row blocks, waves 4-7 one: ONE scalar branch selects the loop body
+            {
+                // waves that own one row block fewer take the shorter loop body: ONE scalar branch, none around the MFMAs
                 auto stage = [&](auto nmb_c) __attribute__((always_inline)) {
                     constexpr int NMB = decltype(nmb_c)::value;
                     typename TR::frag_t wf[2][NB];
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) wf[0][nb] = load_frag<T>(Ws, LDW, nb * 16, 0);
 #pragma unroll
-                    for (int kk = 0; kk < KPS; ++kk) {
-                        if (kk + 1 < KPS) {
+                    for (int kk = 0; kk < NKC; ++kk) {
+                        if (kk + 1 < NKC) {
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb) wf[(kk + 1) & 1][nb] = load_frag<T>(Ws, LDW, nb * 16, (kk + 1) * KCH);
                         }
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                            for (int mb = 0; mb < NMB; ++mb) mma(acc[mb][nb], wf[kk & 1][nb], xf[mb][st * KPS + kk]);
+                            for (int mb = 0; mb < NMB; ++mb) mma(acc[mb][nb], wf[kk & 1][nb], xf[mb][kk]);
                     }
                 };
                 if (wv + GF_WAVES * (GF_MBW - 1) < GF_MB) stage(std::integral_constant<int, GF_MBW>{});
@@ -242,14 +243,16 @@ __global__ __launch_bounds__(GF_THREADS, 2) void gdfn_fused_kernel(GdfnDev a) {
                 for (int nb = 0; nb < NB; ++nb)
                     *reinterpret_cast<f32x4*>(trow + nb * 16) = valid[mb] ? acc[mb][nb] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            __syncthreads();              // t tile complete
+            // ---- (3, of the previous slab) project_out of u_{s-1}, in the same barrier interval as this slab's project_in
+            if (s > 0) ymma(buf ^ 1);
+            __syncthreads();              // t tile complete; the project_in stage, the previous project_out stage and u_{s-1} are dead
 
             // ---- (2) depthwise 3x3 + gate.  thread = (side, 4 channels, PPT pixels of one tile row); sides in adjacent lanes
             {
                 const int side = tid & 1, it = tid >> 1;
                 const int c4 = it & 7, rem = it >> 3, iy = rem / (GF_TW / PPT), ix0 = (rem % (GF_TW / PPT)) * PPT;
                 const float* tsrc = Ts + (iy * GF_HW + ix0) * LDT + side * SLAB + c4 * 4;
-                const float* wsrc = tapsS + side * SLAB + c4 * 4;
+                const float* wsrc = tapsS + buf * 9 * 2 * SLAB + side * SLAB + c4 * 4;
                 f32x4 w[9];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const f32x4*>(wsrc + t * 2 * SLAB);
@@ -281,24 +284,22 @@ __global__ __launch_bounds__(GF_THREADS, 2) void gdfn_fused_kernel(GdfnDev a) {
                     const f32x4 mine = side ? res[HPX + i] : res[i], send = side ? res[i] : res[HPX + i];
                     f32x4 other;
                     for (int e = 0; e < 4; ++e) other[e] = __shfl_xor(send[e], 1);
-                    const f32x4 g = side ? other : mine, p = side ? mine : other;      // g: gelu-side value, p: partner
+                    const f32x4 g_ = side ? other : mine, p_ = side ? mine : other;    // g_: gelu-side value, p_: partner
                     f32x4 o;
-                    for (int e = 0; e < 4; ++e) o[e] = Math<T>::gelu(g[e]) * p[e];
+                    for (int e = 0; e < 4; ++e) o[e] = Math<T>::gelu(g_[e]) * p_[e];
                     store4<T>(Us + (iy * GF_TW + ix0 + (side ? HPX : 0) + i) * LDU + c4 * 4, o);
                 }
             }
-            __syncthreads();              // u tile complete
-
-            // ---- (3) y[channels of this wave, pixel block pb] += W_out[:, slab] u_s^T
-            {
-                const typename TR::frag_t uf = load_frag<T>(Us, LDU, pb * 16, 0);
-#pragma unroll
-                for (int ob = 0; ob < NOBW; ++ob) mma(yacc[ob], load_frag<T>(Wos, LDO, (och * NOBW + ob) * 16, 0), uf);
+            if (g + 1 < gsteps) {         // next step's weights / taps to LDS, the step after into registers
+                wstore(buf ^ 1);
+                if (g + 2 < gsteps) wload((g + 2) % nslab);
             }
+            __syncthreads();              // u tile complete; next step's weights in place
         }
+        ymma(((tile - sp * tpw) * nslab + nslab - 1) & 1);        // project_out of the last slab
 
-        // ---- y + a (one rounding), staged as [pixel][channel], stored as whole 16-byte row chunks
-        __syncthreads();                  // every wave is past its last reads of the slab tiles
+        // ---- y + a (one rounding), staged as [pixel][channel] over the u | t tiles, stored as whole 16-byte row chunks
+        __syncthreads();                  // every wave is past its last read of u
         {
             const int px = pb * 16 + (lane & 15), cr = (och * NOBW) * 16 + (lane >> 4) * 4;
             const T* arow = X + (img + (long)(ty0 + px / GF_TW) * a.W + tx0 + px % GF_TW) * a.ldx + cr;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(GF_THREADS, 2) void gdfn_fused_kernel(GdfnDev a) {
                 store16<T>(Y + (img + (long)(ty0 + px / GF_TW) * a.W + tx0 + px % GF_TW) * a.ldy + c, load16<T>(Ys + px * LDY + c));
             }
         }
-        // (the next tile's first barrier orders these reads of Ys before its weight stores)
+        __syncthreads();                  // the next tile's first t rows land on the output tile
     }
 }
 
