@@ -155,10 +155,25 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
         }
     };
     if (CF::STAGE) wload(0, 0);
+    // C = 128: a wave multiplies the same 32 tokens (half `wv & 1` of the window) in every unit of phase (a); their LN-ed rows
+    // are read from LDS ONCE as MFMA fragments and stay in registers over all heads (a unit: 1204 -> 732 cycles by the
+    // shader-clock stamps, the launch 2-4 % shorter).  Narrower nets lose a wave per SIMD to the 32 registers, wider ones two.
+    constexpr bool XREG = CF::STAGE && C == 128;
+    constexpr int NKX = XREG ? C / TR::KCHUNK : 1;
+    frag_t xf[2][NKX];
 
     for (int h = 0; h < CF::HEADS; ++h) {
         __syncthreads();   // Xs ready (h=0) / previous head's K, V^T, bias column and P tile (= the weight stage) no longer read
         if (h == 0) WIN_MARK(1);
+        if constexpr (XREG) {
+            if (h == 0) {
+#pragma unroll
+                for (int kc = 0; kc < NKX; ++kc) {
+                    xf[0][kc] = load_frag<T>(Xs, CF::LDX, (wv & 1) * 32, kc * TR::KCHUNK);
+                    xf[1][kc] = load_frag<T>(Xs, CF::LDX, (wv & 1) * 32 + 16, kc * TR::KCHUNK);
+                }
+            }
+        }
         if (tid < 225) rpbs[tid] = a.rpb[tid * CF::HEADS + h];
         constexpr int TPW = HD / 16;                 // channel tiles per q/k/v
         if constexpr (CF::STAGE) {
@@ -187,8 +202,8 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
 #pragma unroll
                     for (int kc = 0; kc < NKC; ++kc) {
                         const frag_t w = load_frag<T>(Wst, CF::LDWS, ctl * 16, kc * TR::KCHUNK);
-                        mma(c0, w, load_frag<T>(Xs, CF::LDX, th * 32, kc * TR::KCHUNK));
-                        mma(c1, w, load_frag<T>(Xs, CF::LDX, th * 32 + 16, kc * TR::KCHUNK));
+                        mma(c0, w, XREG ? xf[0][XREG ? kc : 0] : load_frag<T>(Xs, CF::LDX, th * 32, kc * TR::KCHUNK));
+                        mma(c1, w, XREG ? xf[1][XREG ? kc : 0] : load_frag<T>(Xs, CF::LDX, th * 32 + 16, kc * TR::KCHUNK));
                     }
                     const int cr = cti * 16 + (lane >> 4) * 4;        // 4 consecutive channels of the head
                     const float sc = part == 0 ? scale : 1.f;
@@ -204,8 +219,8 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
 #pragma unroll
                     for (int kc = 0; kc < NKC; ++kc) {
                         const frag_t w = load_frag<T>(Wst, CF::LDWS, ctl * 16, kc * TR::KCHUNK);
-                        mma(c0, load_frag<T>(Xs, CF::LDX, th * 32, kc * TR::KCHUNK), w);
-                        mma(c1, load_frag<T>(Xs, CF::LDX, th * 32 + 16, kc * TR::KCHUNK), w);
+                        mma(c0, XREG ? xf[0][XREG ? kc : 0] : load_frag<T>(Xs, CF::LDX, th * 32, kc * TR::KCHUNK), w);
+                        mma(c1, XREG ? xf[1][XREG ? kc : 0] : load_frag<T>(Xs, CF::LDX, th * 32 + 16, kc * TR::KCHUNK), w);
                     }
                     const float bb = a.bqkv[wrow + (lane & 15)];
                     for (int r = 0; r < 4; ++r) { c0[r] += bb; c1[r] += bb; }

@@ -457,3 +457,36 @@ def test_graphed_forward_matches_eager():
         out = run(x, p)
         assert torch.equal(out, ref), i
     assert any("graph" in e for e in run.entries.values())
+
+
+def test_fused_gdfn_in_the_no_grad_forward():
+    """The no_grad forward runs PromptFusion's feed-forward as ONE launch (mphsir_gdfn_fused) once the level holds >= 16384
+    pixels.  Same net, same input, both forms: they agree to bf16 rounding, and against the fp32 forward of the same weights
+    the fused form (t kept in fp32 on chip) is not the less accurate one."""
+    from mp_hsir_amd import ops
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    torch.manual_seed(5)
+    net = MP_HSIR_Net(compute_dtype=torch.bfloat16, clip_prompt="surrogate").cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.rand((4, 31, 64, 64), generator=g, device="cuda")
+    p = torch.tensor([0, 1, 2, 3], device="cuda")
+    calls = []
+    orig = ops.gdfn_fused
+    ops.gdfn_fused = lambda *a, **k: (calls.append(a[0].shape), orig(*a, **k))[1]
+    keep = ops.GDFN_FUSED_MIN_PIXELS
+    try:
+        with torch.no_grad():
+            y_fused = net(x, p)
+            n_fused = len(calls)
+            ops.GDFN_FUSED_MIN_PIXELS = 1 << 62
+            y_chain = net(x, p)
+            assert len(calls) == n_fused
+            net.compute_dtype = torch.float32
+            ops.bump_weight_epoch()
+            y32 = net(x, p)
+    finally:
+        ops.gdfn_fused, ops.GDFN_FUSED_MIN_PIXELS = orig, keep
+    assert n_fused >= 1, "the fused GDFN kernel did not run"
+    e_f, e_c = M.rel_l2(y_fused.float().cpu(), y32.float().cpu()), M.rel_l2(y_chain.float().cpu(), y32.float().cpu())
+    assert M.rel_l2(y_fused.float().cpu(), y_chain.float().cpu()) < 2e-2
+    assert e_f < 4e-2 and e_f < e_c * 1.25 + 1e-4, (e_f, e_c)
