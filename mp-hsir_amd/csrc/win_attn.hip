@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
             for (int r = 0; r < 4; ++r) p[r] *= inv;
             store4<T>(Ps + qi * CF::LDP + kt * 16 + (lane >> 4) * 4, p);
         }
-        __syncthreads();
+        wave_barrier();    // P rows of this wave's 16 queries are read back by this wave only (V^T is complete since the barrier above)
         if (h == 0) WIN_MARK(3);
 
         // ---- (c) O^T = V^T P^T -> O [tok][hd] (over the q tile rows of this wave) ---------------
@@ -349,13 +349,13 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
                 mma(o, load_frag<T>(Vt, CF::LDV, ct * 16, kk), load_frag<T>(Ps, CF::LDP, wv * 16, kk));
             store4<T>(Qs + qi * CF::LDQ + ct * 16 + (lane >> 4) * 4, o);
         }
-        __syncthreads();
+        wave_barrier();    // O overwrites this wave's own q rows (nobody else reads them) and is read back by this wave only
         if (h == 0) WIN_MARK(4);
-        if (a.Oattn) {   // training: keep softmax(QK^T)V (before proj) for the proj weight gradient
+        if (a.Oattn) {   // training: keep softmax(QK^T)V (before proj) for the proj weight gradient; a wave stores its own 16 rows
             constexpr int VPH = HD / VEC;
             T* Oa = reinterpret_cast<T*>(a.Oattn);
-            for (int idx = tid; idx < 64 * VPH; idx += 256) {
-                const int t = idx / VPH, c0 = (idx % VPH) * VEC;
+            for (int idx = lane; idx < 16 * VPH; idx += 64) {
+                const int t = wv * 16 + idx / VPH, c0 = (idx % VPH) * VEC;
                 store16<T>(Oa + ((long)blockIdx.x * 64 + t) * C + h * HD + c0, load16<T>(Qs + t * CF::LDQ + c0));
             }
         }
