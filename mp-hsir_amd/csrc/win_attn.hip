@@ -312,13 +312,16 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
             for (int kt = 0; kt < 4; ++kt) mma(s[kt], load_frag<T>(Ks, CF::LDQ, kt * 16, kk), qf);
         }
         const int qi = wv * 16 + (lane & 15), qy = qi >> 3, qx = qi & 7, qreg = reg[qi];
+        // relative-position index of (query qi, key kj = 16 kt + 4 (lane >> 4) + r): (qy - ky + 7) * 15 + (qx - kx + 7) with
+        // ky = 2 kt + (lane >> 5), kx = 4 ((lane >> 4) & 1) + r  ->  one per-lane base minus the compile-time 30 kt + r
+        const float* rp = rpbs + (qy + 7) * 15 + qx + 7 - 15 * (lane >> 5) - 4 * ((lane >> 4) & 1);
+        const int* kreg = reg + (lane >> 4) * 4;
         float mx = -3.0e38f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
             for (int r = 0; r < 4; ++r) {
-                const int kj = kt * 16 + (lane >> 4) * 4 + r;
-                float v = s[kt][r] + rpbs[(qy - (kj >> 3) + 7) * 15 + (qx - (kj & 7) + 7)];
-                if (reg[kj] != qreg) v += -100.0f;
+                float v = s[kt][r] + rp[-(30 * kt + r)];
+                if (kreg[kt * 16 + r] != qreg) v += -100.0f;
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
