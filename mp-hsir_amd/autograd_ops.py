@@ -115,12 +115,15 @@ def _pgsstb_attn_infer(blk, k1, x):
     heads, shift = blk.num_heads, blk.shift_size
     sa, mu, _ = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"], pk["bproj"],
                                  pk["pg"], heads, shift, gate=False)
-    # (no side branch for the gate here: beside the fused pass A, whose workgroups fill the LDS of every CU, it costs 2 % of the
-    # 512x512 forward instead of saving time)
-    gate = ops.pg_gate_fwd(mu, pk["pg"])
     sa2 = sa.reshape(-1, Cc)
     v, gp, spart = _pass_a_infer(sa2, sp["wqkv"], sp["w9"], B, H, W, Cc, heads)
+    # the prompt gate forks AFTER pass A is issued (beside the fused pass A, whose workgroups fill the LDS of every CU, it costs
+    # 2 % of the 512x512 forward): it runs beside the partial-sum reduction and the fold, three small latency-bound launches
+    # (7.62 -> 7.58 ms)
+    with ops.side_stream(sa, ops.SIDE_BRANCH) as br:
+        gate = ops.pg_gate_fwd(mu, pk["pg"])
     Mb = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt)
+    br.join()
     y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
     return y.reshape(B, H, W, Cc)
 
