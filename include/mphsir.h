@@ -369,6 +369,11 @@ int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY, int64_t l
  * (b, slab) of the grid (nblk, ceil(C/96)) then walks the 8x16-pixel tiles b, b + nblk, ... -- size nblk for about one workgroup
  * per CU instead of one partial block per ~128 pixels. */
 int mphsir_dwconv3x3_wgrad_tiled(int32_t H, int32_t W, int32_t C, int dtype);
+/* Both gradients of one depthwise 3x3 in one launch, for the shapes mphsir_dwconv3x3_wgrad_tiled accepts:
+ * dX = mphsir_dwconv3x3(dY, flip=1) and partial = mphsir_dwconv3x3_wgrad(X, dY) (same layout, same nblk rule) with dY read once.
+ * X = the conv's input, dY = the gradient of its output; dX must not alias dY. */
+int mphsir_dwconv3x3_bwd(const void* X, int64_t ldx, const void* dY, int64_t lddy, const float* w9, int64_t ldw, void* dX, int64_t lddx,
+                         float* partial, int32_t nblk, int32_t B, int32_t H, int32_t W, int32_t C, int dtype, void* stream);
 
 /* backward of the GDFN gate u = gelu_erf(T[:, :HP]) * T[:, HP:] (FFN/FeedForward.forward :263, :389):
  * given dU [M][HP] writes U (recomputed, for d project_out) and dT [M][2*HP].                          */
@@ -472,6 +477,7 @@ int mphsir_pack_gather(const float* arena, const int32_t* index, void* dst, int6
 #define MPHSIR_K_RESAMPLE 23
 #define MPHSIR_K_QKV_DWCONV_GRAM 24
 #define MPHSIR_K_GDFN_FUSED 25
+#define MPHSIR_K_DWCONV_BWD 26
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -156,6 +156,8 @@ _SYMBOLS = {
     "mphsir_gdfn_fused_tile_width": (c_int, [c_int32]),
     "mphsir_dwconv3x3": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                  c_int32, c_int, c_void_p]),
+    "mphsir_dwconv3x3_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32,
+                                     c_int32, c_int32, c_int, c_void_p]),
     "mphsir_dwconv3x3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                        c_int32, c_int, c_void_p]),
     "mphsir_flat_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,

@@ -80,8 +80,8 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     if joint:
         t_all = torch.as_strided(t_q, (B, H, W, 3 * C), t_q.stride())
         w9_all = torch.as_strided(w9q, (9, 3 * C), w9q.stride())
-        dt_all = ops.dwconv3x3(dall4, w9_all, flip=True)
-        dw_all = ops.dwconv3x3_wgrad(t_all, dall4, col_ranges=[(0, 3 * C)])             # (3C, 9): the parameter's layout
+        # both gradients of the depthwise conv in one launch (dall read once); dw_all (3C, 9): the parameter's layout
+        dt_all, dw_all = ops.dwconv3x3_bwd(t_all, dall4, w9_all, col_ranges=[(0, 3 * C)])
         return (dt_all[..., :C], dt_all[..., C:2 * C], dt_all[..., 2 * C:], dw_all[:C], dw_all[C:2 * C], dw_all[2 * C:],
                 dtemp, dwo)
     dq4, dk4, dv4 = dall4[..., :C], dall4[..., C:2 * C], dall4[..., 2 * C:]
@@ -284,8 +284,8 @@ class _GdfnRes(torch.autograd.Function):
             u, dtdw = ops.gdfn_gate_bwd(tdw, du)
             d_out_w = ops.gemm_tn_blocks(dy, u, [(0, D)], ncols=hid).reshape(D, hid, 1, 1)
             dtdw4 = dtdw.reshape(B, H, W, 2 * HP)
-            dt_ = ops.dwconv3x3(dtdw4, pf["w9"], flip=True).reshape(-1, 2 * HP)
-            d_dw = ops.dwconv3x3_wgrad(t4, dtdw4, col_ranges=[(0, hid), (HP, hid)]).reshape(2 * hid, 1, 3, 3)
+            dt_, d_dw = ops.dwconv3x3_bwd(t4, dtdw4, pf["w9"], col_ranges=[(0, hid), (HP, hid)])
+            dt_, d_dw = dt_.reshape(-1, 2 * HP), d_dw.reshape(2 * hid, 1, 3, 3)
             lw, lb = ln.pair()
             da, dlw, dlb, xn = ops.ln_bwd_tok(a2, ops.gemm_tok(dt_, pf["w_inT"]), dy, lw, lb)
             d_in_w = ops.gemm_tn_blocks(dt_, xn, [(0, hid), (HP, hid)]).reshape(2 * hid, D, 1, 1)

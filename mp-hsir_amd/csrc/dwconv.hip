@@ -367,6 +367,130 @@ __global__ __launch_bounds__(DT_THREADS, 2) void dwconv3x3_wgrad_tile_kernel(DwW
     }
 }
 
+// ---- both gradients of a depthwise 3x3 in one pass (tile form shapes) ------------------------------------------------------------
+// dX[p] = sum_taps w[tap] dY[p - tap]   and   dW[tap] = sum_p X[p] dY[p - tap]   read the SAME nine shifted dY values per pixel:
+// the dY halo tile goes through LDS (fp32) as in dwconv3x3_tile_kernel, X comes straight from global for the interior pixels
+// (8 bytes per pixel and thread), a thread = 4 channels x a strip of 8 pixels produces its dX values and adds X[p] dY[p - tap]
+// to its nine tap sums, which stay in registers while the persistent workgroup (pblk, slab) walks its tiles; one ordered LDS
+// reduction at the end.  Against dwconv3x3(flip) + dwconv3x3_wgrad: dY is read once instead of twice (5 -> 4 tensor passes),
+// one launch instead of two.
+struct DwBwdDev {
+    const void* X; long ldx; const void* dY; long lddy; const float* w9; long ldw; void* dX; long lddx; float* part;
+    int B, H, W, C, nblk;
+};
+
+template <class T>
+__global__ __launch_bounds__(DT_THREADS, 2) void dwconv3x3_bwd_tile_kernel(DwBwdDev a) {
+    constexpr int VEC = Vec16<T>::N;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    float* Ts = reinterpret_cast<float*>(smem_v);          // [180][DT_LD] dY halo tile; at the end: [16 strips][9][DT_CS] partial sums
+    const int tid = threadIdx.x;
+    const int tilesx = a.W / DT_TW, tiles = (a.H / DT_TH) * tilesx;
+    const long total = (long)a.B * tiles;
+    const int slab = blockIdx.y, cs0 = slab * DT_CS, cw = (a.C - cs0) < DT_CS ? (a.C - cs0) : DT_CS, vpr = cw / VEC, qpr = cw / 4;
+    const bool on = tid < qpr * 16;
+    const int c4 = tid % qpr, st = tid / qpr, iy = st >> 1, ix0 = (st & 1) * 8;
+    typedef typename ElemTraits<T>::vec4_t v4_t;
+
+    constexpr int NV = (DT_ROWS * (DT_CS / VEC) + DT_THREADS - 1) / DT_THREADS;       // 5
+    Vec16<T> gv[NV];
+    v4_t xy[8];
+    auto gload = [&](long t) __attribute__((always_inline)) {
+        const int b = (int)(t / tiles), tile = (int)(t % tiles);
+        const int ty0 = (tile / tilesx) * DT_TH, tx0 = (tile % tilesx) * DT_TW;
+        const T* G = reinterpret_cast<const T*>(a.dY) + (long)b * a.H * a.W * a.lddy + cs0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + DT_THREADS * i, r = idx / vpr, v = idx % vpr;
+            const int y = ty0 - 1 + r / DT_HW, x = tx0 - 1 + r % DT_HW;
+            if (r < DT_ROWS && y >= 0 && y < a.H && x >= 0 && x < a.W) gv[i] = load16<T>(G + ((long)y * a.W + x) * a.lddy + v * VEC);
+            else gv[i] = Vec16<T>{};
+        }
+        if (on) {
+            const T* xs = reinterpret_cast<const T*>(a.X) + ((long)b * a.H * a.W + (long)(ty0 + iy) * a.W + tx0 + ix0) * a.ldx + cs0 + c4 * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xy[i] = *reinterpret_cast<const v4_t*>(xs + (long)i * a.ldx);
+        }
+    };
+    // window position (r, c) holds dY[p + (r-1, c-1)] = dY[p - tap] for tap (1-r, 1-c): it meets the flipped tap 8 - (3r + c)
+    f32x4 w[9], acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        w[t] = on ? *reinterpret_cast<const f32x4*>(a.w9 + (8 - t) * a.ldw + cs0 + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    long t = blockIdx.x;
+    if (t < total) gload(t);
+    for (; t < total; t += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + DT_THREADS * i, r = idx / vpr, v = idx % vpr;
+            if (r < DT_ROWS) {
+                float* dst = Ts + r * DT_LD + v * VEC;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{gv[i].get(0), gv[i].get(1), gv[i].get(2), gv[i].get(3)};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{gv[i].get(4), gv[i].get(5), gv[i].get(6), gv[i].get(7)};
+            }
+        }
+        f32x4 xin[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xin[i] = f32x4{to_f32(xy[i][0]), to_f32(xy[i][1]), to_f32(xy[i][2]), to_f32(xy[i][3])};
+        const int b = (int)(t / tiles), tile = (int)(t % tiles);
+        const int ty0 = (tile / tilesx) * DT_TH, tx0 = (tile % tilesx) * DT_TW;
+        __syncthreads();
+        if (t + gridDim.x < total) gload(t + gridDim.x);
+        if (on) {
+            const float* tsrc = Ts + (iy * DT_HW + ix0) * DT_LD + c4 * 4;
+            auto tvec = [&](int r, int col) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(tsrc + (r * DT_HW + col) * DT_LD); };
+            T* xdst = reinterpret_cast<T*>(a.dX) + ((long)b * a.H * a.W + (long)(ty0 + iy) * a.W + tx0 + ix0) * a.lddx + cs0 + c4 * 4;
+            f32x4 cl[3], cm[3], cr[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { cl[r] = tvec(r, 0); cm[r] = tvec(r, 1); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) cr[r] = tvec(r, i + 2);
+                f32x4 o = cl[0] * w[0];
+                o = __builtin_elementwise_fma(cm[0], w[1], o);
+                o = __builtin_elementwise_fma(cr[0], w[2], o);
+#pragma unroll
+                for (int r = 1; r < 3; ++r) {
+                    o = __builtin_elementwise_fma(cl[r], w[r * 3], o);
+                    o = __builtin_elementwise_fma(cm[r], w[r * 3 + 1], o);
+                    o = __builtin_elementwise_fma(cr[r], w[r * 3 + 2], o);
+                }
+                store4<T>(xdst + (long)i * a.lddx, o);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    acc[r * 3] = __builtin_elementwise_fma(cl[r], xin[i], acc[r * 3]);
+                    acc[r * 3 + 1] = __builtin_elementwise_fma(cm[r], xin[i], acc[r * 3 + 1]);
+                    acc[r * 3 + 2] = __builtin_elementwise_fma(cr[r], xin[i], acc[r * 3 + 2]);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
+            }
+        }
+        __syncthreads();           // the tile is free for the next stage (and, after the last tile, for the strip sums)
+    }
+    float* red = Ts;                                       // [16][9][DT_CS], tap-major in the PARAMETER's tap order
+    if (on)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) *reinterpret_cast<f32x4*>(red + (st * 9 + tp) * DT_CS + c4 * 4) = acc[8 - tp];
+    __syncthreads();
+    for (int i = tid; i < 9 * cw; i += DT_THREADS) {
+        const int tp = i / cw, c = i % cw;
+        float s = 0.f;
+        for (int k = 0; k < 16; ++k) s += red[(k * 9 + tp) * DT_CS + c];
+        a.part[((long)blockIdx.x * 9 + tp) * a.C + cs0 + c] = s;
+    }
+}
+
+template <class T> static int launch_dw_bwd_tile(const DwBwdDev& d, hipStream_t s) {
+    const size_t shmem = (size_t)DT_ROWS * DT_LD * sizeof(float);       // >= 16 * 9 * DT_CS floats
+    allow_big_lds(dwconv3x3_bwd_tile_kernel<T>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_DWCONV_BWD, (dwconv3x3_bwd_tile_kernel<T>), dim3(d.nblk, (d.C + DT_CS - 1) / DT_CS), dim3(DT_THREADS), shmem, s, d);
+    return MPHSIR_OK;
+}
+
 template <class T> static int launch_dw_wgrad_tile(const DwWgDev& d, hipStream_t s) {
     const size_t shmem = (size_t)DT_ROWS * DT_LD * sizeof(float);       // >= 16 * 9 * DT_CS floats
     allow_big_lds(dwconv3x3_wgrad_tile_kernel<T>, shmem);
@@ -454,4 +578,20 @@ extern "C" int mphsir_dwconv3x3_wgrad(const void* X, int64_t ldx, const void* dY
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_WGRAD, (dwconv3x3_wgrad_kernel<f16_t>), grid, dim3(256), shmem, s, d);
     }
     return MPHSIR_OK;
+}
+
+extern "C" int mphsir_dwconv3x3_bwd(const void* X, int64_t ldx, const void* dY, int64_t lddy, const float* w9, int64_t ldw, void* dX, int64_t lddx,
+                                    float* partial, int32_t nblk, int32_t B, int32_t H, int32_t W, int32_t C, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(X && dY && w9 && dX && partial, "dwconv3x3_bwd: null pointer");
+    MPHSIR_REQUIRE(B > 0 && nblk > 0 && mphsir_dwconv3x3_wgrad_tiled(H, W, C, dtype),
+                   "dwconv3x3_bwd: (H=%d, W=%d, C=%d, dtype=%d) not covered (16-bit types, H %% 8 == 0, W %% 16 == 0, C %% 32 == 0: ask "
+                   "mphsir_dwconv3x3_wgrad_tiled; otherwise mphsir_dwconv3x3(flip=1) + mphsir_dwconv3x3_wgrad)", H, W, C, dtype);
+    MPHSIR_REQUIRE(aligned16(X) && aligned16(dY) && aligned16(dX) && aligned16(w9) && (ldx * 2) % 16 == 0 && (lddy * 2) % 16 == 0 &&
+                       (lddx * 2) % 16 == 0 && (ldw * 4) % 16 == 0, "dwconv3x3_bwd: 16-byte alignment required");
+    MPHSIR_REQUIRE(dX != dY, "dwconv3x3_bwd: dX must not alias dY (neighbouring tiles read dY's halo)");
+    DwBwdDev d{X, (long)ldx, dY, (long)lddy, w9, (long)ldw, dX, (long)lddx, partial, B, H, W, C, nblk};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == MPHSIR_BF16 ? launch_dw_bwd_tile<bf16_t>(d, s) : launch_dw_bwd_tile<f16_t>(d, s);
 }

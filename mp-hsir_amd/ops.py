@@ -745,6 +745,37 @@ def dwconv3x3_wgrad(x, dy, nblk=None, col_ranges=None):
     return out
 
 
+def dwconv3x3_bwd_fits(H, W, C, dtype):
+    return bool(_lib.load().mphsir_dwconv3x3_wgrad_tiled(H, W, C, _DT[dtype]))
+
+
+def dwconv3x3_bwd(x, dy, w9, col_ranges=None):
+    """Both gradients of y = dwconv3x3(x, w9) in one launch: -> (dx, dw) with dx = dwconv3x3(dy, w9, flip=True) and
+    dw = dwconv3x3_wgrad(x, dy, col_ranges=col_ranges).  Shapes dwconv3x3_bwd_fits accepts; else the two launches."""
+    lib = _lib.load()
+    _check(x, dy, w9)
+    B, H, W, C = x.shape
+    if not dwconv3x3_bwd_fits(H, W, C, x.dtype):
+        return dwconv3x3(dy, w9, flip=True), dwconv3x3_wgrad(x, dy, col_ranges=col_ranges)
+    assert x.stride(3) == 1 and dy.stride(3) == 1 and dy.shape == x.shape
+    for t in (x, dy):
+        assert t.stride(1) == W * t.stride(2) and t.stride(0) == H * t.stride(1)
+    nblk = max(1, min(B * (H // 8) * (W // 16), 256 // ((C + 95) // 96)))
+    dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    part = torch.empty((nblk, 9, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mphsir_dwconv3x3_bwd(_p(x), x.stride(2), _p(dy), dy.stride(2), _p(w9), w9.stride(0), _p(dx), C, _p(part), nblk,
+                                        B, H, W, C, _DT[x.dtype], _stream(x)), "dwconv3x3_bwd")
+    _acct("dwconv3x3_bwd", 36.0 * B * H * W * C, 3.0 * B * H * W * C * x.element_size())
+    if col_ranges is None:
+        return dx, reduce_parts(part)
+    out = torch.empty((sum(nc for _, nc in col_ranges), 9), dtype=torch.float32, device=x.device)
+    o = 0
+    for c0, nc in col_ranges:
+        reduce_block(part, 0, 9, c0, nc, out[o:o + nc], transpose=True)
+        o += nc
+    return dx, out
+
+
 def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None, rows_per_batch=0):
     """-> dx, xn, h, dpre, part (see include/mphsir.h).  x, dy, dm: contiguous (M,C).  With keep (DropPath factors, one
     per rows_per_batch rows) dm is ignored as input: the kernel computes keep*dy itself and it is returned as a 6th value."""

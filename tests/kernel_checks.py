@@ -301,6 +301,40 @@ def check_dwconv_plain(dev, dtype, shape):
     assert rel_l2(dw, wr.grad.reshape(C, 9).t()) < TOL[dtype]
 
 
+DW_BWD_CASES = [(1, 8, 16, 32), (2, 16, 32, 96), (1, 24, 16, 128), (2, 8, 32, 352)]
+DW_BWD_CASES_GPU = [(32, 64, 64, 384), (4, 64, 64, 704), (2, 128, 128, 192)]
+
+
+def check_dwconv_bwd(dev, dtype, shape):
+    """mphsir_dwconv3x3_bwd (dX and dW of one depthwise conv in one launch) vs the two launches (dX bitwise: the same tap order)
+    and vs torch autograd in fp64; the parameter-layout output (col_ranges) as well."""
+    _use(dev)
+    import torch.nn.functional as F
+    from mp_hsir_amd import ops
+    B, H, W, C = shape
+    assert ops.dwconv3x3_bwd_fits(H, W, C, dtype)
+    x, dy = rnd(shape, 51, dtype), rnd(shape, 52, dtype)
+    w = rnd((C, 1, 3, 3), 53, scale=1 / 3)
+    w9 = ops.pack_dw(w)
+    dx, dw = ops.dwconv3x3_bwd(x, dy, w9)
+    assert torch.equal(dx, ops.dwconv3x3(dy, w9, flip=True))
+    xr = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.double().cpu().requires_grad_(True)
+    F.conv2d(xr, wr, None, 1, 1, 1, C).backward(dy.double().cpu().permute(0, 3, 1, 2))
+    assert rel_l2(dx, xr.grad.permute(0, 2, 3, 1)) < TOL[dtype]
+    assert rel_l2(dw, wr.grad.reshape(C, 9).t()) < TOL[dtype]
+    assert rel_l2(dw, ops.dwconv3x3_wgrad(x, dy)) < 1e-5
+    half = C // 2 // 8 * 8
+    _, dwp = ops.dwconv3x3_bwd(x, dy, w9, col_ranges=[(0, half - 2), (half, C - half)])
+    ref = wr.grad.reshape(C, 9)
+    assert rel_l2(dwp, torch.cat([ref[:half - 2], ref[half:]], dim=0)) < TOL[dtype]
+    # strided views (a channel range of a wider tensor), as the backward of pass A passes them
+    wide_x, wide_dy = rnd((B, H, W, C + 32), 54, dtype), rnd((B, H, W, C + 32), 55, dtype)
+    dx2, dw2 = ops.dwconv3x3_bwd(wide_x[..., 32:], wide_dy[..., :C], w9)
+    dx2r, dw2r = ops.dwconv3x3_bwd(wide_x[..., 32:].contiguous(), wide_dy[..., :C].contiguous(), w9)
+    assert torch.equal(dx2, dx2r) and torch.equal(dw2, dw2r)
+
+
 def check_gated_mlp_bwd(dev, dtype, C, hid, variant=0):
     """HIP data-gradient kernel + token-reduction GEMMs vs autograd of the fp64 oracle."""
     _use(dev)

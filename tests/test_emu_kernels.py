@@ -88,6 +88,15 @@ def test_dwconv_plain(dtype, shape):
     K.check_dwconv_plain("cpu", dtype, shape)
 
 
+@pytest.mark.parametrize("shape", K.DW_BWD_CASES)
+def test_dwconv_bwd(shape):
+    K.check_dwconv_bwd("cpu", torch.bfloat16, shape)
+
+
+def test_dwconv_bwd_f16():
+    K.check_dwconv_bwd("cpu", torch.float16, (1, 8, 32, 64))
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("C,hid", [(32, 85), (96, 255)])
 def test_gated_mlp_bwd(dtype, C, hid):

@@ -148,6 +148,12 @@ def test_dwconv_plain(dtype, shape):
     K.check_dwconv_plain("cuda", dtype, shape)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", K.DW_BWD_CASES + K.DW_BWD_CASES_GPU)
+def test_dwconv_bwd(dtype, shape):
+    K.check_dwconv_bwd("cuda", dtype, shape)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("C,hid", [(32, 85), (96, 255), (64, 170), (128, 340), (256, 680), (192, 510)])
 def test_gated_mlp_bwd(dtype, C, hid):
