@@ -128,11 +128,15 @@ template <class T, int C, int HD> struct WinBwdPick {
     static constexpr bool XL = WinBwdCfg<T, C, HD, true>::BYTES <= 80 * 1024;
 };
 
-template <class T, int C, int HD, bool XL>
-__global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
+// XR (C <= 128, 16-bit): the LN(x) fragments of the 32 tokens a wave multiplies in every q/k/v unit (half `wv & 1` of the
+// window) live in REGISTERS for the whole kernel -- the tile passes through the (still unused) q|k tiles once -- so the
+// footprint is the one without the X tile (52 KB at C = 128: three workgroups per CU instead of two) at no re-read.
+template <class T, int C, int HD, bool XL, bool XR = false>
+__global__ __launch_bounds__(256, XR ? 3 : 1) void win_attn_bwd_kernel(WinBwdDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
     typedef WinBwdCfg<T, C, HD, XL> CF;
+    static_assert(!XR || (!XL && CF::HDP == HD && CF::STAGE && 64 * (C + CF::PAD) <= 4 * CF::QS), "XR: no X tile, no K padding, staged weights");
     constexpr int VEC = Vec16<T>::N;
     constexpr int TPW = HD / 16;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
             Vec16<T> o;
             for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
             if (XL) store16<T>(Xs + t * CF::LDX + c0, o);
+            if (XR) store16<T>(Qr + t * CF::LDX + c0, o);      // transit through the q|k tiles (written only from phase (a) on)
             store16<T>(xnw + c0, o);
             Vec16<T> d = load16<T>(dSA + pix * C + c0);
             for (int e = 0; e < VEC; ++e) d.set(e, d.get(e) + dmu[c0 + e] * (1.0f / 64.0f));
@@ -229,9 +234,20 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
         }
     };
     if (CF::STAGE) wload(0, 0);
+    constexpr int NKX = XR ? C / TR::KCHUNK : 1;
+    frag_t xf[2][NKX];
 
     for (int h = 0; h < CF::HEADS; ++h) {
         __syncthreads();      // h = 0: the side outputs / X tile are visible to the whole workgroup; h > 0: tiles free
+        if constexpr (XR) {
+            if (h == 0) {     // (the first stage's barriers order these reads before the first q rows are written)
+#pragma unroll
+                for (int kc = 0; kc < NKX; ++kc) {
+                    xf[0][kc] = load_frag<T>(Qr, CF::LDX, (wv & 1) * 32, kc * TR::KCHUNK);
+                    xf[1][kc] = load_frag<T>(Qr, CF::LDX, (wv & 1) * 32 + 16, kc * TR::KCHUNK);
+                }
+            }
+        }
         if (CF::ALIAS && CF::HDP != HD)   // P overwrote the zero padding of v
             for (int i = tid; i < 64 * (CF::HDP - HD); i += 256) {
                 const int rr = i / (CF::HDP - HD), cc = HD + i % (CF::HDP - HD);
@@ -257,7 +273,14 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinBwdDev a) {
                 const int ctl = u >> 1, cti = r0 / 16 + ctl, th = u & 1;
                 f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
                 const int wrow = (which < 3 ? which * C : 0) + h * HD + cti * 16;
-                if (XL && which < 3) {                   // wave-uniform: LDS operand
+                if (XR && which < 3) {                   // register operand (th == wv & 1 for every unit of a wave)
+#pragma unroll
+                    for (int kc = 0; kc < NKC; ++kc) {
+                        const frag_t w = load_frag<T>(Wst, CF::LDWS, ctl * 16, kc * TR::KCHUNK);
+                        mma(c0, w, xf[0][XR ? kc : 0]);
+                        mma(c1, w, xf[1][XR ? kc : 0]);
+                    }
+                } else if (XL && which < 3) {            // wave-uniform: LDS operand
 #pragma unroll
                     for (int kc = 0; kc < NKC; ++kc) {
                         const frag_t w = load_frag<T>(Wst, CF::LDWS, ctl * 16, kc * TR::KCHUNK);
@@ -558,7 +581,19 @@ static int launch_win_bwd_xl(const WinBwdDev& d, hipStream_t s) {
 }
 
 template <class T, int C, int HD>
+static int launch_win_bwd_xr(const WinBwdDev& d, hipStream_t s) {
+    typedef WinBwdCfg<T, C, HD, false> CF;
+    allow_big_lds(win_attn_bwd_kernel<T, C, HD, false, true>, CF::BYTES);
+    const int nblk = d.g.B * (d.g.H / 8) * (d.g.W / 8);
+    MPHSIR_LAUNCH(MPHSIR_K_WIN_ATTN_BWD, (win_attn_bwd_kernel<T, C, HD, false, true>), dim3(nblk), dim3(256), CF::BYTES, s, d);
+    return MPHSIR_OK;
+}
+
+template <class T, int C, int HD>
 static int launch_win_bwd(const WinBwdDev& d, hipStream_t s) {
+    // measured (tools/bench_win.py, batch 32): C=64 76.8 -> 61.6 us, C=128 / 64-wide heads 132.6 -> 122.3; C=128 / 32-wide heads
+    // 45.4 -> 47.3 (164 registers under the three-wave bound): that shape keeps the LDS tile
+    if constexpr (sizeof(T) == 2 && (C == 64 || (C == 128 && HD == 64)) && (HD == 32 || HD == 64)) return launch_win_bwd_xr<T, C, HD>(d, s);
     constexpr bool PICK = WinBwdPick<T, C, HD>::XL;
     constexpr int ov = -1;                      // (the X-tile placement is WinBwdPick's: measured both ways)
     if constexpr (WinBwdCfg<T, C, HD, true>::FITS) {
