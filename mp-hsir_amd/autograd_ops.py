@@ -39,7 +39,7 @@ class _GatedMlp(torch.autograd.Function):
                                                           pk["W1T"], pk["W2T"], keep=k2, rows_per_batch=H * W)
         hid = blk.mlp.fc2.weight.shape[1]
         HP = h.shape[1]
-        with ops.reduce_scope():                                   # one ordered-sum launch for all five partial buffers
+        with ops.reduce_scope(leaf=True):                                   # one ordered-sum launch for all five partial buffers
             dW2, db2 = ops.gemm_tn_blocks(dm, h, [(0, Cc)], ncols=hid, colsum=True)             # drops the padded hidden columns
             dW1, db1 = ops.gemm_tn_blocks(dpre, xn, [(0, hid), (HP, hid)], colsum=True)            # value rows | gate rows
             dln = ops.reduce_parts(part)
@@ -85,9 +85,12 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
         return (dt_all[..., :C], dt_all[..., C:2 * C], dt_all[..., 2 * C:], dw_all[:C], dw_all[C:2 * C], dw_all[2 * C:],
                 dtemp, dwo)
     dq4, dk4, dv4 = dall4[..., :C], dall4[..., C:2 * C], dall4[..., 2 * C:]
+    # the three tap gradients are row ranges of ONE buffer: the callers join them as a view (a cat would READ sums that may
+    # not have been launched yet, ops.deferred_reductions)
+    dw3 = torch.empty((3 * C, 9), dtype=torch.float32, device=v.device)
     return (ops.dwconv3x3(dq4, w9q, flip=True), ops.dwconv3x3(dk4, w9k, flip=True), ops.dwconv3x3(dv4, w9v, flip=True),
-            ops.dwconv3x3_wgrad(t_q, dq4, col_ranges=[(0, C)]), ops.dwconv3x3_wgrad(t_k, dk4, col_ranges=[(0, C)]),
-            ops.dwconv3x3_wgrad(t_v, dv4, col_ranges=[(0, C)]), dtemp, dwo)
+            ops.dwconv3x3_wgrad(t_q, dq4, col_ranges=[(0, C)], out=dw3[:C]), ops.dwconv3x3_wgrad(t_k, dk4, col_ranges=[(0, C)], out=dw3[C:2 * C]),
+            ops.dwconv3x3_wgrad(t_v, dv4, col_ranges=[(0, C)], out=dw3[2 * C:]), dtemp, dwo)
 
 
 _PG_KEYS = ("linear_down.weight", "linear_up.weight", "linear_prompt.weight", "prompt_param", "q.weight", "kv.weight",
@@ -180,7 +183,7 @@ class _PgsstbAttn(torch.autograd.Function):
         pk = blk.packed(dt)
         sp = blk.gobal_spectral_attn.packed(dt)
         dy = dy.contiguous()
-        with ops.reduce_scope():      # every split partial of this backward is summed by ONE launch when the scope exits
+        with ops.reduce_scope(leaf=True):      # every split partial of this backward is summed by ONE launch when the scope exits
             # (1) branch sum  y = x + keep*(sa*gate + out)
             d_out, d_sa, dgate = ops.combine_bwd(dy, sa, gate, k1, shift)
             # (3, issued first on a side branch) local spectral-prompt gate: one launch per block + one token-reduction GEMM
@@ -229,6 +232,7 @@ def _join_taps(*dw):
         off += w.numel() * w.element_size()
     if ok:
         return torch.as_strided(w0, (sum(w.shape[0] for w in dw), 9), (9, 1))
+    ops.flush_deferred()            # the cat reads the sums: they must have been launched
     return torch.cat(dw, dim=0)
 
 
@@ -278,7 +282,7 @@ class _GdfnRes(torch.autograd.Function):
         D = a2.shape[1]
         dy = dy.contiguous()
         t4 = t.reshape(B, H, W, 2 * HP)
-        with ops.reduce_scope():
+        with ops.reduce_scope(leaf=True):
             tdw = ops.dwconv3x3(t4, pf["w9"]).reshape(-1, 2 * HP)
             du = ops.gemm_tok(dy, pf["w_outT"])                                 # (M,HP)
             u, dtdw = ops.gdfn_gate_bwd(tdw, du)
@@ -338,7 +342,7 @@ class _SelfChannelAttnRes(torch.autograd.Function):
         w9 = pa["w9"]
         da = da.contiguous()
         q4 = q.reshape(B, H, W, 3 * D)
-        with ops.reduce_scope():      # every split partial of this backward is summed by ONE launch when the scope exits
+        with ops.reduce_scope(leaf=True):      # every split partial of this backward is summed by ONE launch when the scope exits
             dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
                 da, q4[..., :D], q4[..., D:2 * D], q4[..., 2 * D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
                 attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W, qk=qk)
@@ -391,7 +395,7 @@ class _CrossChannelAttnRes(torch.autograd.Function):
         w9 = pa["w9"]
         da = da.contiguous()
         tq4, tkv4 = tq.reshape(B, H, W, D), tkv.reshape(B, H, W, 2 * D)
-        with ops.reduce_scope():      # every split partial of this backward is summed by ONE launch when the scope exits
+        with ops.reduce_scope(leaf=True):      # every split partial of this backward is summed by ONE launch when the scope exits
             dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
                 da, tq4, tkv4[..., :D], tkv4[..., D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
                 attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)

@@ -281,6 +281,7 @@ class DataParallelEngine:
     def _gather_bucket(self, bi):
         """autograd hands every gradient over as a fresh tensor (p.grad was None): move the bucket's gradients into
         the arena with one multi-tensor copy instead of one accumulate kernel per parameter."""
+        ops.flush_deferred()      # (only non-empty when a bucket hook fires in the middle of the backward pass)
         ps, views = self._bucket_members[bi]
         # _foreach_copy_ takes its multi-tensor kernel only when EVERY pair has identical dense strides; one transposed /
         # strided gradient view in the list silently turns the whole bucket into one copy launch per parameter (measured:
@@ -331,10 +332,11 @@ class DataParallelEngine:
 
     def _backward(self, loss):
         """loss.backward(), through the loss scale when the fp16 path is on"""
-        if self._use_scaler(loss.device):
-            (loss * self.scaler[0]).backward()
-        else:
-            loss.backward()
+        with ops.deferred_reductions():      # the parameter-gradient sums of all backward functions in a few big launches at the end
+            if self._use_scaler(loss.device):
+                (loss * self.scaler[0]).backward()
+            else:
+                loss.backward()
 
     def _optimizer_step(self, lr, hyper=None):
         """AdamW over the arenas (1/world folded in); fp16 path: non-finite check + unscale + skip + scale update"""

@@ -98,10 +98,20 @@ class side_stream:
 _SCOPE = None
 
 
+_DEFERRED = None      # list of segments while `deferred_reductions` is active (the engine's backward), else None
+
+
 class reduce_scope:
     """Inside the scope every `reduce_parts` call only records its segment and returns the (not yet written) output
     tensor; one mphsir_reduce_parts launch per <= 32 segments fills them when the scope exits.  Callers may slice /
-    reshape the outputs inside the scope but must not READ them (no kernels on them) before it exits."""
+    reshape the outputs inside the scope but must not READ them (no kernels on them) before it exits.
+
+    leaf=True declares that every sum of the scope is the gradient of a leaf parameter (nothing downstream of the backward
+    function reads it): inside `deferred_reductions` those sums are then not launched at scope exit but handed to the
+    enclosing context, which launches them together (see there)."""
+
+    def __init__(self, leaf=False):
+        self.leaf = leaf
 
     def __enter__(self):
         global _SCOPE
@@ -114,9 +124,46 @@ class reduce_scope:
         _SCOPE = self.prev
         if exc[0] is None:
             _flush_gemms(self.gemms)            # the deferred weight-gradient GEMMs, grouped ...
-            _flush(self.segs)                   # ... then the ordered sums of everything they (and others) wrote
+            if self.leaf and _DEFERRED is not None:
+                # ... their sums later, with everybody else's.  The output is kept alive through a detached alias: the tensor
+                # object itself must stay uniquely referenced so that AccumulateGrad adopts it instead of cloning (= reading) it
+                for g in self.segs:
+                    g["keep"] = (g["keep"][0], g["keep"][1].detach())
+                _DEFERRED.extend(self.segs)
+            else:
+                _flush(self.segs)               # ... then the ordered sums of everything they (and others) wrote
         self.segs, self.gemms = [], []
         return False
+
+
+class deferred_reductions:
+    """`with ops.deferred_reductions():` around a whole backward pass: the partial-sum reductions of every reduce_scope(leaf=True)
+    -- parameter gradients, which nothing reads before the optimizer / the gradient hand-over -- are collected and launched
+    together when the context exits (or at `flush_deferred()`), 32 segments per launch, instead of one small latency-bound
+    launch per backward function on the critical path between two backward functions (85 launches of ~15 us per training
+    step).  Only the engine turns this on: it knows when gradients are read.  The partials stay allocated until then."""
+
+    def __enter__(self):
+        global _DEFERRED
+        self.prev = _DEFERRED
+        _DEFERRED = []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        segs, _DEFERRED = _DEFERRED, self.prev
+        if exc[0] is None:
+            _flush(segs)
+        return False
+
+
+def flush_deferred():
+    """Launch what `deferred_reductions` has collected so far (the engine calls this before it reads gradients in the middle
+    of a backward pass: the bucket hooks of the data-parallel path)."""
+    if _DEFERRED:
+        segs = _DEFERRED[:]
+        del _DEFERRED[:]
+        _flush(segs)
 
 
 def _flush_gemms(gemms):
@@ -718,10 +765,10 @@ def dwconv3x3(x, w9, flip=False):
     return y
 
 
-def dwconv3x3_wgrad(x, dy, nblk=None, col_ranges=None):
+def dwconv3x3_wgrad(x, dy, nblk=None, col_ranges=None, out=None):
     """-> fp32 [9][C] = sum_p x[p+tap] * dy[p].  With col_ranges=[(c0, nc), ...] the result is returned in the
     parameter's own layout instead: (sum nc, 9), channel-major, only those channel ranges (transposed + un-padded inside
-    the partial reduction)."""
+    the partial reduction); `out` = a (sum nc, 9) fp32 view to write that into (e.g. a row range of a joint buffer)."""
     lib = _lib.load()
     _check(x, dy)
     B, H, W, C = x.shape
@@ -737,7 +784,9 @@ def dwconv3x3_wgrad(x, dy, nblk=None, col_ranges=None):
     _acct("dwconv3x3_wgrad", 18.0 * B * H * W * C, 2.0 * B * H * W * C * x.element_size())
     if col_ranges is None:
         return reduce_parts(part)
-    out = torch.empty((sum(nc for _, nc in col_ranges), 9), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((sum(nc for _, nc in col_ranges), 9), dtype=torch.float32, device=x.device)
+    assert tuple(out.shape) == (sum(nc for _, nc in col_ranges), 9) and out.dtype == torch.float32
     o = 0
     for c0, nc in col_ranges:
         reduce_block(part, 0, 9, c0, nc, out[o:o + nc], transpose=True)

@@ -490,3 +490,50 @@ def test_fused_gdfn_in_the_no_grad_forward():
     e_f, e_c = M.rel_l2(y_fused.float().cpu(), y32.float().cpu()), M.rel_l2(y_chain.float().cpu(), y32.float().cpu())
     assert M.rel_l2(y_fused.float().cpu(), y_chain.float().cpu()) < 2e-2
     assert e_f < 4e-2 and e_f < e_c * 1.25 + 1e-4, (e_f, e_c)
+
+
+def test_deferred_parameter_gradient_sums_are_bitwise_the_immediate_ones():
+    """The engine collects the partial-sum reductions of all parameter gradients of a backward pass and launches them together
+    (ops.deferred_reductions).  Every gradient must be bitwise what the per-function launches produce -- in particular no
+    gradient may be read (cloned by AccumulateGrad) before its sum has been launched."""
+    from mp_hsir_amd import ops
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    torch.manual_seed(11)
+    net = MP_HSIR_Net(compute_dtype=torch.bfloat16, clip_prompt="surrogate").cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(12)
+    xs = [torch.rand((2, 31, 64, 64), generator=g, device="cuda") for _ in range(3)]
+    cs = [torch.rand((2, 31, 64, 64), generator=g, device="cuda") for _ in range(3)]
+    p = torch.tensor([1, 4], device="cuda")
+
+    def grads(i, deferred):
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(100 + i)                      # DropPath draws
+        loss = (net(xs[i], p).clamp(0, 1) - cs[i]).abs().mean()
+        if deferred:
+            with ops.deferred_reductions():
+                loss.backward()
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        return {n: q.grad.clone() for n, q in net.named_parameters() if q.grad is not None}
+
+    ref = grads(0, False)
+    grads(1, True)                                      # different data through the same allocator blocks
+    grads(2, False)
+    got = grads(0, True)
+    assert ref.keys() == got.keys() and len(ref) > 600
+    bad = [n for n in ref if not torch.equal(ref[n], got[n])]
+    assert not bad, bad[:8]
+    launches = []
+    orig = ops._flush
+    ops._flush = lambda segs: (launches.append(len(segs)), orig(segs))[1]
+    try:
+        grads(1, True)
+        n_def = list(launches)
+        del launches[:]
+        grads(1, False)
+        n_imm = list(launches)
+    finally:
+        ops._flush = orig
+    # (the forward's own sums -- Gram partials read by the fold right away -- stay one launch each in both runs)
+    assert sum(n_def) == sum(n_imm) and len([n for n in n_def if n]) < len([n for n in n_imm if n]) // 2, (n_def, len(n_imm))
