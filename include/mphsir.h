@@ -333,6 +333,11 @@ int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream);
 int mphsir_conv3x3_tok(const void* X, int64_t ldx, const void* W, void* Y, int64_t ldy, int32_t B, int32_t H, int32_t Wd,
                        int32_t Cin, int32_t N, int dtype, void* stream);
 int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B, int32_t H, int32_t Wd, int32_t Cin, int dtype, void* stream);
+/* Weight gradient of the same conv WITHOUT the im2col matrix: partial[split][co][tap*Cin + ci] = sum over the pixels of the split of
+ * dY[p][co] * X[p + tap][ci] (X gathered inside the token-reduction GEMM, zeros outside the image); 16-bit types.  The caller sums
+ * the nsplit partials (mphsir_reduce_parts).  Replaces mphsir_im2col3x3 + mphsir_gemm_tn on the 16-bit path. */
+int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* Cpart, int32_t B, int32_t H, int32_t W,
+                         int32_t Cout, int32_t Cin, int32_t nsplit, int dtype, void* stream);
 
 /* ---- token-reduction GEMM (weight gradients) --------------------------------------------------------
  * Cpart[b][s][n1][n2] = sum over the s-th token range of A[b][m][n1] * B[b][m][n2]  (fp32 partials;

@@ -176,6 +176,7 @@ _SYMBOLS = {
     "mphsir_pg_gate_bwd": (c_int, [ctypes.POINTER(PgBwdArgs), c_void_p]),
     "mphsir_conv3x3_tok": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int, c_void_p]),
+    "mphsir_conv3x3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_im2col3x3": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_gdfn_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "mphsir_gated_mlp_bwd": (c_int, [ctypes.POINTER(MlpBwdArgs), c_int, c_void_p]),

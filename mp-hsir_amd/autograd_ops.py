@@ -547,7 +547,10 @@ class _Conv3x3(torch.autograd.Function):
             dx = ops.conv3x3_tok(dyp, pk["bwd"])
             dx = dx if dx.shape[-1] == Cin else dx[..., :Cin].contiguous()
         if ctx.needs_input_grad[1]:
-            g = ops.gemm_tn(dyp.reshape(-1, Co32), ops.im2col3x3(xp))[:Cout]
+            if dyp.dtype in (torch.bfloat16, torch.float16):      # the gather happens inside the token-reduction GEMM
+                g = ops.conv3x3_wgrad(dyp.reshape(-1, Co32), xp)[:Cout]
+            else:
+                g = ops.gemm_tn(dyp.reshape(-1, Co32), ops.im2col3x3(xp))[:Cout]
             dw = g.reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
         return dx, dw, None
 

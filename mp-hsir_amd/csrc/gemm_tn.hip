@@ -19,6 +19,9 @@ struct TnDev {
     float* Cp;
     float* colsum;      // optional [batch][nsplit][N1]: partial column sums of A (bias gradients for free)
     long M; int N1, N2, nsplit;
+    // implicit im2col of a dense 3x3 conv's weight gradient (cC > 0; transposed-read kernel only): B is the conv INPUT
+    // X [M = images*cH*cW][cC channels] and column tap*cC + ci of the logical operand is X[m + tap][ci] (zero outside the image)
+    int cH, cW, cC;
 };
 
 // R1, R2 in {1,2}: the workgroup's output tile is (64*R1) x (64*R2); wave w owns rows [16*R1*w, 16*R1*(w+1)).
@@ -208,6 +211,16 @@ __device__ __forceinline__ void tn_tr_body(const TnDev& a, char* smem, int L, in
     const bool okA = n1_0 + chA * 8 < a.N1, okB = n2_0 + chB * 8 < a.N2;
     const T* pA = A + (m_lo + rowA) * a.lda + n1_0 + chA * 8;
     const T* pB = B + (m_lo + rowB) * a.ldb + n2_0 + chB * 8;
+    // conv weight gradient: this thread's 8 columns belong to ONE tap (cC % 8 == 0): its rows are the input rows shifted by the
+    // tap, read only where the shifted pixel is inside the image
+    int cdy = 0, cdx = 0;
+    const int cHW = a.cH * a.cW;
+    if (a.cC) {
+        const int colB = n2_0 + chB * 8, tap = colB / a.cC, ci = colB - tap * a.cC;
+        cdy = tap / 3 - 1;
+        cdx = tap - (tap / 3) * 3 - 1;
+        pB = B + (m_lo + rowB + (long)cdy * a.cW + cdx) * a.ldb + ci;
+    }
     const int ldsA = tr_off<W1>(rowA, chA), ldsB = IMG_A + tr_off<W2>(rowB, chB);
     static_assert(tr_off<W1>(RSA, 0) == RSA * W1 * 2 && tr_off<W2>(RSB, 0) == RSB * W2 * 2, "row stride must not change the swizzle");
     Vec16<T> xA[NIA], xB[NIB];
@@ -219,7 +232,13 @@ __device__ __forceinline__ void tn_tr_body(const TnDev& a, char* smem, int L, in
         }
 #pragma unroll
         for (int it = 0; it < NIB; ++it) {
-            if (okB && m0 + rowB + RSB * it < m_hi) xB[it] = load16<T>(pB + (long)(RSB * it) * a.ldb);
+            bool ok = okB && m0 + rowB + RSB * it < m_hi;
+            if (a.cC) {           // wave-uniform
+                const unsigned p = (unsigned)(m0 + rowB + RSB * it) % (unsigned)cHW, py = p / (unsigned)a.cW;     // M < 2^31: 32-bit division
+                const int y = (int)py + cdy, x = (int)(p - py * (unsigned)a.cW) + cdx;
+                ok = ok && y >= 0 && y < a.cH && x >= 0 && x < a.cW;
+            }
+            if (ok) xB[it] = load16<T>(pB + (long)(RSB * it) * a.ldb);
             else xB[it] = Vec16<T>{};
         }
         pA += (long)KT * a.lda;
@@ -387,4 +406,21 @@ extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t
     if (dtype == MPHSIR_BF16) { MPHSIR_TN_GRP(bf16_t) }
     MPHSIR_TN_GRP(f16_t)
 #undef MPHSIR_TN_GRP
+}
+
+extern "C" int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* Cpart, int32_t B, int32_t H, int32_t W,
+                                    int32_t Cout, int32_t Cin, int32_t nsplit, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(dY && X && Cpart, "conv3x3_wgrad: null pointer");
+    MPHSIR_REQUIRE(dtype == MPHSIR_BF16 || dtype == MPHSIR_F16, "conv3x3_wgrad: 16-bit element types only (otherwise mphsir_im2col3x3 + mphsir_gemm_tn)");
+    MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cin > 0 && Cout % 8 == 0 && Cin % 8 == 0 && nsplit > 0 && nsplit < 65536,
+                   "conv3x3_wgrad: bad shape (Cout, Cin must be multiples of 8)");
+    MPHSIR_REQUIRE(aligned16(dY) && aligned16(X) && (lddy * 2) % 16 == 0 && (ldx * 2) % 16 == 0, "conv3x3_wgrad: 16-byte alignment required");
+    TnDev d{dY, (long)lddy, 0, X, (long)ldx, 0, Cpart, nullptr, (long)B * H * W, Cout, 9 * Cin, nsplit, H, W, Cin};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define MPHSIR_CW_TR(T16) return Cout > 64 ? launch_tn_tr<T16, 128, 128>(d, 1, s) : launch_tn_tr<T16, 64, 128>(d, 1, s);
+    if (dtype == MPHSIR_BF16) { MPHSIR_CW_TR(bf16_t) }
+    MPHSIR_CW_TR(f16_t)
+#undef MPHSIR_CW_TR
 }

@@ -1090,6 +1090,24 @@ def conv3x3_tok(x, wp):
     return y
 
 
+def conv3x3_wgrad(dy2, x, nsplit=None):
+    """Weight gradient of conv3x3_tok without the im2col matrix: dy2 (M, Np), x (B,H,W,Cp) channels-last, M = B*H*W ->
+    fp32 (Np, 9*Cp) = sum_p dy2[p,:]^T [x[p+tap,:] for the 9 taps] (16-bit types; fp32: im2col3x3 + gemm_tn)."""
+    lib = _lib.load()
+    _check(dy2, x)
+    B, H, W, Cp = x.shape
+    M, Np = dy2.shape
+    assert x.is_contiguous() and dy2.stride(1) == 1 and M == B * H * W and x.dtype == dy2.dtype and x.dtype in _HALF
+    if nsplit is None:
+        tiles = ((Np + 127) // 128 if Np > 64 else 1) * ((9 * Cp + 127) // 128)
+        nsplit = max(1, min(M // 256, 128, max(1, int(256 * 2 * TN_BIG_ROUNDS) // tiles)))
+    part = torch.empty((1, nsplit, Np, 9 * Cp), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mphsir_conv3x3_wgrad(_p(dy2), dy2.stride(0), _p(x), Cp, _p(part), B, H, W, Np, Cp, nsplit, _DT[x.dtype], _stream(x)),
+               "conv3x3_wgrad")
+    _acct("gemm_tn", 2.0 * M * Np * 9 * Cp, M * (Np + Cp) * x.element_size() + part.numel() * 4.0)
+    return reduce_parts(part, batched=True, immediate=True)[0]
+
+
 def im2col3x3(x):
     """x (B,H,W,Cp) -> (B*H*W, 9*Cp) gathered neighbourhoods (zero padding)."""
     lib = _lib.load()

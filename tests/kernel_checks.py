@@ -412,6 +412,12 @@ def check_conv3x3(dev, dtype, B, H, W, Cin, Cout):
     assert rel_l2(y, yr.detach().permute(0, 2, 3, 1)) < TOL[dtype]
     assert rel_l2(dx, xr.grad.permute(0, 2, 3, 1)) < TOL[dtype]
     assert rel_l2(dw, wr.grad) < TOL[dtype]
+    if dtype != torch.float32:      # the same weight gradient with the gather inside the token-reduction GEMM (no im2col matrix)
+        dw2 = ops.conv3x3_wgrad(dyp.reshape(-1, Co32), xp, nsplit=3)[:Cout].reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
+        assert rel_l2(dw2, wr.grad) < TOL[dtype]
+        assert rel_l2(dw2, dw) < 1e-5
+        dw3 = ops.conv3x3_wgrad(dyp.reshape(-1, Co32), xp)[:Cout].reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
+        assert rel_l2(dw3, dw) < 1e-5
 
 
 def check_reduce_parts(dev):
