@@ -286,6 +286,8 @@ typedef struct mphsir_win_attn_bwd_args {
     const void* Wqkv; const float* bqkv; const float* rpb; const void* WprojT;
     void* dQKV; void* XNw; void* dSAt; float* drpb;
     int32_t B, H, W, C, heads, shift;
+    int32_t head_split;       /* tuning: 0 = auto; n = the heads of a window are dealt to n workgroups (n divides heads) -- small launches
+                                 (the latent level: 128 windows for 256 CUs) otherwise leave most of the chip idle; results identical */
 } mphsir_win_attn_bwd_args;
 int mphsir_win_attn_bwd(const mphsir_win_attn_bwd_args* a, int dtype, void* stream);
 int mphsir_win_attn_bwd_fits(int32_t C, int32_t heads, int dtype);

@@ -88,7 +88,7 @@ class MlpBwdArgs(ctypes.Structure):
 class WinAttnBwdArgs(ctypes.Structure):
     """mirror of struct mphsir_win_attn_bwd_args"""
     _fields_ = [(n, c_void_p) for n in ("X", "dSA", "dmu", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "WprojT", "dQKV", "XNw",
-                                         "dSAt", "drpb")] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift")]
+                                         "dSAt", "drpb")] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift", "head_split")]
 
 
 class FoldBwdArgs(ctypes.Structure):

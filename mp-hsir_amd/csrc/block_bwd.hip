@@ -11,8 +11,6 @@
 //   ln_bwd_win    d_x = d_res + LayerNorm_backward(d_xn) with d_xn in window-token order (un-shift /
 //                 un-window by address arithmetic), plus per-window partials of d(norm1 weight/bias).
 // All reductions are ordered (no atomics): results are bitwise reproducible.
-#include <stdlib.h>
-
 #include "mphsir_dev.h"
 #include "mphsir_host.h"
 
@@ -93,6 +91,8 @@ struct WinBwdDev {
     void* dSAt;                         // [B*nW*64][C]   total d_sa (adds dmu/64), window-token order
     float* drpb;                        // [B*nW][225][HEADS]
     WinGeom g;
+    int hsplit;                         // the heads of a window are dealt to hsplit workgroups (grid.y): small launches (the latent level has
+                                        // 128 windows for 256 CUs) get one workgroup per (window, head group) instead of half a chip idle
 };
 
 // LDS plan.  Per head the kernel holds four row-major [64 tok][HDP] tiles (q, k, v, dO_h) and the two 64x64 matrices
@@ -233,14 +233,16 @@ __global__ __launch_bounds__(256, XR ? 3 : 1) void win_attn_bwd_kernel(WinBwdDev
             if (idx < WVT) store16<T>(dS + (idx / (C / VEC)) * CF::LDWS + (idx % (C / VEC)) * VEC, wpre[i]);
         }
     };
-    if (CF::STAGE) wload(0, 0);
+    // heads h_lo .. h_hi-1 of this window (every workgroup of the window writes the same XNw / dSAt rows: identical values)
+    const int hpb = CF::HEADS / a.hsplit, h_lo = blockIdx.y * hpb, h_hi = h_lo + hpb;
+    if (CF::STAGE) wload(h_lo, 0);
     constexpr int NKX = XR ? C / TR::KCHUNK : 1;
     frag_t xf[2][NKX];
 
-    for (int h = 0; h < CF::HEADS; ++h) {
-        __syncthreads();      // h = 0: the side outputs / X tile are visible to the whole workgroup; h > 0: tiles free
+    for (int h = h_lo; h < h_hi; ++h) {
+        __syncthreads();      // first head: the side outputs / X tile are visible to the whole workgroup; later: tiles free
         if constexpr (XR) {
-            if (h == 0) {     // (the first stage's barriers order these reads before the first q rows are written)
+            if (h == h_lo) {  // (the first stage's barriers order these reads before the first q rows are written)
 #pragma unroll
                 for (int kc = 0; kc < NKX; ++kc) {
                     xf[0][kc] = load_frag<T>(Qr, CF::LDX, (wv & 1) * 32, kc * TR::KCHUNK);
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256, XR ? 3 : 1) void win_attn_bwd_kernel(WinBwdDev
             if (sub > 0) __syncthreads();            // the previous stage's fragments are read
             wstore();
             if (sub + 1 < NSUB) wload(h, sub + 1);
-            else if (h + 1 < CF::HEADS) wload(h + 1, 0);
+            else if (h + 1 < h_hi) wload(h + 1, 0);
             __syncthreads();
             for (int u = wv; u < 2 * TPS; u += 4) {
                 const int ctl = u >> 1, cti = r0 / 16 + ctl, th = u & 1;
@@ -576,7 +578,7 @@ static int launch_win_bwd_xl(const WinBwdDev& d, hipStream_t s) {
     static_assert(CF::FITS, "win_attn_bwd tiles do not fit LDS");
     allow_big_lds(win_attn_bwd_kernel<T, C, HD, XL>, CF::BYTES);
     const int nblk = d.g.B * (d.g.H / 8) * (d.g.W / 8);
-    MPHSIR_LAUNCH(MPHSIR_K_WIN_ATTN_BWD, (win_attn_bwd_kernel<T, C, HD, XL>), dim3(nblk), dim3(256), CF::BYTES, s, d);
+    MPHSIR_LAUNCH(MPHSIR_K_WIN_ATTN_BWD, (win_attn_bwd_kernel<T, C, HD, XL>), dim3(nblk, d.hsplit), dim3(256), CF::BYTES, s, d);
     return MPHSIR_OK;
 }
 
@@ -585,7 +587,7 @@ static int launch_win_bwd_xr(const WinBwdDev& d, hipStream_t s) {
     typedef WinBwdCfg<T, C, HD, false> CF;
     allow_big_lds(win_attn_bwd_kernel<T, C, HD, false, true>, CF::BYTES);
     const int nblk = d.g.B * (d.g.H / 8) * (d.g.W / 8);
-    MPHSIR_LAUNCH(MPHSIR_K_WIN_ATTN_BWD, (win_attn_bwd_kernel<T, C, HD, false, true>), dim3(nblk), dim3(256), CF::BYTES, s, d);
+    MPHSIR_LAUNCH(MPHSIR_K_WIN_ATTN_BWD, (win_attn_bwd_kernel<T, C, HD, false, true>), dim3(nblk, d.hsplit), dim3(256), CF::BYTES, s, d);
     return MPHSIR_OK;
 }
 
@@ -646,8 +648,17 @@ extern "C" int mphsir_win_attn_bwd(const mphsir_win_attn_bwd_args* a, int dtype,
                        a->XNw && a->dSAt && a->drpb, "win_attn_bwd: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "win_attn_bwd: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(geom_ok(a->B, a->H, a->W, a->shift) && a->heads > 0 && a->C % a->heads == 0, "win_attn_bwd: bad geometry");
+    // fewer than two workgroups per CU: deal the heads of a window to 2, 4, .. workgroups (measured, tools/bench_winb_hs.py: 128 windows
+    // of C = 256 / 8 heads 92.9 -> 36.7 us with 4 groups, 42.7 with 8; 256 windows 98 -> 63 with 2; 512 windows are best left whole)
+    int hsplit = 1;
+    const long nwin = (long)a->B * (a->H / 8) * (a->W / 8);
+    while (nwin * hsplit < 512 && a->heads % (2 * hsplit) == 0) hsplit *= 2;
+    if (a->head_split > 0) {
+        MPHSIR_REQUIRE(a->heads % a->head_split == 0, "win_attn_bwd: head_split=%d must divide heads=%d", a->head_split, a->heads);
+        hsplit = a->head_split;
+    }
     WinBwdDev d{a->X, a->dSA, a->dmu, a->ln_w, a->ln_b, a->Wqkv, a->bqkv, a->rpb, a->WprojT, a->dQKV, a->XNw, a->dSAt, a->drpb,
-                WinGeom{a->B, a->H, a->W, a->shift}};
+                WinGeom{a->B, a->H, a->W, a->shift}, hsplit};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return MPHSIR_DISPATCH_T(dtype, (dispatch_win_bwd<T_>(d, a->C, a->C / a->heads, s)));
 }

@@ -875,7 +875,7 @@ def win_attn_bwd_fits(C, heads, dtype):
     return bool(_lib.load().mphsir_win_attn_bwd_fits(C, heads, _DT[dtype]))
 
 
-def win_attn_bwd(x, dsa, dmu, ln_w, ln_b, Wqkv, bqkv, rpb, WprojT, heads, shift):
+def win_attn_bwd(x, dsa, dmu, ln_w, ln_b, Wqkv, bqkv, rpb, WprojT, heads, shift, head_split=0):
     """-> dqkv (M,3C) and xn (M,C) in window-token order, dsa_total (B,H,W,C), drpb (B*nW,225,heads) fp32."""
     lib = _lib.load()
     _check(x, dsa, dmu, Wqkv, WprojT)
@@ -890,7 +890,7 @@ def win_attn_bwd(x, dsa, dmu, ln_w, ln_b, Wqkv, bqkv, rpb, WprojT, heads, shift)
     a.X, a.dSA, a.dmu, a.ln_w, a.ln_b = _p(x), _p(dsa), _p(dmu), _p(ln_w), _p(ln_b)
     a.Wqkv, a.bqkv, a.rpb, a.WprojT = _p(Wqkv), _p(bqkv), _p(rpb), _p(WprojT)
     a.dQKV, a.XNw, a.dSAt, a.drpb = _p(dqkv), _p(xnw), _p(dsat), _p(drpb)
-    a.B, a.H, a.W, a.C, a.heads, a.shift = B, H, W, C, heads, shift
+    a.B, a.H, a.W, a.C, a.heads, a.shift, a.head_split = B, H, W, C, heads, shift, head_split
     _lib.check(lib.mphsir_win_attn_bwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "win_attn_bwd")
     _acct("win_attn_bwd", M * (8.0 * C * C + 10.0 * 64 * C), 7.0 * M * C * x.element_size())
     return dqkv, xnw, dsat, drpb

@@ -547,6 +547,25 @@ def check_pgsstb_backward_oracle(dev, dtype, name, B=2, hw=(16, 16), drop_path=T
     return errs
 
 
+def check_win_attn_bwd_head_split(dev, dtype, C=128, heads=4, shape=(2, 16, 16)):
+    """win_attn_bwd with the heads of a window dealt to several workgroups returns exactly what one workgroup per window does."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    x, dsa = rnd((B, H, W, C), 71, dtype), rnd((B, H, W, C), 72, dtype)
+    dmu = rnd((B * H * W // 64, C), 73)
+    lnw, lnb = 1 + 0.1 * rnd((C,), 74), 0.1 * rnd((C,), 75)
+    wqkv, bqkv = rnd((3 * C, C), 76, dtype, scale=C ** -0.5), 0.1 * rnd((3 * C,), 77)
+    rpb = 0.2 * rnd((225, heads), 78)
+    wprojT = rnd((C, C), 79, dtype, scale=C ** -0.5)
+    ref = ops.win_attn_bwd(x, dsa, dmu, lnw, lnb, wqkv, bqkv, rpb, wprojT, heads, 4, head_split=1)
+    for hs in (2, heads):
+        out = ops.win_attn_bwd(x, dsa, dmu, lnw, lnb, wqkv, bqkv, rpb, wprojT, heads, 4, head_split=hs)
+        assert all(torch.equal(a, b) for a, b in zip(out, ref)), hs
+    auto = ops.win_attn_bwd(x, dsa, dmu, lnw, lnb, wqkv, bqkv, rpb, wprojT, heads, 4)
+    assert all(torch.equal(a, b) for a, b in zip(auto, ref))
+
+
 def check_combine_bwd(dev, dtype, C=128, shift=4):
     """mphsir_combine_bwd against its definition (backward of gemm_tok epilogue 2)."""
     _use(dev)

@@ -203,3 +203,7 @@ def test_resamplers(dtype):
     K.check_resamplers("cpu", dtype)
     K.check_resamplers("cpu", dtype, B=2, ps=8, D=16, H=64, W=64)       # the 8x upsample of the 512x512 path, scaled down
     K.check_resamplers("cpu", dtype, B=1, ps=4, D=16, H=48, W=64)       # ratios 12 and 16: the backward's gather bounds
+
+
+def test_win_attn_bwd_head_split():
+    K.check_win_attn_bwd_head_split("cpu", torch.bfloat16)

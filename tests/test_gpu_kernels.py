@@ -297,3 +297,8 @@ def test_resamplers(dtype):
     K.check_resamplers("cuda", dtype, B=2, ps=64, D=64, H=512, W=512)
     K.check_resamplers("cuda", dtype, B=4, ps=32, D=128, H=32, W=48)
     K.check_resamplers("cuda", dtype, B=1, ps=4, D=32, H=48, W=64)          # ratios 12 and 16: the backward's gather bounds
+
+
+def test_win_attn_bwd_head_split():
+    K.check_win_attn_bwd_head_split("cuda", torch.bfloat16)
+    K.check_win_attn_bwd_head_split("cuda", torch.float16, C=256, heads=8, shape=(4, 16, 16))
