@@ -166,9 +166,11 @@ __device__ __forceinline__ void pg_mfma_rows(f32x4 (&acc)[NT], f32x4 (&wf)[8][NT
 }
 
 // ---- the forward chain for the workgroup's 16 windows (shared by both kernels); ends with o2 in sm[.][PG_O2] --------------
-template <bool KEEP_AT>
+// R > 0: the low-rank width as a compile-time constant (8, 12, 16 in the shipped nets): every r-long dot product of the chain is
+// a per-thread loop over LDS whose trip count the compiler must know to unroll it and keep its reads in flight together
+template <bool KEEP_AT, int R>
 __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s, int win0) {
-    const int C = a.C, r = a.r, pgw = r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
+    const int C = a.C, r = R > 0 ? R : a.r, pgw = r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     // the weight fragments of the two C-sized products are requested first ...
     const int rows[2] = {wv * 32, wv * 32 + 16}, rowd[1] = {wv * 16};
     const bool has_d = wv * 16 < r;
@@ -291,11 +293,12 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     __syncthreads();
 }
 
+template <int R>
 __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), a.C, a.r, false);
-    const int C = a.C, r = a.r, pgw = r, tid = threadIdx.x, win0 = blockIdx.x * PG_NWIN;
-    pg_forward_chain<false>(a, s, win0);
+    const int C = a.C, r = R > 0 ? R : a.r, pgw = r, tid = threadIdx.x, win0 = blockIdx.x * PG_NWIN;
+    const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), C, r, false);
+    pg_forward_chain<false, R>(a, s, win0);
     PG_MARK(7);
     // g = Wup o2: one thread per (window, channel), coalesced along c
     const FastDiv byC(C);
@@ -310,10 +313,11 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
     PG_MARK(8);
 }
 
+template <int R>
 __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), a.C, a.r, true, a.stage_wdn != 0);
-    const int C = a.C, r = a.r, pgw = r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), win0 = blockIdx.x * PG_NWIN;
+    const int C = a.C, r = R > 0 ? R : a.r, pgw = r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), win0 = blockIdx.x * PG_NWIN;
+    const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), C, r, true, a.stage_wdn != 0);
     // Wprompt column fragments of this wave's first two d-mu tiles (used at the very end): requested now, they cost no
     // round trip later
     const int nct = C / 16;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         const int w = byC.div(i), c = i - w * C;
         s.dg[w * s.LDC + c] = win0 + w < a.nW ? a.dgate[(long)(win0 + w) * C + c] : 0.f;
     }
-    pg_forward_chain<true>(a, s, win0);           // its first barrier also covers the dg tile
+    pg_forward_chain<true, R>(a, s, win0);           // its first barrier also covers the dg tile
     PG_MARK(7);
     const float sc = rsqrtf((float)r);
     // do2 = Wup^T dg  (r rows x 16 windows, K = C): MFMA with the weight read column-wise
@@ -479,10 +483,19 @@ extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
             nullptr, a->nW, a->C, a->r, 0, 0, 0, 0, g_pg_dbg};
     const size_t shmem = pg_lds_bytes(a->C, a->r, false);
     MPHSIR_REQUIRE(shmem <= 160 * 1024, "pg_gate_fwd: (C=%d, r=%d) needs %d bytes of LDS", a->C, a->r, (int)shmem);
-    allow_big_lds(pg_gate_fwd_kernel, shmem);
-    MPHSIR_LAUNCH(MPHSIR_K_PG_GATE, pg_gate_fwd_kernel, dim3((a->nW + PG_NWIN - 1) / PG_NWIN), dim3(256), shmem,
-                  reinterpret_cast<hipStream_t>(stream), d);
-    return MPHSIR_OK;
+    const dim3 grid((a->nW + PG_NWIN - 1) / PG_NWIN);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define MPHSIR_PG_FWD(R_)                                                                        \
+    do {                                                                                         \
+        allow_big_lds(pg_gate_fwd_kernel<R_>, shmem);                                            \
+        MPHSIR_LAUNCH(MPHSIR_K_PG_GATE, pg_gate_fwd_kernel<R_>, grid, dim3(256), shmem, s, d);    \
+        return MPHSIR_OK;                                                                        \
+    } while (0)
+    if (a->r == 8) MPHSIR_PG_FWD(8);
+    if (a->r == 12) MPHSIR_PG_FWD(12);
+    if (a->r == 16) MPHSIR_PG_FWD(16);
+    MPHSIR_PG_FWD(0);
+#undef MPHSIR_PG_FWD
 }
 
 extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
@@ -498,8 +511,17 @@ extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
     d.stage_wdn = pg_lds_bytes(a->C, a->r, true, true) <= 160 * 1024 ? 1 : 0;
     const size_t shmem = pg_lds_bytes(a->C, a->r, true, d.stage_wdn != 0);
     MPHSIR_REQUIRE(shmem <= 160 * 1024, "pg_gate_bwd: (C=%d, r=%d) needs %d bytes of LDS", a->C, a->r, (int)shmem);
-    allow_big_lds(pg_gate_bwd_kernel, shmem);
-    MPHSIR_LAUNCH(MPHSIR_K_PG_GATE_BWD, pg_gate_bwd_kernel, dim3((a->nW + PG_NWIN - 1) / PG_NWIN), dim3(256), shmem,
-                  reinterpret_cast<hipStream_t>(stream), d);
-    return MPHSIR_OK;
+    const dim3 grid((a->nW + PG_NWIN - 1) / PG_NWIN);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define MPHSIR_PG_BWD(R_)                                                                            \
+    do {                                                                                             \
+        allow_big_lds(pg_gate_bwd_kernel<R_>, shmem);                                                \
+        MPHSIR_LAUNCH(MPHSIR_K_PG_GATE_BWD, pg_gate_bwd_kernel<R_>, grid, dim3(256), shmem, s, d);    \
+        return MPHSIR_OK;                                                                            \
+    } while (0)
+    if (a->r == 8) MPHSIR_PG_BWD(8);
+    if (a->r == 12) MPHSIR_PG_BWD(12);
+    if (a->r == 16) MPHSIR_PG_BWD(16);
+    MPHSIR_PG_BWD(0);
+#undef MPHSIR_PG_BWD
 }
