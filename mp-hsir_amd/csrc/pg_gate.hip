@@ -302,13 +302,35 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
     PG_MARK(7);
     // g = Wup o2: one thread per (window, channel), coalesced along c
     const FastDiv byC(C);
-    for (int i = tid; i < PG_NWIN * C; i += 256) {
-        const int w = byC.div(i), c = i - w * C;
-        if (win0 + w >= a.nW) continue;
-        const float* o2 = s.sm + w * PG_SMW + PG_O2;
-        float acc = 0.f;
-        for (int j = 0; j < r; ++j) acc += s.Wup[c * s.RP + j] * o2[j];
-        a.gate[(long)(win0 + w) * C + c] = acc;
+    if (R > 0 && R % 4 == 0 && (256 % C == 0 || C % 256 == 0)) {
+        // the thread's channel is the same in every round (c = tid % C): its Wup row stays in registers, o2 of the round's window
+        // comes as 16-byte broadcast reads (the rows of `sm` are 16-byte aligned: 15 r + 4 floats with r % 4 == 0)
+        constexpr int RR = R > 0 ? R : 4;
+        const int c = tid % C;
+        float wrow[RR];
+#pragma unroll
+        for (int j = 0; j < RR; ++j) wrow[j] = s.Wup[c * s.RP + j];
+        for (int i = tid; i < PG_NWIN * C; i += 256) {
+            const int w = byC.div(i);
+            if (win0 + w >= a.nW) continue;
+            const float* o2 = s.sm + w * PG_SMW + PG_O2;
+            float acc = 0.f;
+#pragma unroll
+            for (int j4 = 0; j4 < RR / 4; ++j4) {
+                const f32x4 ov = *reinterpret_cast<const f32x4*>(o2 + 4 * j4);
+                for (int e = 0; e < 4; ++e) acc += wrow[4 * j4 + e] * ov[e];
+            }
+            a.gate[(long)(win0 + w) * C + c] = acc;
+        }
+    } else {
+        for (int i = tid; i < PG_NWIN * C; i += 256) {
+            const int w = byC.div(i), c = i - w * C;
+            if (win0 + w >= a.nW) continue;
+            const float* o2 = s.sm + w * PG_SMW + PG_O2;
+            float acc = 0.f;
+            for (int j = 0; j < r; ++j) acc += s.Wup[c * s.RP + j] * o2[j];
+            a.gate[(long)(win0 + w) * C + c] = acc;
+        }
     }
     PG_MARK(8);
 }
