@@ -34,10 +34,10 @@ struct FoldBwdDev {
 constexpr int FB_THREADS = 1024, FB_WAVES = FB_THREADS / 64;   // only B*heads (64..256) workgroups exist: make each one wide
 __host__ __device__ constexpr int fb_co(int hd) { return hd > 64 ? 32 : 128; }     // rows per chunk = 16 per wave (LDS budget at head_dim 96)
 
-template <class T>
+template <class T, int HDT>      // HDT > 0: the head width as a compile-time constant (loops over it unroll), 0: runtime
 __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    const int HD = a.HD, C = a.C, HEADS = C / HD, LD = HD + 8, NT = HD / 16, FB_CO = fb_co(HD);
+    const int HD = HDT > 0 ? HDT : a.HD, C = a.C, HEADS = C / HD, LD = HD + 8, NT = HD / 16, FB_CO = fb_co(HD);
     float* G = reinterpret_cast<float*>(smem_v);      // raw Gram                  [HD][LD]
     float* A = G + HD * LD;                           // probabilities             [HD][LD]
     float* D = A + HD * LD;                           // dA -> dGtilde -> dG       [HD][LD]
@@ -225,15 +225,23 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
     MPHSIR_REQUIRE(HD % 16 == 0, "spectral_fold_bwd: head_dim %d must be a multiple of 16", HD);
     const size_t shmem = ((3 * (size_t)HD + 2 * fb_co(HD)) * (HD + 8) + 9 * (size_t)HD) * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MPHSIR_F32) {
-        allow_big_lds(spectral_fold_bwd_kernel<float>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<float>), dim3(a->B * a->heads), dim3(FB_THREADS), shmem, s, d);
-    } else if (dtype == MPHSIR_BF16) {
-        allow_big_lds(spectral_fold_bwd_kernel<bf16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<bf16_t>), dim3(a->B * a->heads), dim3(FB_THREADS), shmem, s, d);
-    } else {
-        allow_big_lds(spectral_fold_bwd_kernel<f16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<f16_t>), dim3(a->B * a->heads), dim3(FB_THREADS), shmem, s, d);
-    }
-    return MPHSIR_OK;
+#define MPHSIR_FB_LAUNCH(T_, HD_)                                                                                                       \
+    do {                                                                                                                              \
+        allow_big_lds(spectral_fold_bwd_kernel<T_, HD_>, shmem);                                                                      \
+        MPHSIR_LAUNCH(MPHSIR_K_FOLD_BWD, (spectral_fold_bwd_kernel<T_, HD_>), dim3(a->B * a->heads), dim3(FB_THREADS), shmem, s, d);   \
+        return MPHSIR_OK;                                                                                                             \
+    } while (0)
+#define MPHSIR_FB_HD(T_)                               \
+    do {                                               \
+        if (HD == 32) MPHSIR_FB_LAUNCH(T_, 32);        \
+        if (HD == 48) MPHSIR_FB_LAUNCH(T_, 48);        \
+        if (HD == 64) MPHSIR_FB_LAUNCH(T_, 64);        \
+        if (HD == 96) MPHSIR_FB_LAUNCH(T_, 96);        \
+        MPHSIR_FB_LAUNCH(T_, 0);                       \
+    } while (0)
+    if (dtype == MPHSIR_F32) MPHSIR_FB_HD(float);
+    if (dtype == MPHSIR_BF16) MPHSIR_FB_HD(bf16_t);
+    MPHSIR_FB_HD(f16_t);
+#undef MPHSIR_FB_HD
+#undef MPHSIR_FB_LAUNCH
 }

@@ -331,10 +331,11 @@ struct FoldDev {
 // C=256 / 8 heads co=32 meant 2048 workgroups of 1024 threads, 8 of them redoing each softmax: 33 us a launch).
 constexpr int FOLD_CO = 32, FOLD_THREADS = 1024;      // few workgroups: make each one wide
 
-template <class T>
+// HDT > 0: the head width as a compile-time constant (32, 48, 64, 96): the HD-long dot products and row loops unroll
+template <class T, int HDT>
 __global__ __launch_bounds__(FOLD_THREADS) void spectral_fold_kernel(FoldDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    const int HD = a.HD, C = a.C, HEADS = C / HD;
+    const int HD = HDT > 0 ? HDT : a.HD, C = a.C, HEADS = C / HD;
     float* G = reinterpret_cast<float*>(smem_v);      // [HD][HD+1] -> attention probabilities
     const int LDG = HD + 1;
     float* nq = G + HD * LDG;                         // [HD]
@@ -639,17 +640,25 @@ extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* 
     const size_t shmem = ((size_t)HD * (HD + 1) + 2 * HD + (size_t)co * (HD + 1)) * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(a->B * a->heads, a->C / co);
-    if (dtype == MPHSIR_F32) {
-        allow_big_lds(spectral_fold_kernel<float>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<float>), grid, dim3(FOLD_THREADS), shmem, s, d);
-    } else if (dtype == MPHSIR_BF16) {
-        allow_big_lds(spectral_fold_kernel<bf16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<bf16_t>), grid, dim3(FOLD_THREADS), shmem, s, d);
-    } else {
-        allow_big_lds(spectral_fold_kernel<f16_t>, shmem);
-        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<f16_t>), grid, dim3(FOLD_THREADS), shmem, s, d);
-    }
-    return MPHSIR_OK;
+#define MPHSIR_FOLD_LAUNCH(T_, HD_)                                                                                       \
+    do {                                                                                                                \
+        allow_big_lds(spectral_fold_kernel<T_, HD_>, shmem);                                                            \
+        MPHSIR_LAUNCH(MPHSIR_K_SPECTRAL_FOLD, (spectral_fold_kernel<T_, HD_>), grid, dim3(FOLD_THREADS), shmem, s, d);   \
+        return MPHSIR_OK;                                                                                               \
+    } while (0)
+#define MPHSIR_FOLD_HD(T_)                                 \
+    do {                                                   \
+        if (HD == 32) MPHSIR_FOLD_LAUNCH(T_, 32);          \
+        if (HD == 48) MPHSIR_FOLD_LAUNCH(T_, 48);          \
+        if (HD == 64) MPHSIR_FOLD_LAUNCH(T_, 64);          \
+        if (HD == 96) MPHSIR_FOLD_LAUNCH(T_, 96);          \
+        MPHSIR_FOLD_LAUNCH(T_, 0);                         \
+    } while (0)
+    if (dtype == MPHSIR_F32) MPHSIR_FOLD_HD(float);
+    if (dtype == MPHSIR_BF16) MPHSIR_FOLD_HD(bf16_t);
+    MPHSIR_FOLD_HD(f16_t);
+#undef MPHSIR_FOLD_HD
+#undef MPHSIR_FOLD_LAUNCH
 }
 
 extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* stream) {
