@@ -170,6 +170,50 @@ __global__ __launch_bounds__(256) void gemm_tok_kernel(GemmDev a) {
             Vec16<T> v = load16<T>(Cs + tok * LDCS + c);
             store16<T>(Y + m * a.ldy + n, v);
         }
+    } else if constexpr (NW <= 2 && sizeof(T) == 2) {
+        // ---- residual / branch-sum epilogues, 16-bit types: acc + bias -> fp32 LDS tile [token][channel] -> a thread finishes 8
+        // consecutive channels of a token: 16-byte loads of R (and SA), 16-byte store, still ONE rounding.  (Straight from the
+        // transposed accumulators a lane moved 8 bytes of 16 different rows per instruction: those launches ran at 1.3-2.7 TB/s.)
+        constexpr int LDF = GT_BN * NW + 4;
+        float* Cf = reinterpret_cast<float*>(smem);                           // [64][LDF]
+        __syncthreads();                                                      // every wave is done with the staging tiles
+    #pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            if (ntile + w * 64 >= a.N) continue;
+            const int nl = wv * 16 + w * 64 + (lane >> 4) * 4;
+            f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n0 + nl);
+    #pragma unroll
+            for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(Cf + (mt * 16 + (lane & 15)) * LDF + nl) = acc[w][mt] + bias4;
+        }
+        __syncthreads();
+        T* Y = reinterpret_cast<T*>(a.Y);
+        const T* R = reinterpret_cast<const T*>(a.R);
+        const T* SA = reinterpret_cast<const T*>(a.SA);
+        const int hw = EPI == 2 ? a.H * a.Wimg : 1;
+        const int ncols = (a.N - n0) < GT_BN * NW ? (a.N - n0) : GT_BN * NW, cpr = ncols / VEC;      // 16-byte chunks per row
+        for (int idx = tid; idx < 64 * cpr; idx += 256) {
+            const int tok = idx / cpr, c = (idx % cpr) * VEC;
+            const long m = m0 + tok;
+            const int n = n0 + c;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(Cf + tok * LDF + c), v1 = *reinterpret_cast<const f32x4*>(Cf + tok * LDF + c + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const Vec16<T> r = load16<T>(R + m * a.ldr + n);
+            Vec16<T> o;
+            if (EPI == 1) {
+                for (int e = 0; e < 8; ++e) o.set(e, v[e] + r.get(e));
+            } else {
+                const int b = (int)(m / hw), p = (int)(m % hw), y = p / a.Wimg, x = p % a.Wimg;
+                const int ys = (y - a.shift + a.H) % a.H, xs = (x - a.shift + a.Wimg) % a.Wimg;   // shifted-frame coords
+                const float* gp = a.gate + ((long)b * (hw / 64) + (ys >> 3) * (a.Wimg >> 3) + (xs >> 3)) * a.N + n;
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                const float kf = a.keep ? a.keep[b] : 1.f;
+                const Vec16<T> sa = load16<T>(SA + m * a.ldsa + n);
+                for (int e = 0; e < 8; ++e) o.set(e, r.get(e) + kf * (sa.get(e) * g[e] + v[e]));
+            }
+            store16<T>(Y + m * a.ldy + n, o);
+        }
     } else {
         T* Y = reinterpret_cast<T*>(a.Y);
         const T* R = reinterpret_cast<const T*>(a.R);
@@ -203,7 +247,8 @@ template <class T, int EPI, bool LN, int NW>
 static int launch_gemm_nw(const GemmDev& d, hipStream_t s) {
     dim3 grid(d.M / GT_BM, (d.N + GT_BN * NW - 1) / (GT_BN * NW));
     const size_t stage = 2 * 64 * (size_t)(GT_KC + LDS_PAD_BYTES / sizeof(T)) * sizeof(T) + 128 * sizeof(float);
-    const size_t epil = 64 * (size_t)(GT_BN * NW + LDS_PAD_BYTES / sizeof(T)) * sizeof(T);
+    const size_t epil = EPI == 0 ? 64 * (size_t)(GT_BN * NW + LDS_PAD_BYTES / sizeof(T)) * sizeof(T)
+                                 : ((NW <= 2 && sizeof(T) == 2) ? 64 * (size_t)(GT_BN * NW + 4) * sizeof(float) : 0);
     const size_t shmem = stage > epil ? stage : epil;
     allow_big_lds(gemm_tok_kernel<T, EPI, LN, NW>, shmem);
     MPHSIR_LAUNCH(MPHSIR_K_GEMM_TOK, (gemm_tok_kernel<T, EPI, LN, NW>), grid, dim3(256), shmem, s, d);
