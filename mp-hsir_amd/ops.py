@@ -925,9 +925,9 @@ def ln_bwd_tok(x2, dxn, dres, ln_w, ln_b):
     return dx, g[0], g[1], xn
 
 
-TN_GROUPED = os.environ.get("MPHSIR_TN_GROUPED", "1") != "0"      # weight-gradient GEMMs of a backward function in one launch
+TN_GROUPED = True          # weight-gradient GEMMs of a backward function in one launch
 TN_BIG_TILES = True        # bf16 token-reduction GEMMs use the transposed-LDS-read kernel (ds_read_b64_tr_b16)
-TN_BIG_ROUNDS = float(os.environ.get("MPHSIR_TN_ROUNDS", "0.5"))        # ... and aim for this many full rounds of resident workgroups
+TN_BIG_ROUNDS = 0.5        # ... and aim for this many full rounds of resident workgroups (0.5 measured best: tools/bench_tn.py sets it)
 
 
 def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, reduce=True):
