@@ -196,7 +196,7 @@ typedef struct mphsir_gate_args {
 } mphsir_gate_args;
 int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* stream);
 
-/* ---- the whole GDFN feed-forward block in one launch (inference) -----------------------------------
+/* ---- the whole GDFN feed-forward block in one launch ---------------------------------------------------
  * Y = X + project_out( gelu_erf(x1) * x2 ),  [x1|x2] = dwconv3x3(project_in(LayerNorm(X)))
  * Replaces `x + self.ffn(self.norm2(x))` of CrossTransformer.forward (net/MP_HSIR.py:286) and
  * TransformerBlock.forward (:477) with FFN / FeedForward.forward (:259-265 == :385-391): the 2*hid-wide
@@ -216,6 +216,8 @@ typedef struct mphsir_gdfn_args {
     const void* Wout;
     void* Y; int64_t ldy;
     int32_t B, H, W, D, HP, nsplit;
+    void* T; int64_t ldt;     /* optional (training): t = project_in(LayerNorm(X)) [B*H*W][ldt >= 2*HP] in the storage type, laid out like the
+                                 output of mphsir_gemm_tok with Win -- what the backward of the depthwise conv / the gate needs */
 } mphsir_gdfn_args;
 int mphsir_gdfn_fused(const mphsir_gdfn_args* a, int dtype, void* stream);
 int mphsir_gdfn_fused_fits(int32_t D, int32_t HP, int32_t H, int32_t W, int dtype);

@@ -76,7 +76,7 @@ class GdfnArgs(ctypes.Structure):
     """mirror of struct mphsir_gdfn_args"""
     _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("Win", c_void_p), ("w9", c_void_p),
                 ("ldw", c_int64), ("Wout", c_void_p), ("Y", c_void_p), ("ldy", c_int64)] + \
-               [(n, c_int32) for n in ("B", "H", "W", "D", "HP", "nsplit")]
+               [(n, c_int32) for n in ("B", "H", "W", "D", "HP", "nsplit")] + [("T", c_void_p), ("ldt", c_int64)]
 
 
 class MlpBwdArgs(ctypes.Structure):

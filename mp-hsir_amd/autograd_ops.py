@@ -265,9 +265,14 @@ class _GdfnRes(torch.autograd.Function):
     def forward(ctx, ffn, ln, geom, a2, ln_w, ln_b, w_in, w_dw, w_out):
         B, H, W = geom
         pf = ffn.packed(a2.dtype)
-        t = ops.gemm_tok(a2, pf["w_in"], ln=ln.pair())
-        u = ops.dwconv_gate(t, pf["w9"], B, H, W)
-        y = ops.gemm_tok(u, pf["w_out"], epi=1, res=a2)
+        D, HP = a2.shape[1], pf["w_out"].shape[1]
+        if B * H * W >= ops.GDFN_FUSED_MIN_PIXELS and ops.gdfn_fused_fits(D, HP, H, W, a2.dtype):
+            # one launch; t (what the backward needs) is written, the gate product never reaches HBM
+            y, t = ops.gdfn_fused(a2, ln.pair(), pf["w_in"], pf["w9"], pf["w_out"], B, H, W, keep=True)
+        else:
+            t = ops.gemm_tok(a2, pf["w_in"], ln=ln.pair())
+            u = ops.dwconv_gate(t, pf["w9"], B, H, W)
+            y = ops.gemm_tok(u, pf["w_out"], epi=1, res=a2)
         ctx.ffn, ctx.ln, ctx.geom = ffn, ln, geom
         ctx.save_for_backward(a2, t)
         return y

@@ -1,4 +1,4 @@
-// gdfn_fused: the whole gated depthwise feed-forward of a (Cross)TransformerBlock in ONE launch, inference form.
+// gdfn_fused: the whole gated depthwise feed-forward of a (Cross)TransformerBlock in ONE launch (training: t is written too).
 //
 // Reference: FFN.forward / FeedForward.forward net/MP_HSIR.py:259-265 == :385-391 inside the pre-norm residual of
 // CrossTransformer.forward :286 / TransformerBlock.forward :477:
@@ -49,6 +49,7 @@ struct GdfnDev {
     const void* Wout;                            // [D][HP]
     void* Y; long ldy;
     int B, H, W, HP, nsplit;
+    void* Tout; long ldt;                        // training: t = project_in(LN(a)) [B*H*W][ldt >= 2 HP], kept for the backward
 };
 
 template <class T, int D> struct GfLds {
@@ -65,7 +66,7 @@ template <class T, int D> struct GfLds {
     static_assert(bytes <= 160 * 1024, "fused GDFN tile does not fit LDS");
 };
 
-template <class T, int D>
+template <class T, int D, bool KEEP>
 __global__ __launch_bounds__(GF_THREADS, 2) void gdfn_fused_kernel(GdfnDev a) {
     typedef ElemTraits<T> TR;
     typedef GfLds<T, D> L;
@@ -247,6 +248,18 @@ __global__ __launch_bounds__(GF_THREADS, 2) void gdfn_fused_kernel(GdfnDev a) {
             if (s > 0) ymma(buf ^ 1);
             __syncthreads();              // t tile complete; the project_in stage, the previous project_out stage and u_{s-1} are dead
 
+            if constexpr (KEEP) {          // training: the interior pixels' t values of this slab go to HBM as 16-byte chunks
+                T* Tg = reinterpret_cast<T*>(a.Tout);
+                for (int idx = tid; idx < GF_PIX * (2 * SLAB / VEC); idx += GF_THREADS) {
+                    const int px = idx / (2 * SLAB / VEC), cv = idx % (2 * SLAB / VEC), ch = cv * VEC;
+                    const float* src = Ts + ((px / GF_TW + 1) * GF_HW + px % GF_TW + 1) * LDT + ch;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                    Vec16<T> o;
+                    for (int e = 0; e < 4; ++e) { o.set(e, v0[e]); o.set(4 + e, v1[e]); }
+                    const long col = ch < SLAB ? s * SLAB + ch : HP + s * SLAB + ch - SLAB;
+                    store16<T>(Tg + (img + (long)(ty0 + px / GF_TW) * a.W + tx0 + px % GF_TW) * a.ldt + col, o);
+                }
+            }
             // ---- (2) depthwise 3x3 + gate.  thread = (side, 4 channels, PPT pixels of one tile row); sides in adjacent lanes
             {
                 const int side = tid & 1, it = tid >> 1;
@@ -318,12 +331,16 @@ __global__ __launch_bounds__(GF_THREADS, 2) void gdfn_fused_kernel(GdfnDev a) {
     }
 }
 
+template <class T, int D, bool KEEP>
+static int launch_gdfn_k(const GdfnDev& d, hipStream_t s) {
+    const size_t shmem = GfLds<T, D>::bytes;
+    allow_big_lds(gdfn_fused_kernel<T, D, KEEP>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_GDFN_FUSED, (gdfn_fused_kernel<T, D, KEEP>), dim3(d.B * d.nsplit), dim3(GF_THREADS), shmem, s, d);
+    return MPHSIR_OK;
+}
 template <class T, int D>
 static int launch_gdfn(const GdfnDev& d, hipStream_t s) {
-    const size_t shmem = GfLds<T, D>::bytes;
-    allow_big_lds(gdfn_fused_kernel<T, D>, shmem);
-    MPHSIR_LAUNCH(MPHSIR_K_GDFN_FUSED, (gdfn_fused_kernel<T, D>), dim3(d.B * d.nsplit), dim3(GF_THREADS), shmem, s, d);
-    return MPHSIR_OK;
+    return d.Tout ? launch_gdfn_k<T, D, true>(d, s) : launch_gdfn_k<T, D, false>(d, s);
 }
 
 template <class T> struct GdfnShapes {
@@ -368,7 +385,10 @@ extern "C" int mphsir_gdfn_fused(const mphsir_gdfn_args* a, int dtype, void* str
                        (a->ldy * 2) % 16 == 0 && a->ldx >= a->D && a->ldy >= a->D && a->ldw >= 2 * a->HP,
                    "gdfn_fused: 16-byte alignment / row pitch");
     MPHSIR_REQUIRE(a->X != a->Y, "gdfn_fused: Y must not alias X (neighbouring tiles read X's halo)");
-    GdfnDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->Win, a->w9, (long)a->ldw, a->Wout, a->Y, (long)a->ldy, a->B, a->H, a->W, a->HP, a->nsplit};
+    if (a->T)
+        MPHSIR_REQUIRE(aligned16(a->T) && (a->ldt * 2) % 16 == 0 && a->ldt >= 2 * a->HP, "gdfn_fused: T must be 16-byte aligned with ldt >= 2 HP");
+    GdfnDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->Win, a->w9, (long)a->ldw, a->Wout, a->Y, (long)a->ldy, a->B, a->H, a->W, a->HP, a->nsplit,
+              a->T, (long)a->ldt};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return MPHSIR_DISPATCH_T(dtype, (GdfnShapes<T_>::run(d, a->D, s)));
 }

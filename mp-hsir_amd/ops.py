@@ -640,9 +640,9 @@ def gdfn_fused_fits(D, HP, H, W, dtype):
     return bool(_lib.load().mphsir_gdfn_fused_fits(D, HP, H, W, _DT[dtype]))
 
 
-def gdfn_fused(x2, ln, w_in, w9, w_out, B, H, W, nsplit=None):
-    """x2 (M,D) -> x2 + project_out(gelu(x1) * x2'),  [x1|x2'] = dwconv3x3(project_in(LN(x2)))  in one launch (no_grad
-    path: nothing is kept for a backward).  w_in (2HP,D), w9 (9,2HP) fp32, w_out (D,HP)."""
+def gdfn_fused(x2, ln, w_in, w9, w_out, B, H, W, nsplit=None, keep=False):
+    """x2 (M,D) -> x2 + project_out(gelu(x1) * x2'),  [x1|x2'] = dwconv3x3(project_in(LN(x2)))  in one launch.
+    w_in (2HP,D), w9 (9,2HP) fp32, w_out (D,HP).  keep=True (training) also returns t = project_in(LN(x2)) (M,2HP)."""
     lib = _lib.load()
     _check(x2, w_in, w9, w_out, ln[0], ln[1])
     M, ldx = _rows(x2)
@@ -655,9 +655,11 @@ def gdfn_fused(x2, ln, w_in, w9, w_out, B, H, W, nsplit=None):
     a = _lib.GdfnArgs()
     a.X, a.ldx, a.ln_w, a.ln_b, a.Win, a.w9, a.ldw, a.Wout = _p(x2), ldx, _p(ln[0]), _p(ln[1]), _p(w_in), _p(w9), w9.stride(0), _p(w_out)
     a.Y, a.ldy, a.B, a.H, a.W, a.D, a.HP, a.nsplit = _p(y), D, B, H, W, D, HP, nsplit
+    t = torch.empty((M, 2 * HP), dtype=x2.dtype, device=x2.device) if keep else None
+    a.T, a.ldt = _p(t), 2 * HP
     _lib.check(lib.mphsir_gdfn_fused(ctypes.byref(a), _DT[x2.dtype], _stream(x2)), "gdfn_fused")
-    _acct("gdfn_fused", 2.0 * M * 3 * HP * D + M * HP * 40.0, 2.0 * M * D * x2.element_size())
-    return y
+    _acct("gdfn_fused", 2.0 * M * 3 * HP * D + M * HP * 40.0, (2.0 * M * D + (2.0 * M * HP if keep else 0.0)) * x2.element_size())
+    return (y, t) if keep else y
 
 
 # workgroups of the fused GDFN (its tile takes ~100 KB of LDS: one per CU at a time; two rounds measured 3 % faster than one: 291 vs 300 us)

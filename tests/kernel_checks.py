@@ -278,6 +278,11 @@ def check_gdfn_fused(dev, dtype, D, hid, shape, nsplit):
     assert rel_l2(y, y3) < tol
     # the fused form is the more accurate of the two (no rounding of t)
     assert rel_l2(y.reshape(B, H, W, D), ref) <= rel_l2(y3.reshape(B, H, W, D), ref) * 1.05 + 1e-6
+    # training form: the same y (bitwise) plus t = project_in(LN(x)) as the three-launch chain's first GEMM writes it
+    yk, tk = ops.gdfn_fused(x2, (lnw, lnb), w_in, w9, w_out, B, H, W, nsplit=nsplit, keep=True)
+    assert torch.equal(yk, y)
+    assert tk.shape == t.shape and rel_l2(tk, t) < TOL[dtype] * 0.5
+    assert float((tk.float() - t.float()).abs().max()) <= float(t.float().abs().max()) * 2.0 ** -7
 
 
 def check_dwconv_plain(dev, dtype, shape):
