@@ -929,7 +929,7 @@ def ln_bwd_tok(x2, dxn, dres, ln_w, ln_b):
 
 TN_GROUPED = True          # weight-gradient GEMMs of a backward function in one launch
 TN_BIG_TILES = True        # bf16 token-reduction GEMMs use the transposed-LDS-read kernel (ds_read_b64_tr_b16)
-TN_BIG_ROUNDS = 0.5        # ... and aim for this many full rounds of resident workgroups (0.5 measured best: tools/bench_tn.py sets it)
+TN_BIG_ROUNDS = 1.0        # ... and aim for this many full rounds of resident workgroups (re-measured with the partial sums deferred: 0.5 / 0.75 / 1 / 2 -> 22.48 / 22.33 / 22.37 / 22.47 ms per step)
 
 
 def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, reduce=True):
