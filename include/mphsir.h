@@ -387,6 +387,12 @@ int mphsir_dwconv3x3_bwd(const void* X, int64_t ldx, const void* dY, int64_t ldd
 /* backward of the GDFN gate u = gelu_erf(T[:, :HP]) * T[:, HP:] (FFN/FeedForward.forward :263, :389):
  * given dU [M][HP] writes U (recomputed, for d project_out) and dT [M][2*HP].                          */
 int mphsir_gdfn_gate_bwd(const void* T, const void* dU, void* U, void* dT, int64_t M, int32_t HP, int dtype, void* stream);
+/* The same backward with the depthwise conv recomputed inside (T here is the conv's INPUT t = project_in(LN(x)), [B*H*W][2*HP] contiguous,
+ * w9 fp32 [9][ldw >= 2*HP]): u and d(conv output) leave in one pass, the conv output never reaches HBM.  Shapes
+ * mphsir_dwconv_gate_bwd_fits accepts (16-bit types, H % 8 == 0, W % 16 == 0); U [B*H*W][HP], dT [B*H*W][2*HP] contiguous. */
+int mphsir_dwconv_gate_bwd(const void* T, const float* w9, int64_t ldw, const void* dU, void* U, void* dT, int32_t B, int32_t H, int32_t W,
+                           int32_t HP, int dtype, void* stream);
+int mphsir_dwconv_gate_bwd_fits(int32_t H, int32_t W, int32_t HP, int dtype);
 
 /* ---- sizes of the caller-allocated partial / workspace buffers (bytes) ----------------------------------------------------------
  * The library never allocates: split partials and factor rows are outputs the caller provides.  These helpers return

@@ -288,9 +288,8 @@ class _GdfnRes(torch.autograd.Function):
         dy = dy.contiguous()
         t4 = t.reshape(B, H, W, 2 * HP)
         with ops.reduce_scope(leaf=True):
-            tdw = ops.dwconv3x3(t4, pf["w9"]).reshape(-1, 2 * HP)
             du = ops.gemm_tok(dy, pf["w_outT"])                                 # (M,HP)
-            u, dtdw = ops.gdfn_gate_bwd(tdw, du)
+            u, dtdw = ops.dwconv_gate_bwd(t, pf["w9"], du, B, H, W)             # the depthwise conv is recomputed inside
             d_out_w = ops.gemm_tn_blocks(dy, u, [(0, D)], ncols=hid).reshape(D, hid, 1, 1)
             dtdw4 = dtdw.reshape(B, H, W, 2 * HP)
             dt_, d_dw = ops.dwconv3x3_bwd(t4, dtdw4, pf["w9"], col_ranges=[(0, hid), (HP, hid)])

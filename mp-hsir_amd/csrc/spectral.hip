@@ -403,6 +403,7 @@ struct GateDev {
     const float* w9; long ldw;          // [9][2*HP]
     void* U; long ldu;                  // [B*H*W][HP]
     int B, H, W, HP;
+    const void* dU; void* dT;           // backward form (tile kernel): dU [B*H*W][HP] in, d(dwconv output) [B*H*W][2*HP] out (both contiguous)
 };
 
 // GDFN middle (FFN/FeedForward.forward net/MP_HSIR.py:261-263, :387-389): u = gelu(dw(t)[:HP]) * dw(t)[HP:]
@@ -462,7 +463,9 @@ __global__ __launch_bounds__(256) void dwconv_gate_kernel(GateDev a) {
 constexpr int GT2_TH = 8, GT2_TW = 16, GT2_HW = GT2_TW + 2, GT2_ROWS = (GT2_TH + 2) * GT2_HW, GT2_CH = 48, GT2_LD = 2 * GT2_CH + 4;
 constexpr int GT2_THREADS = 512;
 
-template <class T>
+// BWD: the same pass recomputes [x1|x2] = dwconv(t) and emits the gate's backward next to u -- d x1 = du x2 gelu'(x1),
+// d x2 = du gelu(x1) -- instead of dwconv3x3 writing [x1|x2] to HBM for gdfn_gate_bwd_kernel to read back.
+template <class T, bool BWD>
 __global__ __launch_bounds__(GT2_THREADS, 4) void dwconv_gate_tile_kernel(GateDev a) {
     constexpr int VEC = Vec16<T>::N;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
@@ -552,16 +555,36 @@ __global__ __launch_bounds__(GT2_THREADS, 4) void dwconv_gate_tile_kernel(GateDe
         for (int e = 0; e < 4; ++e) other[e] = __shfl_xor(send[e], 1);
         const f32x4 g = side ? other : mine, p = side ? mine : other;      // g: gelu-side value, p: partner
         f32x4 o;
-        for (int e = 0; e < 4; ++e) o[e] = Math<T>::gelu(g[e]) * p[e];
-        if (on) store4<T>(U + ((long)(ty0 + iy) * a.W + tx0 + ix0 + (side ? 4 : 0) + i) * a.ldu + c4 * 4, o);
+        const long pix = (long)(ty0 + iy) * a.W + tx0 + ix0 + (side ? 4 : 0) + i;
+        if constexpr (BWD) {
+            const long row = (long)b * a.H * a.W + pix;
+            f32x4 d1 = f32x4{0.f, 0.f, 0.f, 0.f}, d2 = d1;
+            if (on) {
+                const f32x4 du = load4<T>(reinterpret_cast<const T*>(a.dU) + row * a.HP + cs0 + c4 * 4);
+                for (int e = 0; e < 4; ++e) {
+                    float ge, dge;
+                    Math<T>::gelu_pair(g[e], ge, dge);
+                    o[e] = ge * p[e];
+                    d1[e] = du[e] * p[e] * dge;
+                    d2[e] = du[e] * ge;
+                }
+                T* dT = reinterpret_cast<T*>(a.dT) + row * 2 * a.HP + cs0 + c4 * 4;
+                store4<T>(dT, d1);
+                store4<T>(dT + a.HP, d2);
+            }
+        } else {
+            for (int e = 0; e < 4; ++e) o[e] = Math<T>::gelu(g[e]) * p[e];
+        }
+        if (on) store4<T>(U + pix * a.ldu + c4 * 4, o);
     }
 }
 
-template <class T> static int launch_gate_tile(const GateDev& d, hipStream_t s) {
+template <class T, bool BWD = false> static int launch_gate_tile(const GateDev& d, hipStream_t s) {
     const long nblk = (long)d.B * (d.H / GT2_TH) * (d.W / GT2_TW) * ((d.HP + GT2_CH - 1) / GT2_CH);
     const size_t shmem = ((size_t)GT2_ROWS * GT2_LD + 9 * 2 * GT2_CH) * sizeof(float);
-    allow_big_lds(dwconv_gate_tile_kernel<T>, shmem);
-    MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_tile_kernel<T>), dim3((unsigned)((nblk + 7) / 8 * 8)), dim3(GT2_THREADS), shmem, s, d);
+    allow_big_lds(dwconv_gate_tile_kernel<T, BWD>, shmem);
+    MPHSIR_LAUNCH(BWD ? MPHSIR_K_GDFN_GATE_BWD : MPHSIR_K_DWCONV_GATE, (dwconv_gate_tile_kernel<T, BWD>), dim3((unsigned)((nblk + 7) / 8 * 8)),
+                  dim3(GT2_THREADS), shmem, s, d);
     return MPHSIR_OK;
 }
 
@@ -669,7 +692,7 @@ extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* st
     const int esz = dtype == MPHSIR_F32 ? 4 : 2;
     MPHSIR_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->HP > 0 && a->HP % 8 == 0, "dwconv_gate: bad shape");
     MPHSIR_REQUIRE(aligned16(a->T) && aligned16(a->U) && (a->ldt * esz) % 16 == 0 && (a->ldu * esz) % 16 == 0, "dwconv_gate: 16-byte alignment required");
-    GateDev d{a->T, (long)a->ldt, a->w9, (long)a->ldw, a->U, (long)a->ldu, a->B, a->H, a->W, a->HP};
+    GateDev d{a->T, (long)a->ldt, a->w9, (long)a->ldw, a->U, (long)a->ldu, a->B, a->H, a->W, a->HP, nullptr, nullptr};
     MPHSIR_REQUIRE(a->W % 8 == 0, "dwconv_gate: W must be a multiple of 8");
     const long total = (long)a->B * a->H * (a->W / 8) * (a->HP / (16 / esz));
     const long blocks = ((total + 255) / 256 + 7) / 8 * 8;            // multiple of 8: XCD-contiguous order
@@ -683,4 +706,22 @@ extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* st
     else
         MPHSIR_LAUNCH(MPHSIR_K_DWCONV_GATE, (dwconv_gate_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, s, d);
     return MPHSIR_OK;
+}
+
+extern "C" int mphsir_dwconv_gate_bwd_fits(int32_t H, int32_t W, int32_t HP, int dtype) {
+    return ((dtype == MPHSIR_BF16 || dtype == MPHSIR_F16) && H > 0 && W > 0 && H % mphsir::GT2_TH == 0 && W % mphsir::GT2_TW == 0 && HP > 0 && HP % 8 == 0) ? 1 : 0;
+}
+
+extern "C" int mphsir_dwconv_gate_bwd(const void* T, const float* w9, int64_t ldw, const void* dU, void* U, void* dT, int32_t B, int32_t H, int32_t W,
+                                      int32_t HP, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(T && w9 && dU && U && dT, "dwconv_gate_bwd: null pointer");
+    MPHSIR_REQUIRE(B > 0 && mphsir_dwconv_gate_bwd_fits(H, W, HP, dtype),
+                   "dwconv_gate_bwd: (H=%d, W=%d, HP=%d, dtype=%d) not covered (16-bit types, H %% 8 == 0, W %% 16 == 0, HP %% 8 == 0: otherwise "
+                   "mphsir_dwconv3x3 + mphsir_gdfn_gate_bwd)", H, W, HP, dtype);
+    MPHSIR_REQUIRE(aligned16(T) && aligned16(dU) && aligned16(U) && aligned16(dT) && ldw >= 2 * HP, "dwconv_gate_bwd: 16-byte alignment / ldw");
+    GateDev d{T, 2L * HP, w9, (long)ldw, U, (long)HP, B, H, W, HP, dU, dT};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == MPHSIR_BF16 ? launch_gate_tile<bf16_t, true>(d, s) : launch_gate_tile<f16_t, true>(d, s);
 }

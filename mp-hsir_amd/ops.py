@@ -1007,6 +1007,21 @@ def gdfn_gate_bwd(t, du):
     return u, dt_
 
 
+def dwconv_gate_bwd(t, w9, du, B, H, W):
+    """Backward of u = gelu(x1) * x2, [x1|x2] = dwconv3x3(t), with the conv recomputed inside: t (M,2*HP), du (M,HP) contiguous ->
+    (u (M,HP), d[x1|x2] (M,2*HP)).  Shapes the tile form covers; else dwconv3x3 + gdfn_gate_bwd."""
+    lib = _lib.load()
+    _check(t, w9, du)
+    M, HP = du.shape
+    assert t.shape == (M, 2 * HP) and t.is_contiguous() and du.is_contiguous() and M == B * H * W
+    if not lib.mphsir_dwconv_gate_bwd_fits(H, W, HP, _DT[t.dtype]):
+        return gdfn_gate_bwd(dwconv3x3(t.reshape(B, H, W, 2 * HP), w9).reshape(M, 2 * HP), du)
+    u, dt_ = torch.empty_like(du), torch.empty_like(t)
+    _lib.check(lib.mphsir_dwconv_gate_bwd(_p(t), _p(w9), w9.stride(0), _p(du), _p(u), _p(dt_), B, H, W, HP, _DT[t.dtype], _stream(t)), "dwconv_gate_bwd")
+    _acct("gdfn_gate_bwd", 66.0 * M * HP, 6.0 * M * HP * t.element_size())
+    return u, dt_
+
+
 def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True):
     """-> W2 (B,2C,2C) in `dtype`, dWo (C,C) fp32, dtemp (heads,) fp32 (reduce=False: the per-sample partials
     (B,C,C) / (B,heads) instead, for the caller to pass to reduce_parts)."""

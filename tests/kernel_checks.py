@@ -285,6 +285,37 @@ def check_gdfn_fused(dev, dtype, D, hid, shape, nsplit):
     assert float((tk.float() - t.float()).abs().max()) <= float(t.float().abs().max()) * 2.0 ** -7
 
 
+def check_dwconv_gate_bwd(dev, dtype, shape=(2, 16, 32), hid=85):
+    """dwconv_gate_bwd (depthwise conv recomputed inside the gate backward) vs fp64 autograd of u = gelu(dw(t)[:hid]) * dw(t)[hid:],
+    and vs the two launches dwconv3x3 -> gdfn_gate_bwd (which round the conv output to the storage type in between)."""
+    _use(dev)
+    import torch.nn.functional as F
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    HP = ops.round_up(hid, 32)
+    M = B * H * W
+    t = torch.zeros((M, 2 * HP), dtype=dtype, device=dev)
+    tv = rnd((M, 2 * hid), 81, dtype)
+    t[:, :hid], t[:, HP:HP + hid] = tv[:, :hid], tv[:, hid:]
+    du = torch.zeros((M, HP), dtype=dtype, device=dev)
+    du[:, :hid] = rnd((M, hid), 82, dtype)
+    w = rnd((2 * hid, 1, 3, 3), 83, scale=1 / 3)
+    w9 = torch.zeros((9, 2 * HP), device=dev)
+    w9s = ops.pack_dw(w)
+    w9[:, :hid], w9[:, HP:HP + hid] = w9s[:, :hid], w9s[:, hid:]
+    u, dtd = ops.dwconv_gate_bwd(t, w9, du, B, H, W)
+    u2, dtd2 = ops.gdfn_gate_bwd(ops.dwconv3x3(t.reshape(B, H, W, 2 * HP), w9).reshape(M, 2 * HP), du)
+    tr = tv.double().cpu().reshape(B, H, W, 2 * hid).permute(0, 3, 1, 2)
+    xr = F.conv2d(tr, w.double().cpu(), None, 1, 1, 1, 2 * hid).requires_grad_(True)
+    ur = F.gelu(xr[:, :hid]) * xr[:, hid:]
+    ur.backward(du[:, :hid].double().cpu().reshape(B, H, W, hid).permute(0, 3, 1, 2))
+    g = xr.grad.permute(0, 2, 3, 1).reshape(M, 2 * hid)
+    assert rel_l2(u[:, :hid], ur.detach().permute(0, 2, 3, 1).reshape(M, hid)) < TOL[dtype]
+    assert rel_l2(dtd[:, :hid], g[:, :hid]) < TOL[dtype] and rel_l2(dtd[:, HP:HP + hid], g[:, hid:]) < TOL[dtype]
+    assert rel_l2(u, u2) < TOL[dtype] and rel_l2(dtd, dtd2) < TOL[dtype]
+    assert float(dtd[:, hid:HP].abs().max()) == 0.0 and float(dtd[:, HP + hid:].abs().max()) == 0.0      # padded channels stay zero
+
+
 def check_dwconv_plain(dev, dtype, shape):
     """forward, backward-data (flipped taps) and weight gradient of the depthwise 3x3 vs torch autograd (fp64)."""
     _use(dev)

@@ -207,3 +207,8 @@ def test_resamplers(dtype):
 
 def test_win_attn_bwd_head_split():
     K.check_win_attn_bwd_head_split("cpu", torch.bfloat16)
+
+
+def test_dwconv_gate_bwd():
+    K.check_dwconv_gate_bwd("cpu", torch.bfloat16)
+    K.check_dwconv_gate_bwd("cpu", torch.float16, shape=(1, 8, 16), hid=170)

@@ -302,3 +302,9 @@ def test_resamplers(dtype):
 def test_win_attn_bwd_head_split():
     K.check_win_attn_bwd_head_split("cuda", torch.bfloat16)
     K.check_win_attn_bwd_head_split("cuda", torch.float16, C=256, heads=8, shape=(4, 16, 16))
+
+
+def test_dwconv_gate_bwd():
+    K.check_dwconv_gate_bwd("cuda", torch.bfloat16)
+    K.check_dwconv_gate_bwd("cuda", torch.float16, shape=(1, 8, 16), hid=170)
+    K.check_dwconv_gate_bwd("cuda", torch.bfloat16, shape=(4, 64, 64), hid=340)
