@@ -49,7 +49,10 @@ template <class T, int C, int HD> struct WinAttnCfg {
     static constexpr size_t REST = (64 * LDX + 2 * 64 * LDQ + HD * LDV) * sizeof(T) + (225 + 64) * 4;
     static constexpr int SR = (REST + (size_t)HD * LDWS * sizeof(T) <= 160 * 1024) ? HD : 16;
     static constexpr bool STAGE = REST + (size_t)SR * LDWS * sizeof(T) <= 160 * 1024;
-    static constexpr size_t XS = 64 * LDX, QS = 64 * LDQ, VS = HD * LDV,
+    // XR (C = 128, 16-bit, staged weights): the LN-ed tile only passes through LDS (inside the q | k | v^T tiles, which are
+    // not written before phase (a)) on its way into the waves' registers, and the output tile is staged there too: no X region
+    static constexpr bool XR = STAGE && C == 128 && sizeof(T) == 2 && HDP == HD && 64 * LDX <= 2 * 64 * LDQ + HD * LDV;
+    static constexpr size_t XS = XR ? 0 : 64 * LDX, QS = 64 * LDQ, VS = HD * LDV,
                             PS = (!STAGE || 64 * LDP > SR * LDWS) ? 64 * LDP : SR * LDWS;
     static constexpr size_t T_ELEMS = XS + 2 * QS + VS + PS;
     static constexpr size_t F_WORDS = 225 + 64;                      // bias column of one head, region ids
@@ -58,15 +61,19 @@ template <class T, int C, int HD> struct WinAttnCfg {
     static_assert(C % 32 == 0 && HD % 16 == 0 && C % HD == 0, "unsupported width");
 };
 
+// three waves per SIMD where the registers allow it without spilling (32-wide heads: 156; 64-wide heads need 230 -- held to 168 the
+// kernel spills 74 registers and a launch goes from 99 to 156 us)
+template <class T, int C, int HD> constexpr int win_min_waves() { return WinAttnCfg<T, C, HD>::XR && HD <= 32 ? 3 : 1; }
+
 template <class T, int C, int HD>
-__global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
+__global__ __launch_bounds__(256, (win_min_waves<T, C, HD>())) void win_attn_kernel(WinAttnDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
     typedef WinAttnCfg<T, C, HD> CF;
     constexpr int VEC = Vec16<T>::N;
     constexpr int NCT = C / 16;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    T* Xs = reinterpret_cast<T*>(smem_v);
+    T* Xs = reinterpret_cast<T*>(smem_v);                        // XR: aliases the q | k | v^T tiles
     T* Qs = Xs + CF::XS;
     T* Ks = Qs + CF::QS;
     T* Vt = Ks + CF::QS;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void win_attn_kernel(WinAttnDev a) {
     // C = 128: a wave multiplies the same 32 tokens (half `wv & 1` of the window) in every unit of phase (a); their LN-ed rows
     // are read from LDS ONCE as MFMA fragments and stay in registers over all heads (a unit: 1204 -> 732 cycles by the
     // shader-clock stamps, the launch 2-4 % shorter).  Narrower nets lose a wave per SIMD to the 32 registers, wider ones two.
-    constexpr bool XREG = CF::STAGE && C == 128;
+    constexpr bool XREG = CF::XR;
     constexpr int NKX = XREG ? C / TR::KCHUNK : 1;
     frag_t xf[2][NKX];
 
