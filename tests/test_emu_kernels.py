@@ -212,3 +212,37 @@ def test_win_attn_bwd_head_split():
 def test_dwconv_gate_bwd():
     K.check_dwconv_gate_bwd("cpu", torch.bfloat16)
     K.check_dwconv_gate_bwd("cpu", torch.float16, shape=(1, 8, 16), hid=170)
+
+
+def test_entry_points_reject_bad_arguments():
+    """The C-ABI entry points validate their arguments and report through mphsir_last_error (no launch, no crash): shapes a kernel
+    does not cover, splits that do not divide, aliasing outputs, missing alignment."""
+    from mp_hsir_amd import ops
+    K._use("cpu")
+    bf = torch.bfloat16
+    x = K.rnd((1, 8, 16, 64), 1, bf)
+    w9 = torch.zeros((9, 64))
+    # depthwise backward: odd sizes are not covered by the one-launch form (the wrapper falls back; the entry point refuses)
+    assert not ops.dwconv3x3_bwd_fits(8, 24, 64, bf) and not ops.dwconv3x3_bwd_fits(8, 16, 64, torch.float32)
+    # fused GDFN: widths / dtypes outside the table, a tile split that does not divide
+    assert not ops.gdfn_fused_fits(96, 256, 8, 16, bf) and not ops.gdfn_fused_fits(64, 192, 8, 16, torch.float32)
+    D, HP = 64, 192
+    x2 = x.reshape(-1, D)
+    ln = (torch.ones(D), torch.zeros(D))
+    w_in, w_out, w9g = torch.zeros((2 * HP, D), dtype=bf), torch.zeros((D, HP), dtype=bf), torch.zeros((9, 2 * HP))
+    with pytest.raises(RuntimeError, match="nsplit"):
+        ops.gdfn_fused(x2, ln, w_in, w9g, w_out, 1, 8, 16, nsplit=3)
+    # window-attention backward: head_split must divide the heads
+    C, heads = 128, 4
+    xw, dsa = K.rnd((1, 8, 8, C), 2, bf), K.rnd((1, 8, 8, C), 3, bf)
+    args = (xw, dsa, torch.zeros((1, C)), torch.ones(C), torch.zeros(C), torch.zeros((3 * C, C), dtype=bf), torch.zeros(3 * C),
+            torch.zeros((225, heads)), torch.zeros((C, C), dtype=bf), heads, 0)
+    with pytest.raises(RuntimeError, match="head_split"):
+        ops.win_attn_bwd(*args, head_split=3)
+    # the row-walking pass A refuses a segment count that leaves fewer than four rows
+    xa = K.rnd((1 * 8 * 32, 64), 4, bf)
+    with pytest.raises(RuntimeError, match="row_segments"):
+        ops.qkv_dwconv_gram(xa, torch.zeros((192, 64), dtype=bf), torch.zeros((9, 192)), 1, 8, 32, 64, 2, row_segments=4)
+    # conv weight gradient without im2col: 16-bit types only
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.conv3x3_wgrad(torch.zeros((128, 32)), torch.zeros((1, 8, 16, 32)))
