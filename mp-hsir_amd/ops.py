@@ -510,18 +510,24 @@ def qkv_dwconv_gram_fits(C, heads, H, W, dtype):
 FUSED_WGS = 512
 
 
-def choose_nsplit_fused(B, H, W):
-    """workgroups per sample for the fused pass A (8x16-pixel tiles): up to ~FUSED_WGS workgroups in all."""
+def fused_wgs(C):
+    """workgroup target of the tile form: one round of one workgroup per CU at C >= 256 (measured, tools/bench_c256.py:
+    128x128 32.4 -> 27.8 us, batch 32 of 16x16 20.1 -> 16.3 us against two rounds), FUSED_WGS below"""
+    return 256 if C >= 256 else FUSED_WGS
+
+
+def choose_nsplit_fused(B, H, W, C=0):
+    """workgroups per sample for the fused pass A (8x16-pixel tiles): up to ~fused_wgs(C) workgroups in all."""
     n = (H // 8) * (W // 16)
-    while n > 1 and B * n > FUSED_WGS and n % 2 == 0:
+    while n > 1 and B * n > fused_wgs(C) and n % 2 == 0:
         n //= 2
     return n
 
 
-def choose_head_groups(B, nsplit, heads):
-    """workgroups per tile set for the fused pass A: split the heads while that still adds workgroups below ~1024"""
+def choose_head_groups(B, nsplit, heads, C=0):
+    """workgroups per tile set for the fused pass A: split the heads while that still adds workgroups below the target"""
     g = 1
-    while g < heads and heads % (2 * g) == 0 and B * nsplit * 2 * g <= FUSED_WGS:
+    while g < heads and heads % (2 * g) == 0 and B * nsplit * 2 * g <= fused_wgs(C):
         g *= 2
     return g
 
@@ -561,7 +567,7 @@ def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_g
             row_segments = choose_row_segments(B, H, W, C, heads)
     if row_segments:
         nsplit = (W // 32) * row_segments
-    nsplit = nsplit or choose_nsplit_fused(B, H, W)
+    nsplit = nsplit or choose_nsplit_fused(B, H, W, C)
     hd = C // heads
     v = torch.empty((M, C), dtype=x.dtype, device=x.device)
     gp = torch.empty((B, nsplit, heads, hd, hd), dtype=torch.float32, device=x.device)
@@ -572,7 +578,7 @@ def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_g
         a.ln_w, a.ln_b = _p(ln[0]), _p(ln[1])
     a.V, a.ldvo, a.Gpart, a.Spart = _p(v), C, _p(gp), _p(sp)
     a.B, a.H, a.W, a.C, a.heads, a.nsplit = B, H, W, C, heads, nsplit
-    a.head_groups = 1 if row_segments else (head_groups or choose_head_groups(B, nsplit, heads))
+    a.head_groups = 1 if row_segments else (head_groups or choose_head_groups(B, nsplit, heads, C))
     a.row_segments = row_segments
     t = qk = None
     if keep:
