@@ -27,6 +27,7 @@ struct PgDev {
     void* L; void* R;           // backward: [nW][KL], [nW][KR] factor rows (fp32 or bf16)
     int nW, C, r, KL, KR, lr_bf16;
     int stage_wdn;              // backward: linear_down also staged in LDS (when the budget allows)
+    int wpg;                    // windows this workgroup owns (<= PG_NWIN = the MFMA N axis; the rest of it idles): small launches use fewer
     unsigned long long* dbg;    // diagnostics (mphsir_debug): shader-clock stamps of workgroup 0 at the phase boundaries
 };
 static unsigned long long* g_pg_dbg = nullptr;
@@ -170,7 +171,7 @@ __device__ __forceinline__ void pg_mfma_rows(f32x4 (&acc)[NT], f32x4 (&wf)[8][NT
 // a per-thread loop over LDS whose trip count the compiler must know to unroll it and keep its reads in flight together
 template <bool KEEP_AT, int R>
 __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s, int win0) {
-    const int C = a.C, r = R > 0 ? R : a.r, pgw = r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
+    const int C = a.C, r = R > 0 ? R : a.r, pgw = r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), nwl = a.wpg;
     // the weight fragments of the two C-sized products are requested first ...
     const int rows[2] = {wv * 32, wv * 32 + 16}, rowd[1] = {wv * 16};
     const bool has_d = wv * 16 < r;
@@ -182,7 +183,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     // weights, linear_up (and linear_down for the backward's rank-r term) -- all in flight together, one barrier
     const FastDiv byC(C), byR(r);
 #pragma unroll 4
-    for (int i = tid; i < PG_NWIN * C; i += 256) {
+    for (int i = tid; i < nwl * C; i += 256) {
         const int w = byC.div(i), c = i - w * C;
         s.mu[w * s.LDC + c] = win0 + w < a.nW ? a.mu[(long)(win0 + w) * C + c] : 0.f;
     }
@@ -221,6 +222,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     PG_MARK(2);
     // softmax over the 128 logits: wave wv owns windows 4wv .. 4wv+3
     for (int ww = 0; ww < 4; ++ww) {
+        if (wv * 4 + ww >= nwl) break;               // wave-uniform
         float* lw = s.w + (wv * 4 + ww) * s.LDW;
         const float l0 = lw[lane], l1 = lw[lane + 64];
         float m = fmaxf(l0, l1);
@@ -232,7 +234,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     }
     // kv = Wkv d  (one thread per (window, row))
     const FastDiv by2R(2 * r);
-    for (int i = tid; i < PG_NWIN * 2 * r; i += 256) {
+    for (int i = tid; i < nwl * 2 * r; i += 256) {
         const int w = by2R.div(i), m = i - w * 2 * r;
         const float* d = s.sm + w * PG_SMW + PG_D;
         float acc = 0.f;
@@ -242,7 +244,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     __syncthreads();
     PG_MARK(3);
     // s = w^T P
-    for (int i = tid; i < PG_NWIN * r; i += 256) {
+    for (int i = tid; i < nwl * r; i += 256) {
         const int w = byR.div(i), j = i - w * r;
         const float* lw = s.w + w * s.LDW;
         float acc = 0.f;
@@ -252,7 +254,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     __syncthreads();
     PG_MARK(4);
     // q = Wq s
-    for (int i = tid; i < PG_NWIN * r; i += 256) {
+    for (int i = tid; i < nwl * r; i += 256) {
         const int w = byR.div(i), m = i - w * r;
         const float* sv = s.sm + w * PG_SMW + PG_S;
         float acc = 0.f;
@@ -263,7 +265,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     PG_MARK(5);
     // o_i = sum_j softmax_j(q_i k_j / sqrt r) v_j
     const float sc = rsqrtf((float)r);
-    for (int i = tid; i < PG_NWIN * r; i += 256) {
+    for (int i = tid; i < nwl * r; i += 256) {
         const int w = byR.div(i), m = i - w * r;
         const float* kv = s.sm + w * PG_SMW + PG_KV;
         const float qs = s.sm[w * PG_SMW + PG_Q + m] * sc;
@@ -283,7 +285,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
     __syncthreads();
     PG_MARK(6);
     // o2 = Wproj o + b
-    for (int i = tid; i < PG_NWIN * r; i += 256) {
+    for (int i = tid; i < nwl * r; i += 256) {
         const int w = byR.div(i), m = i - w * r;
         const float* o = s.sm + w * PG_SMW + PG_O;
         float acc = s.bpp[m];
@@ -296,7 +298,7 @@ __device__ __forceinline__ void pg_forward_chain(const PgDev& a, const PgLds& s,
 template <int R>
 __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    const int C = a.C, r = R > 0 ? R : a.r, pgw = r, tid = threadIdx.x, win0 = blockIdx.x * PG_NWIN;
+    const int C = a.C, r = R > 0 ? R : a.r, pgw = r, tid = threadIdx.x, nwl = a.wpg, win0 = blockIdx.x * nwl;
     const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), C, r, false);
     pg_forward_chain<false, R>(a, s, win0);
     PG_MARK(7);
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
         float wrow[RR];
 #pragma unroll
         for (int j = 0; j < RR; ++j) wrow[j] = s.Wup[c * s.RP + j];
-        for (int i = tid; i < PG_NWIN * C; i += 256) {
+        for (int i = tid; i < nwl * C; i += 256) {
             const int w = byC.div(i);
             if (win0 + w >= a.nW) continue;
             const float* o2 = s.sm + w * PG_SMW + PG_O2;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
             a.gate[(long)(win0 + w) * C + c] = acc;
         }
     } else {
-        for (int i = tid; i < PG_NWIN * C; i += 256) {
+        for (int i = tid; i < nwl * C; i += 256) {
             const int w = byC.div(i), c = i - w * C;
             if (win0 + w >= a.nW) continue;
             const float* o2 = s.sm + w * PG_SMW + PG_O2;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
 template <int R>
 __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
-    const int C = a.C, r = R > 0 ? R : a.r, pgw = r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), win0 = blockIdx.x * PG_NWIN;
+    const int C = a.C, r = R > 0 ? R : a.r, pgw = r, tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), nwl = a.wpg, win0 = blockIdx.x * nwl;
     const PgLds s = pg_lds(reinterpret_cast<float*>(smem_v), C, r, true, a.stage_wdn != 0);
     // Wprompt column fragments of this wave's first two d-mu tiles (used at the very end): requested now, they cost no
     // round trip later
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     if (wv + 4 < nct) pg_load_chunk<1, true>(wfb, a.Wprompt, C, C, 128, colB, 0, 128);
     const FastDiv byC(C), byR(r);
 #pragma unroll 4
-    for (int i = tid; i < PG_NWIN * C; i += 256) {
+    for (int i = tid; i < nwl * C; i += 256) {
         const int w = byC.div(i), c = i - w * C;
         s.dg[w * s.LDC + c] = win0 + w < a.nW ? a.dgate[(long)(win0 + w) * C + c] : 0.f;
     }
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     }
     __syncthreads();
     PG_MARK(8);
-    for (int i = tid; i < PG_NWIN * r; i += 256) {          // do = Wproj^T do2
+    for (int i = tid; i < nwl * r; i += 256) {          // do = Wproj^T do2
         const int w = byR.div(i), m = i - w * r;
         const float* do2 = s.sm + w * PG_SMW + PG_DO2;
         float acc = 0.f;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     __syncthreads();
     PG_MARK(9);
     // row i: rs_i = sum_j A_ij do_i v_j;  dS_ij = A_ij (do_i v_j - rs_i);  dq_i = sc sum_j dS_ij k_j
-    for (int i = tid; i < PG_NWIN * r; i += 256) {
+    for (int i = tid; i < nwl * r; i += 256) {
         const int w = byR.div(i), m = i - w * r;
         const float* A = s.At + w * s.LDA + m * s.RP;
         const float* kv = s.sm + w * PG_SMW + PG_KV;
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     __syncthreads();
     PG_MARK(10);
     // column j: dk_j = sc sum_i dS_ij q_i ; dv_j = sum_i A_ij do_i   (dS re-formed from A and the row sums rs_i)
-    for (int i = tid; i < PG_NWIN * r; i += 256) {
+    for (int i = tid; i < nwl * r; i += 256) {
         const int w = byR.div(i), j = i - w * r;
         const float* sm = s.sm + w * PG_SMW;
         const float vj = sm[PG_KV + r + j];
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     }
     __syncthreads();
     PG_MARK(11);
-    for (int i = tid; i < PG_NWIN * r; i += 256) {          // dd = Wkv^T dkv ; ds = Wq^T dq
+    for (int i = tid; i < nwl * r; i += 256) {          // dd = Wkv^T dkv ; ds = Wq^T dq
         const int w = byR.div(i), j = i - w * r;
         const float* dkv = s.sm + w * PG_SMW + PG_DKV;
         const float* dq = s.sm + w * PG_SMW + PG_DQ;
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     }
     __syncthreads();
     PG_MARK(12);
-    for (int i = tid; i < PG_NWIN * 128; i += 256) {        // dw[p] = P[p] . ds
+    for (int i = tid; i < nwl * 128; i += 256) {        // dw[p] = P[p] . ds
         const int w = i >> 7, p = i & 127;
         const float* ds = s.sm + w * PG_SMW + PG_DS;
         float acc = 0.f;
@@ -430,6 +432,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
     PG_MARK(13);
     for (int ww = 0; ww < 4; ++ww) {                        // dlogit = w (dw - sum w dw)
         const int w = wv * 4 + ww;
+        if (w >= nwl) break;                                // wave-uniform
         const float w0 = s.w[w * s.LDW + lane], w1 = s.w[w * s.LDW + lane + 64];
         const float d0 = s.dl[w * s.LDW + lane], d1 = s.dl[w * s.LDW + lane + 64];
         const float tot = wave_sum(w0 * d0 + w1 * d1);
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
             const f32x4 wd = *reinterpret_cast<const f32x4*>(wdn + (long)m * C + c0);
             for (int j = 0; j < 4; ++j) acc[0][j] += wd[j] * dd[m];
         }
-        if (win0 + w < a.nW) *reinterpret_cast<f32x4*>(a.dmu + (long)(win0 + w) * C + c0) = acc[0];
+        if (w < nwl && win0 + w < a.nW) *reinterpret_cast<f32x4*>(a.dmu + (long)(win0 + w) * C + c0) = acc[0];
     }
     PG_MARK(15);
     // ---- factor rows: L = [dg(C) | do2(r) | dkv(2r) | dq(r) | w(128) | dlogit(128) | dd(r) | 0..],
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
         else if (a.lr_bf16 == MPHSIR_F16) reinterpret_cast<f16_t*>(base)[idx] = (f16_t)v;
         else reinterpret_cast<float*>(base)[idx] = v;
     };
-    for (int w = wv; w < PG_NWIN && win0 + w < a.nW; w += 4) {
+    for (int w = wv; w < nwl && win0 + w < a.nW; w += 4) {
         const float* sm = s.sm + w * PG_SMW;
         const long L0 = (long)(win0 + w) * a.KL, R0 = (long)(win0 + w) * a.KR;
         for (int c = lane; c < C; c += 64) { put(a.L, L0 + c, s.dg[w * s.LDC + c]); put(a.R, R0 + 5 * r + 1 + c, s.mu[w * s.LDC + c]); }
@@ -493,7 +496,18 @@ __global__ __launch_bounds__(256) void pg_gate_bwd_kernel(PgDev a) {
 
 }  // namespace mphsir
 
-namespace mphsir { void pg_debug_buffer(unsigned long long* p) { g_pg_dbg = p; } }      // mphsir_debug(MPHSIR_DEBUG_PG_GATE, ...)
+namespace mphsir {
+// windows per workgroup: 16 fill the MFMA N axis, but the chain is latency-bound and every phase loops over (windows x index)
+// items, so a launch that cannot fill the chip anyway takes fewer windows per workgroup -- as many workgroups as fit one round
+// (measured, tools/bench_pg.py: 2048 windows 15.3 -> 13.5 us with 8; 512 windows 13.1 -> 10.1 and 128 windows 19.1 -> 14.1 with 2;
+// 4096 windows stay at 16: with 8 they need two rounds)
+static int pg_windows_per_wg(int nW) {
+    int w = PG_NWIN;
+    while (w > 2 && (nW + w / 2 - 1) / (w / 2) <= 256) w /= 2;
+    return w;
+}
+void pg_debug_buffer(unsigned long long* p) { g_pg_dbg = p; }
+}      // mphsir_debug(MPHSIR_DEBUG_PG_GATE, ...)
 
 extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
     using namespace mphsir;
@@ -502,10 +516,10 @@ extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
                    "pg_gate_fwd: null pointer");
     MPHSIR_REQUIRE(a->nW > 0 && a->C > 0 && a->C % 16 == 0 && a->r > 0 && a->r <= PG_RMAX, "pg_gate_fwd: need C %% 16 == 0 and 0 < r <= 32");
     PgDev d{a->mu, nullptr, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, a->gate, nullptr, nullptr,
-            nullptr, a->nW, a->C, a->r, 0, 0, 0, 0, g_pg_dbg};
+            nullptr, a->nW, a->C, a->r, 0, 0, 0, 0, pg_windows_per_wg(a->nW), g_pg_dbg};
     const size_t shmem = pg_lds_bytes(a->C, a->r, false);
     MPHSIR_REQUIRE(shmem <= 160 * 1024, "pg_gate_fwd: (C=%d, r=%d) needs %d bytes of LDS", a->C, a->r, (int)shmem);
-    const dim3 grid((a->nW + PG_NWIN - 1) / PG_NWIN);
+    const dim3 grid((a->nW + d.wpg - 1) / d.wpg);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define MPHSIR_PG_FWD(R_)                                                                        \
     do {                                                                                         \
@@ -529,11 +543,11 @@ extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
     MPHSIR_REQUIRE(a->KL >= a->C + 5 * a->r + 256 && a->KR >= 5 * a->r + 1 + a->C, "pg_gate_bwd: factor widths too small");
     MPHSIR_REQUIRE(!a->lr_bf16 || (a->KL % 8 == 0 && a->KR % 8 == 0), "pg_gate_bwd: bf16 factor rows need KL, KR multiples of 8");
     PgDev d{a->mu, a->dgate, a->Wprompt, a->prompt_param, a->Wq, a->Wkv, a->Wdown, a->Wpproj, a->bpproj, a->Wup, nullptr, a->dmu, a->L, a->R,
-            a->nW, a->C, a->r, a->KL, a->KR, a->lr_bf16, 0, g_pg_dbg};
+            a->nW, a->C, a->r, a->KL, a->KR, a->lr_bf16, 0, pg_windows_per_wg(a->nW), g_pg_dbg};
     d.stage_wdn = pg_lds_bytes(a->C, a->r, true, true) <= 160 * 1024 ? 1 : 0;
     const size_t shmem = pg_lds_bytes(a->C, a->r, true, d.stage_wdn != 0);
     MPHSIR_REQUIRE(shmem <= 160 * 1024, "pg_gate_bwd: (C=%d, r=%d) needs %d bytes of LDS", a->C, a->r, (int)shmem);
-    const dim3 grid((a->nW + PG_NWIN - 1) / PG_NWIN);
+    const dim3 grid((a->nW + d.wpg - 1) / d.wpg);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define MPHSIR_PG_BWD(R_)                                                                            \
     do {                                                                                             \
