@@ -13,7 +13,7 @@ def t_us(fn, n=20):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-for (B, H, C, heads) in [(32, 16, 256, 8), (32, 32, 128, 4), (16, 16, 256, 8), (1, 128, 256, 8)]:
+for (B, H, C, heads) in [(32, 16, 256, 8), (32, 32, 128, 4), (16, 16, 256, 8), (1, 128, 256, 8), (32, 64, 128, 2), (32, 64, 64, 2)]:
     blk = PGSSTB(C, heads, [64, 64], 8, 4, 0.0, 2.66, 8, 128).to(dev)
     pk = blk.packed(dt)
     x = torch.randn(B, H, H, C, device=dev, dtype=dt); dsa = torch.randn(B, H, H, C, device=dev, dtype=dt)
