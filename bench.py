@@ -291,19 +291,50 @@ def extra_configs(dev):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, one fresh process per GPU (the reference's
+    `devices=opt.num_gpus`, train.py:118), relay rank 0's JSON line and fail if any rank fails.  Runs before this process
+    touches the GPU (device_count() does not initialise it) and never re-execs: the children are ordinary subprocesses.
+    MPHSIR_SHARE_GPU=1 (test hook, with MPHSIR_DIST_BACKEND=gloo) lets the ranks share the GPUs that exist."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("MPHSIR_SHARE_GPU", "0") != "1":
+        print("bench.py: --gpus %d asked for, %d GPU(s) visible on this node (set MPHSIR_SHARE_GPU=1 MPHSIR_DIST_BACKEND=gloo to "
+              "let ranks share a GPU: a test hook, not a benchmark)" % (n, have), file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].stdout.read().decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print("bench.py: rank(s) failed: %s" % ", ".join("rank %d exit %d" % rc for rc in bad), file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     cube_proc, cube_out = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "natural_scene" and not args.forward_only:
-        # the oracle's 512x512 forward (about two minutes of CPU) runs beside the GPU legs, before this process touches the GPU
-        import subprocess
-        import tempfile
-        cube_out = os.path.join(tempfile.gettempdir(), "mphsir_cpu_cube_%d.json" % os.getpid())
-        cube_proc = subprocess.Popen([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; bench.cube_forward_worker(%r, %d)"
-                                      % (ROOT, cube_out, min(32, os.cpu_count() or 1))], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if world > 1 and torch.cuda.device_count() < world and os.environ.get("MPHSIR_SHARE_GPU", "0") != "1" \
+            and os.environ.get("MPHSIR_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible" % (world, torch.cuda.device_count()))
     dev = torch.device("cuda", local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     backend = None
@@ -359,6 +390,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t)
     value = world * args.batch * args.steps / dt_s
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "natural_scene" and not args.forward_only:
+        # the oracle's 512x512 forward (about two minutes of CPU on 32 threads) is started only now, AFTER the headline leg, as an
+        # ordinary child process: it overlaps the diagnostic legs below (which take the best of two runs), never the headline
+        import subprocess
+        import tempfile
+        cube_out = os.path.join(tempfile.gettempdir(), "mphsir_cpu_cube_%d.json" % os.getpid())
+        cube_proc = subprocess.Popen([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; bench.cube_forward_worker(%r, %d)"
+                                      % (ROOT, cube_out, min(32, os.cpu_count() or 1))], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
     comm = None
     if world > 1 and not args.forward_only:
@@ -404,19 +443,24 @@ def main():
             ach, peak, unit, bound = flops / (ms * 1e-3) / 1e12, PEAK_MFMA_TF[args.dtype], "TFLOP/s", "mfma"
         else:
             ach, peak, unit, bound = nbytes / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        # HBM bytes per launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) of the newest training profile
+        # under profiles/ -- a file, not this run (PMC collection needs rocprofv3 around the process): `traffic_source` names it
+        traffic, traffic_source = None, None
         try:
             import glob
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-            if pm and not args.forward_only:
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_train_b32_bf16_graph_pmc_summary.json")))
+            if pm and not args.forward_only and args.model == "natural_scene" and args.dtype == "bf16" and args.batch == 32:
                 e = json.load(open(pm[-1])).get(dom, {})
                 if "hbm_read_bytes_per_launch" in e:
                     traffic = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+                    traffic_source = "committed profile " + os.path.relpath(pm[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)"
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
         roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": traffic, "algorithmic_per_launch": round((flops if bound == "mfma" else nbytes) / launches),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "algorithmic_per_launch": round((flops if bound == "mfma" else nbytes) / launches),
                     "launches_per_step": launches,
+                    # bytes the kernel moves beyond its inputs (split-K partial sums): overhead, NOT part of `achieved`
+                    "partials_bytes_per_step": acct.get(dom + ":partials", [0, 0.0, 0.0])[2],
                     "avg_launch_us": round(ms * 1e3 / launches, 2), "flops_per_step": flops, "bytes_per_step": nbytes,
                     "tflops_equiv": round(flops / (ms * 1e-3) / 1e12, 2),
                     "kernel_ms_per_step": {k: round(v[1], 3) for k, v in sorted(per.items())},

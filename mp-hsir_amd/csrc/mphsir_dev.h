@@ -221,7 +221,7 @@ __device__ __forceinline__ void wave_barrier() {
 #ifndef MPHSIR_LDS_DMA16
 #define MPHSIR_LDS_DMA16(gbase, byte_off, lds_wave_base)                                                                \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                        \
-                 :: "v"(byte_off), "s"(gbase), "s"((unsigned)(unsigned long long)(lds_wave_base)) : "memory")
+                 :: "v"(byte_off), "s"(gbase), "s"((unsigned)(unsigned long long)(lds_wave_base)) : "memory", "m0")
 #endif
 
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx b runs on XCD b % 8, each XCD has its own L2).  For

@@ -304,8 +304,9 @@ __global__ __launch_bounds__(256) void pg_gate_fwd_kernel(PgDev a) {
     PG_MARK(7);
     // g = Wup o2: one thread per (window, channel), coalesced along c
     const FastDiv byC(C);
-    if (R > 0 && R % 4 == 0 && (256 % C == 0 || C % 256 == 0)) {
-        // the thread's channel is the same in every round (c = tid % C): its Wup row stays in registers, o2 of the round's window
+    if (R > 0 && R % 4 == 0 && 256 % C == 0) {
+        // the thread's channel is the same in every round (c = tid % C; C divides 256 -- at C > 256 item tid + 256 k is channel
+        // (tid + 256 k) % C, a different one per round: the generic loop below): its Wup row stays in registers, o2 of the round's window
         // comes as 16-byte broadcast reads (the rows of `sm` are 16-byte aligned: 15 r + 4 floats with r % 4 == 0)
         constexpr int RR = R > 0 ? R : 4;
         const int c = tid % C;

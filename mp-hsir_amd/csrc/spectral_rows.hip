@@ -67,6 +67,8 @@ template <class T, int C, int HD> struct RwCfg {
     static constexpr int XPE = 8 * CH1;                      // elements per ring pixel row
     static constexpr int NCH = RW_RPX * CH1;                 // chunks per ring slot
     static constexpr int NDI = (NCH + 63) / 64, NDQ = (NDI + NW - 1) / NW;    // DMA instructions per row / per wave
+    // the counted vmcnt wait in front of the ring barrier tells apart only waves that issue NDQ and NDQ - 1 instructions per row
+    static_assert(NDQ <= 2, "row ring: a wave issuing fewer than NDQ - 1 DMA instructions per row would wait on too large a count");
     static constexpr int OPE = 3 * CT + 8;                   // row image [q | k | v] + 16 B
     static constexpr int NT = HD / 16, NTW = HPG * NT * NT, TPW = (NTW + NW - 1) / NW;
     static constexpr size_t ring_elems = (size_t)RW_RING * NCH * 8, img_elems = (size_t)2 * RW_SW * OPE;

@@ -590,6 +590,7 @@ def qkv_dwconv_gram(x, wqkv, w9, B, H, W, C, heads, ln=None, nsplit=None, head_g
     _acct("qkv_dwconv_gram", M * (6.0 * C * C + 54.0 * C + 2.0 * C * hd), (7.0 if keep else 2.0) * M * C * x.element_size()
           + wqkv.numel() * x.element_size() + gp.numel() * 4 + sp.numel() * 4)
     _acct("qkv_dwconv_gram:qk", 2.0 * M * C * hd, 0.0)
+    _acct("qkv_dwconv_gram:rows" if row_segments else "qkv_dwconv_gram:tile", 0.0, 0.0)      # which form ran (tests assert on it)
     if keep:
         return v, gp, sp, nsplit, t, qk
     return v, gp, sp, nsplit
@@ -970,7 +971,9 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, redu
                                       b.stride(0) if batched else 0, _p(part), _p(cs), M, N1, N2, nsplit, Bt, int(bool(tile128)),
                                       _DT[a.dtype], _stream(a)),
                    "gemm_tn")
-    _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size() + part.numel() * 4.0)
+    # algorithmic bytes = the two token matrices, read once; the kernel's own split partials are overhead, accounted apart
+    _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size())
+    _acct("gemm_tn:partials", 0.0, part.numel() * 4.0)
     if not reduce:
         return (part, cs) if colsum else part
     out = reduce_parts(part, batched=True, immediate=immediate)
@@ -1127,7 +1130,8 @@ def conv3x3_wgrad(dy2, x, nsplit=None):
     part = torch.empty((1, nsplit, Np, 9 * Cp), dtype=torch.float32, device=x.device)
     _lib.check(lib.mphsir_conv3x3_wgrad(_p(dy2), dy2.stride(0), _p(x), Cp, _p(part), B, H, W, Np, Cp, nsplit, _DT[x.dtype], _stream(x)),
                "conv3x3_wgrad")
-    _acct("gemm_tn", 2.0 * M * Np * 9 * Cp, M * (Np + Cp) * x.element_size() + part.numel() * 4.0)
+    _acct("gemm_tn", 2.0 * M * Np * 9 * Cp, M * (Np + Cp) * x.element_size())
+    _acct("gemm_tn:partials", 0.0, part.numel() * 4.0)
     return reduce_parts(part, batched=True, immediate=True)[0]
 
 

@@ -41,10 +41,13 @@ def set_seed(seed):
     torch.cuda.manual_seed_all(seed)
 
 
-def saved_clip_table(path, task_classes):
+def saved_clip_table(ckpt, task_classes):
     """the CLIP text-embedding table a checkpoint of this script carries, if it fits a model with `task_classes` tasks
-    (a natural-scene checkpoint, 6 x 512, warm-starting the remote-sensing model, 7 x 512, brings no table)"""
-    table = torch.load(path, map_location="cpu").get("mphsir_clip_prompt")
+    (a natural-scene checkpoint, 6 x 512, warm-starting the remote-sensing model, 7 x 512, brings no table).
+    ckpt: the loaded checkpoint dict, or a path."""
+    if not isinstance(ckpt, dict):
+        ckpt = torch.load(ckpt, map_location="cpu")
+    table = ckpt.get("mphsir_clip_prompt")
     return table if table is not None and tuple(table.shape) == (task_classes, 512) else None
 
 
@@ -54,7 +57,7 @@ def load_warm_start(net, path, device, engine=None, resume=False):
     checkpoint written by save_checkpoint) also restores the optimizer state into `engine` and returns the epoch to
     continue at.  A saved CLIP table of the model's own shape must match the model's (a model built on other text
     embeddings would silently mis-evaluate); a table of another shape belongs to the other configuration and is ignored."""
-    ckpt = torch.load(path, map_location=device)
+    ckpt = path if isinstance(path, dict) else torch.load(path, map_location=device)      # main() loads the file once for both helpers
     state = ckpt["state_dict"]
     own = {"net." + k: v for k, v in net.state_dict().items()}
     kept = {k[4:]: v for k, v in state.items() if k in own and own[k].shape == v.shape}
@@ -63,11 +66,12 @@ def load_warm_start(net, path, device, engine=None, resume=False):
     if table is not None and tuple(table.shape) == tuple(net.clip_prompts.shape) and \
             not torch.allclose(table.float().cpu(), net.clip_prompts.float().cpu(), atol=1e-5):
         raise RuntimeError("%s was trained with other CLIP text embeddings than this model was built with; build the model "
-                           "with clip_prompt=ckpt['mphsir_clip_prompt']" % path)
+                           "with clip_prompt=ckpt['mphsir_clip_prompt']" % (path if not isinstance(path, dict) else "the checkpoint"))
     resume_epoch = 0
     if resume:
         if engine is None or "mphsir_optimizer" not in ckpt:
-            raise RuntimeError("--resume 1 needs a checkpoint written by this script (optimizer state); %s has none" % path)
+            raise RuntimeError("--resume 1 needs a checkpoint written by this script (optimizer state); %s has none"
+                               % (path if not isinstance(path, dict) else "this one"))
         engine.load_optimizer_state(ckpt["mphsir_optimizer"])
         resume_epoch = int(ckpt.get("epoch", -1)) + 1
     return len(kept), resume_epoch
@@ -91,17 +95,23 @@ def main():
     set_seed(opt.seed)
     cfg = MODELS[opt.model or opt.data_type]
     clip_prompt = "surrogate" if opt.allow_surrogate_clip else None      # None: encode with OpenAI clip, or raise
+    ckpt = None
     if opt.ckpt_path is not None:
-        saved = saved_clip_table(opt.ckpt_path, cfg["task_classes"])
+        ckpt = torch.load(opt.ckpt_path, map_location="cpu")          # once: the CLIP table now, weights (+ optimizer) below
+        saved = saved_clip_table(ckpt, cfg["task_classes"])
         clip_prompt = saved if saved is not None else clip_prompt
     dtypes = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}
     net = MP_HSIR_Net(**cfg, clip_prompt=clip_prompt, compute_dtype=dtypes[opt.precision]).to(dev).train()
     eng = DataParallelEngine(net, lr=opt.lr, use_graph=bool(opt.graph))
     start_epoch = 0
     if opt.ckpt_path is not None:
-        n, start_epoch = load_warm_start(net, opt.ckpt_path, dev, eng, resume=bool(opt.resume))
+        n, start_epoch = load_warm_start(net, ckpt, dev, eng, resume=bool(opt.resume))
         if rank == 0:
             print("warm start: %d tensors from %s, %s at epoch %d" % (n, opt.ckpt_path, "resuming" if opt.resume else "starting", start_epoch))
+            if not opt.resume and "mphsir_optimizer" in ckpt:
+                print("note: %s also holds optimizer state of epoch %s; this run starts at epoch 0 with a fresh optimizer (the reference's "
+                      "warm start, train.py:109-116) -- pass --resume 1 to continue that run instead" % (opt.ckpt_path, ckpt.get("epoch")))
+        ckpt = None
         if start_epoch >= opt.epochs:
             raise SystemExit("--resume 1: %s already holds epoch %d of --epochs %d: nothing left to train" % (opt.ckpt_path, start_epoch - 1, opt.epochs))
     data_type = opt.model or opt.data_type

@@ -49,6 +49,28 @@ FULL_CASES = {
     "remote_mode8": dict(cfg=REMOTE_CFG, shape=(1, 100, 64, 64), recipe="inpaint90", task=[4]),
 }
 
+# Full-SIZE cubes: the reference run once per case in fp32 on the shapes test.py feeds the model
+# (test.py:150-188: 512x512x31 natural cubes; :440-469 / BASELINE configs[3]: the 172-band remote-sensing width), stored as
+# summary statistics -- norm, mean, CUBE_SAMPLES seeded samples, per-band means, PSNR -- because the tensors are 32-180 MB.
+RS172_CFG = dict(in_channel=172, out_channel=172, dim=96, task_classes=7)
+CUBE_CASES = {
+    "nat512": dict(cfg=NATURAL_CFG, shape=(1, 31, 512, 512), recipe="gaussian70", task=[0]),
+    "rs172_256": dict(cfg=RS172_CFG, shape=(1, 172, 256, 256), recipe="inpaint90", task=[4]),
+}
+CUBE_SAMPLES = 4096
+
+
+def cube_inputs(name):
+    from golden.detfill import seeded_input
+    c = CUBE_CASES[name]
+    clean = seeded_input(name + ":clean", c["shape"])
+    if c["recipe"] == "gaussian70":          # dataset_utils.py:293-298, test.py:554
+        degraded = clean + seeded_input(name + ":noise", c["shape"], "normal") * (70.0 / 255.0)
+    else:                                    # inpaint, dataset_utils.py:743-749: keep where rand > ratio (0.9)
+        degraded = clean * (seeded_input(name + ":mask", c["shape"]) > 0.9).float()
+    return c, clean, degraded
+
+
 # parameter-gradient tensors stored in full in tiny_grad.npz (everything else: norm/sum/samples)
 GRAD_KEYS_FULL = ("encoder_level1.blocks.1.", "prompt1.", "fusion1.", "patch_embed.", "output.",
                   "reduce_chan_level2.", "down1_2.", "up2_1.")

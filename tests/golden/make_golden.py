@@ -236,6 +236,52 @@ def gen_full():
     np.savez_compressed(os.path.join(HERE, "full.npz"), **out)
 
 
+def gen_cubes(which=None):
+    """the reference itself at FULL size, once per CUBE_CASES entry, in fp32 (fp64 would need > 60 GB for the
+    window-attention intermediates of a 512x512 cube); ~150-250 s each on 8 threads.  Stored: summary statistics only."""
+    import time
+    from golden.cases import CUBE_CASES, CUBE_SAMPLES, cube_inputs
+    path = os.path.join(HERE, "cubes.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    for name in (which or CUBE_CASES):
+        c, clean, degraded = cube_inputs(name)
+        net = build_ref_net(c["cfg"], torch.float32)
+        t0 = time.time()
+        with torch.no_grad():
+            y = net(degraded, task_tensor(c["task"]))
+        idx = sample_indices("cube:" + name, y.numel(), CUBE_SAMPLES)
+        out[name + "/norm"] = np.array(float(y.double().norm()))
+        out[name + "/mean"] = np.array(float(y.double().mean()))
+        out[name + "/samples"] = to_np(y.flatten()[idx])
+        out[name + "/band_means"] = y.double().mean(dim=(0, 2, 3)).numpy()
+        out[name + "/band_norms"] = y.double().flatten(2).norm(dim=2)[0].numpy()
+        out[name + "/psnr_restored"] = np.array(psnr_ref(to_np(y), clean.numpy()))
+        out[name + "/psnr_degraded"] = np.array(psnr_ref(degraded.numpy(), clean.numpy()))
+        print("cube", name, tuple(y.shape), "norm", out[name + "/norm"], "psnr", out[name + "/psnr_restored"], "%.0f s" % (time.time() - t0), flush=True)
+        del net, y
+    np.savez_compressed(path, **out)
+
+
+def gen_schedule():
+    """a18: the reference's own LinearWarmupCosineAnnealingLR (utils/schedulers.py:295-346) driven as train.py:67-86 drives it
+    -- AdamW(lr), warmup_epochs = int(0.1 * epochs), max_epochs = epochs, eta_min = 1e-6, one scheduler.step() per epoch
+    (the chainable get_lr form Lightning calls) -- for the reference's default run (100 epochs) and a 300-epoch run."""
+    from utils.schedulers import LinearWarmupCosineAnnealingLR
+    out = {}
+    for epochs, lr in ((100, 2e-4), (300, 2e-4), (20, 1e-3)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=lr)
+        sch = LinearWarmupCosineAnnealingLR(optimizer=opt, warmup_epochs=int(0.1 * epochs), max_epochs=epochs, eta_min=1e-6)
+        lrs = []
+        for _ in range(epochs + 1):          # lr in force during epoch e, e = 0 .. epochs
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out["e%d_lr%g" % (epochs, lr)] = np.array(lrs, dtype=np.float64)
+        print("schedule", epochs, lr, lrs[:3], lrs[-2:])
+    np.savez_compressed(os.path.join(HERE, "schedule.npz"), **out)
+
+
 def gen_keys():
     """state_dict key/shape/dtype manifests for the two shipped configurations."""
     import json
@@ -251,7 +297,7 @@ def gen_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["keys", "tiny", "grad", "blocks", "full"]
+    which = sys.argv[1:] or ["keys", "tiny", "grad", "blocks", "full", "schedule", "cubes"]
     if "keys" in which:
         gen_keys()
     if "tiny" in which:
@@ -262,3 +308,7 @@ if __name__ == "__main__":
         gen_blocks()
     if "full" in which:
         gen_full()
+    if "schedule" in which:
+        gen_schedule()
+    if "cubes" in which or any(w.startswith("cube:") for w in which):
+        gen_cubes([w[5:] for w in which if w.startswith("cube:")] or None)

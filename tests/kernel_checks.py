@@ -653,6 +653,25 @@ def check_pg_gate_bwd(dev, C, cr, nW=20, factor_dtype=torch.float32):
         assert rel_l2(g[k].reshape(shapes[k]), Pd["pg." + k].grad) < tol, (k, rel_l2(g[k].reshape(shapes[k]), Pd["pg." + k].grad))
 
 
+def check_pg_gate_fwd(dev, C, cr, nW=20):
+    """mphsir_pg_gate_fwd on its own against the oracle's pg_spectral_gate (MP_HSIR.py:136-152) -- incl. widths the shipped
+    nets do not have (C = 512 with r = 16: the register-resident Wup path must not take them)."""
+    _use(dev)
+    from golden.detfill import det_value
+    from mp_hsir_amd import ops
+    r = C // cr
+    shapes = {"linear_down.weight": (r, C), "linear_up.weight": (C, r), "linear_prompt.weight": (128, C), "prompt_param": (1, 1, 128, r),
+              "q.weight": (r, r), "kv.weight": (2 * r, r), "proj.weight": (r, r), "proj.bias": (r,)}
+    P = {k: det_value("local_spectral_attn." + k, shp).float() for k, shp in shapes.items()}
+    pg = {k: v.to(dev).contiguous() for k, v in P.items()}
+    pg["prompt_param"] = pg["prompt_param"].reshape(128, r).contiguous()
+    mu = rnd((nW, C), 323)
+    gate = ops.pg_gate_fwd(mu, pg)
+    Pd = {"pg." + k: v.double() for k, v in P.items()}
+    want = O.pg_spectral_gate(Pd, "pg.", mu.double().cpu()[:, None, :].expand(-1, 64, -1))
+    assert rel_l2(gate, want) < 2e-5, rel_l2(gate, want)
+
+
 def check_channel_attention_bwd(dev, dtype, C, heads, shape, cross=False):
     """The channel ("spectral") attention backward chain -- gemm_tn (dM), spectral_fold_bwd, the [dq|dk] / dv token GEMMs,
     depthwise backward + tap gradients -- as the prompt modules use it (self: TransformerBlock :289-322; cross:

@@ -65,6 +65,66 @@ def check_full_forward(dev, name, dtype=torch.float32, tol=1e-3, dpsnr=0.01):
     return err, dp
 
 
+def check_full_size_cube(dev, name, oracle_threads=32):
+    """Full-SIZE parity (test.py:150-188 / :440-469 shapes): the HIP forward of one whole cube
+      (1) fp32 and bf16 against summary statistics of the REFERENCE run at that size (tests/golden/cubes.npz: norm, mean,
+          4096 seeded samples, per-band norms, PSNR), and
+      (2) fp32 and bf16 against the fp32 oracle run here on the host, as full tensors: rel-L2 < 1e-3 and dPSNR < 0.01 dB for
+          fp32 (the north_star bar), < 4e-2 for bf16;
+    and asserts that the 16-bit forward ran the forms that only exist at this size: the row-walking pass A, the fused GDFN,
+    the pre-reduced Gram partials (> 64 slots), the host-free shift mask at thousands of windows."""
+    import time
+    from golden.cases import CUBE_SAMPLES, cube_inputs, sample_indices
+    from mp_hsir_amd import ops
+    from oracle import mp_hsir_oracle as O
+    c, clean, degraded = cube_inputs(name)
+    g = np.load(os.path.join(GOLDEN, "cubes.npz"))
+    net = build_net(c["cfg"], dev, torch.float32)
+    task = torch.tensor(c["task"])
+    x = degraded.to(dev)
+    with torch.no_grad():
+        y32 = net(x, task.to(dev)).float().cpu()
+        net.set_compute_dtype(torch.bfloat16)
+        ops.ACCOUNT = {}
+        try:
+            y16 = net(x, task.to(dev)).float().cpu()
+        finally:
+            acct, ops.ACCOUNT = ops.ACCOUNT, None
+    forms = {k: v[0] for k, v in acct.items()}
+    res = {"forms": {k: forms.get(k, 0) for k in ("qkv_dwconv_gram:rows", "qkv_dwconv_gram:tile", "gdfn_fused", "dwconv_gram")}}
+    if dev != "cpu":
+        assert forms.get("qkv_dwconv_gram:rows", 0) >= 12 and forms.get("gdfn_fused", 0) >= 2, forms
+    # (1) the reference's own statistics
+    idx = sample_indices("cube:" + name, y32.numel(), CUBE_SAMPLES)
+    want_s, want_n = torch.from_numpy(g[name + "/samples"]), float(g[name + "/norm"])
+    for tag, y, tol, dps in (("f32", y32, 1e-3, 0.01), ("bf16", y16, 4e-2, 0.25)):
+        e_s = rel_l2(y.flatten()[idx], want_s)
+        e_n = abs(float(y.double().norm()) - want_n) / want_n
+        e_b = rel_l2(y.double().flatten(2).norm(dim=2)[0], g[name + "/band_norms"])
+        dp = abs(psnr(y, clean) - float(g[name + "/psnr_restored"]))
+        res["ref_" + tag] = dict(samples=e_s, norm=e_n, band_norms=e_b, dpsnr=dp)
+        assert e_s < tol and e_n < tol and e_b < tol and dp < dps, (name, tag, res)
+    # (2) the oracle on this host, full tensors
+    P = {k: v.detach().cpu().float() for k, v in net.state_dict().items() if not k.endswith("attn_mask")}
+    prev = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(oracle_threads, os.cpu_count() or 1)))
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            want = O.mp_hsir_forward(P, O.make_cfg(**c["cfg"]), degraded, task, surrogate_clip_prompt(c["cfg"]["task_classes"]))
+    finally:
+        torch.set_num_threads(prev)
+    res["oracle_seconds"] = time.time() - t0
+    res["oracle_vs_ref_samples"] = rel_l2(want.flatten()[idx], want_s)
+    assert res["oracle_vs_ref_samples"] < 1e-4, res
+    for tag, y, tol, dps in (("f32", y32, 1e-3, 0.01), ("bf16", y16, 4e-2, 0.25)):
+        e = rel_l2(y, want)
+        dp = abs(psnr(y, clean) - psnr(want, clean))
+        res["oracle_" + tag] = dict(rel_l2=e, dpsnr=dp)
+        assert e < tol and dp < dps, (name, tag, res)
+    return res
+
+
 def check_tiny_gradients(dev, dtype=torch.float32, tol=1e-4):
     """L1-after-clamp loss and every parameter gradient of the tiny net vs the reference (tiny_grad.npz)."""
     from golden.cases import GRAD_KEYS_FULL, sample_indices

@@ -159,6 +159,11 @@ def test_combine_bwd(dtype):
     K.check_combine_bwd("cpu", dtype)
 
 
+def test_pg_gate_fwd():
+    K.check_pg_gate_fwd("cpu", 128, 8)
+    K.check_pg_gate_fwd("cpu", 512, 32, nW=5)      # r = 16 at C > 256: not the fixed-channel path
+
+
 def test_pg_gate_bwd():
     K.check_pg_gate_bwd("cpu", 128, 8)
     K.check_pg_gate_bwd("cpu", 384, 32, nW=5, factor_dtype=torch.bfloat16)

@@ -235,6 +235,13 @@ def test_combine_bwd(dtype, C, shift):
     K.check_combine_bwd("cuda", dtype, C, shift)
 
 
+@pytest.mark.parametrize("C,cr,nW", [(64, 8, 320), (128, 8, 77), (256, 32, 64), (384, 32, 16), (512, 32, 40), (768, 64, 9), (192, 8, 33)])
+def test_pg_gate_fwd(C, cr, nW):
+    """the gate kernel alone vs the oracle, incl. C > 256 with r in {8, 12, 16} (C = 512 / r = 16, C = 768 / r = 12: a thread's
+    channel changes from round to round there -- the register-resident Wup row path is for C | 256 only)"""
+    K.check_pg_gate_fwd("cuda", C, cr, nW=nW)
+
+
 @pytest.mark.parametrize("factor_dtype", K.DTYPES)
 @pytest.mark.parametrize("C,cr", [(64, 8), (128, 16), (256, 32), (128, 8), (96, 8), (192, 16), (384, 32), (192, 8)])
 def test_pg_gate_bwd(factor_dtype, C, cr):

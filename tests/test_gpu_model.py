@@ -72,7 +72,18 @@ def test_batch_coupling_and_large_cube():
     assert not torch.allclose(y1[0], y16[0])
 
 
-from golden.cases import BLOCK_CASES
+from golden.cases import BLOCK_CASES, CUBE_CASES
+
+
+@pytest.mark.timeout(2400)
+@pytest.mark.parametrize("name", list(CUBE_CASES))
+def test_full_size_cube_vs_reference_and_oracle(name):
+    """missing-item 1 of the round-3 review: one whole 512x512x31 natural cube (test.py:150-188) and one 256x256 cube of the
+    172-band remote-sensing width (test.py:440-469, BASELINE configs[3]) -- fp32 and bf16 HIP forward against the reference's
+    statistics at that size and against the fp32 oracle run on this host, full tensors (see check_full_size_cube)."""
+    res = M.check_full_size_cube("cuda", name)
+    print(name, res)
+
 
 
 @pytest.mark.parametrize("name", list(BLOCK_CASES))
@@ -251,6 +262,29 @@ def test_bench_two_ranks_gloo_on_one_gpu(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["global_batch"] == 8 and line["roofline"] is not None
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher (train.py:118 `devices=opt.num_gpus`): the script starts the two ranks itself
+    (gloo test hook: both on this box's GPU), relays rank 0's line with n_gpus = 2 and comm.ranks = 2; asking for more GPUs
+    than the node has, without the hook, exits non-zero with a message instead of silently benchmarking one GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "3", "--batch", "4",
+                        "--no-cpu-baseline", "--no-roofline"], env=dict(env, MPHSIR_DIST_BACKEND="gloo", MPHSIR_SHARE_GPU="1"),
+                       capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["global_batch"] == 8 and line["comm"]["ranks"] == 2
+    if torch.cuda.device_count() < 8:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
 
 
 def test_training_step_bf16_natural_runs_and_learns():

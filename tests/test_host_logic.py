@@ -120,3 +120,17 @@ def test_data_parallel_engine_world2_gloo(tmp_path):
     for k, v in net.state_dict().items():
         assert torch.allclose(r0["state"][k], v, rtol=2e-5, atol=2e-6), k
     assert torch.equal(r0["state"]["unused.weight"], unused0)
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus 8` on a node with fewer GPUs exits non-zero with a message (it used to benchmark one GPU and print
+    n_gpus: 1); the check runs before anything touches a GPU, so it holds on the CPU-only build box too."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MPHSIR_SHARE_GPU")}
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this node has 8 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
