@@ -341,7 +341,7 @@ int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B, int32_t H
  * dY[p][co] * X[p + tap][ci] (X gathered inside the token-reduction GEMM, zeros outside the image); 16-bit types.  The caller sums
  * the nsplit partials (mphsir_reduce_parts).  Replaces mphsir_im2col3x3 + mphsir_gemm_tn on the 16-bit path. */
 int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* Cpart, int32_t B, int32_t H, int32_t W,
-                         int32_t Cout, int32_t Cin, int32_t nsplit, int dtype, void* stream);
+                         int32_t Cout, int32_t Cin, int32_t nsplit, int32_t form /* 1 | 2, as mphsir_gemm_tn's tile128 */, int dtype, void* stream);
 
 /* ---- token-reduction GEMM (weight gradients) --------------------------------------------------------
  * Cpart[b][s][n1][n2] = sum over the s-th token range of A[b][m][n1] * B[b][m][n2]  (fp32 partials;
@@ -349,8 +349,11 @@ int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ld
  * views (batch strides in elements).  This is dW = dY^T X of every Linear / 1x1 conv on the path and the
  * per-sample dM = d_out^T v of the folded channel attention (autograd of net/MP_HSIR.py, train.py:58-67).
  * colsum_part (optional, [batch][nsplit][N1]): partial column sums of A = the matching bias gradient.
- * tile128 != 0 selects the large-tile variant: fp32 128x128 tiles; bf16 the transposed-LDS-read kernel
- * (ds_read_b64_tr_b16, no transposing stores, two LDS stages) with a 64- or 128-wide tile per operand.       */
+ * tile128 != 0 selects the large-tile variant: fp32 128x128 tiles; 16-bit types: 1 = the transposed-LDS-read kernel
+ * (ds_read_b64_tr_b16, no transposing stores, two LDS stages, register-staged loads, 256-thread workgroups, ~2 per CU)
+ * with a 64- or 128-wide tile per operand; 2 = its ring form: one 512-thread workgroup per CU (size nsplit for ~256
+ * workgroups), token rows by LDS-DMA into a ring of 32-token slots, two wave groups whose tiles are combined in LDS:
+ * half the partial tiles per launch, written as whole 16-byte row chunks.                                          */
 int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
                    float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch,
                    int32_t tile128, int dtype, void* stream);
@@ -362,7 +365,7 @@ typedef struct mphsir_gemm_tn_problem {
     float* Cpart; float* colsum_part;
     int64_t M; int32_t N1, N2, nsplit, pad_;
 } mphsir_gemm_tn_problem;
-int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t n, int dtype, void* stream);
+int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t n, int32_t form /* 1 | 2 */, int dtype, void* stream);
 
 /* ---- plain depthwise 3x3 (backward building blocks) ----------------------------------------------
  * mphsir_dwconv3x3: Y[p][c] = sum_taps X[p+tap][c] * w9[tap][c] (zero padding); flip=1 uses the spatially

@@ -178,13 +178,13 @@ _SYMBOLS = {
     "mphsir_pg_gate_bwd": (c_int, [ctypes.POINTER(PgBwdArgs), c_void_p]),
     "mphsir_conv3x3_tok": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int, c_void_p]),
-    "mphsir_conv3x3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    "mphsir_conv3x3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_im2col3x3": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_gdfn_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "mphsir_gated_mlp_bwd": (c_int, [ctypes.POINTER(MlpBwdArgs), c_int, c_void_p]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
     "mphsir_reduce_parts": (c_int, [ctypes.POINTER(ReduceSeg), c_int32, c_void_p]),
-    "mphsir_gemm_tn_group": (c_int, [ctypes.POINTER(TnProblem), c_int32, c_int, c_void_p]),
+    "mphsir_gemm_tn_group": (c_int, [ctypes.POINTER(TnProblem), c_int32, c_int32, c_int, c_void_p]),
     "mphsir_pack_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }
 

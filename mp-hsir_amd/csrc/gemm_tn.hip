@@ -320,6 +320,217 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_group_kernel(TnGroupDev g) 
     tn_tr_body<T, W1, W2>(a, reinterpret_cast<char*>(smem_v), (int)blockIdx.x - b0, 0);
 }
 
+// ---- ring form (16-bit types): ONE 512-thread workgroup per CU, token rows by LDS-DMA ------------------------------------------
+// A workgroup is EIGHT waves = two groups of four: its token range goes through a ring of 32-token slots filled by LDS-DMA
+// (global_load_lds_dwordx4 straight into the swizzled image the transposed reads want: the swizzle sits in the per-lane SOURCE
+// address, the destination is lane-linear; no staging registers, RG_RING - 2 slots in flight all the time, retired by a counted
+// vmcnt in front of an LDS-only barrier); group g multiplies slot 2 it + g.  Both groups keep a full (W1 x W2) tile of
+// accumulators; at the end group 1's tile is added to group 0's through LDS (always in that order: deterministic) and the sum
+// leaves as whole 16-byte row chunks: half the partial tiles per launch of two 4-wave workgroups.  Rows outside the token range /
+// the image (conv weight gradient) and columns outside the matrix are fetched from a page of zeros.
+// Measured on MI355X (tools/bench_tn.py, tools/lab/ring_lab.hip): a bare DMA ring streams 5.9 TB/s with one
+// workgroup per CU, and problems with ONE output tile run 1.2-1.7x faster in this form (dWproj 64x64 at M = 131072: 19.1 -> 11.5
+// us, 192x64: 23.3 -> 16.6, 128x128: 27.2 -> 21.0).  Problems with several tiles do NOT: the tiles of a token range re-read the
+// shared operand (dWqkv 384x128: 134 MB from HBM but 201 MB into the CUs), the kernel above already moves those CU-side bytes at
+// 5.4 TB/s, and with one workgroup per CU this form moves them more slowly (56 us against 37).  The host picks the form per
+// problem (ops.gemm_tn).
+constexpr int RG_ST = 32;            // tokens per ring slot (= one MFMA K chunk)
+constexpr int RG_RING = 8;           // ring slots; two are being multiplied, the others are in flight
+__device__ __attribute__((aligned(16))) const unsigned char g_tn_zero_page[16] = {0};
+
+template <class T, int W1, int W2>
+__device__ __forceinline__ void tn_ring_body(const TnDev& a, char* smem, int L, int bz) {
+    constexpr int RW = W1 / 64, NT = W2 / 16;
+    constexpr int IMG_A = RG_ST * W1 * 2, IMG_B = RG_ST * W2 * 2, SLOT = IMG_A + IMG_B;
+    constexpr int NIA = IMG_A / 1024, NIB = IMG_B / 1024, NI = NIA + NIB;      // DMA instructions (1 KB each) per slot
+    constexpr int CMAX = (NI + 7) / 8, CMIN = NI / 8;                          // ... per wave: waves < NI % 8 issue CMAX, the others CMIN
+    static_assert(NI >= 8 && CMAX <= 2, "ring form: 8..16 DMA instructions per slot");
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), grp = wv >> 2, wv4 = wv & 3;
+    const int t2n = (a.N2 + W2 - 1) / W2, ntiles = ((a.N1 + W1 - 1) / W1) * t2n;
+    const int tile = (L >> 3) % ntiles, sp = (L & 7) + 8 * (L / (8 * ntiles));      // XCD-aware map, as in gemm_tn_kernel
+    if (sp >= a.nsplit) return;
+    const int n1_0 = (tile / t2n) * W1, n2_0 = (tile % t2n) * W2;
+    const long per = ((a.M + a.nsplit - 1) / a.nsplit + 63) / 64 * 64;
+    const long m_lo = (long)sp * per, m_hi = (m_lo + per < a.M) ? m_lo + per : a.M;
+    const int nslots = m_hi > m_lo ? (int)((m_hi - m_lo + RG_ST - 1) / RG_ST) : 0;
+    const char* A = reinterpret_cast<const char*>(a.A) + (long)bz * a.abs * 2;
+    const char* B = reinterpret_cast<const char*>(a.B) + (long)bz * a.bbs * 2;
+    const char* zero = reinterpret_cast<const char*>(g_tn_zero_page);
+
+    // ---- this wave's DMA instructions: q = wv (+ 8); per lane: row inside the slot, source chunk (the swizzle of tr_off applied to
+    // the SOURCE column: LDS byte 16 * lane of the instruction's 1 KB holds chunk pos ^ swz(row) of its row)
+    const char* src[CMAX];          // source of slot 0 (valid or not: see ok*)
+    long step[CMAX];                // bytes per slot
+    int row[CMAX];                  // row inside the slot
+    bool colok[CMAX], isb[CMAX];
+    unsigned ldsoff[CMAX];          // wave-uniform byte offset inside the slot
+    int cdy = 0, cdx = 0;           // conv weight gradient: the tap of this lane's 8 columns of B
+    const int cHW = a.cH * a.cW;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        const int q = wv + 8 * c;                       // wave-uniform
+        const bool b = q >= NIA;
+        const int j = b ? q - NIA : q;
+        int r, pos, sw;
+        if ((b ? W2 : W1) == 128) { r = 4 * j + (lane >> 4); pos = lane & 15; sw = ((r & 3) << 2) | ((r >> 2) & 3); }
+        else { r = 8 * j + (lane >> 3); pos = lane & 7; sw = (((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2); }
+        const int ch = pos ^ sw;
+        row[c] = r;
+        isb[c] = b;
+        ldsoff[c] = (b ? IMG_A : 0) + 1024 * j;
+        const int col = (b ? n2_0 : n1_0) + ch * 8;
+        colok[c] = q < NI && col < (b ? a.N2 : a.N1);
+        const long ld = b ? a.ldb : a.lda;
+        step[c] = (long)RG_ST * ld * 2;
+        if (b && a.cC) {
+            const int tap = col / a.cC, ci = col - tap * a.cC;
+            cdy = tap / 3 - 1;
+            cdx = tap - (tap / 3) * 3 - 1;
+            src[c] = B + ((m_lo + r + (long)cdy * a.cW + cdx) * ld + ci) * 2;
+        } else {
+            src[c] = (b ? B : A) + ((m_lo + r) * ld + col) * 2;
+        }
+    }
+    auto issue = [&](int sidx) __attribute__((always_inline)) {          // DMA of slot sidx (wave-uniform) into its ring position
+        char* slot = smem + (sidx % RG_RING) * SLOT;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            if (wv + 8 * c >= NI) continue;                              // wave-uniform
+            const long m = m_lo + (long)sidx * RG_ST + row[c];
+            bool ok = colok[c] && m < m_hi;
+            if (isb[c] && a.cC) {                                        // wave-uniform
+                const unsigned p = (unsigned)m % (unsigned)cHW, py = p / (unsigned)a.cW;     // M < 2^31: 32-bit division
+                const int y = (int)py + cdy, x = (int)(p - py * (unsigned)a.cW) + cdx;
+                ok = ok && y >= 0 && y < a.cH && x >= 0 && x < a.cW;
+            }
+            const char* g = ok ? src[c] + (long)sidx * step[c] : zero;
+            MPHSIR_LDS_DMA16P(g, slot + ldsoff[c]);
+        }
+    };
+
+    f32x4 acc[RW][NT];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = a.colsum != nullptr && (tile % t2n) == 0;
+    f32x4 accs[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typename ElemTraits<T>::frag_t ones;
+    for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
+    const TrLane tla = tr_lane<W1>(), tlb = tr_lane<W2>();
+
+    constexpr int LEAD = RG_RING - 2;                 // slots issued ahead of the pair being multiplied
+    for (int s0 = 0; s0 < LEAD && s0 < nslots; ++s0) issue(s0);
+    const int niter = (nslots + 1) / 2;
+    const bool many = wv < NI % 8 || NI % 8 == 0;     // this wave issues CMAX instructions per slot (else CMIN)
+    for (int it = 0; it < niter; ++it) {
+        // slots 2 it, 2 it + 1 must have landed; the LEAD - 2 younger slots stay in flight (vmcnt counts in issue order).  Near
+        // the end fewer younger ones exist: wait for everything.
+        if (2 * it + LEAD <= nslots) {
+            if (many) wait_vmcnt<(LEAD - 2) * CMAX>();
+            else wait_vmcnt<(LEAD - 2) * (CMIN > 0 ? CMIN : 1)>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        lds_barrier();                                // ... for every wave; and everybody is done with the pair of iteration it - 1
+        if (2 * it + LEAD < nslots) issue(2 * it + LEAD);
+        if (2 * it + LEAD + 1 < nslots) issue(2 * it + LEAD + 1);
+        const int sidx = 2 * it + grp;
+        if (sidx < nslots) {
+            const char* slot = smem + (sidx % RG_RING) * SLOT;
+            typename ElemTraits<T>::frag_t af[RW];
+#pragma unroll
+            for (int i = 0; i < RW; ++i) af[i] = tr_frag<T, W1>(slot, tla, (wv4 * RW + i) * 16, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const typename ElemTraits<T>::frag_t bf = tr_frag<T, W2>(slot + IMG_A, tlb, nt * 16, 0);
+#pragma unroll
+                for (int i = 0; i < RW; ++i) mma(acc[i][nt], af[i], bf);
+            }
+            if (do_cs)
+#pragma unroll
+                for (int i = 0; i < RW; ++i) mma(accs[i], af[i], ones);
+        }
+    }
+    // ---- the two groups' tiles -> one partial tile: group 1 through LDS (the ring is dead), group 0 adds (fixed order), everybody
+    // stores whole 16-byte row chunks
+    constexpr int LDC = W2 + 4;
+    float* Cs = reinterpret_cast<float*>(smem);                 // [W1][LDC]
+    float* Ss = Cs + W1 * LDC;                                  // [W1] column sums
+    wait_vmcnt<0>();
+    lds_barrier();
+    for (int g = 1; g >= 0; --g) {
+        if (grp == g) {
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* p = Cs + ((wv4 * RW + i) * 16 + (lane >> 4) * 4 + r) * LDC + nt * 16 + (lane & 15);
+                        *p = g ? acc[i][nt][r] : acc[i][nt][r] + *p;
+                    }
+                if (do_cs && (lane & 15) == 0)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* p = Ss + (wv4 * RW + i) * 16 + (lane >> 4) * 4 + r;
+                        *p = g ? accs[i][r] : accs[i][r] + *p;
+                    }
+            }
+        }
+        lds_barrier();
+    }
+    float* Cp = a.Cp + (((long)bz * a.nsplit + sp) * a.N1) * a.N2;
+    constexpr int CPR = W2 / 4;                                 // 16-byte chunks per tile row
+    for (int idx = tid; idx < W1 * CPR; idx += 512) {
+        const int r = idx / CPR, c = (idx % CPR) * 4, n1 = n1_0 + r, n2 = n2_0 + c;
+        if (n1 < a.N1 && n2 < a.N2) *reinterpret_cast<f32x4*>(Cp + (long)n1 * a.N2 + n2) = *reinterpret_cast<const f32x4*>(Cs + r * LDC + c);
+    }
+    if (do_cs && tid < W1 && n1_0 + tid < a.N1) a.colsum[((long)bz * a.nsplit + sp) * a.N1 + n1_0 + tid] = Ss[tid];
+}
+
+template <class T, int W1, int W2> constexpr size_t tn_ring_lds() {
+    constexpr size_t ring = (size_t)RG_RING * RG_ST * (W1 + W2) * 2, comb = (size_t)W1 * (W2 + 4) * 4 + W1 * 4;
+    return ring > comb ? ring : comb;
+}
+
+template <class T, int W1, int W2>
+__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(TnDev a) {
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    tn_ring_body<T, W1, W2>(a, reinterpret_cast<char*>(smem_v), blockIdx.x, blockIdx.z);
+}
+
+template <class T, int W1, int W2>
+__global__ __launch_bounds__(512) void gemm_tn_ring_group_kernel(TnGroupDev g) {
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    TnDev a = g.p[0];
+    int b0 = 0;
+#pragma unroll
+    for (int k = 1; k < MPHSIR_TN_GROUP_MAX; ++k)
+        if (k < g.n && (int)blockIdx.x >= g.blk0[k]) { a = g.p[k]; b0 = g.blk0[k]; }
+    tn_ring_body<T, W1, W2>(a, reinterpret_cast<char*>(smem_v), (int)blockIdx.x - b0, 0);
+}
+
+template <class T, int W1, int W2>
+static int launch_tn_ring_group(const TnGroupDev& g, hipStream_t s) {
+    const size_t shmem = tn_ring_lds<T, W1, W2>();
+    allow_big_lds(gemm_tn_ring_group_kernel<T, W1, W2>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_ring_group_kernel<T, W1, W2>), dim3(g.blk0[g.n]), dim3(512), shmem, s, g);
+    return MPHSIR_OK;
+}
+
+template <class T, int W1, int W2>
+static int launch_tn_ring(const TnDev& d, int batch, hipStream_t s) {
+    const int ntiles = ((d.N1 + W1 - 1) / W1) * ((d.N2 + W2 - 1) / W2);
+    dim3 grid(ntiles * ((d.nsplit + 7) / 8 * 8), 1, batch);
+    const size_t shmem = tn_ring_lds<T, W1, W2>();
+    allow_big_lds(gemm_tn_ring_kernel<T, W1, W2>, shmem);
+    MPHSIR_LAUNCH(MPHSIR_K_GEMM_TN, (gemm_tn_ring_kernel<T, W1, W2>), grid, dim3(512), shmem, s, d);
+    return MPHSIR_OK;
+}
+
 template <class T, int W1, int W2>
 static int launch_tn_tr_group(const TnGroupDev& g, hipStream_t s) {
     const size_t shmem = 2 * (size_t)(W1 + W2) * 64 * 2;
@@ -368,7 +579,15 @@ extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride
     const bool big = tile128 > 0;
     if (dtype == MPHSIR_F32) return big ? launch_tn<float, 2, 2>(d, batch, s) : launch_tn<float, 1, 1>(d, batch, s);
     if (!big) return dtype == MPHSIR_BF16 ? launch_tn<bf16_t, 1, 1>(d, batch, s) : launch_tn<f16_t, 1, 1>(d, batch, s);
-    // 16-bit "big": the transposed-read kernel; each operand's tile width follows its matrix width
+    // 16-bit "big": the transposed-read kernel (1) or its ring form (2); each operand's tile width follows its matrix width
+#define MPHSIR_TN_RING(T16)                                                                                             \
+    if (N1 > 64) return N2 > 64 ? launch_tn_ring<T16, 128, 128>(d, batch, s) : launch_tn_ring<T16, 128, 64>(d, batch, s); \
+    return N2 > 64 ? launch_tn_ring<T16, 64, 128>(d, batch, s) : launch_tn_ring<T16, 64, 64>(d, batch, s);
+    if (tile128 == 2) {
+        if (dtype == MPHSIR_BF16) { MPHSIR_TN_RING(bf16_t) }
+        MPHSIR_TN_RING(f16_t)
+    }
+#undef MPHSIR_TN_RING
 #define MPHSIR_TN_TR(T16)                                                                                             \
     if (N1 > 64) return N2 > 64 ? launch_tn_tr<T16, 128, 128>(d, batch, s) : launch_tn_tr<T16, 128, 64>(d, batch, s); \
     return N2 > 64 ? launch_tn_tr<T16, 64, 128>(d, batch, s) : launch_tn_tr<T16, 64, 64>(d, batch, s);
@@ -377,11 +596,12 @@ extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride
 #undef MPHSIR_TN_TR
 }
 
-extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t n, int dtype, void* stream) {
+extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t n, int32_t form, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(probs && n > 0 && n <= MPHSIR_TN_GROUP_MAX, "gemm_tn_group: 1..%d problems per call", MPHSIR_TN_GROUP_MAX);
     MPHSIR_REQUIRE(dtype == MPHSIR_BF16 || dtype == MPHSIR_F16, "gemm_tn_group: 16-bit element types only (the transposed-LDS-read kernel)");
+    MPHSIR_REQUIRE(form == 1 || form == 2, "gemm_tn_group: form 1 (transposed-read kernel) or 2 (ring form)");
     TnGroupDev g;
     g.n = n;
     bool wide1 = false, wide2 = false;
@@ -400,6 +620,14 @@ extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t
     }
     g.blk0[n] = blocks;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define MPHSIR_TN_GRPR(T16)                                                                                       \
+    if (wide1) return wide2 ? launch_tn_ring_group<T16, 128, 128>(g, s) : launch_tn_ring_group<T16, 128, 64>(g, s); \
+    return wide2 ? launch_tn_ring_group<T16, 64, 128>(g, s) : launch_tn_ring_group<T16, 64, 64>(g, s);
+    if (form == 2) {
+        if (dtype == MPHSIR_BF16) { MPHSIR_TN_GRPR(bf16_t) }
+        MPHSIR_TN_GRPR(f16_t)
+    }
+#undef MPHSIR_TN_GRPR
 #define MPHSIR_TN_GRP(T16)                                                                                    \
     if (wide1) return wide2 ? launch_tn_tr_group<T16, 128, 128>(g, s) : launch_tn_tr_group<T16, 128, 64>(g, s); \
     return wide2 ? launch_tn_tr_group<T16, 64, 128>(g, s) : launch_tn_tr_group<T16, 64, 64>(g, s);
@@ -409,7 +637,7 @@ extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t
 }
 
 extern "C" int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* Cpart, int32_t B, int32_t H, int32_t W,
-                                    int32_t Cout, int32_t Cin, int32_t nsplit, int dtype, void* stream) {
+                                    int32_t Cout, int32_t Cin, int32_t nsplit, int32_t form, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(dY && X && Cpart, "conv3x3_wgrad: null pointer");
@@ -419,6 +647,12 @@ extern "C" int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X,
     MPHSIR_REQUIRE(aligned16(dY) && aligned16(X) && (lddy * 2) % 16 == 0 && (ldx * 2) % 16 == 0, "conv3x3_wgrad: 16-byte alignment required");
     TnDev d{dY, (long)lddy, 0, X, (long)ldx, 0, Cpart, nullptr, (long)B * H * W, Cout, 9 * Cin, nsplit, H, W, Cin};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define MPHSIR_CW_RING(T16) return Cout > 64 ? launch_tn_ring<T16, 128, 128>(d, 1, s) : launch_tn_ring<T16, 64, 128>(d, 1, s);
+    if (form == 2) {
+        if (dtype == MPHSIR_BF16) { MPHSIR_CW_RING(bf16_t) }
+        MPHSIR_CW_RING(f16_t)
+    }
+#undef MPHSIR_CW_RING
 #define MPHSIR_CW_TR(T16) return Cout > 64 ? launch_tn_tr<T16, 128, 128>(d, 1, s) : launch_tn_tr<T16, 64, 128>(d, 1, s);
     if (dtype == MPHSIR_BF16) { MPHSIR_CW_TR(bf16_t) }
     MPHSIR_CW_TR(f16_t)

@@ -218,11 +218,39 @@ __device__ __forceinline__ void wave_barrier() {
 // As assembly the transfer is invisible to that bookkeeping; the code that issues it retires it with a counted
 // s_waitcnt vmcnt(N) before the barrier that publishes the row.  (MPHSIR_LDS_DMA16 is the one customisation point of this
 // header: the CPU emulation of the test suite supplies a memcpy.)
+// M0 (the LDS destination base) is compiler-reserved and not preserved around a statement: it is written in the SAME statement
+// that reads it, and saved / restored there (cdna_hip_programming.md, "LDS-DMA recipe").
+// MPHSIR_LDS_DMA16P is the same transfer with a full 64-bit source POINTER per lane (a lane may point anywhere, e.g. at a page of
+// zeros for rows outside the matrix).
 #ifndef MPHSIR_LDS_DMA16
 #define MPHSIR_LDS_DMA16(gbase, byte_off, lds_wave_base)                                                                \
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                        \
-                 :: "v"(byte_off), "s"(gbase), "s"((unsigned)(unsigned long long)(lds_wave_base)) : "memory", "m0")
+    do {                                                                                                                \
+        unsigned keep_m0_;                                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"  \
+                     : "=&s"(keep_m0_) : "v"(byte_off), "s"(gbase), "s"((unsigned)(unsigned long long)(lds_wave_base)) : "memory"); \
+    } while (0)
+#define MPHSIR_LDS_DMA16P(gptr, lds_wave_base)                                                                          \
+    do {                                                                                                                \
+        unsigned keep_m0_;                                                                                              \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"  \
+                     : "=&s"(keep_m0_) : "v"(gptr), "s"((unsigned)(unsigned long long)(lds_wave_base)) : "memory");     \
+    } while (0)
 #endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() -- and even a fence that names only the local address space --
+// makes hipcc drain the vector-memory counter (an LDS-DMA in flight is a pending LDS write to it: s_waitcnt vmcnt(0) lgkmcnt(0)),
+// which would serialise a DMA ring and the global stores with every step.  So: this wave's LDS operations are retired by
+// hand (lgkmcnt(0): DS operations complete in order), the compiler is told not to move memory operations across the point,
+// and the rows that must have landed are retired by a counted vmcnt wait in front of the call.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0); vmcnt and expcnt left at their maxima
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);           // nothing of the next step is scheduled into this one (register pressure)
+}
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
+template <int N> __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14)); }
 
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx b runs on XCD b % 8, each XCD has its own L2).  For
 // streaming kernels whose neighbouring workgroups share input rows (3x3 stencils) this maps XCD x to one contiguous

@@ -87,21 +87,7 @@ __device__ __forceinline__ float dpp_row_shl1(float old, float src) {     // lan
 __device__ __forceinline__ float lane_fetch(int byte_addr, float v) {     // ds_bpermute_b32: the value of lane byte_addr / 4
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() -- and even a fence that names only the local address space --
-// makes hipcc drain the vector-memory counter (an LDS-DMA in flight is a pending LDS write to it: s_waitcnt vmcnt(0) lgkmcnt(0)),
-// which would serialise the DMA ring and the global stores with every step.  So: this wave's LDS operations are retired by
-// hand (lgkmcnt(0): DS operations complete in order), the compiler is told not to move memory operations across the point,
-// and the rows that must have landed are retired by the counted vmcnt wait in front of the call.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0); vmcnt and expcnt left at their maxima
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);           // nothing of the next step is scheduled into this one (register pressure)
-}
 __device__ __forceinline__ float pick4(f32x4 v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); }
-// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
-template <int N> __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14)); }
 
 // DBG builds only (mphsir_debug armed): shader-clock stamps of workgroup 0 / wave 0 at walk step 9
 #define RW_MARK(k) do { if (DBG && blockIdx.x == 0 && tid == 0 && i == 9) a.dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)

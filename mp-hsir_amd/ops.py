@@ -176,7 +176,8 @@ def _flush_gemms(gemms):
             q = arr[k]
             q.A, q.lda, q.B, q.ldb, q.Cpart, q.colsum_part = g["A"], g["lda"], g["B"], g["ldb"], g["Cpart"], g["cs"]
             q.M, q.N1, q.N2, q.nsplit = g["M"], g["N1"], g["N2"], g["nsplit"]
-        _lib.check(lib.mphsir_gemm_tn_group(arr, len(chunk), _DT[chunk[0]["keep"][0].dtype], _stream(chunk[0]["keep"][0])), "gemm_tn_group")
+        form = TN_FORM or (2 if all(g["form"] == 2 for g in chunk) else 1)
+        _lib.check(lib.mphsir_gemm_tn_group(arr, len(chunk), form, _DT[chunk[0]["keep"][0].dtype], _stream(chunk[0]["keep"][0])), "gemm_tn_group")
 
 
 def _flush(segs):
@@ -936,6 +937,10 @@ def ln_bwd_tok(x2, dxn, dres, ln_w, ln_b):
 
 TN_GROUPED = True          # weight-gradient GEMMs of a backward function in one launch
 TN_BIG_TILES = True        # bf16 token-reduction GEMMs use the transposed-LDS-read kernel (ds_read_b64_tr_b16)
+# 16-bit big-tile kernel: 1 = transposed-read kernel (256 threads, ~2 workgroups per CU), 2 = its ring form (512 threads, one per CU),
+# 0 = per problem: the ring form where it measured faster -- ONE output tile, unbatched, >= 65536 tokens (tools/bench_tn.py) -- else 1
+TN_FORM = int(os.environ.get("MPHSIR_TN_FORM", "0"))
+TN_RING_WGS = 256          # ring form: workgroups per launch aimed at (one per CU)
 TN_BIG_ROUNDS = 1.0        # ... and aim for this many full rounds of resident workgroups (re-measured with the partial sums deferred: 0.5 / 0.75 / 1 / 2 -> 22.48 / 22.33 / 22.37 / 22.47 ms per step)
 
 
@@ -951,11 +956,15 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, redu
     assert a.stride(-1) == 1 and b.stride(-1) == 1 and b.shape[-2] == M and a.dtype == b.dtype
     if tile128 is None:
         tile128 = TN_BIG_TILES and a.dtype in _HALF
+    form = TN_FORM or (2 if (N1 <= 128 and N2 <= 128 and not batched and M >= 65536) else 1)
     if nsplit is None:
         if tile128 and a.dtype in _HALF:     # transposed-read kernel: 64/128-wide tile per operand, 2 workgroups per CU
             tiles = ((N1 + 127) // 128 if N1 > 64 else 1) * ((N2 + 127) // 128 if N2 > 64 else 1) * Bt
-            resident = 2 if (N1 > 64 and N2 > 64) else (4 if (N1 <= 64 and N2 <= 64) else 3)    # workgroups per CU (LDS, VGPRs)
-            nsplit = max(1, min(M // 256, 128, max(1, int(256 * resident * TN_BIG_ROUNDS) // tiles)))
+            if form == 2:                    # ring form: one 512-thread workgroup per CU
+                nsplit = max(1, min(M // 256, 128, max(1, TN_RING_WGS // tiles)))
+            else:
+                resident = 2 if (N1 > 64 and N2 > 64) else (4 if (N1 <= 64 and N2 <= 64) else 3)    # workgroups per CU (LDS, VGPRs)
+                nsplit = max(1, min(M // 256, 128, max(1, int(256 * resident * TN_BIG_ROUNDS) // tiles)))
         else:
             ts = 128 if tile128 else 64
             tiles = ((N1 + ts - 1) // ts) * ((N2 + ts - 1) // ts) * Bt
@@ -965,10 +974,11 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, redu
     if _SCOPE is not None and TN_GROUPED and not immediate and not batched and tile128 and a.dtype in _HALF:
         # nothing but the partial reduction at the end of the scope reads the result: issue it there, grouped
         _SCOPE.gemms.append(dict(A=a.data_ptr(), lda=a.stride(-2), B=b.data_ptr(), ldb=b.stride(-2), Cpart=part.data_ptr(),
-                                 cs=cs.data_ptr() if colsum else None, M=M, N1=N1, N2=N2, nsplit=nsplit, keep=(a, b, part, cs)))
+                                 cs=cs.data_ptr() if colsum else None, M=M, N1=N1, N2=N2, nsplit=nsplit, form=form, keep=(a, b, part, cs)))
     else:
         _lib.check(lib.mphsir_gemm_tn(_p(a), a.stride(-2), a.stride(0) if batched else 0, _p(b), b.stride(-2),
-                                      b.stride(0) if batched else 0, _p(part), _p(cs), M, N1, N2, nsplit, Bt, int(bool(tile128)),
+                                      b.stride(0) if batched else 0, _p(part), _p(cs), M, N1, N2, nsplit, Bt,
+                                      (form if a.dtype in _HALF else 1) if tile128 else 0,
                                       _DT[a.dtype], _stream(a)),
                    "gemm_tn")
     # algorithmic bytes = the two token matrices, read once; the kernel's own split partials are overhead, accounted apart
@@ -1126,9 +1136,9 @@ def conv3x3_wgrad(dy2, x, nsplit=None):
     assert x.is_contiguous() and dy2.stride(1) == 1 and M == B * H * W and x.dtype == dy2.dtype and x.dtype in _HALF
     if nsplit is None:
         tiles = ((Np + 127) // 128 if Np > 64 else 1) * ((9 * Cp + 127) // 128)
-        nsplit = max(1, min(M // 256, 128, max(1, int(256 * 2 * TN_BIG_ROUNDS) // tiles)))
+        nsplit = max(1, min(M // 256, 128, max(1, (TN_RING_WGS if TN_FORM == 2 else int(256 * 2 * TN_BIG_ROUNDS)) // tiles)))
     part = torch.empty((1, nsplit, Np, 9 * Cp), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mphsir_conv3x3_wgrad(_p(dy2), dy2.stride(0), _p(x), Cp, _p(part), B, H, W, Np, Cp, nsplit, _DT[x.dtype], _stream(x)),
+    _lib.check(lib.mphsir_conv3x3_wgrad(_p(dy2), dy2.stride(0), _p(x), Cp, _p(part), B, H, W, Np, Cp, nsplit, TN_FORM or 1, _DT[x.dtype], _stream(x)),
                "conv3x3_wgrad")
     _acct("gemm_tn", 2.0 * M * Np * 9 * Cp, M * (Np + Cp) * x.element_size())
     _acct("gemm_tn:partials", 0.0, part.numel() * 4.0)

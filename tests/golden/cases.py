@@ -54,8 +54,9 @@ FULL_CASES = {
 # summary statistics -- norm, mean, CUBE_SAMPLES seeded samples, per-band means, PSNR -- because the tensors are 32-180 MB.
 RS172_CFG = dict(in_channel=172, out_channel=172, dim=96, task_classes=7)
 CUBE_CASES = {
-    "nat512": dict(cfg=NATURAL_CFG, shape=(1, 31, 512, 512), recipe="gaussian70", task=[0]),
-    "rs172_256": dict(cfg=RS172_CFG, shape=(1, 172, 256, 256), recipe="inpaint90", task=[4]),
+    # min_rows / min_gdfn: launches of the row-walking pass A / the fused GDFN the 16-bit forward must take at that size
+    "nat512": dict(cfg=NATURAL_CFG, shape=(1, 31, 512, 512), recipe="gaussian70", task=[0], min_rows=16, min_gdfn=2),
+    "rs172_256": dict(cfg=RS172_CFG, shape=(1, 172, 256, 256), recipe="inpaint90", task=[4], min_rows=10, min_gdfn=1),
 }
 CUBE_SAMPLES = 4096
 

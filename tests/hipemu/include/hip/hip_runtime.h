@@ -322,6 +322,7 @@ inline void global_load_lds(const void* src, void* dst, int size) { memcpy((char
 #define address_space(n)
 #define __builtin_amdgcn_global_load_lds(src, dst, size, off, aux) hipemu::global_load_lds((const void*)(src), (void*)(dst), size)
 #define MPHSIR_LDS_DMA16(gbase, byte_off, lds_wave_base) hipemu::global_load_lds((const char*)(gbase) + (byte_off), (void*)(lds_wave_base), 16)
+#define MPHSIR_LDS_DMA16P(gptr, lds_wave_base) hipemu::global_load_lds((const void*)(gptr), (void*)(lds_wave_base), 16)
 #define __builtin_amdgcn_s_barrier() hipemu::block_sync()
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

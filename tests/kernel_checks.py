@@ -408,6 +408,22 @@ def check_gated_mlp_bwd(dev, dtype, C, hid, variant=0):
     assert rel_l2(dln[0], lw.grad) < tol and rel_l2(dln[1], lb.grad) < tol
 
 
+class tn_form:
+    """`with tn_form(f):` runs the 16-bit big-tile token-reduction GEMMs in form f (1 = transposed-read kernel, 2 = ring form)."""
+
+    def __init__(self, form):
+        self.form = form
+
+    def __enter__(self):
+        from mp_hsir_amd import ops
+        self.prev, ops.TN_FORM = ops.TN_FORM, self.form
+
+    def __exit__(self, *exc):
+        from mp_hsir_amd import ops
+        ops.TN_FORM = self.prev
+        return False
+
+
 def check_gemm_tn(dev, dtype, M, N1, N2, nsplit, batch, tile128=None):
     _use(dev)
     from mp_hsir_amd import ops

@@ -93,7 +93,7 @@ def check_full_size_cube(dev, name, oracle_threads=32):
     forms = {k: v[0] for k, v in acct.items()}
     res = {"forms": {k: forms.get(k, 0) for k in ("qkv_dwconv_gram:rows", "qkv_dwconv_gram:tile", "gdfn_fused", "dwconv_gram")}}
     if dev != "cpu":
-        assert forms.get("qkv_dwconv_gram:rows", 0) >= 12 and forms.get("gdfn_fused", 0) >= 2, forms
+        assert forms.get("qkv_dwconv_gram:rows", 0) >= c["min_rows"] and forms.get("gdfn_fused", 0) >= c["min_gdfn"], forms
     # (1) the reference's own statistics
     idx = sample_indices("cube:" + name, y32.numel(), CUBE_SAMPLES)
     want_s, want_n = torch.from_numpy(g[name + "/samples"]), float(g[name + "/norm"])

@@ -121,15 +121,21 @@ def test_gemm_tn_tile128(dtype):
 
 
 @pytest.mark.parametrize("M,N1,N2,nsplit,batch", [(200, 64, 128, 2, 0), (130, 136, 48, 1, 0), (96, 40, 56, 3, 2)])
-def test_gemm_tn_transposed_read_widths(M, N1, N2, nsplit, batch):
+@pytest.mark.parametrize("form", [1, 2])
+def test_gemm_tn_transposed_read_widths(M, N1, N2, nsplit, batch, form):
     import torch
-    K.check_gemm_tn("cpu", torch.bfloat16, M, N1, N2, nsplit, batch, tile128=True)
+    with K.tn_form(form):
+        K.check_gemm_tn("cpu", torch.bfloat16, M, N1, N2, nsplit, batch, tile128=True)
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 8, 31, 32), (2, 8, 4, 32, 31), (1, 8, 8, 64, 48)])
-def test_conv3x3(dtype, B, H, W, Cin, Cout):
-    K.check_conv3x3("cpu", dtype, B, H, W, Cin, Cout)
+@pytest.mark.parametrize("form", [1, 2])
+def test_conv3x3(dtype, B, H, W, Cin, Cout, form):
+    if form == 1 and dtype == torch.float32:
+        pytest.skip("fp32 has one form")
+    with K.tn_form(form):
+        K.check_conv3x3("cpu", dtype, B, H, W, Cin, Cout)
 
 
 def test_reduce_parts():
@@ -145,8 +151,10 @@ def test_reduce_block():
     K.check_reduce_block("cpu")
 
 
-def test_gemm_tn_grouped():
-    K.check_gemm_tn_grouped("cpu")
+@pytest.mark.parametrize("form", [1, 2])
+def test_gemm_tn_grouped(form):
+    with K.tn_form(form):
+        K.check_gemm_tn_grouped("cpu")
 
 
 @pytest.mark.parametrize("dtype,name", [(torch.float32, "nat_refine"), (torch.bfloat16, "rs_refine"), (torch.float32, "nat_latent")])

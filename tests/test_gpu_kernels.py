@@ -181,8 +181,12 @@ def test_gemm_tn(dtype, M, N1, N2, nsplit, batch):
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 8, 31, 32), (2, 8, 4, 32, 31), (1, 8, 8, 64, 48), (4, 64, 64, 31, 64),
                                              (2, 16, 16, 256, 512), (2, 64, 64, 128, 31)])
-def test_conv3x3(dtype, B, H, W, Cin, Cout):
-    K.check_conv3x3("cuda", dtype, B, H, W, Cin, Cout)
+@pytest.mark.parametrize("form", [1, 2])
+def test_conv3x3(dtype, B, H, W, Cin, Cout, form):
+    if form == 1 and dtype == torch.float32:
+        pytest.skip("fp32 has one form")
+    with K.tn_form(form):
+        K.check_conv3x3("cuda", dtype, B, H, W, Cin, Cout)
 
 
 def test_reduce_parts():
@@ -196,16 +200,20 @@ def test_pack_gather(dtype):
 
 @pytest.mark.parametrize("M,N1,N2,nsplit,batch", [(200, 64, 128, 2, 0), (130, 136, 48, 1, 0), (96, 40, 56, 3, 2), (8192, 704, 128, 8, 0),
                                                   (4096, 128, 352, 5, 0), (4096, 64, 64, 4, 3), (4096, 384, 64, 7, 0)])
-def test_gemm_tn_transposed_read_widths(M, N1, N2, nsplit, batch):
-    K.check_gemm_tn("cuda", torch.bfloat16, M, N1, N2, nsplit, batch, tile128=True)
+@pytest.mark.parametrize("form", [1, 2])
+def test_gemm_tn_transposed_read_widths(M, N1, N2, nsplit, batch, form):
+    with K.tn_form(form):
+        K.check_gemm_tn("cuda", torch.bfloat16, M, N1, N2, nsplit, batch, tile128=True)
 
 
 def test_reduce_block():
     K.check_reduce_block("cuda")
 
 
-def test_gemm_tn_grouped():
-    K.check_gemm_tn_grouped("cuda")
+@pytest.mark.parametrize("form", [1, 2])
+def test_gemm_tn_grouped(form):
+    with K.tn_form(form):
+        K.check_gemm_tn_grouped("cuda")
 
 
 # ---- backward kernels at every benchmarked width: fp64 autograd of the oracle, full tensors --------------

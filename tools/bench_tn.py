@@ -1,15 +1,19 @@
-"""gemm_tn variants at the shapes of the training step (bf16)."""
-import sys, warnings
-sys.path.insert(0, '/root/repo')
+"""gemm_tn forms at the shapes of the training step (bf16): transposed-read kernel (form 1) vs ring form (form 2), the GEMM launch
+alone (reduce=False) and with its partial reduction."""
+import sys, warnings, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops
 dev = "cuda"
-def t_us(fn, n=20):
-    for _ in range(3): fn()
-    torch.cuda.synchronize(); s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+def t_us(fn, n=12):
+    """fn(i) runs on input set i (the sets rotate: together they exceed the 256 MB Infinity Cache, so every call reads CLEAN cold
+    data -- a zero_() flush leaves the cache full of dirty lines whose write-back then competes with the reads)"""
+    for i in range(2): fn(i)
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(n): fn()
+    for i in range(n): fn(i)
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
 cases = [("dW1 C128", 131072, 704, 128, 0), ("dW2 C128", 131072, 128, 352, 0), ("dWqkv C128", 131072, 384, 128, 0), ("dWproj C128", 131072, 128, 128, 0),
@@ -17,13 +21,16 @@ cases = [("dW1 C128", 131072, 704, 128, 0), ("dW2 C128", 131072, 128, 352, 0), (
          ("dW1 C256", 8192, 1408, 256, 0), ("dWqkv C256", 8192, 768, 256, 0), ("dW1 C128 r32", 32768, 704, 128, 0), ("dM C128 r32 b32", 1024, 128, 128, 32),
          ("pgLR", 2048, 440, 200, 0)]
 for name, M, N1, N2, bt in cases:
-    a = torch.randn(((bt, M, N1) if bt else (M, N1)), device=dev, dtype=torch.bfloat16)
-    b = torch.randn(((bt, M, N2) if bt else (M, N2)), device=dev, dtype=torch.bfloat16)
     nb = (bt or 1) * M * (N1 + N2) * 2
-    old = t_us(lambda: ops.gemm_tn(a, b, tile128=False))
-    res = []
-    for wgs in (0.5, 1.0, 2.0):
-        ops.TN_BIG_ROUNDS = wgs
-        res.append(t_us(lambda: ops.gemm_tn(a, b, tile128=True)))
-    print("%-18s old %6.1f us (%.2f TB/s) | tr kernel @0.5/1/2 rounds: %s us  (best %.2f TB/s)" % (
-        name, old, nb / old / 1e6, " ".join("%6.1f" % r for r in res), nb / min(res) / 1e6))
+    K = max(2, int(700e6 // nb) + 1)
+    As = [torch.randn(((bt, M, N1) if bt else (M, N1)), device=dev, dtype=torch.bfloat16) for _ in range(K)]
+    Bs = [torch.randn(((bt, M, N2) if bt else (M, N2)), device=dev, dtype=torch.bfloat16) for _ in range(K)]
+    a, b = As[0], Bs[0]
+    out = []
+    for form, wgs in ((1, 0), (2, 256), (2, 512)):
+        ops.TN_FORM, ops.TN_RING_WGS = form, wgs or 256
+        g = t_us(lambda i: ops.gemm_tn(As[i % K], Bs[i % K], reduce=False))
+        gr = t_us(lambda i: ops.gemm_tn(As[i % K], Bs[i % K]))
+        p = ops.gemm_tn(a, b, reduce=False)
+        out.append("form%d%s: %6.1f us (%.2f TB/s) +reduce %6.1f us, partials %5.1f MB" % (form, "/%d" % wgs if wgs else "", g, nb / g / 1e6, gr, p.numel() * 4 / 1e6))
+    print("%-16s %6.1f MB | %s" % (name, nb / 1e6, " | ".join(out)), flush=True)

@@ -1,13 +1,16 @@
-import sys, warnings
-sys.path.insert(0, '/root/repo')
+"""one token-reduction GEMM shape a few times (for tools/pmc_kernel.sh): python tools/run_tn_once.py M N1 N2 form [ring_wgs]"""
+import sys, os, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops
-M, N1, N2 = 131072, 704, 128
-a = torch.randn((M, N1), device="cuda", dtype=torch.bfloat16)
-b = torch.randn((M, N2), device="cuda", dtype=torch.bfloat16)
-ops.TN_BIG_ROUNDS = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-for _ in range(5):
-    ops.gemm_tn(a, b, tile128=True)
-    ops.gemm_tn(a, b, tile128=False)
+M, N1, N2, form = (int(v) for v in sys.argv[1:5])
+ops.TN_FORM = form
+if len(sys.argv) > 5:
+    ops.TN_RING_WGS = int(sys.argv[5])
+K = 6
+As = [torch.randn((M, N1), device="cuda", dtype=torch.bfloat16) for _ in range(K)]
+Bs = [torch.randn((M, N2), device="cuda", dtype=torch.bfloat16) for _ in range(K)]
+for i in range(K):
+    ops.gemm_tn(As[i], Bs[i], reduce=False)
 torch.cuda.synchronize()
