@@ -465,6 +465,17 @@ int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, void* strea
  * parameter arena after an optimizer step; `index` is static (built once from the packers on the host side).   */
 int mphsir_pack_gather(const float* arena, const int32_t* index, void* dst, int64_t n, int dtype, void* stream);
 
+/* multi_copy: n fp32 tensors copied in ONE launch -- the gradient hand-over (autograd's freshly allocated parameter gradients ->
+ * their slots of the flat gradient arena that the all-reduce and mphsir_flat_adamw work on; the reference: DDP's bucket copies,
+ * train.py:118).  table_dev: DEVICE memory, nseg rows of four int64 {src pointer, dst pointer, n floats, first block}; a block
+ * moves up to 4096 floats, first block = the running sum of ceil(n / 4096); total_blocks = that sum over all rows.            */
+int mphsir_multi_copy(const int64_t* table_dev, int32_t nseg, int64_t total_blocks, void* stream);
+
+/* l1_clamp_loss: the reference's training loss and its gradient in one pass (train.py:58-61: clamp(restored, 0, 1) then
+ * nn.L1Loss): part[b] = sum over block b's elements of |clamp(y) - clean| / n (the caller sums the nblocks partials in order =
+ * the loss), grad (optional) = d loss / d y = sign(clamp(y) - clean) / n where 0 <= y <= 1, else 0.  fp32, contiguous.      */
+int mphsir_l1_clamp_loss(const float* y, const float* clean, float* grad, float* part, int64_t n, int32_t nblocks, void* stream);
+
 /* ---- optional per-kernel launch timer (bench.py roofline leg) ----------------------------------
  * When enabled for kernel id `kid`, every launch of that kernel is bracketed by hipEvents on its
  * own stream.  read(): synchronises the recorded events, returns the number of launches and their
@@ -496,6 +507,8 @@ int mphsir_pack_gather(const float* arena, const int32_t* index, void* dst, int6
 #define MPHSIR_K_QKV_DWCONV_GRAM 24
 #define MPHSIR_K_GDFN_FUSED 25
 #define MPHSIR_K_DWCONV_BWD 26
+#define MPHSIR_K_MULTI_COPY 27
+#define MPHSIR_K_L1_LOSS 28
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

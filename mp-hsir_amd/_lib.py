@@ -186,6 +186,8 @@ _SYMBOLS = {
     "mphsir_reduce_parts": (c_int, [ctypes.POINTER(ReduceSeg), c_int32, c_void_p]),
     "mphsir_gemm_tn_group": (c_int, [ctypes.POINTER(TnProblem), c_int32, c_int32, c_int, c_void_p]),
     "mphsir_pack_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "mphsir_multi_copy": (c_int, [c_void_p, c_int32, c_int64, c_void_p]),
+    "mphsir_l1_clamp_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
 }
 
 

@@ -516,7 +516,10 @@ class _Conv1x1(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_tok(dy2.contiguous(), pk["wT"]).reshape(x.shape)
-        dw = ops.gemm_tn(dy2.contiguous(), x2).reshape(w.shape) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            with ops.reduce_scope(leaf=True):          # w is a leaf: the sum joins the deferred parameter-gradient sums
+                dw = ops.gemm_tn(dy2.contiguous(), x2).reshape(w.shape)
         return dx, dw, None
 
 
@@ -551,11 +554,12 @@ class _Conv3x3(torch.autograd.Function):
             dx = ops.conv3x3_tok(dyp, pk["bwd"])
             dx = dx if dx.shape[-1] == Cin else dx[..., :Cin].contiguous()
         if ctx.needs_input_grad[1]:
-            if dyp.dtype in (torch.bfloat16, torch.float16):      # the gather happens inside the token-reduction GEMM
-                g = ops.conv3x3_wgrad(dyp.reshape(-1, Co32), xp)[:Cout]
+            if dyp.dtype in (torch.bfloat16, torch.float16):      # the gather happens inside the token-reduction GEMM; the
+                with ops.reduce_scope(leaf=True):                 # ordered sum writes the (Cout, Cin, 3, 3) layout (w is a leaf)
+                    dw = ops.conv3x3_wgrad(dyp.reshape(-1, Co32), xp, cout=Cout, cin=Cin)
             else:
                 g = ops.gemm_tn(dyp.reshape(-1, Co32), ops.im2col3x3(xp))[:Cout]
-            dw = g.reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
+                dw = g.reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
         return dx, dw, None
 
 

@@ -88,7 +88,82 @@ __global__ __launch_bounds__(256) void pack_gather_kernel(const float* arena, co
     }
 }
 
+// multi_copy: the gradient hand-over.  autograd leaves ~370 freshly allocated fp32 gradient tensors; each goes to its slot of the flat
+// gradient arena.  (torch._foreach_copy_ took 11 launches of its multi-tensor kernel, 0.2 ms per step.)  One launch: the table --
+// rows {src, dst, n floats, first block} in DEVICE memory -- is searched by block index; a block moves up to 4096 floats.
+constexpr int MC_BLOCK = 4096;
+__global__ __launch_bounds__(256) void multi_copy_kernel(const long* __restrict__ table, int nseg) {
+    const long b = blockIdx.x;
+    int lo = 0, hi = nseg - 1;                               // the last row whose first block is <= b (wave-uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[4 * mid + 3] <= b) lo = mid; else hi = mid - 1;
+    }
+    const float* src = reinterpret_cast<const float*>(table[4 * lo]);
+    float* dst = reinterpret_cast<float*>(table[4 * lo + 1]);
+    const long n = table[4 * lo + 2], e0 = (b - table[4 * lo + 3]) * MC_BLOCK;
+    const long e1 = e0 + MC_BLOCK < n ? e0 + MC_BLOCK : n;
+    if ((((unsigned long)src | (unsigned long)dst) & 15) == 0) {
+        for (long e = e0 + 4 * threadIdx.x; e + 4 <= e1; e += 1024) *reinterpret_cast<f32x4*>(dst + e) = *reinterpret_cast<const f32x4*>(src + e);
+        for (long e = e0 + ((e1 - e0) & ~3L) + threadIdx.x; e < e1; e += 256) dst[e] = src[e];
+    } else {
+        for (long e = e0 + threadIdx.x; e < e1; e += 256) dst[e] = src[e];
+    }
+}
+
+// l1_clamp_loss: the training loss of the reference (train.py:58-61: clamp(restored, 0, 1), nn.L1Loss) and its gradient in one
+// pass: part[block] = sum |clamp(y) - c| / n over the block's elements, g = sign(clamp(y) - c) * [0 <= y <= 1] / n (clamp's
+// autograd passes the gradient where 0 <= y <= 1, bounds included; sign(0) = 0).  The caller sums the partials in order.
+__global__ __launch_bounds__(256) void l1_clamp_loss_kernel(const float* __restrict__ y, const float* __restrict__ c, float* __restrict__ g,
+                                                            float* __restrict__ part, long n, float inv_n) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const long stride = (long)gridDim.x * 1024;
+    for (long e = (long)blockIdx.x * 1024 + 4 * threadIdx.x; e < n; e += stride) {
+        if (e + 4 <= n) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e), cv = *reinterpret_cast<const f32x4*>(c + e);
+            f32x4 gv;
+            for (int i = 0; i < 4; ++i) {
+                const float d = fminf(fmaxf(yv[i], 0.f), 1.f) - cv[i];
+                acc += fabsf(d);
+                gv[i] = (yv[i] >= 0.f && yv[i] <= 1.f) ? (d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f)) : 0.f;
+            }
+            if (g) *reinterpret_cast<f32x4*>(g + e) = gv;
+        } else {
+            for (long k = e; k < n; ++k) {
+                const float d = fminf(fmaxf(y[k], 0.f), 1.f) - c[k];
+                acc += fabsf(d);
+                if (g) g[k] = (y[k] >= 0.f && y[k] <= 1.f) ? (d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f)) : 0.f;
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane_id() == 0) red[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+}
+
 }  // namespace mphsir
+
+extern "C" int mphsir_multi_copy(const int64_t* table_dev, int32_t nseg, int64_t total_blocks, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(table_dev && nseg > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "multi_copy: bad arguments");
+    static_assert(sizeof(long) == sizeof(int64_t), "table rows are 64-bit");
+    MPHSIR_LAUNCH(MPHSIR_K_MULTI_COPY, multi_copy_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                  reinterpret_cast<const long*>(table_dev), (int)nseg);
+    return MPHSIR_OK;
+}
+
+extern "C" int mphsir_l1_clamp_loss(const float* y, const float* clean, float* grad, float* part, int64_t n, int32_t nblocks, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(y && clean && part && n > 0 && nblocks > 0 && nblocks <= 65535, "l1_clamp_loss: bad arguments");
+    MPHSIR_REQUIRE(aligned16(y) && aligned16(clean) && (grad == nullptr || aligned16(grad)), "l1_clamp_loss: 16-byte alignment required");
+    MPHSIR_LAUNCH(MPHSIR_K_L1_LOSS, l1_clamp_loss_kernel, dim3((unsigned)nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                  y, clean, grad, part, (long)n, 1.0f / (float)n);
+    return MPHSIR_OK;
+}
 
 extern "C" int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, void* stream) {
     using namespace mphsir;

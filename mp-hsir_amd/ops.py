@@ -261,6 +261,81 @@ def pack_gather(arena, index, dtype, out=None):
     return out
 
 
+class MultiCopy:
+    """dsts[i].copy_(srcs[i]) for lists of contiguous fp32 tensors in ONE launch (mphsir_multi_copy): the table of pointers is
+    written into a pinned host buffer (a small ring of them: an eager caller may run a step ahead of the GPU) and copied to the
+    device on the launch stream -- under hipGraph capture that copy is a node that re-reads the same pinned rows on every replay,
+    and the captured pointers stay valid because a graph's allocations live in its private pool."""
+    BLOCK = 4096
+
+    def __init__(self, device, capacity, ring=4):
+        self.device, self.capacity, self.ring = device, capacity, ring
+        self.host = [torch.empty((capacity, 4), dtype=torch.int64).pin_memory() if device.type == "cuda" else torch.empty((capacity, 4), dtype=torch.int64)
+                     for _ in range(ring)]
+        self.dev = [torch.empty((capacity, 4), dtype=torch.int64, device=device) for _ in range(ring)]
+        self.events = [None] * ring
+        self.turn = 0
+        self.captured = []        # (pinned, device) table pairs that captured graphs read on every replay: never reused
+
+    def __call__(self, dsts, srcs):
+        n = len(dsts)
+        if n == 0:
+            return
+        assert n <= self.capacity
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            h = torch.empty((n, 4), dtype=torch.int64).pin_memory()
+            dv = torch.empty((n, 4), dtype=torch.int64, device=self.device)
+            self.captured.append((h, dv))
+        else:
+            k = self.turn
+            self.turn = (k + 1) % self.ring
+            if self.events[k] is not None:
+                self.events[k].synchronize()                  # the launch that last read this pinned buffer has fetched it
+            h, dv = self.host[k], self.dev[k]
+        rows, blk = [], 0
+        for d, s_ in zip(dsts, srcs):
+            ne = d.numel()
+            rows.append((s_.data_ptr(), d.data_ptr(), ne, blk))
+            blk += (ne + self.BLOCK - 1) // self.BLOCK
+        h[:n] = torch.tensor(rows, dtype=torch.int64)
+        dv[:n].copy_(h[:n], non_blocking=True)
+        _lib.check(_lib.load().mphsir_multi_copy(_p(dv), n, blk, _stream(dv)), "multi_copy")
+        if self.device.type == "cuda" and not capturing:
+            self.events[k] = torch.cuda.Event()
+            self.events[k].record()
+        _acct("multi_copy", 0.0, 8.0 * sum(d.numel() for d in dsts))
+
+
+class _L1ClampLoss(torch.autograd.Function):
+    """mean |clamp(y, 0, 1) - clean| with its gradient from the same pass (mphsir_l1_clamp_loss; train.py:58-61)"""
+
+    @staticmethod
+    def forward(ctx, y, clean):
+        lib = _lib.load()
+        _check(y, clean)
+        y, clean = y.contiguous(), clean.contiguous()
+        assert y.dtype == torch.float32 and clean.dtype == torch.float32 and y.shape == clean.shape
+        n = y.numel()
+        nblk = max(1, min(1024, (n + 1023) // 1024))
+        need = ctx.needs_input_grad[0]
+        g = torch.empty_like(y) if need else None
+        part = torch.empty((nblk, 1), dtype=torch.float32, device=y.device)
+        _lib.check(lib.mphsir_l1_clamp_loss(_p(y), _p(clean), _p(g), _p(part), n, nblk, _stream(y)), "l1_clamp_loss")
+        _acct("l1_clamp_loss", 4.0 * n, 4.0 * n * (3 if need else 2))
+        ctx.g = g
+        return reduce_parts(part, immediate=True).reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        g, ctx.g = ctx.g, None
+        return g.mul_(dloss), None
+
+
+def l1_clamp_loss(y, clean):
+    return _L1ClampLoss.apply(y, clean)
+
+
 def _rows(t):
     """(rows, ld) of a 2-D view whose last dim is contiguous."""
     assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D view"
@@ -1126,9 +1201,11 @@ def conv3x3_tok(x, wp):
     return y
 
 
-def conv3x3_wgrad(dy2, x, nsplit=None):
-    """Weight gradient of conv3x3_tok without the im2col matrix: dy2 (M, Np), x (B,H,W,Cp) channels-last, M = B*H*W ->
-    fp32 (Np, 9*Cp) = sum_p dy2[p,:]^T [x[p+tap,:] for the 9 taps] (16-bit types; fp32: im2col3x3 + gemm_tn)."""
+def conv3x3_wgrad(dy2, x, nsplit=None, cout=None, cin=None):
+    """dy2 (M, Np) [Np % 8 == 0], x (B,H,W,Cp) contiguous [Cp % 8 == 0], 16-bit: the weight gradient of a dense 3x3 conv with the
+    im2col gather inside the token-reduction GEMM.  -> fp32 (Np, 9*Cp) in (tap, channel) column order; with cout / cin given:
+    the nn.Conv2d layout (cout, cin, 3, 3) -- the padded rows / channels dropped and (tap, channel) transposed inside the ordered
+    partial reduction itself (no slice / permute / contiguous launches; deferred like every parameter-gradient sum)."""
     lib = _lib.load()
     _check(dy2, x)
     B, H, W, Cp = x.shape
@@ -1142,7 +1219,14 @@ def conv3x3_wgrad(dy2, x, nsplit=None):
                "conv3x3_wgrad")
     _acct("gemm_tn", 2.0 * M * Np * 9 * Cp, M * (Np + Cp) * x.element_size())
     _acct("gemm_tn:partials", 0.0, part.numel() * 4.0)
-    return reduce_parts(part, batched=True, immediate=True)[0]
+    if cout is None:
+        return reduce_parts(part, batched=True, immediate=True)[0]
+    assert cout <= Np and cin <= Cp
+    out = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    # one segment: batch = output channel, rows = taps, columns = input channels; out[co][ci][tap]: row pitch 1, column stride 9
+    _submit(dict(src=part.data_ptr(), dst=out.data_ptr(), n=cin, stride=Np * 9 * Cp, sbs=9 * Cp, dbs=cin * 9, nsplit=nsplit, nbatch=cout,
+                 rows=9, dcs=9, src_ld=Cp, dst_ld=1, keep=(part, out)), False)
+    return out
 
 
 def im2col3x3(x):

@@ -408,6 +408,47 @@ def check_gated_mlp_bwd(dev, dtype, C, hid, variant=0):
     assert rel_l2(dln[0], lw.grad) < tol and rel_l2(dln[1], lb.grad) < tol
 
 
+def check_l1_clamp_loss(dev):
+    """mphsir_l1_clamp_loss (loss + gradient in one pass) vs the oracle's clamp + L1 and torch autograd through it (train.py:58-61),
+    incl. values exactly on the clamp bounds / equal to the target, a length that is not a multiple of 4, and an upstream factor."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    for shape in ((2, 8, 32, 32), (1, 3, 5, 7), (4, 31, 64, 64)):
+        y = (rnd(shape, 901) * 0.7 + 0.5)
+        c = rnd(shape, 902).abs().clamp(0, 1)
+        with torch.no_grad():
+            y.view(-1)[:4] = torch.tensor([0.0, 1.0, -0.0, float(c.view(-1)[3])])
+        y.requires_grad_(True)
+        loss = ops.l1_clamp_loss(y, c)
+        (loss * 3.0).backward()
+        yr = y.detach().double().cpu().requires_grad_(True)
+        lr = O.l1_after_clamp(yr, c.double().cpu())
+        (lr * 3.0).backward()
+        assert abs(float(loss.detach()) - float(lr.detach())) < 1e-6 * abs(float(lr.detach())) + 1e-9
+        assert rel_l2(y.grad, yr.grad) < 1e-6 and float((y.grad.double().cpu() - yr.grad).abs().max()) < 1e-7 * 3.0 / y.numel() + 1e-12
+
+
+def check_multi_copy(dev):
+    """mphsir_multi_copy: many fp32 tensors -> their arena slots in one launch: lengths around the 4096-float block, a source that
+    is not 16-byte aligned, repeated use of the table ring."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    d = torch.device(dev)
+    lens = (5, 4096, 4097, 12, 100000, 3, 8192, 1)
+    arena = torch.zeros(sum((n + 3) // 4 * 4 for n in lens) + 8, device=d)
+    dsts, o = [], 0
+    for n in lens:
+        dsts.append(arena[o:o + n])
+        o += (n + 3) // 4 * 4
+    mc = ops.MultiCopy(d, 16, ring=2)
+    for rep in range(5):
+        srcs = [rnd((n,), 910 + rep * 16 + i) for i, n in enumerate(lens)]
+        srcs[3] = rnd((16,), 990 + rep)[1:13]
+        mc(dsts, srcs)
+        for a, b in zip(dsts, srcs):
+            assert torch.equal(a.cpu(), b.cpu())
+
+
 class tn_form:
     """`with tn_form(f):` runs the 16-bit big-tile token-reduction GEMMs in form f (1 = transposed-read kernel, 2 = ring form)."""
 
@@ -470,6 +511,12 @@ def check_conv3x3(dev, dtype, B, H, W, Cin, Cout):
         assert rel_l2(dw2, dw) < 1e-5
         dw3 = ops.conv3x3_wgrad(dyp.reshape(-1, Co32), xp)[:Cout].reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
         assert rel_l2(dw3, dw) < 1e-5
+        # the nn.Conv2d layout straight out of the ordered partial reduction (padding dropped, taps transposed there), immediate and
+        # deferred to the end of a reduce_scope: bitwise the slice / permute of the plain form
+        dw4 = ops.conv3x3_wgrad(dyp.reshape(-1, Co32), xp, nsplit=3, cout=Cout, cin=Cin)
+        with ops.reduce_scope():
+            dw5 = ops.conv3x3_wgrad(dyp.reshape(-1, Co32), xp, nsplit=3, cout=Cout, cin=Cin)
+        assert dw4.is_contiguous() and torch.equal(dw4.cpu(), dw2.cpu()) and torch.equal(dw5.cpu(), dw2.cpu())
 
 
 def check_reduce_parts(dev):

@@ -138,6 +138,14 @@ def test_conv3x3(dtype, B, H, W, Cin, Cout, form):
         K.check_conv3x3("cpu", dtype, B, H, W, Cin, Cout)
 
 
+def test_l1_clamp_loss():
+    K.check_l1_clamp_loss("cpu")
+
+
+def test_multi_copy():
+    K.check_multi_copy("cpu")
+
+
 def test_reduce_parts():
     K.check_reduce_parts("cpu")
 

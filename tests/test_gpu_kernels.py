@@ -189,6 +189,14 @@ def test_conv3x3(dtype, B, H, W, Cin, Cout, form):
         K.check_conv3x3("cuda", dtype, B, H, W, Cin, Cout)
 
 
+def test_l1_clamp_loss():
+    K.check_l1_clamp_loss("cuda")
+
+
+def test_multi_copy():
+    K.check_multi_copy("cuda")
+
+
 def test_reduce_parts():
     K.check_reduce_parts("cuda")
 
