@@ -123,17 +123,66 @@ class reduce_scope:
         global _SCOPE
         _SCOPE = self.prev
         if exc[0] is None:
-            _flush_gemms(self.gemms)            # the deferred weight-gradient GEMMs, grouped ...
-            if self.leaf and _DEFERRED is not None:
+            if self.leaf and _DEFERRED is not None and DW_SIDE and _dw_side(self):
+                pass                            # weight-gradient branch: issued beside the data-gradient chain (see _dw_side)
+            elif self.leaf and _DEFERRED is not None:
+                _flush_gemms(self.gemms)
                 # ... their sums later, with everybody else's.  The output is kept alive through a detached alias: the tensor
                 # object itself must stay uniquely referenced so that AccumulateGrad adopts it instead of cloning (= reading) it
                 for g in self.segs:
                     g["keep"] = (g["keep"][0], g["keep"][1].detach())
                 _DEFERRED.extend(self.segs)
             else:
+                _flush_gemms(self.gemms)        # the deferred weight-gradient GEMMs, grouped ...
                 _flush(self.segs)               # ... then the ordered sums of everything they (and others) wrote
         self.segs, self.gemms = [], []
         return False
+
+
+# The parameter-gradient work of a backward function -- its grouped token-reduction GEMMs and the ordered sums of their partials --
+# feeds nothing but the optimizer.  Inside the engine's backward (deferred_reductions) it can leave the launch stream: DW_SIDE = 1
+# issues the sums, DW_SIDE = 2 the GEMMs and the sums, on a second stream forked at the end of the backward function and joined
+# only where gradients are read (end of the backward pass / a bucket hook) -- a parallel branch of the captured graph that fills
+# the CUs the small launches of the lower pyramid levels leave idle, reading the partials while they are still in the Infinity
+# Cache.  Every tensor involved stays referenced until the join (nothing is recycled under the branch).
+DW_SIDE = int(os.environ.get("MPHSIR_DW_SIDE", "2"))
+_DW_STREAM = {}
+_DW_KEEP = []
+
+
+def _dw_side(scope):
+    like = None
+    for g in scope.gemms + scope.segs:
+        like = g["keep"][0]
+        break
+    if like is None or not like.is_cuda:
+        return False
+    dev = like.device
+    st = _DW_STREAM.get(dev)
+    if st is None:
+        st = _DW_STREAM[dev] = torch.cuda.Stream(dev)
+    main = torch.cuda.current_stream(dev)
+    for g in scope.segs:                # AccumulateGrad must find the output uniquely referenced: keep a detached alias
+        g["keep"] = (g["keep"][0], g["keep"][1].detach())
+    if DW_SIDE >= 2:
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            _flush_gemms(scope.gemms)
+            _flush(scope.segs)
+    else:
+        _flush_gemms(scope.gemms)
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            _flush(scope.segs)
+    _DW_KEEP.append((dev, [g["keep"] for g in scope.gemms], [g["keep"] for g in scope.segs]))
+    return True
+
+
+def _dw_join():
+    if _DW_KEEP:
+        for dev in {k[0] for k in _DW_KEEP}:
+            torch.cuda.current_stream(dev).wait_stream(_DW_STREAM[dev])
+        del _DW_KEEP[:]
 
 
 class deferred_reductions:
@@ -154,6 +203,7 @@ class deferred_reductions:
         segs, _DEFERRED = _DEFERRED, self.prev
         if exc[0] is None:
             _flush(segs)
+        _dw_join()
         return False
 
 
@@ -164,6 +214,7 @@ def flush_deferred():
         segs = _DEFERRED[:]
         del _DEFERRED[:]
         _flush(segs)
+    _dw_join()
 
 
 def _flush_gemms(gemms):
@@ -275,7 +326,12 @@ class MultiCopy:
         self.dev = [torch.empty((capacity, 4), dtype=torch.int64, device=device) for _ in range(ring)]
         self.events = [None] * ring
         self.turn = 0
-        self.captured = []        # (pinned, device) table pairs that captured graphs read on every replay: never reused
+        # table pairs for calls made under hipGraph capture: a captured copy node re-reads its pinned rows on every replay, so such a
+        # pair is never reused -- and pinned memory cannot be allocated while a stream is capturing, so they are set aside here
+        pin = device.type == "cuda"
+        self.for_capture = [(torch.empty((capacity, 4), dtype=torch.int64).pin_memory() if pin else torch.empty((capacity, 4), dtype=torch.int64),
+                             torch.empty((capacity, 4), dtype=torch.int64, device=device)) for _ in range(24)]
+        self.captured = []
 
     def __call__(self, dsts, srcs):
         n = len(dsts)
@@ -284,8 +340,10 @@ class MultiCopy:
         assert n <= self.capacity
         capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         if capturing:
-            h = torch.empty((n, 4), dtype=torch.int64).pin_memory()
-            dv = torch.empty((n, 4), dtype=torch.int64, device=self.device)
+            if not self.for_capture:          # more captured hand-overs than tables set aside: the framework's multi-tensor copy
+                torch._foreach_copy_(list(dsts), list(srcs))
+                return
+            h, dv = self.for_capture.pop()
             self.captured.append((h, dv))
         else:
             k = self.turn

@@ -526,11 +526,15 @@ def test_fused_gdfn_in_the_no_grad_forward():
     assert e_f < 4e-2 and e_f < e_c * 1.25 + 1e-4, (e_f, e_c)
 
 
-def test_deferred_parameter_gradient_sums_are_bitwise_the_immediate_ones():
+@pytest.mark.parametrize("dw_side", [0, 1, 2])
+def test_deferred_parameter_gradient_sums_are_bitwise_the_immediate_ones(dw_side, monkeypatch):
     """The engine collects the partial-sum reductions of all parameter gradients of a backward pass and launches them together
-    (ops.deferred_reductions).  Every gradient must be bitwise what the per-function launches produce -- in particular no
-    gradient may be read (cloned by AccumulateGrad) before its sum has been launched."""
+    (ops.deferred_reductions; dw_side = 0) or issues them -- with (2) or without (1) the weight-gradient GEMMs -- on a second
+    stream beside the data-gradient chain.  Every gradient must be bitwise what the per-function launches produce -- in particular
+    no gradient may be read (cloned by AccumulateGrad) before its sum has been launched, and nothing may be recycled under the
+    side branch."""
     from mp_hsir_amd import ops
+    monkeypatch.setattr(ops, "DW_SIDE", dw_side)
     from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
     torch.manual_seed(11)
     net = MP_HSIR_Net(compute_dtype=torch.bfloat16, clip_prompt="surrogate").cuda().train()
@@ -558,6 +562,8 @@ def test_deferred_parameter_gradient_sums_are_bitwise_the_immediate_ones():
     assert ref.keys() == got.keys() and len(ref) > 600
     bad = [n for n in ref if not torch.equal(ref[n], got[n])]
     assert not bad, bad[:8]
+    if dw_side:
+        return
     launches = []
     orig = ops._flush
     ops._flush = lambda segs: (launches.append(len(segs)), orig(segs))[1]
