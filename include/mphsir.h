@@ -68,6 +68,9 @@ typedef struct mphsir_gemm_args {
     const float* gate;          /* [B*nW][N] fp32, epi 2 */
     const float* keep;          /* [B] fp32 DropPath factor (mask/keep_prob) or NULL */
     int32_t H, Wimg, shift;     /* image geometry for window(m), epi 2 */
+    int32_t form;               /* 0 = the library chooses; 1 = one workgroup per 64-token tile; 2 = ring form: persistent workgroups
+                                   that walk the token tiles, a loader wave streaming K-chunks by LDS-DMA ahead of four MFMA
+                                   waves (16-bit types, no LayerNorm prologue; ignored where it does not apply) */
 } mphsir_gemm_args;
 int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* stream);
 

@@ -400,6 +400,11 @@ def _rows(t):
     return t.shape[0], t.stride(0)
 
 
+# token GEMM kernel form (include/mphsir.h, mphsir_gemm_args.form): 0 = the library chooses (ring form for input-heavy shapes, K >= 3 N),
+# 1 = one workgroup per token tile, 2 = ring form wherever it applies
+TOK_FORM = int(os.environ.get("MPHSIR_TOK_FORM", "0"))
+
+
 def gemm_tok(x, w, bias=None, ln=None, epi=0, res=None, sa=None, gate=None, keep=None, geom=None, out=None):
     """Y = epi(pro(X) @ W^T).  x (M,K) row-major view; w (N,K) or per-sample (B,N,K) in x.dtype.
     ln = (weight, bias) fp32 -> LayerNorm prologue.  epi 0/1/2 as in include/mphsir.h.
@@ -429,6 +434,7 @@ def gemm_tok(x, w, bias=None, ln=None, epi=0, res=None, sa=None, gate=None, keep
     a.gate, a.keep = _p(gate), _p(keep)
     if geom is not None:
         a.H, a.Wimg, a.shift = geom
+    a.form = TOK_FORM
     _lib.check(lib.mphsir_gemm_tok(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gemm_tok")
     es = x.element_size()
     _acct("gemm_tok", 2.0 * M * N * K, (M * K + M * N * (1 + (res is not None) + (sa is not None))) * es + w.numel() * es)

@@ -37,6 +37,55 @@ def _use(dev):
     _DEV[0] = dev
 
 
+class tok_form:
+    """`with tok_form(f):` runs the token GEMMs in kernel form f (1 = workgroup per tile, 2 = persistent ring form where it applies)."""
+
+    def __init__(self, form):
+        self.form = form
+
+    def __enter__(self):
+        from mp_hsir_amd import ops
+        self.prev, ops.TOK_FORM = ops.TOK_FORM, self.form
+
+    def __exit__(self, *exc):
+        from mp_hsir_amd import ops
+        ops.TOK_FORM = self.prev
+        return False
+
+
+def check_gemm_tok_ring(dev, dtype, M, N, K, epi, per_sample=0, ldx=None, ldy=None):
+    """the ring form of the token GEMM (persistent workgroups, loader wave + LDS-DMA ring) against the workgroup-per-tile form
+    (bitwise: same products, same accumulation order per output) and the fp64 product: plain / residual / branch-sum epilogues,
+    per-sample weights, strided input and output views, K tails of 32, N tails, more tiles than workgroups and fewer."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    ldx, ldy = ldx or K, ldy or N
+    xw = rnd((M, ldx), 11, dtype)
+    x = xw[:, :K]
+    w = rnd((per_sample, N, K) if per_sample else (N, K), 12, dtype, K ** -0.5)
+    bias = rnd((N,), 13) if epi < 2 else None
+    res = rnd((M, N), 14, dtype) if epi else None
+    H = W_ = 16
+    sa = rnd((M, N), 15, dtype) if epi == 2 else None
+    gate = rnd((M // 64, N), 16) if epi == 2 else None
+    keep = (1.0 + 0.25 * rnd((M // (H * W_),), 17)) if epi == 2 else None
+    outs = []
+    for form in (1, 2):
+        yw = torch.zeros((M, ldy), dtype=dtype, device=x.device)
+        with tok_form(form):
+            ops.gemm_tok(x, w, bias=bias, epi=epi, res=res, sa=sa, gate=gate, keep=keep, geom=(H, W_, 4) if epi == 2 else None, out=yw[:, :N])
+        outs.append(yw)
+    assert torch.equal(outs[0].cpu(), outs[1].cpu()), rel_l2(outs[1], outs[0].double().cpu())
+    if epi < 2:
+        wd = w.double().cpu()
+        xd = x.double().cpu()
+        acc = torch.einsum("bnk,bck->bnc", xd.reshape(per_sample, M // per_sample, K), wd).reshape(M, N) if per_sample else xd @ wd.t()
+        ref = acc + bias.double().cpu() + (res.double().cpu() if epi else 0)
+        assert rel_l2(outs[1][:, :N], ref) < TOL[dtype]
+        if ldy > N:
+            assert float(outs[1][:, N:].abs().max()) == 0.0
+
+
 def check_gemm_tok(dev, dtype, M, N, K, ln, epi):
     _use(dev)
     from mp_hsir_amd import ops

@@ -19,6 +19,13 @@ def test_gemm_tok(dtype, M, N, K_, ln, epi):
     K.check_gemm_tok("cpu", dtype, M, N, K_, ln, epi)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K_,epi,ps,ldx,ldy", [(256, 64, 64, 0, 0, None, None), (512, 96, 96, 1, 0, 128, 104), (1024, 208, 160, 0, 4, None, 256),
+                                                    (512, 128, 64, 2, 2, None, None), (256, 272, 32, 0, 0, None, None), (768, 48, 224, 1, 3, 256, None)])
+def test_gemm_tok_ring(dtype, M, N, K_, epi, ps, ldx, ldy):
+    K.check_gemm_tok_ring("cpu", dtype, M, N, K_, epi, ps, ldx, ldy)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 def test_gemm_tok_per_sample_combine(dtype):
     K.check_gemm_tok_per_sample_combine("cpu", dtype)

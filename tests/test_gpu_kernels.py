@@ -31,6 +31,13 @@ def test_gemm_tok(dtype, M, N, K_, ln, epi):
     K.check_gemm_tok("cuda", dtype, M, N, K_, ln, epi)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K_,epi,ps,ldx,ldy", [(256, 64, 64, 0, 0, None, None), (512, 96, 96, 1, 0, 128, 104), (1024, 208, 160, 0, 4, None, 256),
+                                                    (512, 128, 64, 2, 2, None, None), (256, 272, 32, 0, 0, None, None), (768, 48, 224, 1, 3, 256, None), (131072, 256, 256, 0, 32, 256, 384), (131072, 128, 384, 1, 0, 384, 128), (131072, 128, 128, 2, 32, 128, 128), (65536, 352, 128, 0, 0, None, None), (70016, 64, 192, 1, 0, None, None)])
+def test_gemm_tok_ring(dtype, M, N, K_, epi, ps, ldx, ldy):
+    K.check_gemm_tok_ring("cuda", dtype, M, N, K_, epi, ps, ldx, ldy)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 def test_gemm_tok_per_sample_combine(dtype):
     K.check_gemm_tok_per_sample_combine("cuda", dtype)
