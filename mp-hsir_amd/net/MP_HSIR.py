@@ -470,13 +470,21 @@ class MP_HSIR_Net(nn.Module):                                                   
         clip, w = self.text_prompt(inp_img, task_id)
         x_in = inp_img.to(dt).permute(0, 2, 3, 1).contiguous()                     # channels-last from here on
         e1 = self.encoder_level1(AG.conv3x3(x_in, self.patch_embed.proj))
+        # the prompt branch of each level (ref :827, :835 -- there in program order behind the stages below) is forked where its input
+        # exists and joined where the decoder of that level reads it: a parallel branch of the captured graph (inference only,
+        # see ops.PROMPT_SIDE)
+        fork = ops.PROMPT_SIDE and not torch.is_grad_enabled()
+        with ops.side_stream(e1, fork, "prompt1") as br1:
+            f1 = self.fusion1(e1, self.prompt1(e1, clip, w))
         e2 = self.encoder_level2(AG.pixel_unshuffle2(AG.conv3x3(e1, self.down1_2.body[0])))
+        with ops.side_stream(e2, fork, "prompt2") as br2:
+            f2 = self.fusion2(e2, self.prompt2(e2, clip, w))
         lat = self.latent(AG.pixel_unshuffle2(AG.conv3x3(e2, self.down2_3.body[0])))
         d2_in = AG.pixel_shuffle2(AG.conv3x3(lat, self.up3_2.body[0]))
-        f2 = self.fusion2(e2, self.prompt2(e2, clip, w))
+        br2.join(f2)
         d2 = self.decoder_level2(AG.conv1x1(torch.cat([d2_in, f2], -1), self.reduce_chan_level2))
         d1_in = AG.pixel_shuffle2(AG.conv3x3(d2, self.up2_1.body[0]))
-        f1 = self.fusion1(e1, self.prompt1(e1, clip, w))
+        br1.join(f1)
         r = self.refinement(self.decoder_level1(torch.cat([d1_in, f1], -1)))
         out = AG.conv3x3(r, self.output).permute(0, 3, 1, 2).to(inp_img.dtype) + inp_img
         return out

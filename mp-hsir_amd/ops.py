@@ -56,6 +56,13 @@ _SIDE = {}
 # stream's pool, every branch starts by waiting for the launch stream (a reused block is ordered after its last consumer
 # there), and the caller holds the inputs until the join.
 SIDE_BRANCH = os.environ.get("MPHSIR_SIDE_BRANCH", "1") == "1"
+# the prompt modules of a pyramid level (TVSP + PromptFusion: prompt1 / fusion1 on e1, prompt2 / fusion2 on e2) feed the DECODER of that
+# level only: issued on streams of their own they run beside the encoder / latent / decoder stages below them, whose launches leave
+# part of the chip idle.  Inference only (512x512 forward 7.32 -> 6.97 ms, batch-16 forward 3.70 -> 3.38 ms): in training the branches
+# bought nothing (21.5 ms either way) and, together with the weight-gradient branch below, a two-step AdamW check against the
+# reference failed in graph mode on one prompt parameter -- an ordering between the three streams that was not tracked down, so
+# the combination is not used
+PROMPT_SIDE = os.environ.get("MPHSIR_PROMPT_SIDE", "1") == "1"
 
 
 class side_stream:
@@ -64,15 +71,15 @@ class side_stream:
     (record_stream).  Works under hipGraph capture (fork/join from the capturing stream = parallel graph branches).
     No-op on CPU tensors (emulator) or when disabled."""
 
-    def __init__(self, like, enabled=True):
+    def __init__(self, like, enabled=True, name="gate"):
         self.on = enabled and like.is_cuda
         self.ctx = None
         if self.on:
             dev = like.device
             self.main = torch.cuda.current_stream(dev)
-            self.side = _SIDE.get(dev)
+            self.side = _SIDE.get((dev, name))         # one stream per user: a branch never queues behind another user's work
             if self.side is None:
-                self.side = _SIDE[dev] = torch.cuda.Stream(dev)
+                self.side = _SIDE[(dev, name)] = torch.cuda.Stream(dev)
 
     def __enter__(self):
         if self.on:
@@ -178,11 +185,15 @@ def _dw_side(scope):
     return True
 
 
-def _dw_join():
+def _dw_join(final=True):
+    """the stream that reads gradients waits for the weight-gradient branch.  Only the FINAL join (the end of the backward pass, on
+    the stream backward() was called from) releases the tensors and forgets the branch: a join in the middle -- a backward function
+    that has to read a sum, possibly running on a prompt module's own stream -- makes ITS stream wait and leaves the rest as it is."""
     if _DW_KEEP:
         for dev in {k[0] for k in _DW_KEEP}:
             torch.cuda.current_stream(dev).wait_stream(_DW_STREAM[dev])
-        del _DW_KEEP[:]
+        if final:
+            del _DW_KEEP[:]
 
 
 class deferred_reductions:
@@ -214,7 +225,7 @@ def flush_deferred():
         segs = _DEFERRED[:]
         del _DEFERRED[:]
         _flush(segs)
-    _dw_join()
+    _dw_join(final=False)
 
 
 def _flush_gemms(gemms):
