@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_group_kernel(TnGroupDev g) 
 // accumulators; at the end group 1's tile is added to group 0's through LDS (always in that order: deterministic) and the sum
 // leaves as whole 16-byte row chunks: half the partial tiles per launch of two 4-wave workgroups.  Rows outside the token range /
 // the image (conv weight gradient) and columns outside the matrix are fetched from a page of zeros.
-// Measured on MI355X (tools/bench_tn.py, tools/lab/ring_lab.hip): a bare DMA ring streams 5.9 TB/s with one
+// Measured on MI355X (tools/bench/bench_tn.py, tools/lab/ring_lab.hip): a bare DMA ring streams 5.9 TB/s with one
 // workgroup per CU, and problems with ONE output tile run 1.2-1.7x faster in this form (dWproj 64x64 at M = 131072: 19.1 -> 11.5
 // us, 192x64: 23.3 -> 16.6, 128x128: 27.2 -> 21.0).  Problems with several tiles do NOT: the tiles of a token range re-read the
 // shared operand (dWqkv 384x128: 134 MB from HBM but 201 MB into the CUs), the kernel above already moves those CU-side bytes at

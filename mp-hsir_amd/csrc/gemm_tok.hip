@@ -393,7 +393,7 @@ static int launch_gemm_nw(const GemmDev& d, hipStream_t s) {
 }
 
 // Where the ring form is taken: 16-bit types, no LayerNorm prologue; by default (form 0) only for the shapes it measured faster on
-// MI355X (tools/bench_gemm_shapes.py, MPHSIR_TOK_FORM=1 / 2): the INPUT-heavy ones, K >= 3 N with at most 128 outputs and at least
+// MI355X (tools/bench/bench_gemm_shapes.py, MPHSIR_TOK_FORM=1 / 2): the INPUT-heavy ones, K >= 3 N with at most 128 outputs and at least
 // 512 token tiles (K = 384 -> 128: 38.9 -> 33.9 us at M = 131072, 12.7 -> 10.9 at 32768; K = 704 -> 128: 61.9 -> 53.5 / 21.3 ->
 // 16.3).  Output-heavy shapes lose (128 -> 352: 41 -> 59 us; 64 -> 192: 17 -> 26): a persistent workgroup stores its tile while its
 // MFMA waves wait, three independent workgroups per CU overlap their stores with each other's loads.

@@ -1088,7 +1088,7 @@ def ln_bwd_tok(x2, dxn, dres, ln_w, ln_b):
 TN_GROUPED = True          # weight-gradient GEMMs of a backward function in one launch
 TN_BIG_TILES = True        # bf16 token-reduction GEMMs use the transposed-LDS-read kernel (ds_read_b64_tr_b16)
 # 16-bit big-tile kernel: 1 = transposed-read kernel (256 threads, ~2 workgroups per CU), 2 = its ring form (512 threads, one per CU),
-# 0 = per problem: the ring form where it measured faster -- ONE output tile, unbatched, >= 65536 tokens (tools/bench_tn.py) -- else 1
+# 0 = per problem: the ring form where it measured faster -- ONE output tile, unbatched, >= 65536 tokens (tools/bench/bench_tn.py) -- else 1
 TN_FORM = int(os.environ.get("MPHSIR_TN_FORM", "0"))
 TN_RING_WGS = 256          # ring form: workgroups per launch aimed at (one per CU)
 TN_BIG_ROUNDS = 1.0        # ... and aim for this many full rounds of resident workgroups (re-measured with the partial sums deferred: 0.5 / 0.75 / 1 / 2 -> 22.48 / 22.33 / 22.37 / 22.47 ms per step)

@@ -40,7 +40,7 @@ def test_run_to_run_determinism():
     net = M.build_net(c["cfg"], "cuda", torch.bfloat16)
     x, t = degraded.cuda(), torch.tensor(c["task"]).cuda()
     with torch.no_grad():
-        net(x, t)                      # warm-up: MIOpen picks its dense-conv algorithms on first use
+        net(x, t)                      # warm-up (packed-weight caches are built on first use)
         a, b = net(x, t), net(x, t)
     assert torch.equal(a, b)
 

@@ -1,6 +1,6 @@
 """Diagnostic: a few big gemm_tok shapes in isolation (MPHSIR_GEMM_NW selects the column tiles per workgroup)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mp_hsir_amd import ops
 dev = "cuda"
 for (M, N, K, epi) in [(131072, 384, 128, 0), (131072, 128, 384, 0), (131072, 128, 384, 1), (131072, 192, 64, 0), (131072, 256, 256, 0), (131072, 704, 128, 0)]:

@@ -4,7 +4,7 @@ import collections
 import sys
 import os
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mp_hsir_amd import ops
 from mp_hsir_amd.data import SyntheticPatchSource
 from mp_hsir_amd.engine import DataParallelEngine

@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mp_hsir_amd import ops
 dev = "cuda"; dt = torch.bfloat16
 for (M, C, hid) in [(131072, 128, 340), (32768, 128, 340), (8192, 256, 680), (131072, 64, 170)]:

@@ -2,7 +2,7 @@
 import os
 import sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mp_hsir_amd import ops
 
 dev = "cuda"

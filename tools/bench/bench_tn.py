@@ -1,7 +1,7 @@
 """gemm_tn forms at the shapes of the training step (bf16): transposed-read kernel (form 1) vs ring form (form 2), the GEMM launch
 alone (reduce=False) and with its partial reduction."""
 import sys, warnings, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

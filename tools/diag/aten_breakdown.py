@@ -3,7 +3,7 @@ import os
 import sys
 import torch
 from torch.profiler import ProfilerActivity, profile
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mp_hsir_amd.data import SyntheticPatchSource
 from mp_hsir_amd.engine import DataParallelEngine
 from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net

@@ -1,7 +1,7 @@
 """diagnostic (GPU box): every token-reduction GEMM launch (single, batched, grouped) of one eager training step with its problems and
 its own HIP-event time, largest first.  python tools/diag_tn.py [form]"""
 import sys, os, warnings, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net

@@ -2,7 +2,7 @@
 launches a kernel, with the innermost package frames.  Runs on the GPU box (full net) or here on the CPU-emulated library (tiny net):
     python tools/glue_sites.py [emu]"""
 import collections, os, sys, traceback, warnings
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 warnings.filterwarnings("ignore")

@@ -1,6 +1,6 @@
 """one token-reduction GEMM shape a few times (for tools/pmc_kernel.sh): python tools/run_tn_once.py M N1 N2 form [ring_wgs]"""
 import sys, os, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

@@ -7,7 +7,7 @@ import glob
 import os
 import sys
 from collections import defaultdict
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from summarize_profiles import short
 
 

@@ -1,6 +1,6 @@
 # SQ counters of ONE kernel on its own: bash tools/pmc_kernel.sh <kernel-name substring> <python tool + args ...>   (GPU box, through gpurun)
-#   bash tools/pmc_kernel.sh win_attn_kernel tools/run_win_once.py 128 2 512
-#   bash tools/pmc_kernel.sh gated_mlp_bwd tools/run_mlp_bwd_once.py 128 340 131072
+#   bash tools/pmc_kernel.sh win_attn_kernel tools/pmc/run_win_once.py 128 2 512
+#   bash tools/pmc_kernel.sh gated_mlp_bwd tools/pmc/run_mlp_bwd_once.py 128 340 131072
 # Three passes (the counters do not fit one); prints the LAST launch's value of every counter.  Values are quad-cycles / instruction counts
 # summed over the chip; per wave = value / SQ_WAVES.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
