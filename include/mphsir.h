@@ -53,6 +53,10 @@ int mphsir_device_arch(char* buf, int n);
  *   0  Y = acc (+ bias)
  *   1  Y = R + acc (+ bias)                                      residual add (:282,286,476,477)
  *   2  Y = R + keep[b] * (SA * gate[window(m)] + acc)            PGSSTB branch sum (:715-718)
+ *   3  LayerNorm backward behind a data-gradient GEMM (autograd of norm1 -> qkv, :667, :193): rows m in WINDOW-token order
+ *      (tile m / 64 = one 8x8 window of the shifted frame), acc = d_xn;  Y[pixel(m)] = SA[pixel(m)] + LN_backward(acc; x =
+ *      R[pixel(m)], weight = gate[N]) in IMAGE order, part[m / 64][2][N] = this window's partials of d(LN weight), d(LN bias).
+ *      N <= 256 (the whole row in one tile), no bias, no prologue.  Replaces the d_xn store + mphsir_ln_bwd_win + its re-read.
  * M % 64 == 0, N % 16 == 0, K % 32 == 0; ldx/ldy/ldr/ldsa in elements, multiples of 16 bytes.
  * w_batch_stride (elements) != 0 selects W + (m / rows_per_batch) * w_batch_stride per sample.   */
 typedef struct mphsir_gemm_args {
@@ -67,10 +71,11 @@ typedef struct mphsir_gemm_args {
     const void* SA; int64_t ldsa;
     const float* gate;          /* [B*nW][N] fp32, epi 2 */
     const float* keep;          /* [B] fp32 DropPath factor (mask/keep_prob) or NULL */
-    int32_t H, Wimg, shift;     /* image geometry for window(m), epi 2 */
+    int32_t H, Wimg, shift;     /* image geometry for window(m), epi 2 and 3 */
     int32_t form;               /* 0 = the library chooses; 1 = one workgroup per 64-token tile; 2 = ring form: persistent workgroups
                                    that walk the token tiles, a loader wave streaming K-chunks by LDS-DMA ahead of four MFMA
                                    waves (16-bit types, no LayerNorm prologue; ignored where it does not apply) */
+    float* part;                /* epi 3: [M/64][2][N] fp32 */
 } mphsir_gemm_args;
 int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* stream);
 

@@ -21,7 +21,7 @@ class GemmArgs(ctypes.Structure):
                 ("rows_per_batch", c_int64), ("bias", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p),
                 ("Y", c_void_p), ("ldy", c_int64), ("M", c_int64), ("N", c_int64), ("K", c_int64),
                 ("epi", c_int), ("R", c_void_p), ("ldr", c_int64), ("SA", c_void_p), ("ldsa", c_int64),
-                ("gate", c_void_p), ("keep", c_void_p), ("H", c_int32), ("Wimg", c_int32), ("shift", c_int32), ("form", c_int32)]
+                ("gate", c_void_p), ("keep", c_void_p), ("H", c_int32), ("Wimg", c_int32), ("shift", c_int32), ("form", c_int32), ("part", c_void_p)]
 
 
 class MlpArgs(ctypes.Structure):

@@ -209,12 +209,14 @@ class _PgsstbAttn(torch.autograd.Function):
             # (4) window attention core
             dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
                                                      pk["rpb"], pk["wprojT"], heads, shift)
-            dxn = ops.gemm_tok(dqkv, pk["wqkvT"])
             d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xnw, colsum=True)
             dsat2 = dsat.reshape(M, Cc)
             d_proj_w, d_proj_b = ops.gemm_tn(dsat2, oattn.reshape(M, Cc), colsum=True)
-            # (5) norm1 backward + the residual path
-            dx, part = ops.ln_bwd_win(x, dxn, dy, pk["ln1"][0], shift)
+            # (5) d_xn = dqkv Wqkv, norm1 backward and the residual path: one launch where the row fits a GEMM tile
+            if ops.LN_BWD_EPILOGUE and ops.gemm_tok_ln_bwd_fits(Cc):
+                dx, part = ops.gemm_tok_ln_bwd(dqkv, pk["wqkvT"], x, dy, pk["ln1"][0], shift)
+            else:
+                dx, part = ops.ln_bwd_win(x, ops.gemm_tok(dqkv, pk["wqkvT"]), dy, pk["ln1"][0], shift)
             dln = ops.reduce_parts(part)
             drpb = ops.reduce_parts(drpb)
         d_sdw = _join_taps(dwq, dwk, dwv).reshape(3 * Cc, 1, 3, 3)

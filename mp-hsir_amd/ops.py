@@ -452,6 +452,38 @@ def gemm_tok(x, w, bias=None, ln=None, epi=0, res=None, sa=None, gate=None, keep
     return y
 
 
+
+
+
+def gemm_tok_ln_bwd_fits(C):
+    return C <= 256 and C % 16 == 0
+
+
+def gemm_tok_ln_bwd(dyw, wT, x, dres, ln_w, shift):
+    """dx = dres + LN_backward(dyw @ wT^T) in ONE launch (mphsir_gemm_tok epi 3): dyw (M,K) rows in window-token order (the d[q|k|v] of
+    the window attention backward), wT (C,K) the transposed qkv weight, x / dres (B,H,W,C) in image order.
+    -> (dx (B,H,W,C), part (B*nW,2,C)) exactly as ln_bwd_win(x, gemm_tok(dyw, wT), dres, ln_w, shift) -- on the unrounded product."""
+    lib = _lib.load()
+    _check(dyw, wT, x, dres, ln_w)
+    B, H, W, C = x.shape
+    M, K = dyw.shape
+    assert M == B * H * W and wT.shape == (C, K) and wT.is_contiguous() and wT.dtype == dyw.dtype == x.dtype == dres.dtype
+    assert x.is_contiguous() and dres.is_contiguous() and dyw.stride(1) == 1 and gemm_tok_ln_bwd_fits(C) and ln_w.dtype == torch.float32
+    dx = torch.empty_like(x)
+    part = torch.empty((M // 64, 2, C), dtype=torch.float32, device=x.device)
+    a = _lib.GemmArgs()
+    a.X, a.ldx, a.W = _p(dyw), dyw.stride(0), _p(wT)
+    a.Y, a.ldy = _p(dx), C
+    a.M, a.N, a.K, a.epi = M, C, K, 3
+    a.R, a.ldr, a.SA, a.ldsa, a.gate = _p(x), C, _p(dres), C, _p(ln_w)
+    a.H, a.Wimg, a.shift = H, W, shift
+    a.form, a.part = TOK_FORM, _p(part)
+    _lib.check(lib.mphsir_gemm_tok(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gemm_tok")
+    es = x.element_size()
+    _acct("gemm_tok", 2.0 * M * C * K + 10.0 * M * C, (M * K + 3 * M * C) * es + wT.numel() * es)
+    return dx, part
+
+
 def layernorm_tok(x, ln_w, ln_b, out_dtype):
     """x (M,C) contiguous, fp32 or compute dtype -> LN(x) in out_dtype (statistics in fp32)."""
     lib = _lib.load()

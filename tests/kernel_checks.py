@@ -86,6 +86,36 @@ def check_gemm_tok_ring(dev, dtype, M, N, K, epi, per_sample=0, ldx=None, ldy=No
             assert float(outs[1][:, N:].abs().max()) == 0.0
 
 
+def check_gemm_tok_ln_bwd(dev, dtype, C, shift, B=2, H=16, W=24):
+    """mphsir_gemm_tok epi 3 (LayerNorm backward as the epilogue of the d_xn GEMM) against gemm_tok + ln_bwd_win and against fp64:
+    both kernel forms, window / shift address arithmetic, widths of both nets that fit one tile."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    M, K = B * H * W, 3 * C
+    dyw, wT = rnd((M, K), 31, dtype), rnd((C, K), 32, dtype, K ** -0.5)
+    x, dres = rnd((B, H, W, C), 33, dtype), rnd((B, H, W, C), 34, dtype)
+    lnw = 1 + 0.1 * rnd((C,), 35)
+    outs = []
+    for form in ((1, 2) if dtype != torch.float32 else (1,)):
+        with tok_form(form):
+            outs.append(ops.gemm_tok_ln_bwd(dyw, wT, x, dres, lnw, shift))
+    for dx_, part_ in outs[1:]:
+        assert torch.equal(dx_.cpu(), outs[0][0].cpu()) and torch.equal(part_.cpu(), outs[0][1].cpu())
+    dx, part = outs[0]
+    dx0, part0 = ops.ln_bwd_win(x, ops.gemm_tok(dyw, wT), dres, lnw, shift)
+    tol = 3e-6 if dtype == torch.float32 else TOL[dtype]
+    assert rel_l2(dx, dx0.double().cpu()) < tol and rel_l2(part, part0.double().cpu()) < tol
+    # fp64: d_xn in window order -> image order, LN backward
+    dxn_w = dyw.double().cpu() @ wT.double().cpu().t()
+    dxn = torch.roll(O.from_windows(dxn_w.reshape(-1, 64, C), B, H, W), shifts=(shift, shift), dims=(1, 2))
+    xd = x.double().cpu().requires_grad_(True)
+    wd = lnw.double().cpu().requires_grad_(True)
+    bd = torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    O.layer_norm_c(xd, wd, bd).backward(dxn)
+    assert rel_l2(dx, xd.grad + dres.double().cpu()) < tol
+    assert rel_l2(part.sum(0)[0], wd.grad) < tol and rel_l2(part.sum(0)[1], bd.grad) < tol
+
+
 def check_gemm_tok(dev, dtype, M, N, K, ln, epi):
     _use(dev)
     from mp_hsir_amd import ops

@@ -39,6 +39,12 @@ def test_gemm_tok_ring(dtype, M, N, K_, epi, ps, ldx, ldy):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,shift", [(64, 4), (128, 0), (256, 4), (96, 4), (192, 0), (32, 4)])
+def test_gemm_tok_ln_bwd(dtype, C, shift):
+    K.check_gemm_tok_ln_bwd("cuda", dtype, C, shift, B=32, H=64, W=64)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
 def test_gemm_tok_per_sample_combine(dtype):
     K.check_gemm_tok_per_sample_combine("cuda", dtype)
 
