@@ -455,6 +455,12 @@ def gemm_tok(x, w, bias=None, ln=None, epi=0, res=None, sa=None, gate=None, keep
 
 
 
+# norm1's backward as the epilogue of the d_xn GEMM (mphsir_gemm_tok epi 3) instead of gemm_tok -> ln_bwd_win.  Off: measured on the
+# MI355X the step is not faster with it (21.30-21.73 ms without, 21.80-21.84 with) -- the d_xn round trip it saves (2 C per token)
+# costs less than the four barriers and the fp32 staging tile it adds to every GEMM tile; ln_bwd_win alone streams at 5.5 TB/s
+LN_BWD_EPILOGUE = os.environ.get("MPHSIR_LN_BWD_EPILOGUE", "0") == "1"
+
+
 def gemm_tok_ln_bwd_fits(C):
     return C <= 256 and C % 16 == 0
 
