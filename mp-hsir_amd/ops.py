@@ -60,8 +60,12 @@ SIDE_BRANCH = os.environ.get("MPHSIR_SIDE_BRANCH", "1") == "1"
 # level only: issued on streams of their own they run beside the encoder / latent / decoder stages below them, whose launches leave
 # part of the chip idle.  Inference only (512x512 forward 7.32 -> 6.97 ms, batch-16 forward 3.70 -> 3.38 ms): in training the branches
 # bought nothing (21.5 ms either way) and, together with the weight-gradient branch below, a two-step AdamW check against the
-# reference failed in graph mode on one prompt parameter -- an ordering between the three streams that was not tracked down, so
-# the combination is not used
+# reference failed in graph mode on prompt1.text_prompt_learnable: its gradient comes out of the LAST kernels of the prompt stream's
+# backward (plain torch ops behind the stream's last weight-gradient fork), and in the captured step nothing made the launch stream
+# wait for that tail before the gradient hand-over -- with the sums issued in line the launch stream is merely late enough.  (Making
+# the weight-gradient stream wait for the prompt1 stream at every fork, and with it the final join, makes the check pass 3 / 3; waiting
+# for the gate or the prompt2 stream does not.)  Training therefore does not fork them; a training use would have to join every
+# side stream explicitly at the end of the backward pass
 PROMPT_SIDE = os.environ.get("MPHSIR_PROMPT_SIDE", "1") == "1"
 
 
