@@ -142,6 +142,7 @@ class reduce_scope:
                 # object itself must stay uniquely referenced so that AccumulateGrad adopts it instead of cloning (= reading) it
                 for g in self.segs:
                     g["keep"] = (g["keep"][0], g["keep"][1].detach())
+                _poison(self.segs)
                 _DEFERRED.extend(self.segs)
             else:
                 _flush_gemms(self.gemms)        # the deferred weight-gradient GEMMs, grouped ...
@@ -161,6 +162,19 @@ _DW_STREAM = {}
 _DW_KEEP = []
 
 
+# MPHSIR_DEBUG_DEFERRED=1 (tests): every parameter-gradient sum that is handed out before it has been computed (deferred to the end
+# of the backward pass, or issued on the weight-gradient branch) is first filled with NaN on the LAUNCH stream -- a consumer that
+# reads or clones it early (a shared parameter, a tensor hook, gradient accumulation into an existing .grad, a strided view that
+# AccumulateGrad has to copy) then yields NaN instead of stale memory, and the engine's finite check after the hand-over trips
+DEBUG_DEFERRED = os.environ.get("MPHSIR_DEBUG_DEFERRED", "0") == "1"
+
+
+def _poison(segs):
+    if DEBUG_DEFERRED:
+        for g in segs:
+            g["keep"][1].fill_(float("nan"))
+
+
 def _dw_side(scope):
     like = None
     for g in scope.gemms + scope.segs:
@@ -175,6 +189,7 @@ def _dw_side(scope):
     main = torch.cuda.current_stream(dev)
     for g in scope.segs:                # AccumulateGrad must find the output uniquely referenced: keep a detached alias
         g["keep"] = (g["keep"][0], g["keep"][1].detach())
+    _poison(scope.segs)
     if DW_SIDE >= 2:
         st.wait_stream(main)
         with torch.cuda.stream(st):

@@ -526,6 +526,37 @@ def test_fused_gdfn_in_the_no_grad_forward():
     assert e_f < 4e-2 and e_f < e_c * 1.25 + 1e-4, (e_f, e_c)
 
 
+@pytest.mark.parametrize("model", ["natural_scene", "remote_sensing"])
+@pytest.mark.parametrize("dw_side", [0, 2])
+def test_no_parameter_gradient_is_read_before_its_sum(model, dw_side, monkeypatch):
+    """ops.DEBUG_DEFERRED: every parameter-gradient sum handed out before it is computed is NaN-filled first on the launch stream,
+    so a consumer that read or cloned one early (AccumulateGrad on a strided / shared / hooked gradient, a backward function
+    reading a leaf sum) would leave NaN in the gradient arena.  One engine step of each shipped configuration, deferred and on the
+    weight-gradient branch: every gradient finite, and equal to the run without the poison."""
+    from mp_hsir_amd import ops
+    from mp_hsir_amd.data import SyntheticPatchSource
+    from mp_hsir_amd.engine import DataParallelEngine
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    cfg = dict(natural_scene=dict(in_channel=31, out_channel=31, dim=64, task_classes=6),
+               remote_sensing=dict(in_channel=100, out_channel=100, dim=96, task_classes=7))[model]
+    monkeypatch.setattr(ops, "DW_SIDE", dw_side)
+    grads = []
+    for poison in (False, True):
+        monkeypatch.setattr(ops, "DEBUG_DEFERRED", poison)
+        torch.manual_seed(5)
+        net = MP_HSIR_Net(**cfg, compute_dtype=torch.bfloat16, clip_prompt="surrogate").cuda().train()
+        eng = DataParallelEngine(net, lr=0.0, use_graph=False)
+        src = SyntheticPatchSource(cfg["in_channel"], 64, 2, cfg["task_classes"], "cuda", 2024, 0)
+        for _ in range(2):                       # step 0 builds the arenas, step 1 goes through the one-launch hand-over
+            torch.manual_seed(9)
+            _, x, c, p = src.next()
+            eng.train_step(x, c, p)
+        torch.cuda.synchronize()
+        assert torch.isfinite(eng.flat_g).all(), "a parameter gradient was read before its sum was launched"
+        grads.append(eng.flat_g.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
 @pytest.mark.parametrize("dw_side", [0, 1, 2])
 def test_deferred_parameter_gradient_sums_are_bitwise_the_immediate_ones(dw_side, monkeypatch):
     """The engine collects the partial-sum reductions of all parameter gradients of a backward pass and launches them together
