@@ -531,6 +531,7 @@ extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
     if (a->r == 8) MPHSIR_PG_FWD(8);
     if (a->r == 12) MPHSIR_PG_FWD(12);
     if (a->r == 16) MPHSIR_PG_FWD(16);
+    if (a->r == 24) MPHSIR_PG_FWD(24);        // remote-sensing dec1 / refinement: C = 192, compress_ratio 8
     MPHSIR_PG_FWD(0);
 #undef MPHSIR_PG_FWD
 }
@@ -559,6 +560,7 @@ extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
     if (a->r == 8) MPHSIR_PG_BWD(8);
     if (a->r == 12) MPHSIR_PG_BWD(12);
     if (a->r == 16) MPHSIR_PG_BWD(16);
+    if (a->r == 24) MPHSIR_PG_BWD(24);
     MPHSIR_PG_BWD(0);
 #undef MPHSIR_PG_BWD
 }

@@ -191,11 +191,13 @@ def test_combine_bwd(dtype):
 def test_pg_gate_fwd():
     K.check_pg_gate_fwd("cpu", 128, 8)
     K.check_pg_gate_fwd("cpu", 512, 32, nW=5)      # r = 16 at C > 256: not the fixed-channel path
+    K.check_pg_gate_fwd("cpu", 192, 8, nW=7)       # r = 24: the remote-sensing dec1 / refinement width
 
 
 def test_pg_gate_bwd():
     K.check_pg_gate_bwd("cpu", 128, 8)
     K.check_pg_gate_bwd("cpu", 384, 32, nW=5, factor_dtype=torch.bfloat16)
+    K.check_pg_gate_bwd("cpu", 192, 8, nW=6)
 
 
 @pytest.mark.parametrize("dtype,C,heads,shape,cross", [(torch.float32, 64, 2, (1, 16, 16), False), (torch.bfloat16, 128, 2, (2, 8, 16), True)])

@@ -262,6 +262,11 @@ def test_bench_two_ranks_gloo_on_one_gpu(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["global_batch"] == 8 and line["roofline"] is not None
+    # the roofline object of the contract: algorithmic bytes only (the kernel's own split-K partials apart), where `traffic` comes from
+    rf = line["roofline"]
+    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "partials_bytes_per_step", "timing"):
+        assert key in rf, key
+    assert 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and line["comm"]["ranks"] == 2
 
 
 @pytest.mark.timeout(900)
