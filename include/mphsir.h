@@ -248,7 +248,8 @@ typedef struct mphsir_mlp_args {
     void* Y; int64_t ldy;
     int64_t M; int32_t C, HP;
     int32_t tiles_per_wave;                      /* tuning: 0 = auto; four waves with 1 or 2 token tiles (of 16) per wave; 3 / 4 =
-                                                    eight waves with 1 / 2 tiles (16-bit types) */
+                                                    eight waves with 1 / 2 tiles (16-bit types); 5 = two waves, 32 tokens per
+                                                    workgroup (16-bit types; never chosen by 0: measured slower) */
 } mphsir_mlp_args;
 int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream);
 
@@ -266,7 +267,8 @@ typedef struct mphsir_mlp_bwd_args {
     const void* W1; const float* b1; const void* W1T; const void* W2T;
     void* dX; void* XN; void* H; void* DPRE; float* part;
     int64_t M; int32_t C, HP;
-    int32_t variant;                  /* 0 = library's choice; 1..4 pin a kernel form (tests / tuning), see gated_mlp_bwd.hip */
+    int32_t variant;                  /* 0 = library's choice; 1..4 pin a kernel form (tests / tuning), see gated_mlp_bwd.hip;
+                                         5 = two-wave form for small launches: 32 tokens per workgroup, `part` is [M/32][2][C] */
     const float* keep;                /* optional DropPath factors [M / rows_per_batch]: DM is then an OUTPUT, written */
     int64_t rows_per_batch;           /* here as keep[b] * dY (rounded to the compute dtype) instead of by the caller   */
 } mphsir_mlp_bwd_args;

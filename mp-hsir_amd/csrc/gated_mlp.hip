@@ -145,20 +145,21 @@ __global__ __launch_bounds__(256) void gated_mlp_kernel(MlpDev a) {
 // (768 cycles of its SIMD's matrix pipe) and then ~320 VALU instructions of GELU (1280 cycles): with one wave per SIMD the
 // two never overlap (MFMA-busy 9.6 %); with two, one wave's GELU runs beside the other's MFMAs, and each staged weight
 // chunk feeds twice the tokens.
-template <class T, int C, int TT, int WF = 1> struct MlpLdsCfg {
+// NWV = waves per workgroup: 4 (one per SIMD), 8 (two per SIMD, see above) or 2 (32 tokens per workgroup: on request only, see launch_mlp).
+template <class T, int C, int TT, int NWV = 4> struct MlpLdsCfg {
     static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
-    static constexpr int BM = 64 * TT * WF, NTHR = 256 * WF;
+    static constexpr int BM = 16 * TT * NWV, NTHR = 64 * NWV;
     static constexpr int LDX = C + PAD, LDH = 32 + PAD;
-    static constexpr size_t ELEMS = (size_t)BM * LDX + 64 * LDX + (size_t)C * LDH + 4 * WF * 16 * TT * LDH;
+    static constexpr size_t ELEMS = (size_t)BM * LDX + 64 * LDX + (size_t)C * LDH + NWV * 16 * TT * LDH;
     static constexpr size_t BYTES = ELEMS * sizeof(T);
     static constexpr bool FITS = BYTES <= 160 * 1024;
 };
 
-template <class T, int C, int TT, int WF>
-__global__ __launch_bounds__(256 * WF) void gated_mlp_lds_kernel(MlpDev a) {
+template <class T, int C, int TT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void gated_mlp_lds_kernel(MlpDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
-    typedef MlpLdsCfg<T, C, TT, WF> CF;
+    typedef MlpLdsCfg<T, C, TT, NWV> CF;
     constexpr int LDX = CF::LDX, LDH = CF::LDH, BM = CF::BM, NTHR = CF::NTHR;
     constexpr int VEC = Vec16<T>::N;
     constexpr int NCT = C / 16;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256 * WF) void gated_mlp_lds_kernel(MlpDev a) {
     T* Xs = reinterpret_cast<T*>(smem_v);               // [BM][LDX]
     T* W1s = Xs + BM * LDX;                             // [64][LDX]  value rows 0..31, gate rows 32..63
     T* W2s = W1s + 64 * LDX;                            // [C][LDH]
-    T* Hs = W2s + C * LDH;                              // [4*WF][16*TT][LDH]
+    T* Hs = W2s + C * LDH;                              // [NWV][16*TT][LDH]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int m0 = blockIdx.x * BM;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256 * WF) void gated_mlp_lds_kernel(MlpDev a) {
     // ---- LayerNorm into LDS: 4 adjacent lanes per token, TT passes ---------------------------------
     for (int pass = 0; pass < TT; ++pass) {
         constexpr int NV = C / VEC, VPT = NV / 4;
-        const int r = pass * 64 * WF + (tid >> 2), q = tid & 3;
+        const int r = pass * 16 * NWV + (tid >> 2), q = tid & 3;
         const T* row = X + (long)(m0 + r) * a.ldx;
         Vec16<T> xv[VPT];
         float s = 0.f;
@@ -326,14 +327,14 @@ __global__ __launch_bounds__(256 * WF) void gated_mlp_lds_kernel(MlpDev a) {
     }
 }
 
-template <class T, int C, int TT, int WF = 1>
+template <class T, int C, int TT, int NWV = 4>
 static int launch_mlp_lds(const MlpDev& d, hipStream_t s) {
-    typedef MlpLdsCfg<T, C, TT, WF> CF;
+    typedef MlpLdsCfg<T, C, TT, NWV> CF;
     if constexpr (!CF::FITS) {
         return 1;   // caller falls back
     } else {
-        allow_big_lds(gated_mlp_lds_kernel<T, C, TT, WF>, CF::BYTES);
-        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_lds_kernel<T, C, TT, WF>), dim3(d.M / CF::BM), dim3(CF::NTHR), CF::BYTES, s, d);
+        allow_big_lds(gated_mlp_lds_kernel<T, C, TT, NWV>, CF::BYTES);
+        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_lds_kernel<T, C, TT, NWV>), dim3(d.M / CF::BM), dim3(CF::NTHR), CF::BYTES, s, d);
         return MPHSIR_OK;
     }
 }
@@ -345,8 +346,13 @@ static int launch_mlp(const MlpDev& d, hipStream_t s) {
     // Eight waves with one 16-token tile each (two waves per SIMD) wherever that still leaves a workgroup per CU -- measured at
     // M = 131072, C = 128: 68 us against 92 (four waves, one tile) and 112 (four waves, two tiles: the round-2 default);
     // tpw 1 / 2 force the four-wave forms, 3 / 4 the eight-wave ones (tests, tools/bench_mlp_fwd.py)
-    if (sizeof(T) == 2 && d.M % 128 == 0 && (d.tpw == 3 || (d.tpw == 0 && d.M / 128 >= 256))) rc = launch_mlp_lds<T, C, 1, 2>(d, s);
-    if (rc == 1 && sizeof(T) == 2 && d.M % 256 == 0 && d.tpw == 4) rc = launch_mlp_lds<T, C, 2, 2>(d, s);
+    if (sizeof(T) == 2 && d.M % 128 == 0 && (d.tpw == 3 || (d.tpw == 0 && d.M / 128 >= 256))) rc = launch_mlp_lds<T, C, 1, 8>(d, s);
+    if (rc == 1 && sizeof(T) == 2 && d.M % 256 == 0 && d.tpw == 4) rc = launch_mlp_lds<T, C, 2, 8>(d, s);
+    // two waves, 32 tokens per workgroup: only on request (tpw 5).  Measured as the default for launches of < 256 workgroups at C >= 192
+    // (the latent level) it is SLOWER -- natural step 22.05 -> 22.71 ms, remote-sensing fp16 step 28.55 -> 32.57, batch-16 forward 3.39 ->
+    // 3.51: every workgroup streams ALL weight chunks through LDS by itself, so twice the workgroups are twice the L2 -> LDS weight traffic
+    // on a chain whose length per workgroup does not shrink.  (What would help there is splitting the HIDDEN dimension over workgroups.)
+    if (rc == 1 && sizeof(T) == 2 && d.tpw == 5) rc = launch_mlp_lds<T, C, 1, 2>(d, s);
     if (rc == 1 && d.M % 128 == 0 && d.tpw == 2) rc = launch_mlp_lds<T, C, 2>(d, s);
     if (rc == 1) rc = launch_mlp_lds<T, C, 1>(d, s);
     if (rc != 1) return rc;

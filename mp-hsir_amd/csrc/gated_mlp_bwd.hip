@@ -276,16 +276,21 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
 //   * all three weight slices of a chunk (fc1 rows, W2^T rows, W1^T columns) are staged in LDS once per workgroup
 //     and the NEXT chunk's slices are already in flight in registers during the MFMAs,
 //   * wave-private staging uses wave barriers: two workgroup barriers per chunk remain.
-template <class T, int C, int TT, int WF>      // WF = 2: eight waves (two per SIMD: one wave's GELU / stores beside the other's MFMAs)
-__global__ __launch_bounds__(256 * WF) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
+// NWV waves per workgroup, one (TT) 16-token tile each: 8 = two per SIMD (one wave's GELU / stores beside the other's MFMAs), 4 = the
+// original form, 2 = 32 tokens per workgroup (variant 5, on request only: measured slower at the latent level, where it was meant to
+// put twice as many CUs to work -- every workgroup streams all weight slices through LDS by itself (2.9 MB at C = 256, 4.5 MB at
+// C = 384), so twice the workgroups are twice that traffic; see gated_mlp.hip::launch_mlp).  The LayerNorm-parameter partials are
+// per group of GS = min(64, tokens per workgroup).
+template <class T, int C, int TT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
     constexpr int PAD = LDS_PAD_BYTES / sizeof(T), LDX = C + PAD, LDH = 64 + PAD, LDF = C + 4, VEC = Vec16<T>::N;
     constexpr int NCT = C / 16, NV = C / VEC, VPT = NV / 4;
-    constexpr int TOK = 64 * TT * WF, WT = 16 * TT, NTHR = 256 * WF;
+    constexpr int TOK = 16 * TT * NWV, WT = 16 * TT, NTHR = 64 * NWV, GS = TOK < 64 ? TOK : 64, NG = TOK / GS;
     constexpr int NKC = C / TR::KCHUNK, NKH = 32 / TR::KCHUNK;
     constexpr size_t P0 = 2 * (size_t)TOK * LDX * sizeof(T);
-    constexpr size_t P1 = ((size_t)96 * LDX + (size_t)C * LDH + 4 * WF * WT * LDH) * sizeof(T);
+    constexpr size_t P1 = ((size_t)96 * LDX + (size_t)C * LDH + NWV * WT * LDH) * sizeof(T);
     constexpr size_t P2 = (size_t)TOK * LDF * 4;
     constexpr size_t REG = ((P0 > P1 ? (P0 > P2 ? P0 : P2) : (P1 > P2 ? P1 : P2)) + 15) / 16 * 16;
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256 * WF) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
     T* W1s = reinterpret_cast<T*>(smem);                 // loop: [64][LDX] fc1 rows: value 0..31 | gate 32..63
     T* W2Ts = W1s + 64 * LDX;                            //       [32][LDX] W2^T rows of the chunk
     T* W1Ts = W2Ts + 32 * LDX;                           //       [C][LDH]  W1^T columns: value 0..31 | gate 32..63
-    T* Hs = W1Ts + C * LDH;                              //       [4*WF][WT][LDH] per wave: h, then [dval | dgate]
+    T* Hs = W1Ts + C * LDH;                              //       [NWV][WT][LDH] per wave: h, then [dval | dgate]
     float* Fs = reinterpret_cast<float*>(smem);          // end:  [TOK][LDF] fp32 dxn
     float* stat = reinterpret_cast<float*>(smem + REG);  // mean[TOK], rstd[TOK]
 
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256 * WF) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
     // ---- phase 0: LN(x) (also written to XN) and dm into LDS, 4 adjacent lanes per token; then into fragments ----
 #pragma unroll
     for (int pass = 0; pass < TT; ++pass) {
-        const int r = pass * 64 * WF + (tid >> 2), q = tid & 3;
+        const int r = pass * 16 * NWV + (tid >> 2), q = tid & 3;
         const T* row = X + (m0 + r) * C;
         Vec16<T> xv[VPT];
         float s = 0.f;
@@ -500,17 +505,17 @@ __global__ __launch_bounds__(256 * WF) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
         for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(Fs + tok * LDF + ct * 16 + cr) = out[t][ct];
     }
     __syncthreads();
-    float* part = a.part + (long)blockIdx.x * TT * WF * 2 * C;
-    for (int i = tid; i < TT * WF * C; i += NTHR) {                 // d(ln bias)[c] = sum_tok dxn, per group of 64 tokens
+    float* part = a.part + (long)blockIdx.x * NG * 2 * C;
+    for (int i = tid; i < NG * C; i += NTHR) {                      // d(ln bias)[c] = sum_tok dxn, per group of GS tokens
         const int g = i / C, c = i % C;
         float s = 0.f;
-        for (int t = 0; t < 64; ++t) s += Fs[(g * 64 + t) * LDF + c];
+        for (int t = 0; t < GS; ++t) s += Fs[(g * GS + t) * LDF + c];
         part[(g * 2 + 1) * C + c] = s;
     }
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < TT; ++pass) {
-        const int r = pass * 64 * WF + (tid >> 2), q = tid & 3;
+        const int r = pass * 16 * NWV + (tid >> 2), q = tid & 3;
         const float mean = stat[r], rstd = stat[TOK + r];
         const T* xrow = X + (m0 + r) * C;
         float s1 = 0.f, s2 = 0.f;
@@ -544,42 +549,49 @@ __global__ __launch_bounds__(256 * WF) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < TT * WF * C; i += NTHR) {           // d(ln weight)[c] = sum_tok dxn * xhat
+    for (int i = tid; i < NG * C; i += NTHR) {                // d(ln weight)[c] = sum_tok dxn * xhat
         const int g = i / C, c = i % C;
         float s = 0.f;
-        for (int t = 0; t < 64; ++t) s += Fs[(g * 64 + t) * LDF + c];
+        for (int t = 0; t < GS; ++t) s += Fs[(g * GS + t) * LDF + c];
         part[(g * 2) * C + c] = s;
     }
 }
 
-template <class T, int C, int TT, int WF = 1>
+template <class T, int C, int TT, int NWV = 4>
 constexpr size_t mlp_bwd2_lds() {
-    constexpr size_t PAD = LDS_PAD_BYTES / sizeof(T), LDX = C + PAD, LDH = 64 + PAD, LDF = C + 4, TOK = 64 * TT * WF, WT = 16 * TT;
-    constexpr size_t P0 = 2 * TOK * LDX * sizeof(T), P1 = (96 * LDX + C * LDH + 4 * WF * WT * LDH) * sizeof(T), P2 = TOK * LDF * 4;
+    constexpr size_t PAD = LDS_PAD_BYTES / sizeof(T), LDX = C + PAD, LDH = 64 + PAD, LDF = C + 4, TOK = 16 * TT * NWV, WT = 16 * TT;
+    constexpr size_t P0 = 2 * TOK * LDX * sizeof(T), P1 = (96 * LDX + C * LDH + NWV * WT * LDH) * sizeof(T), P2 = TOK * LDF * 4;
     constexpr size_t REG = ((P0 > P1 ? (P0 > P2 ? P0 : P2) : (P1 > P2 ? P1 : P2)) + 15) / 16 * 16;
     return REG + 2 * TOK * sizeof(float);
 }
 
-template <class T, int C, int TT, int WF = 1>
-constexpr bool mlp_bwd2_fits() { return mlp_bwd2_lds<T, C, TT, WF>() <= 160 * 1024 && (C / Vec16<T>::N) % 4 == 0 && (WF == 1 || sizeof(T) == 2); }
+template <class T, int C, int TT, int NWV = 4>
+constexpr bool mlp_bwd2_fits() { return mlp_bwd2_lds<T, C, TT, NWV>() <= 160 * 1024 && (C / Vec16<T>::N) % 4 == 0 && (NWV == 4 || sizeof(T) == 2); }
 
-template <class T, int C, int TT, int WF = 1>
+template <class T, int C, int TT, int NWV = 4>
 static int launch_mlp_bwd2(const MlpBwdDev& d, hipStream_t s) {
-    if constexpr (mlp_bwd2_fits<T, C, TT, WF>()) {
-        constexpr size_t lds = mlp_bwd2_lds<T, C, TT, WF>();
-        allow_big_lds(gated_mlp_bwd2_kernel<T, C, TT, WF>, lds);
-        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd2_kernel<T, C, TT, WF>), dim3(d.M / (64 * TT * WF)), dim3(256 * WF), lds, s, d);
+    if constexpr (mlp_bwd2_fits<T, C, TT, NWV>()) {
+        constexpr size_t lds = mlp_bwd2_lds<T, C, TT, NWV>();
+        allow_big_lds(gated_mlp_bwd2_kernel<T, C, TT, NWV>, lds);
+        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd2_kernel<T, C, TT, NWV>), dim3(d.M / (16 * TT * NWV)), dim3(64 * NWV), lds, s, d);
     }
     return MPHSIR_OK;
 }
 
 // variant: 0 = choose (second form when it fits LDS; eight waves with one tile each once that still leaves a workgroup per
-// CU), 1 = first form, 2 / 3 = second form, four waves with one / two 16-token tiles per wave, 4 = second form, eight waves.
+// CU), 1 = first form, 2 / 3 = second form, four waves with one / two 16-token tiles per wave, 4 = second form, eight waves,
+// 5 = second form, TWO waves: 32 tokens per workgroup and `part` rows per 32 tokens (the caller sizes it: [M/32][2][C]); never
+// chosen by 0.
 template <class T, int C>
 static int launch_mlp_bwd(const MlpBwdDev& d, int variant, hipStream_t s) {
+    if (variant == 5) {
+        if constexpr (mlp_bwd2_fits<T, C, 1, 2>()) return launch_mlp_bwd2<T, C, 1, 2>(d, s);
+        set_error("gated_mlp_bwd: the two-wave form does not cover C=%d in this element type", C);
+        return MPHSIR_EINVAL;
+    }
     if (variant != 1) {
-        if constexpr (mlp_bwd2_fits<T, C, 1, 2>()) {
-            if (d.M % 128 == 0 && (variant == 4 || (variant == 0 && C <= 128 && d.M / 128 >= 256))) return launch_mlp_bwd2<T, C, 1, 2>(d, s);
+        if constexpr (mlp_bwd2_fits<T, C, 1, 8>()) {
+            if (d.M % 128 == 0 && (variant == 4 || (variant == 0 && C <= 128 && d.M / 128 >= 256))) return launch_mlp_bwd2<T, C, 1, 8>(d, s);
         }
         if constexpr (mlp_bwd2_fits<T, C, 2>()) {
             if (d.M % 128 == 0 && variant == 3) return launch_mlp_bwd2<T, C, 2>(d, s);
@@ -636,6 +648,6 @@ extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, voi
                 (int)a->M, a->HP, a->keep, (long)a->rows_per_batch};
     MPHSIR_REQUIRE(!a->keep || (a->rows_per_batch > 0 && a->M % a->rows_per_batch == 0), "gated_mlp_bwd: keep needs rows_per_batch dividing M");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    MPHSIR_REQUIRE(a->variant >= 0 && a->variant <= 4, "gated_mlp_bwd: variant must be 0..4");
+    MPHSIR_REQUIRE(a->variant >= 0 && a->variant <= 5, "gated_mlp_bwd: variant must be 0..5");
     return MPHSIR_DISPATCH_T(dtype, (dispatch_mlp_bwd<T_>(d, a->C, a->variant, s)));
 }

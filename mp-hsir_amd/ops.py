@@ -581,6 +581,11 @@ def pack_gated_mlp(fc1_w, fc1_b, fc2_w, dtype):
     return W1, b1, W2
 
 
+# two-wave gated MLP kernels (32 tokens per workgroup) for launches of < 256 workgroups at C >= 192 (the latent level).  Off: measured
+# slower (natural step 22.05 -> 22.71 ms, remote-sensing step 28.55 -> 32.57): twice the workgroups stream twice the weights
+MLP_SMALL_FORM = os.environ.get("MPHSIR_MLP_SMALL_FORM", "0") == "1"
+
+
 def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, out=None, tiles_per_wave=0):
     """x (M,C) row-major view -> x + keep * mlp(LN(x)); weights from pack_gated_mlp."""
     lib = _lib.load()
@@ -594,6 +599,8 @@ def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, ou
     a.X, a.ldx, a.ln_w, a.ln_b = _p(x), ldx, _p(ln_w), _p(ln_b)
     a.W1, a.b1, a.W2, a.b2 = _p(W1), _p(b1), _p(W2), _p(b2)
     a.keep, a.rows_per_batch = _p(keep), rows_per_batch
+    if tiles_per_wave == 0 and MLP_SMALL_FORM and x.dtype in _HALF and C >= 192 and M // 64 < 256:
+        tiles_per_wave = 5
     a.Y, a.ldy, a.M, a.C, a.HP, a.tiles_per_wave = _p(y), _rows(y)[1], M, C, HP, tiles_per_wave
     _lib.check(lib.mphsir_gated_mlp_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gated_mlp_fwd")
     _acct("gated_mlp", 6.0 * M * C * HP, 2.0 * M * C * x.element_size() + 3.0 * C * HP * x.element_size())
@@ -1051,11 +1058,13 @@ def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None,
     HP = W2T.shape[0]
     assert x.is_contiguous() and dy.is_contiguous() and (dm is None or dm.is_contiguous()) and W1T.shape == (C, 2 * HP) and W2T.shape == (HP, C)
     dev, dt = x.device, x.dtype
+    if variant == 0 and MLP_SMALL_FORM and dt in _HALF and C >= 192 and M // 64 < 256:
+        variant = 5           # fewer than one 64-token workgroup per CU, each streaming MBs of weights: 32-token workgroups
     dx = torch.empty_like(x)
     xn = torch.empty_like(x)
     h = torch.empty((M, HP), dtype=dt, device=dev)
     dpre = torch.empty((M, 2 * HP), dtype=dt, device=dev)
-    part = torch.empty((M // 64, 2, C), dtype=torch.float32, device=dev)
+    part = torch.empty((M // (32 if variant == 5 else 64), 2, C), dtype=torch.float32, device=dev)
     a = _lib.MlpBwdArgs()
     if keep is not None:
         _check(keep)

@@ -43,6 +43,7 @@ def test_gated_mlp(dtype, C, hid):
     K.check_gated_mlp("cpu", dtype, C, hid)
     K.check_gated_mlp("cpu", dtype, C, hid, tpw=2, M=256)
     if dtype != torch.float32:
+        K.check_gated_mlp("cpu", dtype, C, hid, tpw=5, M=192)              # two waves: 32 tokens per workgroup
         K.check_gated_mlp("cpu", dtype, C, hid, tpw=3, M=256)          # eight waves, one / two tiles per wave
         K.check_gated_mlp("cpu", dtype, C, hid, tpw=4, M=256)
 
@@ -120,6 +121,13 @@ def test_gated_mlp_bwd(dtype, C, hid):
 @pytest.mark.parametrize("C,hid,variant", [(32, 85, 1), (32, 85, 3), (96, 255, 3), (32, 85, 4), (64, 170, 4)])
 def test_gated_mlp_bwd_kernel_forms(dtype, C, hid, variant):
     K.check_gated_mlp_bwd("cpu", dtype, C, hid, variant=variant)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16] if "cpu" == "cpu" else [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,hid", [(32, 85), (96, 255)] if "cpu" == "cpu" else [(32, 85), (96, 255), (128, 340), (192, 510), (256, 680), (384, 1021)])
+def test_gated_mlp_bwd_two_wave_form(dtype, C, hid):
+    """variant 5: 32 tokens per workgroup (small launches at the latent level), LayerNorm partials per 32 tokens"""
+    K.check_gated_mlp_bwd("cpu", dtype, C, hid, variant=5)
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
