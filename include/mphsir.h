@@ -250,6 +250,9 @@ typedef struct mphsir_mlp_args {
     int32_t tiles_per_wave;                      /* tuning: 0 = auto; four waves with 1 or 2 token tiles (of 16) per wave; 3 / 4 =
                                                     eight waves with 1 / 2 tiles (16-bit types); 5 = two waves, 32 tokens per
                                                     workgroup (16-bit types; never chosen by 0: measured slower) */
+    int32_t hsplit;                              /* > 1: small launches (the latent level): the hidden dimension is dealt to hsplit
+                                                    workgroups per token tile, the weights are still read once in total; needs */
+    float* ypart;                                /* ... a workspace [hsplit][M][C] fp32 for the partial fc2 products (summed in order) */
 } mphsir_mlp_args;
 int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream);
 
@@ -271,6 +274,10 @@ typedef struct mphsir_mlp_bwd_args {
                                          5 = two-wave form for small launches: 32 tokens per workgroup, `part` is [M/32][2][C] */
     const float* keep;                /* optional DropPath factors [M / rows_per_batch]: DM is then an OUTPUT, written */
     int64_t rows_per_batch;           /* here as keep[b] * dY (rounded to the compute dtype) instead of by the caller   */
+    int32_t hsplit;                   /* > 1: small launches (the latent level): the hidden dimension dealt to hsplit workgroups per
+                                         token tile (weights still read once in total) + a second launch that sums the partial d_xn in
+                                         order and finishes; variant 0 or 2; needs */
+    float* dxn_part;                  /* ... a workspace [hsplit][M][C] fp32 */
 } mphsir_mlp_bwd_args;
 int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream);
 

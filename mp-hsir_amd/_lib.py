@@ -28,7 +28,8 @@ class MlpArgs(ctypes.Structure):
     """mirror of struct mphsir_mlp_args"""
     _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("W1", c_void_p),
                 ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p), ("keep", c_void_p), ("rows_per_batch", c_int64),
-                ("Y", c_void_p), ("ldy", c_int64), ("M", c_int64), ("C", c_int32), ("HP", c_int32), ("tiles_per_wave", c_int32)]
+                ("Y", c_void_p), ("ldy", c_int64), ("M", c_int64), ("C", c_int32), ("HP", c_int32), ("tiles_per_wave", c_int32),
+                ("hsplit", c_int32), ("ypart", c_void_p)]
 
 
 class WinAttnArgs(ctypes.Structure):
@@ -82,7 +83,8 @@ class GdfnArgs(ctypes.Structure):
 class MlpBwdArgs(ctypes.Structure):
     """mirror of struct mphsir_mlp_bwd_args"""
     _fields_ = [(n, c_void_p) for n in ("X", "dY", "DM", "ln_w", "ln_b", "W1", "b1", "W1T", "W2T", "dX", "XN", "H", "DPRE", "part")] + \
-               [("M", c_int64), ("C", c_int32), ("HP", c_int32), ("variant", c_int32), ("keep", c_void_p), ("rows_per_batch", c_int64)]
+               [("M", c_int64), ("C", c_int32), ("HP", c_int32), ("variant", c_int32), ("keep", c_void_p), ("rows_per_batch", c_int64),
+                ("hsplit", c_int32), ("dxn_part", c_void_p)]
 
 
 class WinAttnBwdArgs(ctypes.Structure):

@@ -21,6 +21,8 @@ struct MlpDev {
     void* Y; long ldy;
     int M, HP;
     int tpw;      // token tiles per wave: 0 = auto, 1, 2
+    int hsplit;   // > 1 (LDS form): the hidden dimension is dealt to hsplit workgroups per token tile (grid.y); each writes its fp32
+    float* Ypart; // partial fc2 product [hsplit][M][C]; mlp_combine_kernel adds them, the bias and the residual
 };
 
 template <class T, int C>
@@ -247,18 +249,21 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_lds_kernel(MlpDev a) {
             }
         }
     };
-    wload(0);
+    // hidden split (small launches: the latent level has 128 / 64 token tiles for 256 CUs and every workgroup streams all weight
+    // chunks through LDS): workgroup (tile, blockIdx.y) takes hidden columns [j0, j1) -- the weights are still read ONCE in total
+    const int hsp = a.hsplit > 1 ? a.hsplit : 1, j0 = (int)blockIdx.y * (HP / hsp), j1 = j0 + HP / hsp;
+    wload(j0);
     f32x4 out[TT][NCT];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
 #pragma unroll
         for (int i = 0; i < NCT; ++i) out[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int j = 0; j < HP; j += 32) {
+    for (int j = j0; j < j1; j += 32) {
         __syncthreads();                                   // previous chunk's weight tiles fully consumed
         wstore();
         __syncthreads();
-        if (j + 32 < HP) wload(j + 32);                    // in flight during the MFMAs below
+        if (j + 32 < j1) wload(j + 32);                    // in flight during the MFMAs below
         f32x4 vv[TT][2], gg[TT][2];
 #pragma unroll
         for (int t = 0; t < TT; ++t)
@@ -302,6 +307,16 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_lds_kernel(MlpDev a) {
     }
     __syncthreads();
 
+    if (hsp > 1) {            // partial product of this hidden range: fp32, 4 consecutive channels of a token per lane
+        float* Yp = a.Ypart + ((long)blockIdx.y * a.M + m0) * C;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int tok = (wv * TT + t) * 16 + (lane & 15), cr = (lane >> 4) * 4;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(Yp + (long)tok * C + ct * 16 + cr) = out[t][ct];
+        }
+        return;
+    }
     // ---- epilogue: (acc + b2) -> LDS stage (own rows), then coalesced residual + store -----------------
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
@@ -327,6 +342,33 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_lds_kernel(MlpDev a) {
     }
 }
 
+// y = x + keep * (sum of the hidden-split partials + b2): 8 (fp32: 4) channels of a token per thread
+template <class T>
+__global__ __launch_bounds__(256) void mlp_combine_kernel(MlpDev a, int C) {
+    constexpr int VEC = Vec16<T>::N;
+    const long nv = (long)a.M * C / VEC;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    T* Y = reinterpret_cast<T*>(a.Y);
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) {
+        const long e0 = v * VEC, m = e0 / C;
+        const int c0 = (int)(e0 - m * C);
+        float acc[VEC];
+        for (int e = 0; e < VEC; ++e) acc[e] = a.b2[c0 + e];
+        for (int sp = 0; sp < a.hsplit; ++sp) {            // fixed order: deterministic
+            const float* p = a.Ypart + ((long)sp * a.M + m) * C + c0;
+            for (int q = 0; q < VEC; q += 4) {
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(p + q);
+                for (int r = 0; r < 4; ++r) acc[q + r] += pv[r];
+            }
+        }
+        const float kf = a.keep ? a.keep[m / a.rpb] : 1.f;
+        const Vec16<T> x = load16<T>(X + m * a.ldx + c0);
+        Vec16<T> o;
+        for (int e = 0; e < VEC; ++e) o.set(e, x.get(e) + kf * acc[e]);
+        store16<T>(Y + m * a.ldy + c0, o);
+    }
+}
+
 template <class T, int C, int TT, int NWV = 4>
 static int launch_mlp_lds(const MlpDev& d, hipStream_t s) {
     typedef MlpLdsCfg<T, C, TT, NWV> CF;
@@ -334,7 +376,12 @@ static int launch_mlp_lds(const MlpDev& d, hipStream_t s) {
         return 1;   // caller falls back
     } else {
         allow_big_lds(gated_mlp_lds_kernel<T, C, TT, NWV>, CF::BYTES);
-        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_lds_kernel<T, C, TT, NWV>), dim3(d.M / CF::BM), dim3(CF::NTHR), CF::BYTES, s, d);
+        const int hsp = d.hsplit > 1 ? d.hsplit : 1;
+        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_lds_kernel<T, C, TT, NWV>), dim3(d.M / CF::BM, hsp), dim3(CF::NTHR), CF::BYTES, s, d);
+        if (hsp > 1) {
+            long blocks = ((long)d.M * C / Vec16<T>::N + 255) / 256;
+            MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (mlp_combine_kernel<T>), dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, d, C);
+        }
         return MPHSIR_OK;
     }
 }
@@ -356,6 +403,7 @@ static int launch_mlp(const MlpDev& d, hipStream_t s) {
     if (rc == 1 && d.M % 128 == 0 && d.tpw == 2) rc = launch_mlp_lds<T, C, 2>(d, s);
     if (rc == 1) rc = launch_mlp_lds<T, C, 1>(d, s);
     if (rc != 1) return rc;
+    if (d.hsplit > 1) { set_error("gated_mlp: the hidden split needs the LDS-staged form, which does not fit C=%d in this element type", C); return MPHSIR_EINVAL; }
     constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     const size_t shmem = (64 * (C + PAD) + 4 * 16 * (32 + PAD)) * sizeof(T);
     allow_big_lds(gated_mlp_kernel<T, C>, shmem);
@@ -392,7 +440,11 @@ extern "C" int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* s
                        (a->ldx * esz) % 16 == 0 && (a->ldy * esz) % 16 == 0, "gated_mlp: 16-byte alignment required");
     if (a->keep) MPHSIR_REQUIRE(a->rows_per_batch > 0, "gated_mlp: keep needs rows_per_batch");
     MlpDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->W1, a->b1, a->W2, a->b2, a->keep,
-             (long)(a->rows_per_batch > 0 ? a->rows_per_batch : a->M), a->Y, (long)a->ldy, (int)a->M, a->HP, a->tiles_per_wave};
+             (long)(a->rows_per_batch > 0 ? a->rows_per_batch : a->M), a->Y, (long)a->ldy, (int)a->M, a->HP, a->tiles_per_wave,
+             a->hsplit, a->ypart};
+    if (a->hsplit > 1)
+        MPHSIR_REQUIRE(a->ypart && aligned16(a->ypart) && a->HP % (32 * a->hsplit) == 0 && a->tiles_per_wave <= 2,
+                       "gated_mlp: hsplit needs a workspace ypart [hsplit][M][C] fp32, HP %% (32 hsplit) == 0 and a four-wave form");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return MPHSIR_DISPATCH_T(dtype, (dispatch_mlp<T_>(d, a->C, s)));
 }

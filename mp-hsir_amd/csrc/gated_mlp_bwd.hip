@@ -27,7 +27,9 @@ struct MlpBwdDev {
     float* part;                                     // [M/64][2][C]: d(ln weight), d(ln bias) partial sums
     int M, HP;
     const float* keep; long rpb;                     // optional: DM is written here as keep[row / rpb] * dY
-};
+    int hsplit;                                      // > 1 (second form, four waves): the hidden dimension is dealt to hsplit workgroups per
+    float* dxn_part;                                 // token tile (grid.y); each writes its fp32 partial d_xn [hsplit][M][C]; mlp_bwd_combine_kernel
+};                                                   // sums them in order and finishes (LayerNorm backward, residual, parameter partials)
 
 // STAGE = true: the fc1 rows of the hidden chunk ([64][C]) and the matching columns of W1^T ([C][64]) are loaded
 // once per workgroup into LDS (coalesced) instead of every wave streaming its own fragments through L1.
@@ -266,6 +268,65 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
     }
 }
 
+// d_xn (fp32, [TOK][LDF] in LDS) -> d(LN bias) partials, LayerNorm backward + residual -> dx, d(LN weight) partials.  Shared by the
+// second form's own epilogue and by the combine kernel of the hidden split.  `grp0` = index of the first partial group (of GS tokens).
+template <class T, int C, int TOK, int NTHR, int TT, int RPP>
+__device__ __forceinline__ void mlp_bwd_ln_epilogue(const MlpBwdDev& a, float* Fs, const float* stat, long m0, long grp0, int tid) {
+    constexpr int VEC = Vec16<T>::N, NV = C / VEC, VPT = NV / 4, LDF = C + 4, GS = TOK < 64 ? TOK : 64, NG = TOK / GS;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* dY = reinterpret_cast<const T*>(a.dY);
+    float* part = a.part + grp0 * 2 * C;
+    for (int i = tid; i < NG * C; i += NTHR) {                      // d(ln bias)[c] = sum_tok dxn, per group of GS tokens
+        const int g = i / C, c = i % C;
+        float s = 0.f;
+        for (int t = 0; t < GS; ++t) s += Fs[(g * GS + t) * LDF + c];
+        part[(g * 2 + 1) * C + c] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < TT; ++pass) {
+        const int r = pass * RPP + (tid >> 2), q = tid & 3;
+        const float mean = stat[r], rstd = stat[TOK + r];
+        const T* xrow = X + (m0 + r) * C;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            const Vec16<T> xv = load16<T>(xrow + c0);
+            for (int e = 0; e < VEC; ++e) {
+                const float gw = Fs[r * LDF + c0 + e] * a.ln_w[c0 + e], xh = (xv.get(e) - mean) * rstd;
+                s1 += gw;
+                s2 += gw * xh;
+            }
+        }
+        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+        s1 *= 1.0f / (float)C;
+        s2 *= 1.0f / (float)C;
+        T* dxrow = reinterpret_cast<T*>(a.dX) + (m0 + r) * C;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (q + 4 * i) * VEC;
+            const Vec16<T> xv = load16<T>(xrow + c0);
+            const Vec16<T> dy = load16<T>(dY + (m0 + r) * C + c0);
+            Vec16<T> o;
+            for (int e = 0; e < VEC; ++e) {
+                const float dxn = Fs[r * LDF + c0 + e], xh = (xv.get(e) - mean) * rstd;
+                o.set(e, dy.get(e) + rstd * (dxn * a.ln_w[c0 + e] - s1 - xh * s2));
+                Fs[r * LDF + c0 + e] = dxn * xh;          // for d(ln weight)
+            }
+            store16<T>(dxrow + c0, o);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < NG * C; i += NTHR) {                // d(ln weight)[c] = sum_tok dxn * xhat
+        const int g = i / C, c = i % C;
+        float s = 0.f;
+        for (int t = 0; t < GS; ++t) s += Fs[(g * GS + t) * LDF + c];
+        part[(g * 2) * C + c] = s;
+    }
+}
+
 // ---- second form ------------------------------------------------------------------------------------------------
 // The first form is bound by LDS traffic and barriers (measured 140-170 TFLOP/s): one 16-token tile per wave means
 // every weight fragment read from LDS feeds exactly one MFMA, the token fragments are re-read from LDS for each of
@@ -341,13 +402,13 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
             Vec16<T> o;
             for (int e = 0; e < VEC; ++e) o.set(e, (xv[i].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
             store16<T>(Xs + r * LDX + c0, o);
-            store16<T>(XN + c0, o);
+            if (blockIdx.y == 0) store16<T>(XN + c0, o);          // hidden split: every slab needs LN(x), the first one stores it
             Vec16<T> dmv;
             if (a.keep) {                             // DropPath backward fused: dm = keep[b] * dy, also kept for dW2 / db2
                 const float kf = a.keep[(m0 + r) / a.rpb];
                 const Vec16<T> dyv = load16<T>(dY + (m0 + r) * C + c0);
                 for (int e = 0; e < VEC; ++e) dmv.set(e, kf * dyv.get(e));
-                store16<T>(const_cast<T*>(DM) + (m0 + r) * C + c0, dmv);
+                if (blockIdx.y == 0) store16<T>(const_cast<T*>(DM) + (m0 + r) * C + c0, dmv);
             } else {
                 dmv = load16<T>(DM + (m0 + r) * C + c0);
             }
@@ -403,7 +464,10 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
             }
         }
     };
-    wload(0);
+    // hidden split (small launches, see MlpBwdDev): this workgroup takes hidden columns [j0, j1); h and [dval | dgate] columns are
+    // disjoint between slabs, d_xn is a sum over them
+    const int hsp = a.hsplit > 1 ? a.hsplit : 1, j0 = (int)blockIdx.y * (HP / hsp), j1 = j0 + HP / hsp;
+    wload(j0);
 
     T* Hw = Hs + wv * WT * LDH;
     T* Hout = reinterpret_cast<T*>(a.H);
@@ -415,11 +479,11 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
         for (int i = 0; i < NCT; ++i) out[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int hr = (lane >> 4) * 4, tk = lane & 15;
 
-    for (int j = 0; j < HP; j += 32) {
+    for (int j = j0; j < j1; j += 32) {
         __syncthreads();                 // every wave is done with the previous chunk's slices (and, first time, with Xs/Ds)
         wstore();
         __syncthreads();
-        if (j + 32 < HP) wload(j + 32);  // in flight during the MFMAs below
+        if (j + 32 < j1) wload(j + 32);  // in flight during the MFMAs below
         f32x4 pv[2][TT], pg[2][TT], pe[2][TT];
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -495,6 +559,16 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
         }
         wave_barrier();
     }
+    if (hsp > 1) {           // this slab's share of d_xn: fp32, 4 consecutive channels of a token per lane
+        float* Dp = a.dxn_part + ((long)blockIdx.y * a.M + m0) * C;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int tok = wv * WT + 16 * t + (lane & 15), cr = (lane >> 4) * 4;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(Dp + (long)tok * C + ct * 16 + cr) = out[t][ct];
+        }
+        return;
+    }
     __syncthreads();
 
     // ---- dxn -> fp32 LDS stage; LayerNorm backward; dx = dy + ...; parameter-gradient partials per 64 tokens -----
@@ -505,56 +579,49 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
         for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(Fs + tok * LDF + ct * 16 + cr) = out[t][ct];
     }
     __syncthreads();
-    float* part = a.part + (long)blockIdx.x * NG * 2 * C;
-    for (int i = tid; i < NG * C; i += NTHR) {                      // d(ln bias)[c] = sum_tok dxn, per group of GS tokens
-        const int g = i / C, c = i % C;
+    mlp_bwd_ln_epilogue<T, C, TOK, NTHR, TT, 16 * NWV>(a, Fs, stat, m0, (long)blockIdx.x * NG, tid);
+}
+
+// Hidden split, second launch: d_xn = the slabs' partials summed in order (deterministic) -> the same LayerNorm-backward epilogue,
+// one workgroup per 64 tokens.
+template <class T, int C>
+__global__ __launch_bounds__(256) void mlp_bwd_combine_kernel(MlpBwdDev a) {
+    constexpr int VEC = Vec16<T>::N, NV = C / VEC, VPT = NV / 4, LDF = C + 4;
+    HIP_DYNAMIC_SHARED(f32x4, smem_v)
+    float* Fs = reinterpret_cast<float*>(smem_v);        // [64][LDF]
+    float* stat = Fs + 64 * LDF;                         // mean[64], rstd[64]
+    const int tid = threadIdx.x;
+    const long m0 = (long)blockIdx.x * 64;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    {
+        const int r = tid >> 2, q = tid & 3;
+        const T* row = X + (m0 + r) * C;
+        Vec16<T> xv[VPT];
         float s = 0.f;
-        for (int t = 0; t < GS; ++t) s += Fs[(g * GS + t) * LDF + c];
-        part[(g * 2 + 1) * C + c] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int pass = 0; pass < TT; ++pass) {
-        const int r = pass * 16 * NWV + (tid >> 2), q = tid & 3;
-        const float mean = stat[r], rstd = stat[TOK + r];
-        const T* xrow = X + (m0 + r) * C;
-        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
-            const int c0 = (q + 4 * i) * VEC;
-            const Vec16<T> xv = load16<T>(xrow + c0);
-            for (int e = 0; e < VEC; ++e) {
-                const float gw = Fs[r * LDF + c0 + e] * a.ln_w[c0 + e], xh = (xv.get(e) - mean) * rstd;
-                s1 += gw;
-                s2 += gw * xh;
-            }
+            xv[i] = load16<T>(row + (q + 4 * i) * VEC);
+            for (int e = 0; e < VEC; ++e) s += xv[i].get(e);
         }
-        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
-        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
-        s1 *= 1.0f / (float)C;
-        s2 *= 1.0f / (float)C;
-        T* dxrow = reinterpret_cast<T*>(a.dX) + (m0 + r) * C;
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)C;
+        float d2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int c0 = (q + 4 * i) * VEC;
-            const Vec16<T> xv = load16<T>(xrow + c0);
-            const Vec16<T> dy = load16<T>(dY + (m0 + r) * C + c0);
-            Vec16<T> o;
-            for (int e = 0; e < VEC; ++e) {
-                const float dxn = Fs[r * LDF + c0 + e], xh = (xv.get(e) - mean) * rstd;
-                o.set(e, dy.get(e) + rstd * (dxn * a.ln_w[c0 + e] - s1 - xh * s2));
-                Fs[r * LDF + c0 + e] = dxn * xh;          // for d(ln weight)
-            }
-            store16<T>(dxrow + c0, o);
-        }
+        for (int i = 0; i < VPT; ++i)
+            for (int e = 0; e < VEC; ++e) { const float d = xv[i].get(e) - mean; d2 += d * d; }
+        d2 += __shfl_xor(d2, 1);
+        d2 += __shfl_xor(d2, 2);
+        if (q == 0) { stat[r] = mean; stat[64 + r] = rsqrtf(d2 / (float)C + 1e-5f); }
+    }
+    for (int idx = tid; idx < 64 * (C / 4); idx += 256) {
+        const int t = idx / (C / 4), c = (idx % (C / 4)) * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(a.dxn_part + (m0 + t) * C + c);
+        for (int sp = 1; sp < a.hsplit; ++sp) acc += *reinterpret_cast<const f32x4*>(a.dxn_part + ((long)sp * a.M + m0 + t) * C + c);
+        *reinterpret_cast<f32x4*>(Fs + t * LDF + c) = acc;
     }
     __syncthreads();
-    for (int i = tid; i < NG * C; i += NTHR) {                // d(ln weight)[c] = sum_tok dxn * xhat
-        const int g = i / C, c = i % C;
-        float s = 0.f;
-        for (int t = 0; t < GS; ++t) s += Fs[(g * GS + t) * LDF + c];
-        part[(g * 2) * C + c] = s;
-    }
+    mlp_bwd_ln_epilogue<T, C, 64, 256, 1, 64>(a, Fs, stat, m0, (long)blockIdx.x, tid);
 }
 
 template <class T, int C, int TT, int NWV = 4>
@@ -573,7 +640,13 @@ static int launch_mlp_bwd2(const MlpBwdDev& d, hipStream_t s) {
     if constexpr (mlp_bwd2_fits<T, C, TT, NWV>()) {
         constexpr size_t lds = mlp_bwd2_lds<T, C, TT, NWV>();
         allow_big_lds(gated_mlp_bwd2_kernel<T, C, TT, NWV>, lds);
-        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd2_kernel<T, C, TT, NWV>), dim3(d.M / (16 * TT * NWV)), dim3(64 * NWV), lds, s, d);
+        const int hsp = d.hsplit > 1 ? d.hsplit : 1;
+        MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (gated_mlp_bwd2_kernel<T, C, TT, NWV>), dim3(d.M / (16 * TT * NWV), hsp), dim3(64 * NWV), lds, s, d);
+        if (hsp > 1) {
+            const size_t cl = (64 * (size_t)(C + 4) + 128) * sizeof(float);
+            allow_big_lds(mlp_bwd_combine_kernel<T, C>, cl);
+            MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP_BWD, (mlp_bwd_combine_kernel<T, C>), dim3(d.M / 64), dim3(256), cl, s, d);
+        }
     }
     return MPHSIR_OK;
 }
@@ -584,6 +657,11 @@ static int launch_mlp_bwd2(const MlpBwdDev& d, hipStream_t s) {
 // chosen by 0.
 template <class T, int C>
 static int launch_mlp_bwd(const MlpBwdDev& d, int variant, hipStream_t s) {
+    if (d.hsplit > 1) {          // the hidden split is built on the four-wave second form
+        if constexpr (mlp_bwd2_fits<T, C, 1>()) return launch_mlp_bwd2<T, C, 1>(d, s);
+        set_error("gated_mlp_bwd: the hidden split needs the second form, which does not fit C=%d in this element type", C);
+        return MPHSIR_EINVAL;
+    }
     if (variant == 5) {
         if constexpr (mlp_bwd2_fits<T, C, 1, 2>()) return launch_mlp_bwd2<T, C, 1, 2>(d, s);
         set_error("gated_mlp_bwd: the two-wave form does not cover C=%d in this element type", C);
@@ -645,7 +723,10 @@ extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, voi
     MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->dY) && aligned16(a->DM) && aligned16(a->dX) && aligned16(a->XN) && aligned16(a->H) &&
                        aligned16(a->DPRE) && aligned16(a->W1) && aligned16(a->W1T) && aligned16(a->W2T), "gated_mlp_bwd: 16-byte alignment required");
     MlpBwdDev d{a->X, a->dY, a->DM, a->ln_w, a->ln_b, a->W1, a->b1, a->W1T, a->W2T, a->dX, a->XN, a->H, a->DPRE, a->part,
-                (int)a->M, a->HP, a->keep, (long)a->rows_per_batch};
+                (int)a->M, a->HP, a->keep, (long)a->rows_per_batch, a->hsplit, a->dxn_part};
+    if (a->hsplit > 1)
+        MPHSIR_REQUIRE(a->dxn_part && aligned16(a->dxn_part) && a->HP % (32 * a->hsplit) == 0 && (a->variant == 0 || a->variant == 2),
+                       "gated_mlp_bwd: hsplit needs a workspace dxn_part [hsplit][M][C] fp32, HP %% (32 hsplit) == 0 and variant 0 or 2");
     MPHSIR_REQUIRE(!a->keep || (a->rows_per_batch > 0 && a->M % a->rows_per_batch == 0), "gated_mlp_bwd: keep needs rows_per_batch dividing M");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     MPHSIR_REQUIRE(a->variant >= 0 && a->variant <= 5, "gated_mlp_bwd: variant must be 0..5");

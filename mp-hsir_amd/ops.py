@@ -586,7 +586,21 @@ def pack_gated_mlp(fc1_w, fc1_b, fc2_w, dtype):
 MLP_SMALL_FORM = os.environ.get("MPHSIR_MLP_SMALL_FORM", "0") == "1"
 
 
-def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, out=None, tiles_per_wave=0):
+# hidden split of the gated MLP kernels for small launches (< 256 token tiles at C >= 192: the latent level): 0 = off, else the number of
+# workgroups per token tile is chosen so that about 256 workgroups exist
+MLP_HSPLIT = os.environ.get("MPHSIR_MLP_HSPLIT", "1") == "1"
+
+
+def mlp_hsplit(M, C, HP):
+    if not MLP_HSPLIT or C < 192 or M // 64 >= 256:
+        return 1
+    s, chunks = 1, HP // 32
+    while (M // 64) * s * 2 <= 256 and chunks % (s * 2) == 0:
+        s *= 2
+    return s
+
+
+def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, out=None, tiles_per_wave=0, hsplit=None):
     """x (M,C) row-major view -> x + keep * mlp(LN(x)); weights from pack_gated_mlp."""
     lib = _lib.load()
     _check(x, W1, W2, b1, b2, ln_w, ln_b, keep)
@@ -602,6 +616,11 @@ def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, ou
     if tiles_per_wave == 0 and MLP_SMALL_FORM and x.dtype in _HALF and C >= 192 and M // 64 < 256:
         tiles_per_wave = 5
     a.Y, a.ldy, a.M, a.C, a.HP, a.tiles_per_wave = _p(y), _rows(y)[1], M, C, HP, tiles_per_wave
+    if hsplit is None:
+        hsplit = mlp_hsplit(M, C, HP) if tiles_per_wave == 0 and (x.dtype in _HALF or C < 256) else 1
+    if hsplit > 1:
+        ypart = torch.empty((hsplit, M, C), dtype=torch.float32, device=x.device)
+        a.hsplit, a.ypart, a.tiles_per_wave = hsplit, _p(ypart), 1
     _lib.check(lib.mphsir_gated_mlp_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gated_mlp_fwd")
     _acct("gated_mlp", 6.0 * M * C * HP, 2.0 * M * C * x.element_size() + 3.0 * C * HP * x.element_size())
     return y
@@ -1049,7 +1068,7 @@ def dwconv3x3_bwd(x, dy, w9, col_ranges=None):
     return dx, out
 
 
-def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None, rows_per_batch=0):
+def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None, rows_per_batch=0, hsplit=None):
     """-> dx, xn, h, dpre, part (see include/mphsir.h).  x, dy, dm: contiguous (M,C).  With keep (DropPath factors, one
     per rows_per_batch rows) dm is ignored as input: the kernel computes keep*dy itself and it is returned as a 6th value."""
     lib = _lib.load()
@@ -1075,6 +1094,11 @@ def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None,
     a.W1, a.b1, a.W1T, a.W2T = _p(W1), _p(b1), _p(W1T), _p(W2T)
     a.dX, a.XN, a.H, a.DPRE, a.part = _p(dx), _p(xn), _p(h), _p(dpre), _p(part)
     a.M, a.C, a.HP, a.variant = M, C, HP, variant
+    if hsplit is None:
+        hsplit = mlp_hsplit(M, C, HP) if variant == 0 and dt in _HALF else 1
+    if hsplit > 1:
+        dxn_part = torch.empty((hsplit, M, C), dtype=torch.float32, device=dev)
+        a.hsplit, a.dxn_part = hsplit, _p(dxn_part)
     _lib.check(lib.mphsir_gated_mlp_bwd(ctypes.byref(a), _DT[dt], _stream(x)), "gated_mlp_bwd")
     _acct("gated_mlp_bwd", 12.0 * M * C * HP, (3.0 * M * C + 3.0 * M * HP + M * C) * x.element_size())
     if keep is not None:

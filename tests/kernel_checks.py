@@ -152,7 +152,7 @@ def check_gemm_tok_per_sample_combine(dev, dtype):
     assert rel_l2(y.reshape(B, H, W, C), ref) < TOL[dtype]
 
 
-def check_gated_mlp(dev, dtype, C, hid, tpw=0, M=128):
+def check_gated_mlp(dev, dtype, C, hid, tpw=0, M=128, hsplit=None):
     _use(dev)
     from mp_hsir_amd import ops
     x = rnd((M, C), 1, dtype)
@@ -161,7 +161,7 @@ def check_gated_mlp(dev, dtype, C, hid, tpw=0, M=128):
     lnw, lnb = 1 + 0.1 * rnd((C,), 6), 0.1 * rnd((C,), 7)
     keep = torch.tensor([1.0, 1.5]).to(dev)
     W1, b1, W2 = ops.pack_gated_mlp(P["fc1.weight"], P["fc1.bias"], P["fc2.weight"], dtype)
-    y = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, P["fc2.bias"], keep=keep, rows_per_batch=M // 2, tiles_per_wave=tpw)
+    y = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, P["fc2.bias"], keep=keep, rows_per_batch=M // 2, tiles_per_wave=tpw, hsplit=hsplit)
     Pd = {k: (v.to(dtype) if k.endswith("weight") else v).double().cpu() for k, v in P.items()}
     xn = O.layer_norm_c(x.double().cpu(), lnw.double().cpu(), lnb.double().cpu())
     ref = x.double().cpu() + keep.double().cpu().repeat_interleave(M // 2)[:, None] * O.gated_mlp(Pd, "", xn)
@@ -450,7 +450,7 @@ def check_dwconv_bwd(dev, dtype, shape):
     assert torch.equal(dx2, dx2r) and torch.equal(dw2, dw2r)
 
 
-def check_gated_mlp_bwd(dev, dtype, C, hid, variant=0):
+def check_gated_mlp_bwd(dev, dtype, C, hid, variant=0, hsplit=None):
     """HIP data-gradient kernel + token-reduction GEMMs vs autograd of the fp64 oracle."""
     _use(dev)
     from mp_hsir_amd import ops
@@ -463,9 +463,10 @@ def check_gated_mlp_bwd(dev, dtype, C, hid, variant=0):
     W1, b1, W2 = ops.pack_gated_mlp(P["fc1.weight"], P["fc1.bias"], P["fc2.weight"], dtype)
     HP = W2.shape[1]
     dm = (dy.float() * keep.repeat_interleave(64)[:, None]).to(dtype)
-    dx, xn, h, dpre, part = ops.gated_mlp_bwd(x, dy, dm, lnw, lnb, W1, b1, W1.t().contiguous(), W2.t().contiguous(), variant=variant)
+    dx, xn, h, dpre, part = ops.gated_mlp_bwd(x, dy, dm, lnw, lnb, W1, b1, W1.t().contiguous(), W2.t().contiguous(), variant=variant, hsplit=hsplit)
     # DropPath scaling fused into the kernel: same results, dm produced by the kernel
-    r2 = ops.gated_mlp_bwd(x, dy, None, lnw, lnb, W1, b1, W1.t().contiguous(), W2.t().contiguous(), variant=variant, keep=keep, rows_per_batch=64)
+    r2 = ops.gated_mlp_bwd(x, dy, None, lnw, lnb, W1, b1, W1.t().contiguous(), W2.t().contiguous(), variant=variant, keep=keep, rows_per_batch=64,
+                           hsplit=hsplit)
     assert torch.equal(r2[5].cpu(), dm.cpu()) and torch.equal(r2[0].cpu(), dx.cpu()) and torch.equal(r2[3].cpu(), dpre.cpu())
     dW2 = (dm.float().t() @ h.float())[:, :hid]
     dW1p = dpre.float().t() @ xn.float()

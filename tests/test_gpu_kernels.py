@@ -169,6 +169,17 @@ def test_dwconv_bwd(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,hid,hsplit", [(96, 255, 2), (96, 255, 4), (256, 680, 2), (192, 510, 4), (384, 1021, 4), (384, 1021, 8), (128, 340, 11)])
+def test_gated_mlp_hidden_split(dtype, C, hid, hsplit):
+    """the hidden dimension dealt to hsplit workgroups per token tile (small launches), partial fc2 products summed in order"""
+    if dtype == torch.float32 and C >= 256:
+        pytest.skip("fp32 at C >= 256 does not fit the LDS-staged form the split is built on")
+    K.check_gated_mlp("cuda", dtype, C, hid, M=256, hsplit=hsplit)
+    if dtype != torch.float32 or C < 192:
+        K.check_gated_mlp_bwd("cuda", dtype, C, hid, hsplit=hsplit)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("C,hid", [(32, 85), (96, 255), (64, 170), (128, 340), (256, 680), (192, 510)])
 def test_gated_mlp_bwd(dtype, C, hid):
     K.check_gated_mlp_bwd("cuda", dtype, C, hid)
