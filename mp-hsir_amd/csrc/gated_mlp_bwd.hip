@@ -669,7 +669,9 @@ static int launch_mlp_bwd(const MlpBwdDev& d, int variant, hipStream_t s) {
     }
     if (variant != 1) {
         if constexpr (mlp_bwd2_fits<T, C, 1, 8>()) {
-            if (d.M % 128 == 0 && (variant == 4 || (variant == 0 && C <= 128 && d.M / 128 >= 256))) return launch_mlp_bwd2<T, C, 1, 8>(d, s);
+            // C = 192 (remote-sensing dec1 / refinement): the eight-wave form spills 11 registers there and is still 1.7x the four-wave
+            // form (M = 65536: 238 -> 141 us, tools/bench/bench_mlp_bwd.py); at 16384 tokens the two are level
+            if (d.M % 128 == 0 && (variant == 4 || (variant == 0 && C <= 192 && d.M / 128 >= 256))) return launch_mlp_bwd2<T, C, 1, 8>(d, s);
         }
         if constexpr (mlp_bwd2_fits<T, C, 2>()) {
             if (d.M % 128 == 0 && variant == 3) return launch_mlp_bwd2<T, C, 2>(d, s);

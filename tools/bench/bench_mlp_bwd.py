@@ -1,5 +1,5 @@
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops
@@ -11,7 +11,7 @@ def t_us(fn, n=10):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-for M, C, hid in [(131072, 128, 340), (32768, 128, 340), (131072, 64, 170), (8192, 256, 680)]:
+for M, C, hid in [(131072, 128, 340), (32768, 128, 340), (131072, 64, 170), (8192, 256, 680), (65536, 192, 510), (16384, 192, 510), (65536, 96, 255), (4096, 384, 1021)]:
     x, dy = torch.randn(M, C, device=dev, dtype=dt), torch.randn(M, C, device=dev, dtype=dt)
     fc1w, fc1b, fc2w = torch.randn(2 * hid, C, device=dev) * C ** -0.5, torch.randn(2 * hid, device=dev) * 0.1, torch.randn(C, hid, device=dev) * hid ** -0.5
     lnw, lnb = torch.ones(C, device=dev), torch.zeros(C, device=dev)
