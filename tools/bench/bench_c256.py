@@ -1,5 +1,5 @@
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

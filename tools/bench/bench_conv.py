@@ -1,6 +1,6 @@
 """diagnostic (GPU box): the dense 3x3 conv at the shapes of the 512x512 forward and of the training step."""
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

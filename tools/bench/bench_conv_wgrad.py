@@ -1,6 +1,6 @@
 """diagnostic (GPU box): dense-conv weight gradient, gathered inside the token-reduction GEMM vs im2col + gemm_tn."""
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

@@ -1,7 +1,7 @@
 """Fused pass A (qkv_dwconv_gram) against the two-kernel path (gemm_tok -> dwconv_gram) on the shapes of the 512x512x31
 forward and of the batch-16 64x64 forward.  MPHSIR_FUSED_OCC=1 forces one workgroup per CU."""
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

@@ -1,6 +1,6 @@
 """diagnostic: replayed-hipGraph time of one 512x512x31 bf16 forward (test.py shape).  (GPU box only)"""
 import sys, time, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net

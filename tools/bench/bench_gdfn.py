@@ -1,6 +1,6 @@
 """diagnostic (GPU box): fused GDFN against the three-launch chain at the 512x512 forward's two big shapes."""
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

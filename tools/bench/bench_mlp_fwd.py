@@ -1,7 +1,7 @@
 """gated_mlp forward: four-wave (tiles_per_wave 1, 2) against eight-wave (3: one tile per wave, 4: two) workgroups at the widths /
 token counts of the training step.  GPU box only."""
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

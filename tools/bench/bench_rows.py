@@ -1,7 +1,7 @@
 """Fused pass A: row-walking form (spectral_rows.hip) against the tile form (spectral_fused.hip) on the shapes of the
 512x512x31 forward, the batch-16/32 64x64 steps and the RS widths.  Usage: python tools/bench_rows.py [keep]"""
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

@@ -1,6 +1,6 @@
 """diagnostic (GPU box): win_attn_bwd with the heads of a window dealt to 1, 2, 4, 8 workgroups (head_split)."""
 import os, sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

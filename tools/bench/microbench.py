@@ -1,6 +1,6 @@
 """per-kernel timings at the shapes of one refinement-stage block (B=32, 64x64, C=128, 2 heads) and one latent block."""
 import sys, time, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops

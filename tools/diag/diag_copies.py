@@ -1,6 +1,6 @@
 """count aten::copy_/fill_/sum launches: forward with warm weight cache vs forward after a weight-epoch bump (= repack) vs train step."""
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from torch.profiler import profile, ProfilerActivity

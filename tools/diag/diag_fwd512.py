@@ -1,7 +1,7 @@
 """diagnostic (GPU box): every library launch of one eager 512x512x31 bf16 forward with its shape and its own HIP-event time,
 grouped by (op, shape).  python tools/diag_fwd512.py"""
 import sys, warnings, collections
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net

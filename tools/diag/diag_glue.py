@@ -1,6 +1,6 @@
 """where the non-library time of a training step goes: torch.profiler table of GPU kernels grouped by the torch op that launched them."""
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from torch.profiler import profile, ProfilerActivity

@@ -1,7 +1,7 @@
 """diagnostic (GPU box): every gemm_tok / gemm_tn / reduce launch of one eager training step with its shape and its own HIP-event time,
 grouped by shape -- which shapes the per-kernel totals of bench.py are made of.  python tools/diag_shapes.py [gemm_tok|gemm_tn|...]"""
 import sys, warnings, collections
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net

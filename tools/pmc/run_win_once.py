@@ -1,6 +1,6 @@
 """one shape of win_attn_fwd, a few launches (for rocprofv3 --pmc): python tools/run_win_once.py C heads H [B]"""
 import sys, warnings
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 warnings.filterwarnings("ignore")
 import torch
 from mp_hsir_amd import ops
