@@ -30,7 +30,7 @@ def short(name):
         n = re.sub(r"^\d+", "", m.group(1))
         n = {"qkv_dwconv_gram_rows": "qkv_dwconv_gram"}.get(n, n)
         # kernel forms that share one C-ABI entry point / library kernel id
-        return {"gemm_tn_tr": "gemm_tn", "gemm_tn_tr_group": "gemm_tn", "gemm_tn_ring": "gemm_tn", "gemm_tn_ring_group": "gemm_tn", "gemm_tok_ring": "gemm_tok", "gated_mlp_bwd2": "gated_mlp_bwd", "gated_mlp_lds": "gated_mlp", "dwconv_gram2": "dwconv_gram",
+        return {"gemm_tn_tr": "gemm_tn", "gemm_tn_tr_group": "gemm_tn", "gemm_tn_ring": "gemm_tn", "gemm_tn_ring_group": "gemm_tn", "gemm_tok_ring": "gemm_tok", "mlp_combine": "gated_mlp", "mlp_bwd_combine": "gated_mlp_bwd", "gated_mlp_bwd2": "gated_mlp_bwd", "gated_mlp_lds": "gated_mlp", "dwconv_gram2": "dwconv_gram",
                 "pg_gate_fwd": "pg_gate", "dwconv3x3_tile": "dwconv3x3", "dwconv3x3_wgrad_tile": "dwconv3x3_wgrad", "dwconv_gate_tile": "dwconv_gate", "tvsp_text_map": "resample", "tvsp_text_map_bwd": "resample", "resize_bilinear": "resample",
                 "resize_bilinear_bwd": "resample", "grad_check": "flat_adamw", "scaler_update": "flat_adamw"}.get(n, n)
     return name[:60]
