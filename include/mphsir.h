@@ -358,7 +358,8 @@ int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B, int32_t H
  * dY[p][co] * X[p + tap][ci] (X gathered inside the token-reduction GEMM, zeros outside the image); 16-bit types.  The caller sums
  * the nsplit partials (mphsir_reduce_parts).  Replaces mphsir_im2col3x3 + mphsir_gemm_tn on the 16-bit path. */
 int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* Cpart, int32_t B, int32_t H, int32_t W,
-                         int32_t Cout, int32_t Cin, int32_t nsplit, int32_t form /* 1 | 2, as mphsir_gemm_tn's tile128 */, int dtype, void* stream);
+                         int32_t Cout, int32_t Cin, int32_t nsplit, int32_t form /* 1 | 2, as mphsir_gemm_tn's tile128 */,
+                         int32_t* group_counters /* optional, as mphsir_gemm_tn's */, int dtype, void* stream);
 
 /* ---- token-reduction GEMM (weight gradients) --------------------------------------------------------
  * Cpart[b][s][n1][n2] = sum over the s-th token range of A[b][m][n1] * B[b][m][n2]  (fp32 partials;
@@ -370,10 +371,17 @@ int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ld
  * (ds_read_b64_tr_b16, no transposing stores, two LDS stages, register-staged loads, 256-thread workgroups, ~2 per CU)
  * with a 64- or 128-wide tile per operand; 2 = its ring form: one 512-thread workgroup per CU (size nsplit for ~256
  * workgroups), token rows by LDS-DMA into a ring of 32-token slots, two wave groups whose tiles are combined in LDS:
- * half the partial tiles per launch, written as whole 16-byte row chunks.                                          */
+ * half the partial tiles per launch, written as whole 16-byte row chunks.
+ * group_counters (optional; 16-bit large-tile forms): mphsir_gemm_tn_group_counters(...) ints, ZERO when the launch starts.  With
+ * it the first level of the ordered sum happens inside the launch: of the 8 workgroups that own splits 8g..8g+7 of an output tile
+ * the one that finishes last adds their tiles in split order into slot 8g (whichever workgroup that is: bitwise reproducible)
+ * and zeroes the counter again, so the caller sums the ceil(nsplit/8) slots 0, 8, 16, ... (split stride 8*N1*N2) instead of nsplit.
+ * colsum_part is not touched by this (all nsplit rows stay).  Concurrent launches need disjoint counters.            */
 int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
                    float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch,
-                   int32_t tile128, int dtype, void* stream);
+                   int32_t tile128, int32_t* group_counters, int dtype, void* stream);
+/* counters one problem needs at most (any tile width): batch * ceil(N1/64) * ceil(N2/64) * ceil(nsplit/8) */
+int64_t mphsir_gemm_tn_group_counters(int32_t N1, int32_t N2, int32_t nsplit, int32_t batch);
 /* Up to MPHSIR_TN_GROUP_MAX independent problems of the bf16 large-tile form in ONE launch (same outputs as n calls
  * of mphsir_gemm_tn with batch = 1): the weight-gradient GEMMs of one backward function issued together.         */
 #define MPHSIR_TN_GROUP_MAX 8
@@ -381,6 +389,7 @@ typedef struct mphsir_gemm_tn_problem {
     const void* A; int64_t lda; const void* B; int64_t ldb;
     float* Cpart; float* colsum_part;
     int64_t M; int32_t N1, N2, nsplit, pad_;
+    int32_t* group_counters;      /* optional, as mphsir_gemm_tn's (zero-initialised; disjoint per problem) */
 } mphsir_gemm_tn_problem;
 int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t n, int32_t form /* 1 | 2 */, int dtype, void* stream);
 

@@ -18,6 +18,7 @@ Re-expresses what the reference gets implicitly from pytorch-lightning (train.py
     SURVEY Q3) are detected on the first step and kept out of the arenas -- the reference's AdamW
     skips them too (grad is None), so no weight decay is applied to them.
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -244,7 +245,9 @@ class DataParallelEngine:
         if count:
             self.buckets.append([start, total, count])
         self.arena = (used, offs, total)
-        self._multi_copy = None
+        # built here, outside any capture: its pinned tables cannot be allocated while a stream is capturing (a capture at the
+        # very first hand-over -- graph_warmup=1 -- would otherwise be invalidated)
+        self._multi_copy = ops.MultiCopy(self.flat_g.device, len(used)) if used else None
         self._gviews = [self.flat_g[o:o + p.numel()].view(p.shape) for p, o in zip(used, offs)]
         self._bucket_members = []            # per bucket: (params, arena views)
         bi = 0
@@ -302,8 +305,6 @@ class DataParallelEngine:
                 v.copy_(g)
         if fv:
             # ONE launch for the whole bucket (torch._foreach_copy_: 11 multi-tensor launches, 0.2 ms per step)
-            if self._multi_copy is None:
-                self._multi_copy = ops.MultiCopy(fv[0].device, len(self.arena[0]))
             self._multi_copy(fv, fg)
         for p in ps:
             p.grad = None
@@ -360,6 +361,29 @@ class DataParallelEngine:
         import math
         return [lr, 1.0 - self.betas[0] ** step, math.sqrt(1.0 - self.betas[1] ** step)]
 
+    _HYPER_SLOTS = 4
+
+    def _stage_hyper(self, values):
+        """the step's host-computed scalars (lr, bias corrections) -> the device buffer the captured optimizer reads.  Through a ring
+        of PINNED slots: a copy from pageable memory makes the host wait until the stream has drained -- every step would then start
+        with an idle GPU waiting for the replay to be enqueued.  A slot is reused only after the copy that read it has finished
+        (an event per slot), which also bounds how far the host runs ahead of the GPU (_HYPER_SLOTS steps)."""
+        if os.environ.get("MPHSIR_HYPER_PAGEABLE", "0") == "1":
+            self._hyper.copy_(torch.tensor(values), non_blocking=True)
+            return
+        ring = getattr(self, "_hyper_ring", None)
+        if ring is None:
+            ring = self._hyper_ring = (torch.empty((self._HYPER_SLOTS, len(values)), dtype=torch.float32).pin_memory(), [None] * self._HYPER_SLOTS)
+        host, events = ring
+        k = self.step_count % self._HYPER_SLOTS
+        if events[k] is not None:
+            events[k].synchronize()
+        for i, v in enumerate(values):
+            host[k, i] = float(v)
+        self._hyper.copy_(host[k], non_blocking=True)
+        events[k] = torch.cuda.Event()
+        events[k].record()
+
     def _capture_key(self, degraded, clean, prompt):
         """everything the captured launch sequence depends on besides the buffer contents"""
         return (tuple(degraded.shape), degraded.dtype, tuple(clean.shape), clean.dtype, tuple(prompt.shape), prompt.dtype,
@@ -403,7 +427,7 @@ class DataParallelEngine:
         self._sc.copy_(clean)
         self._sp.copy_(prompt)
         self.step_count += 1
-        self._hyper.copy_(torch.tensor(self._hyper_values(self.lr if lr is None else lr, self.step_count)), non_blocking=True)
+        self._stage_hyper(self._hyper_values(self.lr if lr is None else lr, self.step_count))
         self._graph.replay()
         if self.world > 1:
             if getattr(self, "_overlap", False) and len(self._bucket_order) == len(self.buckets):

@@ -158,8 +158,10 @@ class reduce_scope:
 # the CUs the small launches of the lower pyramid levels leave idle, reading the partials while they are still in the Infinity
 # Cache.  Every tensor involved stays referenced until the join (nothing is recycled under the branch).
 DW_SIDE = int(os.environ.get("MPHSIR_DW_SIDE", "2"))
+DW_BATCH_MB = float(os.environ.get("MPHSIR_DW_BATCH_MB", "256"))
 _DW_STREAM = {}
 _DW_KEEP = []
+_DW_PEND = []
 
 
 # MPHSIR_DEBUG_DEFERRED=1 (tests): every parameter-gradient sum that is handed out before it has been computed (deferred to the end
@@ -190,7 +192,15 @@ def _dw_side(scope):
     for g in scope.segs:                # AccumulateGrad must find the output uniquely referenced: keep a detached alias
         g["keep"] = (g["keep"][0], g["keep"][1].detach())
     _poison(scope.segs)
-    if DW_SIDE >= 2:
+    if DW_SIDE >= 3:                    # the sums of several backward functions in one launch (DW_BATCH_MB of partials)
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            _flush_gemms(scope.gemms)
+            _DW_PEND.extend(scope.segs)
+            if sum(4.0 * g["nbatch"] * max(1, g["rows"]) * g["n"] * g["nsplit"] for g in _DW_PEND) >= DW_BATCH_MB * 1e6:
+                _flush(_DW_PEND)
+                del _DW_PEND[:]
+    elif DW_SIDE >= 2:
         st.wait_stream(main)
         with torch.cuda.stream(st):
             _flush_gemms(scope.gemms)
@@ -209,6 +219,10 @@ def _dw_join(final=True):
     the stream backward() was called from) releases the tensors and forgets the branch: a join in the middle -- a backward function
     that has to read a sum, possibly running on a prompt module's own stream -- makes ITS stream wait and leaves the rest as it is."""
     if _DW_KEEP:
+        if _DW_PEND:
+            with torch.cuda.stream(_DW_STREAM[_DW_KEEP[-1][0]]):
+                _flush(_DW_PEND)
+            del _DW_PEND[:]
         for dev in {k[0] for k in _DW_KEEP}:
             torch.cuda.current_stream(dev).wait_stream(_DW_STREAM[dev])
         if final:
@@ -256,7 +270,7 @@ def _flush_gemms(gemms):
         for k, g in enumerate(chunk):
             q = arr[k]
             q.A, q.lda, q.B, q.ldb, q.Cpart, q.colsum_part = g["A"], g["lda"], g["B"], g["ldb"], g["Cpart"], g["cs"]
-            q.M, q.N1, q.N2, q.nsplit = g["M"], g["N1"], g["N2"], g["nsplit"]
+            q.M, q.N1, q.N2, q.nsplit, q.group_counters = g["M"], g["N1"], g["N2"], g["nsplit"], g.get("cnt")
         form = TN_FORM or (2 if all(g["form"] == 2 for g in chunk) else 1)
         _lib.check(lib.mphsir_gemm_tn_group(arr, len(chunk), form, _DT[chunk[0]["keep"][0].dtype], _stream(chunk[0]["keep"][0])), "gemm_tn_group")
 
@@ -287,21 +301,27 @@ def _submit(seg, immediate):
 
 
 def reduce_parts(part, batched=False, immediate=False):
-    """part fp32 contiguous (nsplit, *shape) [batched: (Bt, nsplit, *shape)] -> sum over the split axis in a fixed order
-    (deterministic), shape (*shape) [(Bt, *shape)].  Deferred to the end of the enclosing `reduce_scope`, if any."""
+    """part fp32 (nsplit, *shape) [batched: (Bt, nsplit, *shape)], each partial contiguous (the split / batch axes may be strided:
+    the slots an in-kernel group sum leaves) -> sum over the split axis in a fixed order (deterministic), shape (*shape)
+    [(Bt, *shape)].  Deferred to the end of the enclosing `reduce_scope`, if any."""
     _check(part)
-    assert part.dtype == torch.float32 and part.is_contiguous()
+    assert part.dtype == torch.float32
     if batched:
         Bt, nsplit, shape = part.shape[0], part.shape[1], tuple(part.shape[2:])
+        sbs, sst = part.stride(0), part.stride(1)
     else:
         Bt, nsplit, shape = 1, part.shape[0], tuple(part.shape[1:])
-    if nsplit == 1:
-        return part[:, 0] if batched else part[0]
-    out = torch.empty(((Bt,) + shape) if batched else shape, dtype=torch.float32, device=part.device)
+        sbs, sst = 0, part.stride(0)
     n = 1
     for d in shape:
         n *= d
-    _submit(dict(src=part.data_ptr(), dst=out.data_ptr(), n=n, stride=n, sbs=nsplit * n, dbs=n, nsplit=nsplit, nbatch=Bt,
+    assert part[0, 0].is_contiguous() if batched else part[0].is_contiguous()
+    if nsplit == 1 and (not batched or Bt == 1 or sbs == n):
+        return part[:, 0] if batched else part[0]
+    # (a single strided slot per batch entry -- the in-kernel group sum of <= 8 splits -- still goes through the launch: callers get
+    # a contiguous tensor)
+    out = torch.empty(((Bt,) + shape) if batched else shape, dtype=torch.float32, device=part.device)
+    _submit(dict(src=part.data_ptr(), dst=out.data_ptr(), n=n, stride=sst, sbs=sbs, dbs=n, nsplit=nsplit, nbatch=Bt,
                  rows=1, dcs=1, src_ld=0, dst_ld=0, keep=(part, out)), immediate)
     return out
 
@@ -312,7 +332,7 @@ def reduce_block(part, r0, nr, c0, nc, out, transpose=False, immediate=False):
     where padded hidden rows are dropped, sub-blocks of a factor product are cut out and tap gradients are transposed,
     instead of in separate copy / cat launches.  Deferred like reduce_parts."""
     _check(part, out)
-    assert part.dtype == torch.float32 and part.is_contiguous() and part.dim() == 3 and out.dtype == torch.float32
+    assert part.dtype == torch.float32 and part.dim() == 3 and part[0].is_contiguous() and out.dtype == torch.float32
     nsplit, R, Cc = part.shape
     assert 0 <= r0 and r0 + nr <= R and 0 <= c0 and c0 + nc <= Cc and out.dim() == 2
     if transpose:
@@ -321,7 +341,7 @@ def reduce_block(part, r0, nr, c0, nc, out, transpose=False, immediate=False):
     else:
         assert tuple(out.shape) == (nr, nc) and out.stride(1) == 1
         dst_ld, dcs = out.stride(0), 1
-    _submit(dict(src=part.data_ptr() + 4 * (r0 * Cc + c0), dst=out.data_ptr(), n=nc, stride=R * Cc, sbs=0, dbs=0, nsplit=nsplit,
+    _submit(dict(src=part.data_ptr() + 4 * (r0 * Cc + c0), dst=out.data_ptr(), n=nc, stride=part.stride(0), sbs=0, dbs=0, nsplit=nsplit,
                  nbatch=1, rows=max(nr, 1), dcs=dcs, src_ld=Cc, dst_ld=dst_ld, keep=(part, out)), immediate)
     if nr == 1:      # the C side treats rows <= 1 as the 1-D form: identical addressing for a single row
         pass
@@ -1181,6 +1201,28 @@ TN_BIG_TILES = True        # bf16 token-reduction GEMMs use the transposed-LDS-r
 # 0 = per problem: the ring form where it measured faster -- ONE output tile, unbatched, >= 65536 tokens (tools/bench/bench_tn.py) -- else 1
 TN_FORM = int(os.environ.get("MPHSIR_TN_FORM", "0"))
 TN_RING_WGS = 256          # ring form: workgroups per launch aimed at (one per CU)
+# first level of the ordered partial sum inside the GEMM launch (groups of 8 splits, see include/mphsir.h): the reduction launch then
+# reads an eighth of the partial bytes.  Counters: a zero-initialised ring per device; every launch takes its own range (concurrent
+# launches on the weight-gradient branch never share one) and leaves it zero.  Bitwise-correct on hardware and slower (21.3 -> 22.6 ms
+# per training step: the last workgroup of a group is a serial tail; csrc/gemm_tn.hip): off by default.
+TN_COMBINE = os.environ.get("MPHSIR_TN_COMBINE", "0") == "1"
+TN_GROUP = 8
+_TN_CNT = {}
+
+
+def _tn_counters(dev, N1, N2, nsplit, Bt):
+    n = Bt * ((N1 + 63) // 64) * ((N2 + 63) // 64) * ((nsplit + 7) // 8)
+    e = _TN_CNT.get(dev)
+    if e is None:
+        e = _TN_CNT[dev] = [torch.zeros(1 << 20, dtype=torch.int32, device=dev), 0]
+    if e[1] + n > e[0].numel():
+        e[1] = 0
+    c = e[0][e[1]:e[1] + n]
+    e[1] += (n + 3) // 4 * 4
+    return c
+
+
+TN_PART_CAP = float(os.environ.get("MPHSIR_TN_PART_CAP", "0.4"))    # 0 / 0.2 / 0.3 / 0.4 / 0.55: 21.59 / 21.82 / 21.47 / 21.43 / 21.45 ms per step (one box)
 TN_BIG_ROUNDS = 1.0        # ... and aim for this many full rounds of resident workgroups (re-measured with the partial sums deferred: 0.5 / 0.75 / 1 / 2 -> 22.48 / 22.33 / 22.37 / 22.47 ms per step)
 
 
@@ -1209,21 +1251,28 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, redu
             ts = 128 if tile128 else 64
             tiles = ((N1 + ts - 1) // ts) * ((N2 + ts - 1) // ts) * Bt
             nsplit = max(1, min(M // 512, 64, max(1, 768 // tiles)))      # ~3 workgroups per CU (measured optimum)
+        if TN_PART_CAP > 0:                      # partial bytes <= TN_PART_CAP x input bytes (small-M problems: the partials ARE the traffic)
+            cap = int(TN_PART_CAP * M * (N1 + N2) * a.element_size() / (N1 * N2 * 4.0))
+            nsplit = max(1, (M + 4095) // 4096, min(nsplit, cap))
     part = torch.empty((Bt, nsplit, N1, N2), dtype=torch.float32, device=a.device)
     cs = torch.empty((Bt, nsplit, N1), dtype=torch.float32, device=a.device) if colsum else None
+    cnt = _tn_counters(a.device, N1, N2, nsplit, Bt) if (TN_COMBINE and tile128 and a.dtype in _HALF and nsplit > 1) else None
     if _SCOPE is not None and TN_GROUPED and not immediate and not batched and tile128 and a.dtype in _HALF:
         # nothing but the partial reduction at the end of the scope reads the result: issue it there, grouped
         _SCOPE.gemms.append(dict(A=a.data_ptr(), lda=a.stride(-2), B=b.data_ptr(), ldb=b.stride(-2), Cpart=part.data_ptr(),
-                                 cs=cs.data_ptr() if colsum else None, M=M, N1=N1, N2=N2, nsplit=nsplit, form=form, keep=(a, b, part, cs)))
+                                 cs=cs.data_ptr() if colsum else None, M=M, N1=N1, N2=N2, nsplit=nsplit, form=form,
+                                 cnt=cnt.data_ptr() if cnt is not None else None, keep=(a, b, part, cs, cnt)))
     else:
         _lib.check(lib.mphsir_gemm_tn(_p(a), a.stride(-2), a.stride(0) if batched else 0, _p(b), b.stride(-2),
                                       b.stride(0) if batched else 0, _p(part), _p(cs), M, N1, N2, nsplit, Bt,
-                                      (form if a.dtype in _HALF else 1) if tile128 else 0,
+                                      (form if a.dtype in _HALF else 1) if tile128 else 0, _p(cnt),
                                       _DT[a.dtype], _stream(a)),
                    "gemm_tn")
     # algorithmic bytes = the two token matrices, read once; the kernel's own split partials are overhead, accounted apart
     _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size())
     _acct("gemm_tn:partials", 0.0, part.numel() * 4.0)
+    if cnt is not None:
+        part = part[:, ::TN_GROUP]             # the slots the in-kernel group sums were left in
     if not reduce:
         return (part, cs) if colsum else part
     out = reduce_parts(part, batched=True, immediate=immediate)
@@ -1380,16 +1429,19 @@ def conv3x3_wgrad(dy2, x, nsplit=None, cout=None, cin=None):
         tiles = ((Np + 127) // 128 if Np > 64 else 1) * ((9 * Cp + 127) // 128)
         nsplit = max(1, min(M // 256, 128, max(1, (TN_RING_WGS if TN_FORM == 2 else int(256 * 2 * TN_BIG_ROUNDS)) // tiles)))
     part = torch.empty((1, nsplit, Np, 9 * Cp), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mphsir_conv3x3_wgrad(_p(dy2), dy2.stride(0), _p(x), Cp, _p(part), B, H, W, Np, Cp, nsplit, TN_FORM or 1, _DT[x.dtype], _stream(x)),
-               "conv3x3_wgrad")
+    cnt = _tn_counters(x.device, Np, 9 * Cp, nsplit, 1) if (TN_COMBINE and nsplit > 1) else None
+    _lib.check(lib.mphsir_conv3x3_wgrad(_p(dy2), dy2.stride(0), _p(x), Cp, _p(part), B, H, W, Np, Cp, nsplit, TN_FORM or 1, _p(cnt), _DT[x.dtype],
+                                        _stream(x)), "conv3x3_wgrad")
     _acct("gemm_tn", 2.0 * M * Np * 9 * Cp, M * (Np + Cp) * x.element_size())
     _acct("gemm_tn:partials", 0.0, part.numel() * 4.0)
+    if cnt is not None:
+        part = part[:, ::TN_GROUP]
     if cout is None:
         return reduce_parts(part, batched=True, immediate=True)[0]
     assert cout <= Np and cin <= Cp
     out = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
     # one segment: batch = output channel, rows = taps, columns = input channels; out[co][ci][tap]: row pitch 1, column stride 9
-    _submit(dict(src=part.data_ptr(), dst=out.data_ptr(), n=cin, stride=Np * 9 * Cp, sbs=9 * Cp, dbs=cin * 9, nsplit=nsplit, nbatch=cout,
+    _submit(dict(src=part.data_ptr(), dst=out.data_ptr(), n=cin, stride=part.stride(1), sbs=9 * Cp, dbs=cin * 9, nsplit=part.shape[1], nbatch=cout,
                  rows=9, dcs=9, src_ld=Cp, dst_ld=1, keep=(part, out)), False)
     return out
 

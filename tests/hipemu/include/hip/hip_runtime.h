@@ -221,6 +221,11 @@ template <class T> inline T __shfl_down(T v, unsigned d, int = 64) {
 }
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
+inline void __threadfence() {}
+#ifndef __HIP_MEMORY_SCOPE_AGENT          // __hip_atomic_load / _store / _fetch_add themselves are clang builtins on the host too
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __expf(float x) { return expf(x); }

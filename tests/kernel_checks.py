@@ -562,6 +562,40 @@ def check_gemm_tn(dev, dtype, M, N1, N2, nsplit, batch, tile128=None):
         assert rel_l2(c2, wide[:, 8:8 + N1].double().cpu().t() @ b.double().cpu()) < (3e-6 if dtype == torch.float32 else 1e-2)
 
 
+def check_gemm_tn_group_sum(dev, dt, M, N1, N2, nsplit, batch=0, form=1, repeats=3):
+    """the in-kernel first level of the ordered partial sum (include/mphsir.h, group_counters): for every group of 8 splits the
+    slot 8g holds ((p0 + p1) + p2) + ... of the partials a launch WITHOUT counters writes -- bitwise, whichever workgroup arrived
+    last (repeated launches agree bitwise) --, the counters are zero again afterwards, and the reduced result equals the ordered sum
+    of those group sums."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    shape_a = (batch, M, N1) if batch else (M, N1)
+    shape_b = (batch, M, N2) if batch else (M, N2)
+    a, b = rnd(shape_a, 57, dt), rnd(shape_b, 58, dt)
+    old = ops.TN_COMBINE, ops.TN_FORM
+    try:
+        ops.TN_FORM = form
+        ops.TN_COMBINE = False
+        raw = ops.gemm_tn(a, b, nsplit=nsplit, reduce=False, tile128=True).clone()          # (Bt, nsplit, N1, N2)
+        ops.TN_COMBINE = True
+        got = [ops.gemm_tn(a, b, nsplit=nsplit, reduce=False, tile128=True).clone() for _ in range(repeats)]
+        full = ops.gemm_tn(a, b, nsplit=nsplit, tile128=True)
+    finally:
+        ops.TN_COMBINE, ops.TN_FORM = old
+    ng = (nsplit + 7) // 8
+    assert got[0].shape[1] == ng
+    for g in range(ng):
+        t = raw[:, 8 * g].clone()
+        for q in range(8 * g + 1, min(8 * g + 8, nsplit)):
+            t = t + raw[:, q]
+        for r in got:
+            assert torch.equal(r[:, g].cpu(), t.cpu()), "group %d" % g
+    for e in ops._TN_CNT.values():
+        assert int(e[0].abs().sum()) == 0, "group counters not left at zero"
+    ref = a.double().cpu().transpose(-1, -2) @ b.double().cpu()
+    assert rel_l2(full, ref) < 1e-2
+
+
 def check_conv3x3(dev, dtype, B, H, W, Cin, Cout):
     """implicit-GEMM dense conv: forward, input gradient (flipped/transposed weights) and weight gradient
     (im2col + token-reduction GEMM) vs torch autograd in fp64."""

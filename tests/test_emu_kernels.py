@@ -160,6 +160,13 @@ def test_gemm_tn_transposed_read_widths(M, N1, N2, nsplit, batch, form):
         K.check_gemm_tn("cpu", torch.bfloat16, M, N1, N2, nsplit, batch, tile128=True)
 
 
+@pytest.mark.parametrize("M,N1,N2,nsplit,batch", [(640, 136, 72, 10, 0), (512, 64, 64, 8, 2), (600, 40, 200, 19, 0)])
+@pytest.mark.parametrize("form", [1, 2])
+def test_gemm_tn_group_sum(M, N1, N2, nsplit, batch, form):
+    import torch
+    K.check_gemm_tn_group_sum("cpu", torch.bfloat16, M, N1, N2, nsplit, batch, form, repeats=1)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 8, 8, 31, 32), (2, 8, 4, 32, 31), (1, 8, 8, 64, 48)])
 @pytest.mark.parametrize("form", [1, 2])

@@ -246,6 +246,16 @@ def test_gemm_tn_transposed_read_widths(M, N1, N2, nsplit, batch, form):
         K.check_gemm_tn("cuda", torch.bfloat16, M, N1, N2, nsplit, batch, tile128=True)
 
 
+@pytest.mark.parametrize("M,N1,N2,nsplit,batch", [(640, 136, 72, 10, 0), (512, 64, 64, 8, 2), (131072, 384, 128, 128, 0), (32768, 704, 128, 85, 0),
+                                                  (8192, 256, 704, 17, 0), (4096, 128, 128, 16, 32)])
+@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gemm_tn_group_sum(M, N1, N2, nsplit, batch, form, dt):
+    """the in-kernel first level of the ordered partial sum: bitwise equal to the two-level sum of a launch without it, across XCDs,
+    repeated launches, both kernel forms, batched and at the step's shapes"""
+    K.check_gemm_tn_group_sum("cuda", dt, M, N1, N2, nsplit, batch, form, repeats=4)
+
+
 def test_reduce_block():
     K.check_reduce_block("cuda")
 

@@ -1,6 +1,6 @@
 """Which lines of the package issue framework (at::native) kernels in a training step?  A TorchDispatchMode logs every aten op that
 launches a kernel, with the innermost package frames.  Runs on the GPU box (full net) or here on the CPU-emulated library (tiny net):
-    python tools/glue_sites.py [emu]"""
+    python tools/diag/glue_sites.py [emu] [fwd]        (fwd: the no-grad forward instead of a training step)"""
 import collections, os, sys, traceback, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -9,7 +9,8 @@ warnings.filterwarnings("ignore")
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
-emu = len(sys.argv) > 1 and sys.argv[1] == "emu"
+emu = "emu" in sys.argv[1:]
+fwd = "fwd" in sys.argv[1:]
 if emu:
     import emu as E
     E.bind_emulator()
@@ -50,12 +51,20 @@ if emu:
 else:
     dev = torch.device("cuda")
     net = MP_HSIR_Net(compute_dtype=torch.bfloat16, clip_prompt="surrogate").to(dev).train()
-    src = SyntheticPatchSource(31, 64, 32, 6, dev, 2024, 0)
-eng = DataParallelEngine(net, lr=2e-4, use_graph=False)
-for _ in range(2):
-    _, x, c, p = src.next(); eng.train_step(x, c, p)
-with Log():
-    _, x, c, p = src.next(); eng.train_step(x, c, p)
+    src = SyntheticPatchSource(31, 512, 1, 6, dev, 2024, 0) if fwd else SyntheticPatchSource(31, 64, 32, 6, dev, 2024, 0)
+if fwd:
+    net.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            _, x, c, p = src.next(); net(x, p)
+        with Log():
+            _, x, c, p = src.next(); net(x, p)
+else:
+    eng = DataParallelEngine(net, lr=2e-4, use_graph=False)
+    for _ in range(2):
+        _, x, c, p = src.next(); eng.train_step(x, c, p)
+    with Log():
+        _, x, c, p = src.next(); eng.train_step(x, c, p)
 print("%d aten ops that launch kernels" % sum(v[0] for v in log.values()))
 for (name, fr), (n, shp) in sorted(log.items(), key=lambda kv: -kv[1][0]):
     print("x%-3d %-28s %s   %s" % (n, name, " <- ".join(reversed(fr)), sorted(shp, key=str)[:3]))
