@@ -1,13 +1,15 @@
 """diagnostic (GPU box, after `rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py ...`): where the last replayed
 training step leaves the GPU idle.  Prints, for the span between the last two optimizer launches: wall time, the union of kernel
 intervals (time with at least one kernel running), time with exactly one / two or more kernels running, and the longest idle gaps with
-the kernels on either side.          python tools/diag/step_gaps.py <trace_dir> [top]"""
+the kernels on either side.          python tools/diag/step_gaps.py <trace_dir> [top] [mark]
+(mark: substring of a kernel that runs exactly once per step / forward; default flat_adamw = the optimizer of a training step)"""
 import csv, glob, os, sys
 d = sys.argv[1]
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+mark = sys.argv[3] if len(sys.argv) > 3 else "flat_adamw"
 f = (glob.glob(os.path.join(d, "*", "*_kernel_trace.csv")) + glob.glob(os.path.join(d, "*_kernel_trace.csv")))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-ad = [i for i, r in enumerate(rows) if "flat_adamw" in r["Kernel_Name"]]
+ad = [i for i, r in enumerate(rows) if mark in r["Kernel_Name"]]
 lo, hi = ad[-2] + 1, ad[-1] + 1
 step = rows[lo:hi]
 t0, t1 = int(rows[ad[-2]]["End_Timestamp"]), int(step[-1]["End_Timestamp"])
