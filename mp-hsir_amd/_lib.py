@@ -7,7 +7,7 @@ import os
 import torch  # noqa: F401  -- must come first: libmphsir.so binds to the HIP runtime PyTorch-ROCm already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "libmphsir.so")
+_PATH = os.path.join(_HERE, os.environ.get("MPHSIR_LIB_AB", "libmphsir.so"))      # MPHSIR_LIB_AB: another in-tree build of the same sources, for A/B timing on one box
 _lib = None
 _is_emu = False
 

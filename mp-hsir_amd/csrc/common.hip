@@ -1,4 +1,6 @@
 // libmphsir: version / error text / launch timer.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -35,6 +37,25 @@ struct ProfLog {
     size_t used = 0;
 };
 static ProfLog g_prof;
+
+bool diag_skip(int kid) {
+    static const unsigned long long mask = [] {
+        unsigned long long m = 0;
+        const char* e = getenv("MPHSIR_DIAG_SKIP");
+        if (e && *e) {
+            for (int k = 0; k < 64; ++k) {
+                const char* n = mphsir_kernel_name(k);
+                if (!n || !*n || n[0] == '?') continue;
+                const size_t len = strlen(n);
+                for (const char* p = strstr(e, n); p; p = strstr(p + 1, n))
+                    if ((p == e || p[-1] == ',') && (p[len] == 0 || p[len] == ',')) m |= 1ull << k;
+            }
+            fprintf(stderr, "mphsir: MPHSIR_DIAG_SKIP=%s -- these kernel families are NOT launched (mask %llx): timing diagnostic, results are garbage\n", e, m);
+        }
+        return m;
+    }();
+    return kid >= 0 && kid < 64 && ((mask >> kid) & 1);
+}
 
 void prof_before(int kid, hipStream_t s) {
     if (kid != g_prof.kid) return;

@@ -16,6 +16,10 @@ void clear_error();
 // launch timer (mphsir_prof_*): brackets launches of one kernel id with events on the launch stream
 void prof_before(int kid, hipStream_t s);
 void prof_after(int kid, hipStream_t s);
+// timing diagnostic: MPHSIR_DIAG_SKIP=name[,name...] (mphsir_kernel_name values) turns the launches of those kernel families into
+// no-ops -- their outputs stay uninitialised, results are GARBAGE -- so that the change of a step's wall time shows what the family
+// costs on the critical path (its kernel time minus whatever ran beside it).  Announced on stderr; never set in tests or the bench.
+bool diag_skip(int kid);
 
 #define MPHSIR_REQUIRE(cond, ...)          \
     do {                                   \
@@ -29,7 +33,7 @@ void prof_after(int kid, hipStream_t s);
 #define MPHSIR_LAUNCH(kid, kern, grid, block, shmem, stream, ...)                                   \
     do {                                                                                            \
         mphsir::prof_before(kid, stream);                                                           \
-        hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);                          \
+        if (!mphsir::diag_skip(kid)) hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__); \
         mphsir::prof_after(kid, stream);                                                            \
         hipError_t e_ = hipGetLastError();                                                          \
         if (e_ != hipSuccess) {                                                                     \

@@ -232,6 +232,7 @@ inline float __expf(float x) { return expf(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }
 inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_fmed3f(x, lo, hi) fminf(fmaxf((x), (lo)), (hi))
 
 // ---- matrix-core emulation: fragment maps per cdna_hip_programming.md §3 -----------------------
 namespace hipemu {
