@@ -1223,7 +1223,7 @@ def _tn_counters(dev, N1, N2, nsplit, Bt):
 
 
 TN_PART_CAP = float(os.environ.get("MPHSIR_TN_PART_CAP", "0.4"))    # 0 / 0.2 / 0.3 / 0.4 / 0.55: 21.59 / 21.82 / 21.47 / 21.43 / 21.45 ms per step (one box)
-TN_BIG_ROUNDS = 1.0        # ... and aim for this many full rounds of resident workgroups (re-measured with the partial sums deferred: 0.5 / 0.75 / 1 / 2 -> 22.48 / 22.33 / 22.37 / 22.47 ms per step)
+TN_BIG_ROUNDS = float(os.environ.get("MPHSIR_TN_ROUNDS", "1.0"))        # ... and aim for this many full rounds of resident workgroups (re-measured with the partial sums deferred: 0.5 / 0.75 / 1 / 2 -> 22.48 / 22.33 / 22.37 / 22.47 ms per step)
 
 
 def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, reduce=True):
