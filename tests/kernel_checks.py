@@ -168,6 +168,74 @@ def check_gated_mlp(dev, dtype, C, hid, tpw=0, M=128, hsplit=None):
     assert rel_l2(y, ref) < TOL[dtype]
 
 
+# ---- fp32 twins of the forms that exist in 16 bits only (round-3 review, weak point 13) ------------------------------------------
+# The oracle comparisons above allow TOL[bf16] = 1.5e-2: wide enough for a wrong small term.  Here the SAME operation runs through the
+# fp32 kernels on the 16-bit-rounded inputs and weights, so that what is left is the 16-bit rounding of the stored intermediates and
+# of the output (bf16: 2^-9 per rounding): the bounds are ~3x tighter.
+TWIN = {torch.bfloat16: 4e-3, torch.float16: 5e-4}      # measured: 1.1e-3 ... 2.6e-3 / 1.4e-4 ... 3.2e-4
+
+
+def check_gated_mlp_fp32_twin(dev, dtype, C=128, hid=340, M=1024, tpw=3, hsplit=None):
+    _use(dev)
+    from mp_hsir_amd import ops
+    x = rnd((M, C), 1, dtype)
+    fc1w, fc1b = rnd((2 * hid, C), 2, scale=C ** -0.5), 0.1 * rnd((2 * hid,), 3)
+    fc2w, fc2b = rnd((C, hid), 4, scale=hid ** -0.5), 0.1 * rnd((C,), 5)
+    lnw, lnb = 1 + 0.1 * rnd((C,), 6), 0.1 * rnd((C,), 7)
+    W1, b1, W2 = ops.pack_gated_mlp(fc1w, fc1b, fc2w, dtype)
+    y = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, fc2b, tiles_per_wave=tpw, hsplit=hsplit)
+    W1f, b1f, W2f = ops.pack_gated_mlp(fc1w.to(dtype).float(), fc1b, fc2w.to(dtype).float(), torch.float32)
+    y32 = ops.gated_mlp_fwd(x.float(), lnw, lnb, W1f, b1f, W2f, fc2b)
+    e = rel_l2(y, y32)
+    assert e < TWIN[dtype], e
+    return e
+
+
+def check_pass_a_rows_fp32_twin(dev, dtype, C=64, heads=2, shape=(1, 32, 64), row_segments=2):
+    """the row-walking fused pass A (16-bit only) against gemm_tok -> dwconv_gram in fp32 on the rounded inputs: v and the summed
+    Gram / norm partials"""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    assert ops.qkv_dwconv_gram_rows_fits(C, heads, H, W, dtype, False)
+    x = rnd((B, H, W, C), 61, dtype)
+    wq = rnd((3 * C, C), 62, scale=C ** -0.5).to(dtype).contiguous()
+    w9 = ops.pack_dw(rnd((3 * C, 1, 3, 3), 63, scale=1 / 3))
+    x2 = x.reshape(-1, C)
+    v, gp, sp, _ = ops.qkv_dwconv_gram(x2, wq, w9, B, H, W, C, heads, row_segments=row_segments, nsplit=(W // 32) * row_segments)
+    t = ops.gemm_tok(x2.float(), wq.float())
+    v0, gp0, sp0, _ = ops.dwconv_gram(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], w9[:, :C], w9[:, C:2 * C], w9[:, 2 * C:], 3 * C, B, H, W, C, heads)
+    ev, eg, es = rel_l2(v, v0), rel_l2(gp.double().sum(1), gp0.double().sum(1)), rel_l2(sp.double().sum(1), sp0.double().sum(1))
+    assert ev < TWIN[dtype] and eg < 2 * TWIN[dtype] and es < 2 * TWIN[dtype], (ev, eg, es)
+    return ev, eg, es
+
+
+def check_gdfn_fused_fp32_twin(dev, dtype, D=64, hid=170, shape=(1, 16, 32)):
+    """the fused GDFN (16-bit only) against the three-launch chain in fp32 on the rounded inputs and weights"""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    HP = ops.round_up(hid, 32)
+    assert ops.gdfn_fused_fits(D, HP, H, W, dtype)
+    x = rnd((B, H, W, D), 41, dtype)
+    wi, wd, wo = rnd((2 * hid, D), 42, scale=D ** -0.5), rnd((2 * hid, 1, 3, 3), 43, scale=1 / 3), rnd((D, hid), 44, scale=hid ** -0.5)
+    lnw, lnb = 1 + 0.1 * rnd((D,), 45), 0.1 * rnd((D,), 46)
+    w_in = torch.zeros((2 * HP, D), dtype=dtype, device=dev)
+    w_in[:hid], w_in[HP:HP + hid] = wi[:hid].to(dtype), wi[hid:].to(dtype)
+    w9 = torch.zeros((9, 2 * HP), device=dev)
+    w9s = ops.pack_dw(wd)
+    w9[:, :hid], w9[:, HP:HP + hid] = w9s[:, :hid], w9s[:, hid:]
+    w_out = torch.zeros((D, HP), dtype=dtype, device=dev)
+    w_out[:, :hid] = wo.to(dtype)
+    x2 = x.reshape(-1, D)
+    y = ops.gdfn_fused(x2, (lnw, lnb), w_in, w9, w_out, B, H, W)
+    t = ops.gemm_tok(x2.float(), w_in.float(), ln=(lnw, lnb))
+    y32 = ops.gemm_tok(ops.dwconv_gate(t, w9, B, H, W), w_out.float(), epi=1, res=x2.float())
+    e = rel_l2(y, y32)
+    assert e < TWIN[dtype], e
+    return e
+
+
 def _block_params(manifest_entry, prefix):
     return {k: v.to(_DEV[0]) for k, v in params_from_manifest(manifest_entry, prefix, dtype=torch.float32).items()}
 

@@ -308,3 +308,13 @@ def test_entry_points_reject_bad_arguments():
     # conv weight gradient without im2col: 16-bit types only
     with pytest.raises((RuntimeError, AssertionError)):
         ops.conv3x3_wgrad(torch.zeros((128, 32)), torch.zeros((1, 8, 16, 32)))
+
+
+# ---- fp32 twins of the 16-bit-only forms: the fp32 kernels on the rounded inputs, ~3x tighter than the oracle tolerance ----------
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_fp32_twins_of_16bit_only_forms(dt):
+    K.check_gated_mlp_fp32_twin("cpu", dt, 128, 340, 256, 3)                 # eight waves
+    K.check_gated_mlp_fp32_twin("cpu", dt, 256, 680, 256, 0, hsplit=2)        # hidden split + ordered combine
+    K.check_pass_a_rows_fp32_twin("cpu", dt, 64, 2, (1, 32, 64), 2)
+    K.check_pass_a_rows_fp32_twin("cpu", dt, 128, 4, (1, 32, 64), 2)
+    K.check_gdfn_fused_fp32_twin("cpu", dt, 64, 170, (1, 16, 32))

@@ -373,3 +373,13 @@ def test_dwconv_gate_bwd():
     K.check_dwconv_gate_bwd("cuda", torch.bfloat16)
     K.check_dwconv_gate_bwd("cuda", torch.float16, shape=(1, 8, 16), hid=170)
     K.check_dwconv_gate_bwd("cuda", torch.bfloat16, shape=(4, 64, 64), hid=340)
+
+
+# ---- fp32 twins of the 16-bit-only forms: the fp32 kernels on the rounded inputs, ~3x tighter than the oracle tolerance ----------
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_fp32_twins_of_16bit_only_forms(dt):
+    K.check_gated_mlp_fp32_twin("cuda", dt, 128, 340, 4096, 3)                 # eight waves
+    K.check_gated_mlp_fp32_twin("cuda", dt, 256, 680, 1024, 0, hsplit=2)        # hidden split + ordered combine
+    K.check_pass_a_rows_fp32_twin("cuda", dt, 64, 2, (1, 64, 128), 2)
+    K.check_pass_a_rows_fp32_twin("cuda", dt, 128, 4, (1, 64, 128), 2)
+    K.check_gdfn_fused_fp32_twin("cuda", dt, 64, 170, (1, 64, 64))
