@@ -253,6 +253,8 @@ typedef struct mphsir_mlp_args {
     int32_t hsplit;                              /* > 1: small launches (the latent level): the hidden dimension is dealt to hsplit
                                                     workgroups per token tile, the weights are still read once in total; needs */
     float* ypart;                                /* ... a workspace [hsplit][M][C] fp32 for the partial fc2 products (summed in order) */
+    const void* R; int64_t ldr;                  /* optional second residual [M][ldr]: Y = (X + keep * mlp(LN(X))) + R -- the skip of a
+                                                    whole BaseBlock (net/MP_HSIR.py:727-761) added by its last block's kernel */
 } mphsir_mlp_args;
 int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream);
 

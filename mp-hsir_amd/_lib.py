@@ -29,7 +29,7 @@ class MlpArgs(ctypes.Structure):
     _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("W1", c_void_p),
                 ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p), ("keep", c_void_p), ("rows_per_batch", c_int64),
                 ("Y", c_void_p), ("ldy", c_int64), ("M", c_int64), ("C", c_int32), ("HP", c_int32), ("tiles_per_wave", c_int32),
-                ("hsplit", c_int32), ("ypart", c_void_p)]
+                ("hsplit", c_int32), ("ypart", c_void_p), ("R", c_void_p), ("ldr", c_int64)]
 
 
 class WinAttnArgs(ctypes.Structure):

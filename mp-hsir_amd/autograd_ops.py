@@ -13,13 +13,14 @@ class _GatedMlp(torch.autograd.Function):
     token-reduction GEMMs / column sums of the three matrices the backward kernel writes."""
 
     @staticmethod
-    def forward(ctx, blk, k2, y, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b):
+    def forward(ctx, blk, k2, y, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, res=None):
+        """res: optional second residual (the input of the enclosing BaseBlock, ref :727-761), added by the same launch"""
         B, H, W, Cc = y.shape
         pk = blk.packed(y.dtype)
         ctx.blk, ctx.k2 = blk, k2
         ctx.save_for_backward(y)
         z = ops.gated_mlp_fwd(y.reshape(-1, Cc), pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"], pk["W2"], pk["b2"],
-                              keep=k2, rows_per_batch=H * W)
+                              keep=k2, rows_per_batch=H * W, res=None if res is None else res.reshape(-1, Cc))
         return z.reshape(B, H, W, Cc)
 
     @staticmethod
@@ -43,7 +44,7 @@ class _GatedMlp(torch.autograd.Function):
             dW2, db2 = ops.gemm_tn_blocks(dm, h, [(0, Cc)], ncols=hid, colsum=True)             # drops the padded hidden columns
             dW1, db1 = ops.gemm_tn_blocks(dpre, xn, [(0, hid), (HP, hid)], colsum=True)            # value rows | gate rows
             dln = ops.reduce_parts(part)
-        return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1], dW1, db1, dW2, db2)
+        return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1], dW1, db1, dW2, db2, dz if ctx.needs_input_grad[9] else None)
 
 
 def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, MbT, temperature, wo, heads, B, H, W, qk=None):
@@ -244,8 +245,9 @@ def getattr_path(mod, dotted):
     return mod
 
 
-def pgsstb(blk, x, k1, k2):
-    """One PGSSTB block (ref :662-723): attention-side residual branch, then the gated-MLP residual branch."""
+def pgsstb(blk, x, k1, k2, res=None):
+    """One PGSSTB block (ref :662-723): attention-side residual branch, then the gated-MLP residual branch (+ res: the skip of the
+    enclosing BaseBlock when this is its last block)."""
     a, sp, pgm = blk.attn, blk.gobal_spectral_attn, blk.local_spectral_attn
     if not torch.is_grad_enabled():
         y = _pgsstb_attn_infer(blk, k1, x)
@@ -254,7 +256,7 @@ def pgsstb(blk, x, k1, k2):
                               a.relative_position_bias_table, sp.temperature, sp.qkv.weight, sp.qkv_dwconv.weight,
                               sp.project_out.weight, *[getattr_path(pgm, k) for k in _PG_KEYS])
     m = blk.mlp
-    return _GatedMlp.apply(blk, k2, y, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+    return _GatedMlp.apply(blk, k2, y, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, res)
 
 
 # ---- GDFN / channel attention sub-chains ------------------------------------------------------------

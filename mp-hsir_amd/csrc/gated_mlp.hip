@@ -23,6 +23,7 @@ struct MlpDev {
     int tpw;      // token tiles per wave: 0 = auto, 1, 2
     int hsplit;   // > 1 (LDS form): the hidden dimension is dealt to hsplit workgroups per token tile (grid.y); each writes its fp32
     float* Ypart; // partial fc2 product [hsplit][M][C]; mlp_combine_kernel adds them, the bias and the residual
+    const void* R; long ldr;   // optional second residual: Y = (X + keep*mlp(LN(X))) + R  (the BaseBlock skip, net/MP_HSIR.py:727-761)
 };
 
 template <class T, int C>
@@ -133,7 +134,12 @@ __global__ __launch_bounds__(256) void gated_mlp_kernel(MlpDev a) {
         const Vec16<T> x = load16<T>(X + (long)m * a.ldx + c0);
         const Vec16<T> h = load16<T>(Xs + r * LDX + c0);
         Vec16<T> o;
-        for (int e = 0; e < VEC; ++e) o.set(e, x.get(e) + kf * h.get(e));
+        if (a.R) {
+            const Vec16<T> rr = load16<T>(reinterpret_cast<const T*>(a.R) + (long)m * a.ldr + c0);
+            for (int e = 0; e < VEC; ++e) o.set(e, (x.get(e) + kf * h.get(e)) + rr.get(e));
+        } else {
+            for (int e = 0; e < VEC; ++e) o.set(e, x.get(e) + kf * h.get(e));
+        }
         store16<T>(Y + (long)m * a.ldy + c0, o);
     }
 }
@@ -337,7 +343,12 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_lds_kernel(MlpDev a) {
         const Vec16<T> x = load16<T>(X + (long)m * a.ldx + c0);
         const Vec16<T> h = load16<T>(Xs + r * LDX + c0);
         Vec16<T> o;
-        for (int e = 0; e < VEC; ++e) o.set(e, x.get(e) + kf * h.get(e));
+        if (a.R) {
+            const Vec16<T> rr = load16<T>(reinterpret_cast<const T*>(a.R) + (long)m * a.ldr + c0);
+            for (int e = 0; e < VEC; ++e) o.set(e, (x.get(e) + kf * h.get(e)) + rr.get(e));
+        } else {
+            for (int e = 0; e < VEC; ++e) o.set(e, x.get(e) + kf * h.get(e));
+        }
         store16<T>(Y + (long)m * a.ldy + c0, o);
     }
 }
@@ -364,7 +375,12 @@ __global__ __launch_bounds__(256) void mlp_combine_kernel(MlpDev a, int C) {
         const float kf = a.keep ? a.keep[m / a.rpb] : 1.f;
         const Vec16<T> x = load16<T>(X + m * a.ldx + c0);
         Vec16<T> o;
-        for (int e = 0; e < VEC; ++e) o.set(e, x.get(e) + kf * acc[e]);
+        if (a.R) {
+            const Vec16<T> rr = load16<T>(reinterpret_cast<const T*>(a.R) + m * a.ldr + c0);
+            for (int e = 0; e < VEC; ++e) o.set(e, (x.get(e) + kf * acc[e]) + rr.get(e));
+        } else {
+            for (int e = 0; e < VEC; ++e) o.set(e, x.get(e) + kf * acc[e]);
+        }
         store16<T>(Y + m * a.ldy + c0, o);
     }
 }
@@ -441,7 +457,8 @@ extern "C" int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* s
     if (a->keep) MPHSIR_REQUIRE(a->rows_per_batch > 0, "gated_mlp: keep needs rows_per_batch");
     MlpDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->W1, a->b1, a->W2, a->b2, a->keep,
              (long)(a->rows_per_batch > 0 ? a->rows_per_batch : a->M), a->Y, (long)a->ldy, (int)a->M, a->HP, a->tiles_per_wave,
-             a->hsplit, a->ypart};
+             a->hsplit, a->ypart, a->R, (long)a->ldr};
+    if (a->R) MPHSIR_REQUIRE(aligned16(a->R) && (a->ldr * esz) % 16 == 0, "gated_mlp: second residual: 16-byte alignment required");
     if (a->hsplit > 1)
         MPHSIR_REQUIRE(a->ypart && aligned16(a->ypart) && a->HP % (32 * a->hsplit) == 0 && a->tiles_per_wave <= 2,
                        "gated_mlp: hsplit needs a workspace ypart [hsplit][M][C] fp32, HP %% (32 hsplit) == 0 and a four-wave form");

@@ -603,6 +603,7 @@ def pack_gated_mlp(fc1_w, fc1_b, fc2_w, dtype):
 
 # two-wave gated MLP kernels (32 tokens per workgroup) for launches of < 256 workgroups at C >= 192 (the latent level).  Off: measured
 # slower (natural step 22.05 -> 22.71 ms, remote-sensing step 28.55 -> 32.57): twice the workgroups stream twice the weights
+BASE_SKIP_FUSED = os.environ.get("MPHSIR_BASE_SKIP_FUSED", "1") == "1"     # BaseBlock's `+ x` inside its last gated-MLP launch (6 launches fewer per forward)
 MLP_SMALL_FORM = os.environ.get("MPHSIR_MLP_SMALL_FORM", "0") == "1"
 
 
@@ -620,10 +621,11 @@ def mlp_hsplit(M, C, HP):
     return s
 
 
-def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, out=None, tiles_per_wave=0, hsplit=None):
-    """x (M,C) row-major view -> x + keep * mlp(LN(x)); weights from pack_gated_mlp."""
+def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, out=None, tiles_per_wave=0, hsplit=None, res=None):
+    """x (M,C) row-major view -> x + keep * mlp(LN(x)) [+ res, a second residual (M,C) row-major view: the skip of a whole BaseBlock
+    folded into its last block's launch]; weights from pack_gated_mlp."""
     lib = _lib.load()
-    _check(x, W1, W2, b1, b2, ln_w, ln_b, keep)
+    _check(x, W1, W2, b1, b2, ln_w, ln_b, keep, res)
     M, ldx = _rows(x)
     C = x.shape[1]
     HP = W2.shape[1]
@@ -633,6 +635,9 @@ def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, ou
     a.X, a.ldx, a.ln_w, a.ln_b = _p(x), ldx, _p(ln_w), _p(ln_b)
     a.W1, a.b1, a.W2, a.b2 = _p(W1), _p(b1), _p(W2), _p(b2)
     a.keep, a.rows_per_batch = _p(keep), rows_per_batch
+    if res is not None:
+        assert res.shape == x.shape and res.dtype == x.dtype
+        a.R, a.ldr = _p(res), _rows(res)[1]
     if tiles_per_wave == 0 and MLP_SMALL_FORM and x.dtype in _HALF and C >= 192 and M // 64 < 256:
         tiles_per_wave = 5
     a.Y, a.ldy, a.M, a.C, a.HP, a.tiles_per_wave = _p(y), _rows(y)[1], M, C, HP, tiles_per_wave
