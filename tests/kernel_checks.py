@@ -152,19 +152,25 @@ def check_gemm_tok_per_sample_combine(dev, dtype):
     assert rel_l2(y.reshape(B, H, W, C), ref) < TOL[dtype]
 
 
-def check_gated_mlp(dev, dtype, C, hid, tpw=0, M=128, hsplit=None):
+def check_gated_mlp(dev, dtype, C, hid, tpw=0, M=128, hsplit=None, res=False):
     _use(dev)
     from mp_hsir_amd import ops
     x = rnd((M, C), 1, dtype)
+    r2 = rnd((M, C + 8), 8, dtype)[:, :C] if res else None          # second residual (BaseBlock skip), a strided view
     P = {"fc1.weight": rnd((2 * hid, C), 2, scale=C ** -0.5), "fc1.bias": 0.1 * rnd((2 * hid,), 3),
          "fc2.weight": rnd((C, hid), 4, scale=hid ** -0.5), "fc2.bias": 0.1 * rnd((C,), 5)}
     lnw, lnb = 1 + 0.1 * rnd((C,), 6), 0.1 * rnd((C,), 7)
     keep = torch.tensor([1.0, 1.5]).to(dev)
     W1, b1, W2 = ops.pack_gated_mlp(P["fc1.weight"], P["fc1.bias"], P["fc2.weight"], dtype)
-    y = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, P["fc2.bias"], keep=keep, rows_per_batch=M // 2, tiles_per_wave=tpw, hsplit=hsplit)
+    y = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, P["fc2.bias"], keep=keep, rows_per_batch=M // 2, tiles_per_wave=tpw, hsplit=hsplit, res=r2)
     Pd = {k: (v.to(dtype) if k.endswith("weight") else v).double().cpu() for k, v in P.items()}
     xn = O.layer_norm_c(x.double().cpu(), lnw.double().cpu(), lnb.double().cpu())
     ref = x.double().cpu() + keep.double().cpu().repeat_interleave(M // 2)[:, None] * O.gated_mlp(Pd, "", xn)
+    if res:
+        ref = ref + r2.double().cpu()
+        if dtype == torch.float32:      # (x + keep mlp) + res in that order: bitwise what the separate add of the unfused path gives
+            y0 = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, P["fc2.bias"], keep=keep, rows_per_batch=M // 2, tiles_per_wave=tpw, hsplit=hsplit)
+            assert torch.equal((y0 + r2).cpu(), y.cpu())
     assert rel_l2(y, ref) < TOL[dtype]
 
 

@@ -318,3 +318,13 @@ def test_fp32_twins_of_16bit_only_forms(dt):
     K.check_pass_a_rows_fp32_twin("cpu", dt, 64, 2, (1, 32, 64), 2)
     K.check_pass_a_rows_fp32_twin("cpu", dt, 128, 4, (1, 32, 64), 2)
     K.check_gdfn_fused_fp32_twin("cpu", dt, 64, 170, (1, 16, 32))
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
+def test_gated_mlp_second_residual(dtype):
+    """mphsir_gated_mlp_fwd with R: every kernel form adds the BaseBlock skip in its epilogue (direct form, LDS forms, hidden-split combine)"""
+    K.check_gated_mlp("cpu", dtype, 32, 85, res=True)
+    K.check_gated_mlp("cpu", dtype, 128, 340, M=256, res=True)
+    if dtype != torch.float32:
+        K.check_gated_mlp("cpu", dtype, 128, 340, tpw=3, M=256, res=True)
+        K.check_gated_mlp("cpu", dtype, 256, 680, M=256, hsplit=2, res=True)
