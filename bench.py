@@ -159,7 +159,7 @@ def cpu_baseline(budget_s=30.0):
                       "counts in detail (patches/s each); bounded to ~%ds" % int(budget_s)}
 
 
-def spectral_roofline(net, dev, lib, steps=5):
+def spectral_roofline(net, dev, lib, steps=20):
     """What north_star names: the spectral attention at 512x512x31 bf16 (forward, batch 1 = one test cube of test.py).
     Times the forward (eager warm-up, then the replayed hipGraph) and, with HIP events on the launch stream, the kernels
     of the global spectral branch; reports them against the roof that bounds each:
