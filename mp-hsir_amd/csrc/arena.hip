@@ -165,12 +165,6 @@ extern "C" int mphsir_l1_clamp_loss(const float* y, const float* clean, float* g
     return MPHSIR_OK;
 }
 
-// threads a segment is spread over before lanes stop sharing items (MPHSIR_REDUCE_FILL overrides: A/B runs)
-static long reduce_fill_threads() {
-    static long v = [] { const char* e = getenv("MPHSIR_REDUCE_FILL"); return e ? atol(e) : 8192L; }();
-    return v;
-}
-
 extern "C" int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, void* stream) {
     using namespace mphsir;
     clear_error();
@@ -188,7 +182,7 @@ extern "C" int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, 
         const long nitems = (long)g.nbatch * rows * ((g.n + 3) / 4);
         int lg = 0;                        // lanes per item: keep <= 32 splits per lane, and small segments still fill waves
         while (lg < 6 && (g.nsplit >> lg) > 32) ++lg;
-        while (lg < 6 && (nitems << lg) < reduce_fill_threads() && (g.nsplit >> lg) > 4) ++lg;
+        while (lg < 6 && (nitems << lg) < 8192 && (g.nsplit >> lg) > 4) ++lg;      // (32 k / 64 k / 128 k threads measured: no difference)
         d.s[k] = RedSegDev{g.src, g.dst, (long)g.n, (long)g.stride, (long)g.src_batch_stride, (long)g.dst_batch_stride, threads, nitems,
                            src_ld, dst_ld, g.nsplit, vec ? 1 : 0, lg, rows, dcs};
         threads += ((nitems << lg) + 63) / 64 * 64;

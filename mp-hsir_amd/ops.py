@@ -158,10 +158,8 @@ class reduce_scope:
 # the CUs the small launches of the lower pyramid levels leave idle, reading the partials while they are still in the Infinity
 # Cache.  Every tensor involved stays referenced until the join (nothing is recycled under the branch).
 DW_SIDE = int(os.environ.get("MPHSIR_DW_SIDE", "2"))
-DW_BATCH_MB = float(os.environ.get("MPHSIR_DW_BATCH_MB", "256"))
 _DW_STREAM = {}
 _DW_KEEP = []
-_DW_PEND = []
 
 
 # MPHSIR_DEBUG_DEFERRED=1 (tests): every parameter-gradient sum that is handed out before it has been computed (deferred to the end
@@ -192,15 +190,7 @@ def _dw_side(scope):
     for g in scope.segs:                # AccumulateGrad must find the output uniquely referenced: keep a detached alias
         g["keep"] = (g["keep"][0], g["keep"][1].detach())
     _poison(scope.segs)
-    if DW_SIDE >= 3:                    # the sums of several backward functions in one launch (DW_BATCH_MB of partials)
-        st.wait_stream(main)
-        with torch.cuda.stream(st):
-            _flush_gemms(scope.gemms)
-            _DW_PEND.extend(scope.segs)
-            if sum(4.0 * g["nbatch"] * max(1, g["rows"]) * g["n"] * g["nsplit"] for g in _DW_PEND) >= DW_BATCH_MB * 1e6:
-                _flush(_DW_PEND)
-                del _DW_PEND[:]
-    elif DW_SIDE >= 2:
+    if DW_SIDE >= 2:
         st.wait_stream(main)
         with torch.cuda.stream(st):
             _flush_gemms(scope.gemms)
@@ -219,10 +209,6 @@ def _dw_join(final=True):
     the stream backward() was called from) releases the tensors and forgets the branch: a join in the middle -- a backward function
     that has to read a sum, possibly running on a prompt module's own stream -- makes ITS stream wait and leaves the rest as it is."""
     if _DW_KEEP:
-        if _DW_PEND:
-            with torch.cuda.stream(_DW_STREAM[_DW_KEEP[-1][0]]):
-                _flush(_DW_PEND)
-            del _DW_PEND[:]
         for dev in {k[0] for k in _DW_KEEP}:
             torch.cuda.current_stream(dev).wait_stream(_DW_STREAM[dev])
         if final:
