@@ -176,6 +176,10 @@ def spectral_roofline(net, dev, lib, steps=20):
     with torch.no_grad():
         for _ in range(2):
             net(x, p)
+        # a kernel's own duration: the parallel branches (prompt gate, prompt modules) are issued in line for the per-kernel table, as
+        # in the training leg -- beside each other their launches stretch; cubes_per_s below is measured WITH the branches
+        side_state = (ops.SIDE_BRANCH, ops.PROMPT_SIDE)
+        ops.SIDE_BRANCH, ops.PROMPT_SIDE = False, False
         ops.ACCOUNT = {}
         net(x, p)
         torch.cuda.synchronize()
@@ -191,6 +195,7 @@ def spectral_roofline(net, dev, lib, steps=20):
             lib.mphsir_prof_enable(-1)
             if n.value:
                 per[name] = (n.value, ms.value)
+        ops.SIDE_BRANCH, ops.PROMPT_SIDE = side_state
         run = GraphedForward(net, warmup=0)
         run(x, p)
         torch.cuda.synchronize()
