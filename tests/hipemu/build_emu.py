@@ -11,12 +11,16 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "mp-hsir_amd", "csrc")
-BUILD = os.path.join(HERE, "_build")
+# HIPEMU_SANITIZE=1: the same sources with AddressSanitizer + UBSan (the GPU pool has no sanitizers: the kernels' LDS tiles and global
+# accesses are checked on the CPU build).  Run the emulator tests with the runtime preloaded:
+#   HIPEMU_SANITIZE=1 LD_PRELOAD=$(clang++ -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 pytest tests/test_emu_kernels.py
+SANITIZE = os.environ.get("HIPEMU_SANITIZE", "0") == "1"
+BUILD = os.path.join(HERE, "_build_asan" if SANITIZE else "_build")
 OUT = os.path.join(BUILD, "libmphsir_emu.so")
 CXX = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-ffp-contract=off", "-mavx2", "-mfma", "-mf16c",
          "-I", os.path.join(HERE, "include"), "-Wno-unused-function", "-Wno-unknown-attributes",
-         "-fno-omit-frame-pointer"]
+         "-fno-omit-frame-pointer"] + (["-fsanitize=address,undefined", "-fno-sanitize=alignment,float-cast-overflow,vptr", "-fno-sanitize-recover=undefined", "-shared-libasan"] if os.environ.get("HIPEMU_SANITIZE", "0") == "1" else [])
 
 
 def _mtime_deps():
@@ -44,7 +48,8 @@ def build(jobs=6):
         objs = list(ex.map(lambda s: _compile(s, dm), srcs))
     if os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(o) for o in objs):
         return OUT
-    r = subprocess.run([CXX, "-shared", "-fPIC", "-o", OUT] + objs, capture_output=True, text=True)
+    r = subprocess.run([CXX, "-shared", "-fPIC"] + (["-fsanitize=address,undefined", "-shared-libasan"] if SANITIZE else []) + ["-o", OUT] + objs,
+                       capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipemu link failed:\n" + r.stderr[-8000:])
     return OUT
