@@ -283,6 +283,27 @@ typedef struct mphsir_mlp_bwd_args {
 } mphsir_mlp_bwd_args;
 int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream);
 
+/* ---- the parameter gradients of the gated MLP without token-sized intermediates (16-bit types) ------------------------
+ * With H == NULL and DPRE == NULL mphsir_gated_mlp_bwd writes neither of them (XN and, with keep, DM are still written), and
+ * this entry point produces dW1, db1, dW2, db2 from XN = LN(X) and DM = keep*dY alone: a workgroup owns a 32*chunks_per_wg-wide
+ * slab of the hidden dimension and a range of 64-token tiles, RECOMPUTES value / gate / dh for its slab on the matrix cores
+ * and keeps its slice of the gradients as fp32 MFMA accumulators over the whole range (gated_mlp_wgrad.hip).  Outputs are
+ * per-range partial sums -- dW1p [ranges][2*HP][C] (value rows j, gate rows HP + j), dW2p [ranges][C][HP],
+ * db1p [ranges][2*HP], db2p [ranges][C] -- for mphsir_reduce_parts (fixed order: deterministic).  ranges: a multiple of 8
+ * (the slabs of a range share an XCD's L2), every range covers ceil(M/64 / ranges) tiles, trailing ranges may be empty
+ * (zeros).  W1 / b1 / W2T as for mphsir_gated_mlp_bwd.  mphsir_gated_mlp_wgrad_fits: which (C, chunks_per_wg, dtype) exist.
+ * Autograd of train.py:58-67 for net/MP_HSIR.py:66-82 (fc1, fc2 of GatedMlp).                                            */
+typedef struct mphsir_mlp_wgrad_args {
+    const void* XN; const void* DM;
+    const void* W1; const float* b1; const void* W2T;
+    float* dW1p; float* dW2p; float* db1p; float* db2p;
+    int64_t M; int32_t C, HP;
+    int32_t ranges;
+    int32_t chunks_per_wg;            /* 1: 256-thread workgroups, two per CU; 2: 512 threads, half the tile reads from L2 per FLOP */
+} mphsir_mlp_wgrad_args;
+int mphsir_gated_mlp_wgrad(const mphsir_mlp_wgrad_args* a, int dtype, void* stream);
+int mphsir_gated_mlp_wgrad_fits(int32_t C, int32_t chunks_per_wg, int dtype);
+
 /* ---- backward of the window-attention side of a PGSSTB block --------------------------------------
  * mphsir_combine_bwd: backward of mphsir_gemm_tok epi 2 (y = R + keep*(SA*gate[win] + acc), net/MP_HSIR.py
  *   :715-718,:153): dOut = keep*dY (written only if keep != NULL), dSA = dOut*gate[win],
@@ -537,6 +558,7 @@ int mphsir_l1_clamp_loss(const float* y, const float* clean, float* grad, float*
 #define MPHSIR_K_DWCONV_BWD 26
 #define MPHSIR_K_MULTI_COPY 27
 #define MPHSIR_K_L1_LOSS 28
+#define MPHSIR_K_GATED_MLP_WGRAD 29
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -87,6 +87,12 @@ class MlpBwdArgs(ctypes.Structure):
                 ("hsplit", c_int32), ("dxn_part", c_void_p)]
 
 
+class MlpWgradArgs(ctypes.Structure):
+    """mirror of struct mphsir_mlp_wgrad_args"""
+    _fields_ = [(n, c_void_p) for n in ("XN", "DM", "W1", "b1", "W2T", "dW1p", "dW2p", "db1p", "db2p")] + \
+               [("M", c_int64), ("C", c_int32), ("HP", c_int32), ("ranges", c_int32), ("chunks_per_wg", c_int32)]
+
+
 class WinAttnBwdArgs(ctypes.Structure):
     """mirror of struct mphsir_win_attn_bwd_args"""
     _fields_ = [(n, c_void_p) for n in ("X", "dSA", "dmu", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "WprojT", "dQKV", "XNw",
@@ -185,6 +191,8 @@ _SYMBOLS = {
     "mphsir_im2col3x3": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_gdfn_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "mphsir_gated_mlp_bwd": (c_int, [ctypes.POINTER(MlpBwdArgs), c_int, c_void_p]),
+    "mphsir_gated_mlp_wgrad": (c_int, [ctypes.POINTER(MlpWgradArgs), c_int, c_void_p]),
+    "mphsir_gated_mlp_wgrad_fits": (c_int, [c_int32, c_int32, c_int]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
     "mphsir_reduce_parts": (c_int, [ctypes.POINTER(ReduceSeg), c_int32, c_void_p]),
     "mphsir_gemm_tn_group": (c_int, [ctypes.POINTER(TnProblem), c_int32, c_int32, c_int, c_void_p]),

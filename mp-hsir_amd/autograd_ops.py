@@ -31,18 +31,24 @@ class _GatedMlp(torch.autograd.Function):
         dt = y.dtype
         pk = blk.packed(dt)
         dz2 = dz.reshape(-1, Cc).contiguous()
+        hid = blk.mlp.fc2.weight.shape[1]
+        HP = pk["W2T"].shape[0]
+        # 16-bit types, big launches: the parameter gradients are recomputed per hidden slab from LN(y) and dm alone
+        # (ops.gated_mlp_wgrad); h and [dval | dgate] then never reach HBM
+        fused = ops.gated_mlp_wgrad_fits(dz2.shape[0], Cc, HP, dt)
         if k2 is None:
             dm = dz2
             dx, xn, h, dpre, part = ops.gated_mlp_bwd(y.reshape(-1, Cc), dz2, dm, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"],
-                                                      pk["W1T"], pk["W2T"])
+                                                      pk["W1T"], pk["W2T"], operands=not fused)
         else:               # DropPath: dm = keep[b] * dz is formed (and kept for dW2 / db2) inside the kernel
             dx, xn, h, dpre, part, dm = ops.gated_mlp_bwd(y.reshape(-1, Cc), dz2, None, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"],
-                                                          pk["W1T"], pk["W2T"], keep=k2, rows_per_batch=H * W)
-        hid = blk.mlp.fc2.weight.shape[1]
-        HP = h.shape[1]
+                                                          pk["W1T"], pk["W2T"], keep=k2, rows_per_batch=H * W, operands=not fused)
         with ops.reduce_scope(leaf=True):                                   # one ordered-sum launch for all five partial buffers
-            dW2, db2 = ops.gemm_tn_blocks(dm, h, [(0, Cc)], ncols=hid, colsum=True)             # drops the padded hidden columns
-            dW1, db1 = ops.gemm_tn_blocks(dpre, xn, [(0, hid), (HP, hid)], colsum=True)            # value rows | gate rows
+            if fused:
+                dW1, db1, dW2, db2 = ops.gated_mlp_wgrad(xn, dm, pk["W1"], pk["b1"], pk["W2T"], hid)
+            else:
+                dW2, db2 = ops.gemm_tn_blocks(dm, h, [(0, Cc)], ncols=hid, colsum=True)             # drops the padded hidden columns
+                dW1, db1 = ops.gemm_tn_blocks(dpre, xn, [(0, hid), (HP, hid)], colsum=True)            # value rows | gate rows
             dln = ops.reduce_parts(part)
         return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1], dW1, db1, dW2, db2, dz if ctx.needs_input_grad[9] else None)
 

@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const long* __restrict_
 // l1_clamp_loss: the training loss of the reference (train.py:58-61: clamp(restored, 0, 1), nn.L1Loss) and its gradient in one
 // pass: part[block] = sum |clamp(y) - c| / n over the block's elements, g = sign(clamp(y) - c) * [0 <= y <= 1] / n (clamp's
 // autograd passes the gradient where 0 <= y <= 1, bounds included; sign(0) = 0).  The caller sums the partials in order.
+// The clamp PROPAGATES NaN like torch.clamp (two compares, both false for a NaN; fminf / fmaxf would return the bound and a
+// diverged run would log a plausible finite loss): a NaN output makes the loss NaN, its gradient entry 0 as in the reference.
+__device__ __forceinline__ float clamp01_nan(float y) { return y < 0.f ? 0.f : (y > 1.f ? 1.f : y); }
 __global__ __launch_bounds__(256) void l1_clamp_loss_kernel(const float* __restrict__ y, const float* __restrict__ c, float* __restrict__ g,
                                                             float* __restrict__ part, long n, float inv_n) {
     __shared__ float red[4];
@@ -124,14 +127,14 @@ __global__ __launch_bounds__(256) void l1_clamp_loss_kernel(const float* __restr
             const f32x4 yv = *reinterpret_cast<const f32x4*>(y + e), cv = *reinterpret_cast<const f32x4*>(c + e);
             f32x4 gv;
             for (int i = 0; i < 4; ++i) {
-                const float d = fminf(fmaxf(yv[i], 0.f), 1.f) - cv[i];
+                const float d = clamp01_nan(yv[i]) - cv[i];
                 acc += fabsf(d);
                 gv[i] = (yv[i] >= 0.f && yv[i] <= 1.f) ? (d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f)) : 0.f;
             }
             if (g) *reinterpret_cast<f32x4*>(g + e) = gv;
         } else {
             for (long k = e; k < n; ++k) {
-                const float d = fminf(fmaxf(y[k], 0.f), 1.f) - c[k];
+                const float d = clamp01_nan(y[k]) - c[k];
                 acc += fabsf(d);
                 if (g) g[k] = (y[k] >= 0.f && y[k] <= 1.f) ? (d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f)) : 0.f;
             }

@@ -168,24 +168,27 @@ __global__ __launch_bounds__(256) void gated_mlp_bwd_kernel(MlpBwdDev a) {
             dg0[r] = e0[r] * va * da;
             dg1[r] = e1[r] * vb * db;
         }
-        // h chunk -> HBM through the per-wave LDS buffer (whole 64-byte row segments per token)
-        store4<T>(Hw + tk * LDH + hr, h0);
-        store4<T>(Hw + tk * LDH + 16 + hr, h1);
-        __syncthreads();
-        {
-            constexpr int VPR = 32 / VEC;                    // vectors per 32-wide row segment
-            for (int i = lane; i < 16 * VPR; i += 64) {
-                const int t = i / VPR, c = (i % VPR) * VEC;
-                store16<T>(Hout + (long)(m0 + wv * 16 + t) * HP + j + c, load16<T>(Hw + t * LDH + c));
+        // h chunk -> HBM through the per-wave LDS buffer (whole 64-byte row segments per token); not when the parameter gradients
+        // come from mphsir_gated_mlp_wgrad (H == DPRE == NULL)
+        if (Hout) {
+            store4<T>(Hw + tk * LDH + hr, h0);
+            store4<T>(Hw + tk * LDH + 16 + hr, h1);
+            __syncthreads();
+            {
+                constexpr int VPR = 32 / VEC;                    // vectors per 32-wide row segment
+                for (int i = lane; i < 16 * VPR; i += 64) {
+                    const int t = i / VPR, c = (i % VPR) * VEC;
+                    store16<T>(Hout + (long)(m0 + wv * 16 + t) * HP + j + c, load16<T>(Hw + t * LDH + c));
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
         store4<T>(Hw + tk * LDH + hr, dv0);
         store4<T>(Hw + tk * LDH + 16 + hr, dv1);
         store4<T>(Hw + tk * LDH + 32 + hr, dg0);
         store4<T>(Hw + tk * LDH + 48 + hr, dg1);
         __syncthreads();
-        {
+        if (Pout) {
             constexpr int VPR = 32 / VEC;
             for (int i = lane; i < 16 * 2 * VPR; i += 64) {
                 const int t = i / (2 * VPR), seg = (i / VPR) & 1, c = (i % VPR) * VEC;
@@ -520,18 +523,21 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
                     dg[f][t][r] = pe[f][t][r] * va * da;
                 }
         }
-        // h chunk -> HBM through the wave's staging rows (whole 64-byte row segments per token)
+        // h chunk -> HBM through the wave's staging rows (whole 64-byte row segments per token); not when the parameter gradients
+        // come from mphsir_gated_mlp_wgrad (H == DPRE == NULL)
+        if (Hout) {
 #pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            store4<T>(Hw + (16 * t + tk) * LDH + hr, hh[0][t]);
-            store4<T>(Hw + (16 * t + tk) * LDH + 16 + hr, hh[1][t]);
+            for (int t = 0; t < TT; ++t) {
+                store4<T>(Hw + (16 * t + tk) * LDH + hr, hh[0][t]);
+                store4<T>(Hw + (16 * t + tk) * LDH + 16 + hr, hh[1][t]);
+            }
+            wave_barrier();
+            for (int i = lane; i < WT * VPH; i += 64) {
+                const int t = i / VPH, c = (i % VPH) * VEC;
+                store16<T>(Hout + (m0 + wv * WT + t) * HP + j + c, load16<T>(Hw + t * LDH + c));
+            }
+            wave_barrier();
         }
-        wave_barrier();
-        for (int i = lane; i < WT * VPH; i += 64) {
-            const int t = i / VPH, c = (i % VPH) * VEC;
-            store16<T>(Hout + (m0 + wv * WT + t) * HP + j + c, load16<T>(Hw + t * LDH + c));
-        }
-        wave_barrier();
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             store4<T>(Hw + (16 * t + tk) * LDH + hr, dv[0][t]);
@@ -540,10 +546,11 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
             store4<T>(Hw + (16 * t + tk) * LDH + 48 + hr, dg[1][t]);
         }
         wave_barrier();
-        for (int i = lane; i < WT * 2 * VPH; i += 64) {
-            const int t = i / (2 * VPH), seg = (i / VPH) & 1, c = (i % VPH) * VEC;
-            store16<T>(Pout + (m0 + wv * WT + t) * 2 * HP + seg * HP + j + c, load16<T>(Hw + t * LDH + seg * 32 + c));
-        }
+        if (Pout)
+            for (int i = lane; i < WT * 2 * VPH; i += 64) {
+                const int t = i / (2 * VPH), seg = (i / VPH) & 1, c = (i % VPH) * VEC;
+                store16<T>(Pout + (m0 + wv * WT + t) * 2 * HP + seg * HP + j + c, load16<T>(Hw + t * LDH + seg * 32 + c));
+            }
         // dxn[c][tok] += W1T[c][j..j+31] * dval + W1T[c][HP+j..] * dgate
 #pragma unroll
         for (int kh = 0; kh < 2 * NKH; ++kh) {
@@ -719,7 +726,7 @@ extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, voi
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(a && a->X && a->dY && a->DM && a->ln_w && a->ln_b && a->W1 && a->b1 && a->W1T && a->W2T && a->dX && a->XN &&
-                       a->H && a->DPRE && a->part, "gated_mlp_bwd: null pointer");
+                       a->part && (!a->H == !a->DPRE), "gated_mlp_bwd: null pointer (H and DPRE: both or neither)");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "gated_mlp_bwd: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->M > 0 && a->M % 64 == 0 && a->HP > 0 && a->HP % 32 == 0, "gated_mlp_bwd: M %% 64 and HP %% 32 must be 0");
     MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->dY) && aligned16(a->DM) && aligned16(a->dX) && aligned16(a->XN) && aligned16(a->H) &&

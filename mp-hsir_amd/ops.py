@@ -126,7 +126,7 @@ class reduce_scope:
 
     def __enter__(self):
         global _SCOPE
-        self.prev, self.segs, self.gemms = _SCOPE, [], []
+        self.prev, self.segs, self.gemms, self.calls = _SCOPE, [], [], []
         _SCOPE = self
         return self
 
@@ -137,6 +137,7 @@ class reduce_scope:
             if self.leaf and _DEFERRED is not None and DW_SIDE and _dw_side(self):
                 pass                            # weight-gradient branch: issued beside the data-gradient chain (see _dw_side)
             elif self.leaf and _DEFERRED is not None:
+                _flush_calls(self.calls)
                 _flush_gemms(self.gemms)
                 # ... their sums later, with everybody else's.  The output is kept alive through a detached alias: the tensor
                 # object itself must stay uniquely referenced so that AccumulateGrad adopts it instead of cloning (= reading) it
@@ -145,9 +146,10 @@ class reduce_scope:
                 _poison(self.segs)
                 _DEFERRED.extend(self.segs)
             else:
+                _flush_calls(self.calls)
                 _flush_gemms(self.gemms)        # the deferred weight-gradient GEMMs, grouped ...
                 _flush(self.segs)               # ... then the ordered sums of everything they (and others) wrote
-        self.segs, self.gemms = [], []
+        self.segs, self.gemms, self.calls = [], [], []
         return False
 
 
@@ -193,14 +195,16 @@ def _dw_side(scope):
     if DW_SIDE >= 2:
         st.wait_stream(main)
         with torch.cuda.stream(st):
+            _flush_calls(scope.calls)
             _flush_gemms(scope.gemms)
             _flush(scope.segs)
     else:
+        _flush_calls(scope.calls)
         _flush_gemms(scope.gemms)
         st.wait_stream(main)
         with torch.cuda.stream(st):
             _flush(scope.segs)
-    _DW_KEEP.append((dev, [g["keep"] for g in scope.gemms], [g["keep"] for g in scope.segs]))
+    _DW_KEEP.append((dev, [g["keep"] for g in scope.gemms] + [c["keep"] for c in scope.calls], [g["keep"] for g in scope.segs]))
     return True
 
 
@@ -245,6 +249,13 @@ def flush_deferred():
         del _DEFERRED[:]
         _flush(segs)
     _dw_join(final=False)
+
+
+def _flush_calls(calls):
+    """calls: deferred weight-gradient launches other than the grouped token-reduction GEMMs (dicts: `run` = the launch on the
+    stream that is current NOW, `keep` = the tensors it reads / writes)."""
+    for c in calls:
+        c["run"]()
 
 
 def _flush_gemms(gemms):
@@ -423,6 +434,7 @@ class _L1ClampLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         g, ctx.g = ctx.g, None
+        assert g is not None, "l1_clamp_loss: its gradient buffer is scaled in place and handed over: backward() runs once"
         return g.mul_(dloss), None
 
 
@@ -1079,9 +1091,10 @@ def dwconv3x3_bwd(x, dy, w9, col_ranges=None):
     return dx, out
 
 
-def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None, rows_per_batch=0, hsplit=None):
+def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None, rows_per_batch=0, hsplit=None, operands=True):
     """-> dx, xn, h, dpre, part (see include/mphsir.h).  x, dy, dm: contiguous (M,C).  With keep (DropPath factors, one
-    per rows_per_batch rows) dm is ignored as input: the kernel computes keep*dy itself and it is returned as a 6th value."""
+    per rows_per_batch rows) dm is ignored as input: the kernel computes keep*dy itself and it is returned as a 6th value.
+    operands=False: h and dpre are not written (returned as None): the parameter gradients come from gated_mlp_wgrad."""
     lib = _lib.load()
     _check(x, dy, dm, W1, W1T, W2T)
     M, C = x.shape
@@ -1092,8 +1105,8 @@ def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None,
         variant = 5           # fewer than one 64-token workgroup per CU, each streaming MBs of weights: 32-token workgroups
     dx = torch.empty_like(x)
     xn = torch.empty_like(x)
-    h = torch.empty((M, HP), dtype=dt, device=dev)
-    dpre = torch.empty((M, 2 * HP), dtype=dt, device=dev)
+    h = torch.empty((M, HP), dtype=dt, device=dev) if operands else None
+    dpre = torch.empty((M, 2 * HP), dtype=dt, device=dev) if operands else None
     part = torch.empty((M // (32 if variant == 5 else 64), 2, C), dtype=torch.float32, device=dev)
     a = _lib.MlpBwdArgs()
     if keep is not None:
@@ -1103,7 +1116,7 @@ def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None,
         a.keep, a.rows_per_batch = _p(keep), rows_per_batch
     a.X, a.dY, a.DM, a.ln_w, a.ln_b = _p(x), _p(dy), _p(dm), _p(ln_w), _p(ln_b)
     a.W1, a.b1, a.W1T, a.W2T = _p(W1), _p(b1), _p(W1T), _p(W2T)
-    a.dX, a.XN, a.H, a.DPRE, a.part = _p(dx), _p(xn), _p(h), _p(dpre), _p(part)
+    a.dX, a.XN, a.H, a.DPRE, a.part = _p(dx), _p(xn), _p(h) if operands else None, _p(dpre) if operands else None, _p(part)
     a.M, a.C, a.HP, a.variant = M, C, HP, variant
     if hsplit is None:
         hsplit = mlp_hsplit(M, C, HP) if variant == 0 and dt in _HALF else 1
@@ -1111,10 +1124,81 @@ def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None,
         dxn_part = torch.empty((hsplit, M, C), dtype=torch.float32, device=dev)
         a.hsplit, a.dxn_part = hsplit, _p(dxn_part)
     _lib.check(lib.mphsir_gated_mlp_bwd(ctypes.byref(a), _DT[dt], _stream(x)), "gated_mlp_bwd")
-    _acct("gated_mlp_bwd", 12.0 * M * C * HP, (3.0 * M * C + 3.0 * M * HP + M * C) * x.element_size())
+    _acct("gated_mlp_bwd", 12.0 * M * C * HP, (3.0 * M * C + (3.0 * M * HP if operands else 0.0) + M * C) * x.element_size())
     if keep is not None:
         return dx, xn, h, dpre, part, dm
     return dx, xn, h, dpre, part
+
+
+MLP_WGRAD = os.environ.get("MPHSIR_MLP_WGRAD", "1") == "1"      # parameter gradients of the gated MLP by recomputation (no h / dpre in HBM)
+MLP_WGRAD_NCH = int(os.environ.get("MPHSIR_MLP_WGRAD_NCH", "0"))  # chunks of 32 hidden units per workgroup: 0 = per shape, 1, 2
+MLP_WGRAD_WGS = int(os.environ.get("MPHSIR_MLP_WGRAD_WGS", "512"))
+MLP_WGRAD_CAP = float(os.environ.get("MPHSIR_MLP_WGRAD_CAP", "1.0"))   # partial bytes <= this x the bytes of the two token matrices
+
+
+def gated_mlp_wgrad_fits(M, C, HP, dtype):
+    return (MLP_WGRAD and dtype in _HALF and M % 64 == 0 and HP % 32 == 0 and M >= 16384
+            and bool(_lib.load().mphsir_gated_mlp_wgrad_fits(C, 1, _DT[dtype])))
+
+
+def mlp_wgrad_plan(M, C, HP, dtype, nch=None, ranges=None):
+    """(chunks per workgroup, token ranges): ~MLP_WGRAD_WGS workgroups, ranges a multiple of 8, partial bytes capped"""
+    lib = _lib.load()
+    if nch is None:
+        nch = MLP_WGRAD_NCH or 1
+    if not lib.mphsir_gated_mlp_wgrad_fits(C, nch, _DT[dtype]):
+        nch = 1
+    S = (HP // 32 + nch - 1) // nch
+    if ranges is None:
+        # one round of resident workgroups (two 256-thread workgroups or one 512-thread workgroup per CU); a partial of
+        # 3 HP C floats per range: capped against the bytes of the two token matrices
+        ranges = max(1, (MLP_WGRAD_WGS // nch) // S)
+        cap = int(MLP_WGRAD_CAP * 2.0 * M * C * 2 / (3.0 * HP * C * 4))
+        ranges = max(8, min(ranges, cap, M // 64) // 8 * 8)
+    return nch, ranges
+
+
+def gated_mlp_wgrad(xn, dm, W1, b1, W2T, hid, nch=None, ranges=None):
+    """The four parameter gradients of the gated MLP from xn = LN(x) and dm = keep*dy (M,C), recomputing value / gate / dh per
+    hidden slab (csrc/gated_mlp_wgrad.hip): -> dW1 (2*hid, C) [value rows | gate rows], db1 (2*hid,), dW2 (C, hid), db2 (C,), fp32,
+    ordered sums of per-range partials (deferred like every reduce_parts; inside a reduce_scope the launch itself is deferred
+    to the scope's exit, i.e. to the weight-gradient branch)."""
+    lib = _lib.load()
+    _check(xn, dm, W1, W2T)
+    M, C = xn.shape
+    HP = W2T.shape[0]
+    assert xn.is_contiguous() and dm.is_contiguous() and W1.shape == (2 * HP, C) and W2T.shape == (HP, C) and xn.dtype in _HALF
+    nch, R = mlp_wgrad_plan(M, C, HP, xn.dtype, nch, ranges)
+    dev = xn.device
+    dW1p = torch.empty((R, 2 * HP, C), dtype=torch.float32, device=dev)
+    dW2p = torch.empty((R, C, HP), dtype=torch.float32, device=dev)
+    db1p = torch.empty((R, 1, 2 * HP), dtype=torch.float32, device=dev)
+    db2p = torch.empty((R, C), dtype=torch.float32, device=dev)
+    a = _lib.MlpWgradArgs()
+    a.XN, a.DM, a.W1, a.b1, a.W2T = _p(xn), _p(dm), _p(W1), _p(b1), _p(W2T)
+    a.dW1p, a.dW2p, a.db1p, a.db2p = _p(dW1p), _p(dW2p), _p(db1p), _p(db2p)
+    a.M, a.C, a.HP, a.ranges, a.chunks_per_wg = M, C, HP, R, nch
+    dt = _DT[xn.dtype]
+
+    def run():
+        _lib.check(lib.mphsir_gated_mlp_wgrad(ctypes.byref(a), dt, _stream(xn)), "gated_mlp_wgrad")
+
+    if _SCOPE is not None:
+        _SCOPE.calls.append(dict(run=run, keep=(xn, dm, W1, b1, W2T, dW1p, dW2p, db1p, db2p, a)))
+    else:
+        run()
+    _acct("gated_mlp_wgrad", 12.0 * M * C * HP, 2.0 * M * C * xn.element_size())
+    _acct("gated_mlp_wgrad:partials", 0.0, (dW1p.numel() + dW2p.numel()) * 4.0)
+    dW1 = torch.empty((2 * hid, C), dtype=torch.float32, device=dev)
+    db1 = torch.empty((1, 2 * hid), dtype=torch.float32, device=dev)
+    dW2 = torch.empty((C, hid), dtype=torch.float32, device=dev)
+    reduce_block(dW1p, 0, hid, 0, C, dW1[:hid])
+    reduce_block(dW1p, HP, hid, 0, C, dW1[hid:])
+    reduce_block(db1p, 0, 1, 0, hid, db1[:, :hid])
+    reduce_block(db1p, 0, 1, HP, hid, db1[:, hid:])
+    reduce_block(dW2p, 0, C, 0, hid, dW2)
+    db2 = reduce_parts(db2p)
+    return dW1, db1[0], dW2, db2
 
 
 def combine_bwd(dy, sa, gate, keep, shift):

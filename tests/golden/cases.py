@@ -49,6 +49,25 @@ FULL_CASES = {
     "remote_mode8": dict(cfg=REMOTE_CFG, shape=(1, 100, 64, 64), recipe="inpaint90", task=[4]),
 }
 
+# Whole-net gradients at REAL width (train.py:58-67 over net/MP_HSIR.py:810-844): both shipped configurations, batch 2 of 64x64
+# patches, the training recipe (clean + Gaussian noise, L1 after clamp), eval mode (DropPath = identity).  full_grad.npz holds,
+# from the REFERENCE run in fp64: the loss, and per parameter gradient its norm + FULLGRAD_SAMPLES seeded samples (tensors up to
+# that many elements: in full), and the names of the parameters autograd leaves without gradient.
+FULLGRAD_CASES = {
+    "natural_b2": dict(cfg=NATURAL_CFG, shape=(2, 31, 64, 64), task=[0, 3], sigma=50.0),
+    "remote_b2": dict(cfg=REMOTE_CFG, shape=(2, 100, 64, 64), task=[4, 6], sigma=30.0),
+}
+FULLGRAD_SAMPLES = 4096
+
+
+def fullgrad_inputs(name):
+    from golden.detfill import seeded_input
+    c = FULLGRAD_CASES[name]
+    clean = seeded_input(name + ":clean", c["shape"])
+    degraded = clean + seeded_input(name + ":noise", c["shape"], "normal") * (c["sigma"] / 255.0)      # degradation_utils.py:25-31
+    return c, clean, degraded
+
+
 # Full-SIZE cubes: the reference run once per case in fp32 on the shapes test.py feeds the model
 # (test.py:150-188: 512x512x31 natural cubes; :440-469 / BASELINE configs[3]: the 172-band remote-sensing width), stored as
 # summary statistics -- norm, mean, CUBE_SAMPLES seeded samples, per-band means, PSNR -- because the tensors are 32-180 MB.

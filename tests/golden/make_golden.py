@@ -262,6 +262,44 @@ def gen_cubes(which=None):
     np.savez_compressed(path, **out)
 
 
+def gen_full_grad(which=None):
+    """the training step's gradients at real width: loss = L1(clamp(net(degraded), 0, 1), clean) (train.py:58-61) of the
+    reference in fp64, batch 2, every parameter gradient as norm + seeded samples (golden.cases.FULLGRAD_CASES)"""
+    import time
+    from golden.cases import FULLGRAD_CASES, FULLGRAD_SAMPLES, fullgrad_inputs
+    path = os.path.join(HERE, "full_grad.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    for name in (which or FULLGRAD_CASES):
+        c, clean, degraded = fullgrad_inputs(name)
+        net = build_ref_net(c["cfg"])
+        for p in net.parameters():
+            p.requires_grad_(True)
+        t0 = time.time()
+        y = net(degraded.double(), task_tensor(c["task"]))
+        loss = F.l1_loss(torch.clamp(y, 0, 1), clean.double())
+        loss.backward()
+        for k in [k for k in out if k.startswith(name + "/")]:
+            del out[k]
+        out[name + "/loss"] = np.array(float(loss))
+        out[name + "/out_norm"] = np.array(float(y.detach().norm()))
+        none_keys = []
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                none_keys.append(k)
+                continue
+            g = p.grad
+            out["%s/norm/%s" % (name, k)] = np.array(float(g.norm()))
+            if g.numel() <= FULLGRAD_SAMPLES:
+                out["%s/full/%s" % (name, k)] = to_np(g)
+            else:
+                idx = sample_indices(name + ":" + k, g.numel(), FULLGRAD_SAMPLES)
+                out["%s/samp/%s" % (name, k)] = to_np(g.flatten()[idx])
+        out[name + "/none_keys"] = np.array(none_keys)
+        print("full grad", name, "loss", float(loss), "none:", len(none_keys), "%.0f s" % (time.time() - t0), flush=True)
+        del net, y, loss
+    np.savez_compressed(path, **out)
+
+
 def gen_schedule():
     """a18: the reference's own LinearWarmupCosineAnnealingLR (utils/schedulers.py:295-346) driven as train.py:67-86 drives it
     -- AdamW(lr), warmup_epochs = int(0.1 * epochs), max_epochs = epochs, eta_min = 1e-6, one scheduler.step() per epoch
@@ -310,5 +348,7 @@ if __name__ == "__main__":
         gen_full()
     if "schedule" in which:
         gen_schedule()
+    if "fullgrad" in which:
+        gen_full_grad()
     if "cubes" in which or any(w.startswith("cube:") for w in which):
         gen_cubes([w[5:] for w in which if w.startswith("cube:")] or None)

@@ -562,6 +562,57 @@ def check_gated_mlp_bwd(dev, dtype, C, hid, variant=0, hsplit=None):
     assert rel_l2(dln[0], lw.grad) < tol and rel_l2(dln[1], lb.grad) < tol
 
 
+def check_gated_mlp_wgrad(dev, dtype, C, hid, M=256, nch=1, ranges=8, keep=True):
+    """mphsir_gated_mlp_wgrad (parameter gradients by recomputation, fp32 accumulators per hidden slab and token range) against
+    (a) autograd of the fp64 oracle and (b) the token-reduction GEMMs of the operands the data-gradient kernel writes (the path
+    it replaces: same 16-bit roundings of h / dval / dgate, so the two agree to fp32 summation order); the data-gradient kernel
+    without operand outputs must give the dx / LN(x) / dm it gives with them, bitwise; a second launch repeats bitwise."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    x, dy = rnd((M, C), 1, dtype), rnd((M, C), 9, dtype)
+    P = {"fc1.weight": rnd((2 * hid, C), 2, scale=C ** -0.5), "fc1.bias": 0.1 * rnd((2 * hid,), 3),
+         "fc2.weight": rnd((C, hid), 4, scale=hid ** -0.5), "fc2.bias": 0.1 * rnd((C,), 5)}
+    lnw, lnb = 1 + 0.1 * rnd((C,), 6), 0.1 * rnd((C,), 7)
+    nb = M // 64
+    kf = (1.0 + 0.25 * torch.arange(nb) / nb).float().to(dev) if keep else None
+    W1, b1, W2 = ops.pack_gated_mlp(P["fc1.weight"], P["fc1.bias"], P["fc2.weight"], dtype)
+    W1T, W2T = W1.t().contiguous(), W2.t().contiguous()
+    HP = W2.shape[1]
+    if keep:
+        dx, xn, h, dpre, part, dm = ops.gated_mlp_bwd(x, dy, None, lnw, lnb, W1, b1, W1T, W2T, keep=kf, rows_per_batch=64)
+        dx2, xn2, h2, dpre2, part2, dm2 = ops.gated_mlp_bwd(x, dy, None, lnw, lnb, W1, b1, W1T, W2T, keep=kf, rows_per_batch=64, operands=False)
+    else:
+        dm = dy
+        dx, xn, h, dpre, part = ops.gated_mlp_bwd(x, dy, dm, lnw, lnb, W1, b1, W1T, W2T)
+        dx2, xn2, h2, dpre2, part2 = ops.gated_mlp_bwd(x, dy, dm, lnw, lnb, W1, b1, W1T, W2T, operands=False)
+        dm2 = dm
+    assert h2 is None and dpre2 is None
+    assert torch.equal(dx.cpu(), dx2.cpu()) and torch.equal(xn.cpu(), xn2.cpu()) and torch.equal(dm.cpu(), dm2.cpu()) and torch.equal(part.cpu(), part2.cpu())
+    dW1, db1, dW2, db2 = ops.gated_mlp_wgrad(xn, dm, W1, b1, W2T, hid, nch=nch, ranges=ranges)
+    again = ops.gated_mlp_wgrad(xn, dm, W1, b1, W2T, hid, nch=nch, ranges=ranges)
+    for u, v in zip((dW1, db1, dW2, db2), again):
+        assert torch.equal(u.cpu(), v.cpu())
+    # (b) the operands path
+    dW2r = (dm.float().t() @ h.float())[:, :hid]
+    dW1p = dpre.float().t() @ xn.float()
+    dW1r = torch.cat([dW1p[:hid], dW1p[HP:HP + hid]], 0)
+    db1p = dpre.float().sum(0)
+    db1r = torch.cat([db1p[:hid], db1p[HP:HP + hid]])
+    db2r = dm.float().sum(0)
+    for got, ref in ((dW1, dW1r), (db1, db1r), (dW2, dW2r), (db2, db2r)):
+        assert got.shape == ref.shape and rel_l2(got, ref.double().cpu()) < 2e-5, rel_l2(got, ref.double().cpu())
+    # (a) oracle autograd
+    Pd = {k: (v.to(dtype) if k.endswith("weight") else v).double().cpu().requires_grad_(True) for k, v in P.items()}
+    xd = x.double().cpu().requires_grad_(True)
+    lw, lb = lnw.double().cpu(), lnb.double().cpu()
+    kd = kf.double().cpu().repeat_interleave(64)[:, None] if keep else 1.0
+    y = xd + kd * O.gated_mlp(Pd, "", O.layer_norm_c(xd, lw, lb))
+    y.backward(dy.double().cpu())
+    tol = TOL[dtype] * 2
+    assert rel_l2(dW2, Pd["fc2.weight"].grad) < tol and rel_l2(dW1, Pd["fc1.weight"].grad) < tol
+    assert rel_l2(db1, Pd["fc1.bias"].grad) < tol and rel_l2(db2, Pd["fc2.bias"].grad) < tol
+
+
 def check_l1_clamp_loss(dev):
     """mphsir_l1_clamp_loss (loss + gradient in one pass) vs the oracle's clamp + L1 and torch autograd through it (train.py:58-61),
     incl. values exactly on the clamp bounds / equal to the target, a length that is not a multiple of 4, and an upstream factor."""
@@ -580,6 +631,24 @@ def check_l1_clamp_loss(dev):
         (lr * 3.0).backward()
         assert abs(float(loss.detach()) - float(lr.detach())) < 1e-6 * abs(float(lr.detach())) + 1e-9
         assert rel_l2(y.grad, yr.grad) < 1e-6 and float((y.grad.double().cpu() - yr.grad).abs().max()) < 1e-7 * 3.0 / y.numel() + 1e-12
+    # non-finite outputs: torch.clamp propagates NaN (the loss becomes NaN: a diverged run must not log a finite loss) and clamps the
+    # infinities; the gradient is 0 at all three, as torch's
+    for bad, loss_nan in ((float("nan"), True), (float("inf"), False), (float("-inf"), False)):
+        y = (rnd((2, 8, 16, 16), 903) * 0.7 + 0.5)
+        c = rnd((2, 8, 16, 16), 904).abs().clamp(0, 1)
+        with torch.no_grad():
+            y.view(-1)[5] = bad
+            y.view(-1)[-2] = bad             # inside the scalar tail handling too when n % 4 != 0 (not here) and in another block
+        y.requires_grad_(True)
+        loss = ops.l1_clamp_loss(y, c)
+        loss.backward()
+        yr = y.detach().double().cpu().requires_grad_(True)
+        lr = O.l1_after_clamp(yr, c.double().cpu())
+        lr.backward()
+        assert bool(torch.isnan(loss.detach())) == loss_nan == bool(torch.isnan(lr.detach()))
+        if not loss_nan:
+            assert abs(float(loss.detach()) - float(lr.detach())) < 1e-6 * abs(float(lr.detach()))
+        assert torch.isfinite(y.grad).all() and float(y.grad.view(-1)[5]) == 0.0 and rel_l2(y.grad, yr.grad) < 1e-6
 
 
 def check_multi_copy(dev):

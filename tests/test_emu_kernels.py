@@ -122,6 +122,13 @@ def test_gated_mlp_hidden_split(dtype, C, hid, hsplit):
         K.check_gated_mlp_bwd("cpu", dtype, C, hid, hsplit=hsplit)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,hid,M,nch,ranges,keep", [(32, 85, 256, 1, 8, True), (64, 170, 640, 2, 8, False), (96, 255, 576, 1, 8, True),
+                                                      (128, 340, 1088, 1, 16, True), (128, 340, 320, 2, 8, False)])
+def test_gated_mlp_wgrad(dtype, C, hid, M, nch, ranges, keep):
+    K.check_gated_mlp_wgrad("cpu", dtype, C, hid, M=M, nch=nch, ranges=ranges, keep=keep)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("C,hid", [(32, 85), (96, 255)])
 def test_gated_mlp_bwd(dtype, C, hid):

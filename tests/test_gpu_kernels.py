@@ -179,6 +179,21 @@ def test_gated_mlp_hidden_split(dtype, C, hid, hsplit):
         K.check_gated_mlp_bwd("cuda", dtype, C, hid, hsplit=hsplit)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,hid,M,nch,ranges,keep", [(32, 85, 256, 1, 8, True), (64, 170, 640, 1, 8, False), (64, 170, 8192, 2, 16, True), (96, 255, 4160, 1, 8, True),
+                                                      (96, 255, 2048, 2, 8, False), (128, 340, 16384, 1, 48, True), (128, 340, 8256, 2, 24, False),
+                                                      (192, 510, 4096, 1, 16, True)])
+def test_gated_mlp_wgrad(dtype, C, hid, M, nch, ranges, keep):
+    """the parameter gradients of the gated MLP by recomputation (no h / [dval | dgate] in HBM): vs the oracle's autograd, vs the
+    operand path it replaces, bitwise repeatable; ragged token ranges, empty ranges, one and two chunks per workgroup"""
+    K.check_gated_mlp_wgrad("cuda", dtype, C, hid, M=M, nch=nch, ranges=ranges, keep=keep)
+
+
+def test_gated_mlp_wgrad_training_shape():
+    """the benchmark's level-1 shape (batch 32 x 64 x 64 tokens, C = 128) with the plan the library chooses"""
+    K.check_gated_mlp_wgrad("cuda", torch.bfloat16, 128, 340, M=131072, nch=None, ranges=None, keep=True)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("C,hid", [(32, 85), (96, 255), (64, 170), (128, 340), (256, 680), (192, 510)])
 def test_gated_mlp_bwd(dtype, C, hid):

@@ -100,6 +100,22 @@ def test_block_gradients_bf16(name):
     print("bf16 block-gradient worst rel-L2", name, M.check_block_gradients("cuda", name, torch.bfloat16, tol=6e-2))
 
 
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("name", ["natural_b2", "remote_b2"])
+def test_whole_net_gradients_at_real_width(name):
+    """missing-item 3 of the round-4 review: the backward of MP_HSIR_Net(31,31,64,T=6) / (100,100,96,T=7) as a whole (U-Net joins,
+    cat splits, prompt branches, deferred sums at real widths), batch 2: fp32 against the reference's fixture and the oracle's fp64
+    autograd (every parameter < 1e-4), bf16 / fp16 against the same with a bar derived from the forward deviation of the run."""
+    res = M.check_full_gradients("cuda", name, torch.bfloat16 if name == "natural_b2" else torch.float16)
+    print(name, res)
+
+
+@pytest.mark.timeout(2400)
+def test_batch32_bf16_step_vs_oracle():
+    """the benchmark's batch (32 x 64x64x31, bf16): loss and sampled parameter gradients of one step against the oracle (fp32, this host)"""
+    print(M.check_batch32_step("cuda"))
+
+
 def test_tiny_net_gradients_fp32():
     assert M.check_tiny_gradients("cuda") < 1e-4
 
