@@ -53,10 +53,6 @@ int mphsir_device_arch(char* buf, int n);
  *   0  Y = acc (+ bias)
  *   1  Y = R + acc (+ bias)                                      residual add (:282,286,476,477)
  *   2  Y = R + keep[b] * (SA * gate[window(m)] + acc)            PGSSTB branch sum (:715-718)
- *   3  LayerNorm backward behind a data-gradient GEMM (autograd of norm1 -> qkv, :667, :193): rows m in WINDOW-token order
- *      (tile m / 64 = one 8x8 window of the shifted frame), acc = d_xn;  Y[pixel(m)] = SA[pixel(m)] + LN_backward(acc; x =
- *      R[pixel(m)], weight = gate[N]) in IMAGE order, part[m / 64][2][N] = this window's partials of d(LN weight), d(LN bias).
- *      N <= 256 (the whole row in one tile), no bias, no prologue.  Replaces the d_xn store + mphsir_ln_bwd_win + its re-read.
  * M % 64 == 0, N % 16 == 0, K % 32 == 0; ldx/ldy/ldr/ldsa in elements, multiples of 16 bytes.
  * w_batch_stride (elements) != 0 selects W + (m / rows_per_batch) * w_batch_stride per sample.   */
 typedef struct mphsir_gemm_args {
@@ -71,11 +67,10 @@ typedef struct mphsir_gemm_args {
     const void* SA; int64_t ldsa;
     const float* gate;          /* [B*nW][N] fp32, epi 2 */
     const float* keep;          /* [B] fp32 DropPath factor (mask/keep_prob) or NULL */
-    int32_t H, Wimg, shift;     /* image geometry for window(m), epi 2 and 3 */
+    int32_t H, Wimg, shift;     /* image geometry for window(m), epi 2 */
     int32_t form;               /* 0 = the library chooses; 1 = one workgroup per 64-token tile; 2 = ring form: persistent workgroups
                                    that walk the token tiles, a loader wave streaming K-chunks by LDS-DMA ahead of four MFMA
                                    waves (16-bit types, no LayerNorm prologue; ignored where it does not apply) */
-    float* part;                /* epi 3: [M/64][2][N] fp32 */
 } mphsir_gemm_args;
 int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* stream);
 
@@ -248,8 +243,7 @@ typedef struct mphsir_mlp_args {
     void* Y; int64_t ldy;
     int64_t M; int32_t C, HP;
     int32_t tiles_per_wave;                      /* tuning: 0 = auto; four waves with 1 or 2 token tiles (of 16) per wave; 3 / 4 =
-                                                    eight waves with 1 / 2 tiles (16-bit types); 5 = two waves, 32 tokens per
-                                                    workgroup (16-bit types; never chosen by 0: measured slower) */
+                                                    eight waves with 1 / 2 tiles (16-bit types) */
     int32_t hsplit;                              /* > 1: small launches (the latent level): the hidden dimension is dealt to hsplit
                                                     workgroups per token tile, the weights are still read once in total; needs */
     float* ypart;                                /* ... a workspace [hsplit][M][C] fp32 for the partial fc2 products (summed in order) */
@@ -272,8 +266,7 @@ typedef struct mphsir_mlp_bwd_args {
     const void* W1; const float* b1; const void* W1T; const void* W2T;
     void* dX; void* XN; void* H; void* DPRE; float* part;
     int64_t M; int32_t C, HP;
-    int32_t variant;                  /* 0 = library's choice; 1..4 pin a kernel form (tests / tuning), see gated_mlp_bwd.hip;
-                                         5 = two-wave form for small launches: 32 tokens per workgroup, `part` is [M/32][2][C] */
+    int32_t variant;                  /* 0 = library's choice; 1..4 pin a kernel form (tests / tuning), see gated_mlp_bwd.hip */
     const float* keep;                /* optional DropPath factors [M / rows_per_batch]: DM is then an OUTPUT, written */
     int64_t rows_per_batch;           /* here as keep[b] * dY (rounded to the compute dtype) instead of by the caller   */
     int32_t hsplit;                   /* > 1: small launches (the latent level): the hidden dimension dealt to hsplit workgroups per
@@ -382,7 +375,7 @@ int mphsir_im2col3x3(const void* X, int64_t ldx, void* Col, int32_t B, int32_t H
  * the nsplit partials (mphsir_reduce_parts).  Replaces mphsir_im2col3x3 + mphsir_gemm_tn on the 16-bit path. */
 int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* Cpart, int32_t B, int32_t H, int32_t W,
                          int32_t Cout, int32_t Cin, int32_t nsplit, int32_t form /* 1 | 2, as mphsir_gemm_tn's tile128 */,
-                         int32_t* group_counters /* optional, as mphsir_gemm_tn's */, int dtype, void* stream);
+                         int dtype, void* stream);
 
 /* ---- token-reduction GEMM (weight gradients) --------------------------------------------------------
  * Cpart[b][s][n1][n2] = sum over the s-th token range of A[b][m][n1] * B[b][m][n2]  (fp32 partials;
@@ -394,17 +387,10 @@ int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ld
  * (ds_read_b64_tr_b16, no transposing stores, two LDS stages, register-staged loads, 256-thread workgroups, ~2 per CU)
  * with a 64- or 128-wide tile per operand; 2 = its ring form: one 512-thread workgroup per CU (size nsplit for ~256
  * workgroups), token rows by LDS-DMA into a ring of 32-token slots, two wave groups whose tiles are combined in LDS:
- * half the partial tiles per launch, written as whole 16-byte row chunks.
- * group_counters (optional; 16-bit large-tile forms): mphsir_gemm_tn_group_counters(...) ints, ZERO when the launch starts.  With
- * it the first level of the ordered sum happens inside the launch: of the 8 workgroups that own splits 8g..8g+7 of an output tile
- * the one that finishes last adds their tiles in split order into slot 8g (whichever workgroup that is: bitwise reproducible)
- * and zeroes the counter again, so the caller sums the ceil(nsplit/8) slots 0, 8, 16, ... (split stride 8*N1*N2) instead of nsplit.
- * colsum_part is not touched by this (all nsplit rows stay).  Concurrent launches need disjoint counters.            */
+ * half the partial tiles per launch, written as whole 16-byte row chunks.                                          */
 int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
                    float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch,
-                   int32_t tile128, int32_t* group_counters, int dtype, void* stream);
-/* counters one problem needs at most (any tile width): batch * ceil(N1/64) * ceil(N2/64) * ceil(nsplit/8) */
-int64_t mphsir_gemm_tn_group_counters(int32_t N1, int32_t N2, int32_t nsplit, int32_t batch);
+                   int32_t tile128, int dtype, void* stream);
 /* Up to MPHSIR_TN_GROUP_MAX independent problems of the bf16 large-tile form in ONE launch (same outputs as n calls
  * of mphsir_gemm_tn with batch = 1): the weight-gradient GEMMs of one backward function issued together.         */
 #define MPHSIR_TN_GROUP_MAX 8
@@ -412,7 +398,6 @@ typedef struct mphsir_gemm_tn_problem {
     const void* A; int64_t lda; const void* B; int64_t ldb;
     float* Cpart; float* colsum_part;
     int64_t M; int32_t N1, N2, nsplit, pad_;
-    int32_t* group_counters;      /* optional, as mphsir_gemm_tn's (zero-initialised; disjoint per problem) */
 } mphsir_gemm_tn_problem;
 int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t n, int32_t form /* 1 | 2 */, int dtype, void* stream);
 

@@ -21,7 +21,7 @@ class GemmArgs(ctypes.Structure):
                 ("rows_per_batch", c_int64), ("bias", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p),
                 ("Y", c_void_p), ("ldy", c_int64), ("M", c_int64), ("N", c_int64), ("K", c_int64),
                 ("epi", c_int), ("R", c_void_p), ("ldr", c_int64), ("SA", c_void_p), ("ldsa", c_int64),
-                ("gate", c_void_p), ("keep", c_void_p), ("H", c_int32), ("Wimg", c_int32), ("shift", c_int32), ("form", c_int32), ("part", c_void_p)]
+                ("gate", c_void_p), ("keep", c_void_p), ("H", c_int32), ("Wimg", c_int32), ("shift", c_int32), ("form", c_int32)]
 
 
 class MlpArgs(ctypes.Structure):
@@ -114,7 +114,7 @@ class PgBwdArgs(ctypes.Structure):
 class TnProblem(ctypes.Structure):
     """mirror of struct mphsir_gemm_tn_problem"""
     _fields_ = [("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64), ("Cpart", c_void_p), ("colsum_part", c_void_p),
-                ("M", c_int64), ("N1", c_int32), ("N2", c_int32), ("nsplit", c_int32), ("pad_", c_int32), ("group_counters", c_void_p)]
+                ("M", c_int64), ("N1", c_int32), ("N2", c_int32), ("nsplit", c_int32), ("pad_", c_int32)]
 
 
 TN_GROUP_MAX = 8
@@ -181,13 +181,12 @@ _SYMBOLS = {
     "mphsir_win_attn_bwd_fits": (c_int, [c_int32, c_int32, c_int]),
     "mphsir_ln_bwd_win": (c_int, [c_void_p] * 6 + [c_int32] * 5 + [c_void_p, c_void_p, c_int32, c_int, c_void_p]),
     "mphsir_gemm_tn": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32,
-                               c_int32, c_int32, c_int32, c_void_p, c_int, c_void_p]),
-    "mphsir_gemm_tn_group_counters": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+                               c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_spectral_fold_bwd": (c_int, [ctypes.POINTER(FoldBwdArgs), c_int, c_void_p]),
     "mphsir_pg_gate_bwd": (c_int, [ctypes.POINTER(PgBwdArgs), c_void_p]),
     "mphsir_conv3x3_tok": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int, c_void_p]),
-    "mphsir_conv3x3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int, c_void_p]),
+    "mphsir_conv3x3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_im2col3x3": (c_int, [c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_gdfn_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int, c_void_p]),
     "mphsir_gated_mlp_bwd": (c_int, [ctypes.POINTER(MlpBwdArgs), c_int, c_void_p]),

@@ -197,7 +197,11 @@ class _PgsstbAttn(torch.autograd.Function):
             # over the windows.  Factor rows in the compute dtype ride in the grouped 16-bit GEMM launch; fp16's narrow exponent
             # would flush the gate's tiny d-logits (w ~ 1/128 of an already small gradient), so that path keeps them in fp32
             with ops.side_stream(dy, ops.SIDE_BRANCH) as br:
-                dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=torch.float32 if dt == torch.float16 else dt)
+                # ... and so do levels with few windows (the latent level: 4 per sample), where a parameter gradient is the sum of a
+                # few hundred signed terms: with bf16 factor rows linear_down / kv of a latent block came out 23 % off in the whole-net
+                # check (the reference's own bf16 autocast: 2 %); the fp32 product of <= 512 rows costs nothing
+                f32_factors = dt == torch.float16 or mu.shape[0] <= 512
+                dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=torch.float32 if f32_factors else dt)
             # (2) global spectral attention
             t4 = t.reshape(B, H, W, 3 * Cc)
             w9 = sp["w9"]
@@ -219,11 +223,10 @@ class _PgsstbAttn(torch.autograd.Function):
             d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xnw, colsum=True)
             dsat2 = dsat.reshape(M, Cc)
             d_proj_w, d_proj_b = ops.gemm_tn(dsat2, oattn.reshape(M, Cc), colsum=True)
-            # (5) d_xn = dqkv Wqkv, norm1 backward and the residual path: one launch where the row fits a GEMM tile
-            if ops.LN_BWD_EPILOGUE and ops.gemm_tok_ln_bwd_fits(Cc):
-                dx, part = ops.gemm_tok_ln_bwd(dqkv, pk["wqkvT"], x, dy, pk["ln1"][0], shift)
-            else:
-                dx, part = ops.ln_bwd_win(x, ops.gemm_tok(dqkv, pk["wqkvT"]), dy, pk["ln1"][0], shift)
+            # (5) d_xn = dqkv Wqkv, then norm1 backward and the residual path.  (The LayerNorm backward as an epilogue of that GEMM
+            # was built and measured slower in round 4 -- four barriers and an fp32 staging tile per GEMM tile against a 2 C per token
+            # round trip -- and removed in round 5.)
+            dx, part = ops.ln_bwd_win(x, ops.gemm_tok(dqkv, pk["wqkvT"]), dy, pk["ln1"][0], shift)
             dln = ops.reduce_parts(part)
             drpb = ops.reduce_parts(drpb)
         d_sdw = _join_taps(dwq, dwk, dwv).reshape(3 * Cc, 1, 3, 3)

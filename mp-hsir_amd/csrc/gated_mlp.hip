@@ -274,17 +274,41 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_lds_kernel(MlpDev a) {
 #pragma unroll
         for (int t = 0; t < TT; ++t)
             for (int u = 0; u < 2; ++u) { vv[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; gg[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // PIPE (eight waves, one token tile per wave, C <= 128: registers to spare at two waves per SIMD): the four weight fragments of
+        // K chunk kc + 1 are requested before the MFMAs of chunk kc and the scheduler is kept from sinking each read down to its use
+        // (left alone it serialises read -> wait -> MFMA with one or two reads in flight: the LDS latency in front of most MFMAs).
+        constexpr bool PIPE = false && NWV == 8 && TT == 1 && C <= 256 && sizeof(T) == 2;   // measured SLOWER on the MI355X (M = 131072, C = 128: 65.8 -> 72.7 us; M = 262144: 120 -> 141): off
+        if constexpr (PIPE) {
+            frag_t wq[2][4];
+            auto fetch = [&](int kc) {
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            const int kk = kc * TR::KCHUNK;
-            const frag_t wv0 = load_frag<T>(W1s, LDX, 0, kk), wv1 = load_frag<T>(W1s, LDX, 16, kk);
-            const frag_t wg0 = load_frag<T>(W1s, LDX, 32, kk), wg1 = load_frag<T>(W1s, LDX, 48, kk);
+                for (int i = 0; i < 4; ++i) wq[kc & 1][i] = load_frag<T>(W1s, LDX, 16 * i, kc * TR::KCHUNK);
+            };
+            fetch(0);
 #pragma unroll
-            for (int t = 0; t < TT; ++t) {
-                mma(vv[t][0], wv0, bx[t][kc]);
-                mma(vv[t][1], wv1, bx[t][kc]);
-                mma(gg[t][0], wg0, bx[t][kc]);
-                mma(gg[t][1], wg1, bx[t][kc]);
+            for (int kc = 0; kc < NKC; ++kc) {
+                const int b = kc & 1;
+                if (kc + 1 < NKC) fetch(kc + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(vv[0][0], wq[b][0], bx[0][kc]);
+                mma(vv[0][1], wq[b][1], bx[0][kc]);
+                mma(gg[0][0], wq[b][2], bx[0][kc]);
+                mma(gg[0][1], wq[b][3], bx[0][kc]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) {
+                const int kk = kc * TR::KCHUNK;
+                const frag_t wv0 = load_frag<T>(W1s, LDX, 0, kk), wv1 = load_frag<T>(W1s, LDX, 16, kk);
+                const frag_t wg0 = load_frag<T>(W1s, LDX, 32, kk), wg1 = load_frag<T>(W1s, LDX, 48, kk);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    mma(vv[t][0], wv0, bx[t][kc]);
+                    mma(vv[t][1], wv1, bx[t][kc]);
+                    mma(gg[t][0], wg0, bx[t][kc]);
+                    mma(gg[t][1], wg1, bx[t][kc]);
+                }
             }
         }
         const int hr = (lane >> 4) * 4;
@@ -297,16 +321,36 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_lds_kernel(MlpDev a) {
                 store4<T>(Hw + (t * 16 + (lane & 15)) * LDH + u * 16 + hr, h);
             }
         wave_barrier();                                    // Hw is wave-private
+        if constexpr (PIPE) {
+            constexpr int GW = NCT % 4 == 0 ? 4 : 2, NG = NCT / GW;      // fc2 fragments in groups, the next group requested a group ahead
+            static_assert(32 == TR::KCHUNK && NCT % GW == 0, "one K chunk per hidden chunk");
+            const frag_t bh = load_frag<T>(Hw, LDH, 0, 0);
+            frag_t w2q[2][GW];
+            auto fetch = [&](int g) {
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += TR::KCHUNK) {
-            frag_t bh[TT];
+                for (int i = 0; i < GW; ++i) w2q[g & 1][i] = load_frag<T>(W2s, LDH, (g * GW + i) * 16, 0);
+            };
+            fetch(0);
 #pragma unroll
-            for (int t = 0; t < TT; ++t) bh[t] = load_frag<T>(Hw, LDH, t * 16, kk);
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) fetch(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const frag_t w2 = load_frag<T>(W2s, LDH, ct * 16, kk);
+                for (int i = 0; i < GW; ++i) mma(out[0][g * GW + i], w2q[g & 1][i], bh);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
-                for (int t = 0; t < TT; ++t) mma(out[t][ct], w2, bh[t]);
+            for (int kk = 0; kk < 32; kk += TR::KCHUNK) {
+                frag_t bh[TT];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) bh[t] = load_frag<T>(Hw, LDH, t * 16, kk);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const frag_t w2 = load_frag<T>(W2s, LDH, ct * 16, kk);
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) mma(out[t][ct], w2, bh[t]);
+                }
             }
         }
         wave_barrier();
@@ -408,14 +452,10 @@ static int launch_mlp(const MlpDev& d, hipStream_t s) {
     int rc = 1;
     // Eight waves with one 16-token tile each (two waves per SIMD) wherever that still leaves a workgroup per CU -- measured at
     // M = 131072, C = 128: 68 us against 92 (four waves, one tile) and 112 (four waves, two tiles: the round-2 default);
-    // tpw 1 / 2 force the four-wave forms, 3 / 4 the eight-wave ones (tests, tools/bench_mlp_fwd.py)
+    // tpw 1 / 2 force the four-wave forms, 3 / 4 the eight-wave ones (tests, tools/bench/bench_mlp_fwd.py).  (A two-wave form, 32 tokens
+    // per workgroup, was measured slower wherever it was tried -- round 4 -- and is gone; small launches split the HIDDEN dimension.)
     if (sizeof(T) == 2 && d.M % 128 == 0 && (d.tpw == 3 || (d.tpw == 0 && d.M / 128 >= 256))) rc = launch_mlp_lds<T, C, 1, 8>(d, s);
     if (rc == 1 && sizeof(T) == 2 && d.M % 256 == 0 && d.tpw == 4) rc = launch_mlp_lds<T, C, 2, 8>(d, s);
-    // two waves, 32 tokens per workgroup: only on request (tpw 5).  Measured as the default for launches of < 256 workgroups at C >= 192
-    // (the latent level) it is SLOWER -- natural step 22.05 -> 22.71 ms, remote-sensing fp16 step 28.55 -> 32.57, batch-16 forward 3.39 ->
-    // 3.51: every workgroup streams ALL weight chunks through LDS by itself, so twice the workgroups are twice the L2 -> LDS weight traffic
-    // on a chain whose length per workgroup does not shrink.  (What would help there is splitting the HIDDEN dimension over workgroups.)
-    if (rc == 1 && sizeof(T) == 2 && d.tpw == 5) rc = launch_mlp_lds<T, C, 1, 2>(d, s);
     if (rc == 1 && d.M % 128 == 0 && d.tpw == 2) rc = launch_mlp_lds<T, C, 2>(d, s);
     if (rc == 1) rc = launch_mlp_lds<T, C, 1>(d, s);
     if (rc != 1) return rc;

@@ -341,10 +341,9 @@ __device__ __forceinline__ void mlp_bwd_ln_epilogue(const MlpBwdDev& a, float* F
 //     and the NEXT chunk's slices are already in flight in registers during the MFMAs,
 //   * wave-private staging uses wave barriers: two workgroup barriers per chunk remain.
 // NWV waves per workgroup, one (TT) 16-token tile each: 8 = two per SIMD (one wave's GELU / stores beside the other's MFMAs), 4 = the
-// original form, 2 = 32 tokens per workgroup (variant 5, on request only: measured slower at the latent level, where it was meant to
-// put twice as many CUs to work -- every workgroup streams all weight slices through LDS by itself (2.9 MB at C = 256, 4.5 MB at
-// C = 384), so twice the workgroups are twice that traffic; see gated_mlp.hip::launch_mlp).  The LayerNorm-parameter partials are
-// per group of GS = min(64, tokens per workgroup).
+// original form.  (A two-wave form, 32 tokens per workgroup, was measured slower at the latent level in round 4 -- every workgroup
+// streams all weight slices through LDS by itself, twice the workgroups are twice that traffic -- and is gone: small launches split
+// the HIDDEN dimension instead.)  The LayerNorm-parameter partials are per group of 64 tokens.
 template <class T, int C, int TT, int NWV>
 __global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
     typedef ElemTraits<T> TR;
@@ -492,18 +491,52 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int t = 0; t < TT; ++t) pv[f][t] = pg[f][t] = pe[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // PIPE (eight waves, C <= 128: registers to spare at two waves per SIMD): the six weight fragments of K chunk kc + 1 are
+        // requested before the MFMAs of chunk kc and the scheduler is kept from sinking each read down to its use -- left alone it
+        // serialises read -> wait -> MFMA with one or two reads in flight, the LDS latency exposed in front of most MFMAs.
+        #ifndef MPHSIR_MLP_BWD_PIPE
+#define MPHSIR_MLP_BWD_PIPE 1
+#endif
+        constexpr bool PIPE = MPHSIR_MLP_BWD_PIPE && NWV == 8 && TT == 1 && C <= 128 && sizeof(T) == 2;
+        if constexpr (PIPE) {
+            frag_t wq[2][6];
+            auto fetch = [&](int kc) {
+                const int kk = kc * TR::KCHUNK, b = kc & 1;
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            const int kk = kc * TR::KCHUNK;
+                for (int f = 0; f < 2; ++f) {
+                    wq[b][3 * f + 0] = load_frag<T>(W1s, LDX, 16 * f, kk);
+                    wq[b][3 * f + 1] = load_frag<T>(W1s, LDX, 32 + 16 * f, kk);
+                    wq[b][3 * f + 2] = load_frag<T>(W2Ts, LDX, 16 * f, kk);
+                }
+            };
+            fetch(0);
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const frag_t wv_ = load_frag<T>(W1s, LDX, 16 * f, kk), wg_ = load_frag<T>(W1s, LDX, 32 + 16 * f, kk);
-                const frag_t w2_ = load_frag<T>(W2Ts, LDX, 16 * f, kk);
+            for (int kc = 0; kc < NKC; ++kc) {
+                const int b = kc & 1;
+                if (kc + 1 < NKC) fetch(kc + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < TT; ++t) {
-                    mma(pv[f][t], wv_, bx[t][kc]);
-                    mma(pg[f][t], wg_, bx[t][kc]);
-                    mma(pe[f][t], w2_, bd[t][kc]);
+                for (int f = 0; f < 2; ++f) {
+                    mma(pv[f][0], wq[b][3 * f + 0], bx[0][kc]);
+                    mma(pg[f][0], wq[b][3 * f + 1], bx[0][kc]);
+                    mma(pe[f][0], wq[b][3 * f + 2], bd[0][kc]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc) {
+                const int kk = kc * TR::KCHUNK;
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const frag_t wv_ = load_frag<T>(W1s, LDX, 16 * f, kk), wg_ = load_frag<T>(W1s, LDX, 32 + 16 * f, kk);
+                    const frag_t w2_ = load_frag<T>(W2Ts, LDX, 16 * f, kk);
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        mma(pv[f][t], wv_, bx[t][kc]);
+                        mma(pg[f][t], wg_, bx[t][kc]);
+                        mma(pe[f][t], w2_, bd[t][kc]);
+                    }
                 }
             }
         }
@@ -552,16 +585,40 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_bwd2_kernel(MlpBwdDev a) {
                 store16<T>(Pout + (m0 + wv * WT + t) * 2 * HP + seg * HP + j + c, load16<T>(Hw + t * LDH + seg * 32 + c));
             }
         // dxn[c][tok] += W1T[c][j..j+31] * dval + W1T[c][HP+j..] * dgate
+        if constexpr (PIPE) {
+            // the same for d_xn: W1^T fragments in groups of four, the next group requested before the current group's MFMAs
+            constexpr int GW = NCT % 4 == 0 ? 4 : 2, NG = 2 * NKH * NCT / GW;
+            static_assert(NCT % GW == 0, "groups of W1^T fragments");
+            frag_t bh[2 * NKH], wt[2][GW];
 #pragma unroll
-        for (int kh = 0; kh < 2 * NKH; ++kh) {
-            frag_t bh[TT];
+            for (int kh = 0; kh < 2 * NKH; ++kh) bh[kh] = load_frag<T>(Hw, LDH, 0, kh * TR::KCHUNK);
+            auto fetch = [&](int g) {
+                const int kh = g / (NCT / GW), c0 = (g % (NCT / GW)) * GW;
 #pragma unroll
-            for (int t = 0; t < TT; ++t) bh[t] = load_frag<T>(Hw, LDH, 16 * t, kh * TR::KCHUNK);
+                for (int i = 0; i < GW; ++i) wt[g & 1][i] = load_frag<T>(W1Ts, LDH, (c0 + i) * 16, kh * TR::KCHUNK);
+            };
+            fetch(0);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const frag_t wt_ = load_frag<T>(W1Ts, LDH, ct * 16, kh * TR::KCHUNK);
+            for (int g = 0; g < NG; ++g) {
+                const int kh = g / (NCT / GW), c0 = (g % (NCT / GW)) * GW;
+                if (g + 1 < NG) fetch(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < TT; ++t) mma(out[t][ct], wt_, bh[t]);
+                for (int i = 0; i < GW; ++i) mma(out[0][c0 + i], wt[g & 1][i], bh[kh]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int kh = 0; kh < 2 * NKH; ++kh) {
+                frag_t bh[TT];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) bh[t] = load_frag<T>(Hw, LDH, 16 * t, kh * TR::KCHUNK);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const frag_t wt_ = load_frag<T>(W1Ts, LDH, ct * 16, kh * TR::KCHUNK);
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) mma(out[t][ct], wt_, bh[t]);
+                }
             }
         }
         wave_barrier();
@@ -660,18 +717,11 @@ static int launch_mlp_bwd2(const MlpBwdDev& d, hipStream_t s) {
 
 // variant: 0 = choose (second form when it fits LDS; eight waves with one tile each once that still leaves a workgroup per
 // CU), 1 = first form, 2 / 3 = second form, four waves with one / two 16-token tiles per wave, 4 = second form, eight waves,
-// 5 = second form, TWO waves: 32 tokens per workgroup and `part` rows per 32 tokens (the caller sizes it: [M/32][2][C]); never
-// chosen by 0.
 template <class T, int C>
 static int launch_mlp_bwd(const MlpBwdDev& d, int variant, hipStream_t s) {
     if (d.hsplit > 1) {          // the hidden split is built on the four-wave second form
         if constexpr (mlp_bwd2_fits<T, C, 1>()) return launch_mlp_bwd2<T, C, 1>(d, s);
         set_error("gated_mlp_bwd: the hidden split needs the second form, which does not fit C=%d in this element type", C);
-        return MPHSIR_EINVAL;
-    }
-    if (variant == 5) {
-        if constexpr (mlp_bwd2_fits<T, C, 1, 2>()) return launch_mlp_bwd2<T, C, 1, 2>(d, s);
-        set_error("gated_mlp_bwd: the two-wave form does not cover C=%d in this element type", C);
         return MPHSIR_EINVAL;
     }
     if (variant != 1) {
@@ -738,6 +788,6 @@ extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, voi
                        "gated_mlp_bwd: hsplit needs a workspace dxn_part [hsplit][M][C] fp32, HP %% (32 hsplit) == 0 and variant 0 or 2");
     MPHSIR_REQUIRE(!a->keep || (a->rows_per_batch > 0 && a->M % a->rows_per_batch == 0), "gated_mlp_bwd: keep needs rows_per_batch dividing M");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    MPHSIR_REQUIRE(a->variant >= 0 && a->variant <= 5, "gated_mlp_bwd: variant must be 0..5");
+    MPHSIR_REQUIRE(a->variant >= 0 && a->variant <= 4, "gated_mlp_bwd: variant must be 0..4");
     return MPHSIR_DISPATCH_T(dtype, (dispatch_mlp_bwd<T_>(d, a->C, a->variant, s)));
 }

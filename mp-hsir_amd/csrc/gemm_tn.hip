@@ -22,75 +22,12 @@ struct TnDev {
     // implicit im2col of a dense 3x3 conv's weight gradient (cC > 0; transposed-read kernel only): B is the conv INPUT
     // X [M = images*cH*cW][cC channels] and column tap*cC + ci of the logical operand is X[m + tap][ci] (zero outside the image)
     int cH, cW, cC;
-    // optional in-kernel first level of the ordered partial sum (16-bit forms): one zero-initialised counter per (batch, tile, group
-    // of 8 consecutive splits); see tn_group_combine
-    int* cnt;
 };
 
-// First level of the ordered sum of the split partials, inside the GEMM launch: the 8 workgroups that own splits 8g .. 8g+7 of an
-// output tile (adjacent block indices = one per XCD) count themselves in after their partial tile is stored and released; the one
-// that arrives LAST adds the group's tiles in split order -- ((p0 + p1) + p2) + ... whichever workgroup does it: bitwise
-// reproducible -- into slot 8g and puts the counter back to zero (the next launch on this counter finds it clean).  The caller then
-// sums slots 0, 8, 16, ...: an eighth of the partial bytes for mphsir_reduce_parts, read while the tiles are still on the die.
-// No workgroup waits for another one (nothing here depends on co-residency).
-// MEASURED (MI355X, batch-32 bf16 training step, A/B on one box): bitwise-correct on hardware across the 8 XCDs, and SLOWER than the
-// separate reduction launch: 21.3 -> 22.6 ms per step in this form, 32.6 ms with fences (below).  The last workgroup's sum is a
-// serial tail (seven 64 KB tiles through device-scope loads, one 8-load batch per ~2 us) at the end of a 30-60 us launch, where the
-// separate mphsir_reduce_parts launch spreads the same reads over the whole chip beside other work.  Off by default (callers pass no
-// counters: ops.TN_COMBINE); kept because it is the ordered in-kernel combine the round-3 review asked for, with its number.
-// Coherence without cache maintenance: the 8 workgroups of a group sit on 8 different XCDs, whose L2s do not see each other's lines.
-// A release / acquire fence pair at device scope (L2 write-back + invalidate per workgroup) is correct and was measured at 21.4 ->
-// 32.6 ms per training step -- it empties the L2s under every kernel that runs beside this one.  Instead the partial tiles of a
-// launch with counters are WRITTEN with device-scope relaxed atomic stores (write-through, sc1) and the last workgroup READS the
-// other seven with device-scope relaxed atomic loads (sc1: not served from its own L2); ordering is the hardware's: every wave
-// waits for its stores to be acknowledged (vmcnt 0) before the workgroup barrier in front of the counter increment.
-__device__ __forceinline__ void tn_store_coherent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void tn_store_coherent4(float* p, const f32x4& v) {
-    typedef unsigned long long u64;
-    union { float f[2]; u64 u; } lo, hi;
-    lo.f[0] = v[0]; lo.f[1] = v[1]; hi.f[0] = v[2]; hi.f[1] = v[3];
-    __hip_atomic_store(reinterpret_cast<u64*>(p), lo.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<u64*>(p) + 1, hi.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <int NTHR>
-__device__ __forceinline__ void tn_group_combine(const TnDev& a, int bz, int sp, int L, int n1_0, int n2_0, int W1, int W2) {
-    if (a.cnt == nullptr) return;                   // kernel-uniform
-    const int g0 = sp & ~7, gsize = a.nsplit - g0 < 8 ? a.nsplit - g0 : 8;
-    if (gsize <= 1) return;                         // workgroup-uniform
-    __shared__ int s_arrived;
-    wait_vmcnt<0>();                                // this wave's (write-through) partial stores are acknowledged ...
-    __syncthreads();                                // ... every wave's are, before the workgroup counts itself in
-    if (threadIdx.x == 0) {
-        int* c = a.cnt + (long)bz * (gridDim.x >> 3) + (L >> 3);
-        const int old = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == gsize - 1) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_arrived = old;
-    }
-    __syncthreads();
-    if (s_arrived != gsize - 1) return;
-    typedef unsigned long long u64;
-    const long ps = (long)a.N1 * a.N2;
-    float* base = a.Cp + ((long)bz * a.nsplit + g0) * ps;
-    const int CPR = W2 / 2;                         // 8-byte chunks per tile row
-    // (four chunks per thread in flight together instead of one: 184+ registers, one workgroup per CU, 22.6 -> 25.6 ms per step)
-    for (int idx = threadIdx.x; idx < W1 * CPR; idx += NTHR) {
-        const int n1 = n1_0 + idx / CPR, n2 = n2_0 + (idx % CPR) * 2;
-        if (n1 < a.N1 && n2 < a.N2) {               // N2 % 8 == 0: whole chunks
-            float* p = base + (long)n1 * a.N2 + n2;
-            union { float f[2]; u64 u; } v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q < gsize) v[q].u = __hip_atomic_load(reinterpret_cast<const u64*>(p + q * ps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float t0 = v[0].f[0], t1 = v[0].f[1];
-#pragma unroll
-            for (int q = 1; q < 8; ++q)
-                if (q < gsize) { t0 += v[q].f[0]; t1 += v[q].f[1]; }
-            p[0] = t0;
-            p[1] = t1;
-        }
-    }
-}
+// (Round 4 built the first level of the ordered partial sum INSIDE this launch -- the last of the 8 workgroups of a split group to
+// arrive, told by a device-scope counter, added the group's tiles in split order.  Bitwise-correct on hardware and slower: 21.3 ->
+// 22.6 ms per training step with write-through partial stores, 32.6 ms with device-scope fences: the last workgroup's sum is a serial
+// tail at the end of a 30-60 us launch.  Removed in round 5; DESIGN.md section 5 keeps the measurement.)
 
 // R1, R2 in {1,2}: the workgroup's output tile is (64*R1) x (64*R2); wave w owns rows [16*R1*w, 16*R1*(w+1)).
 template <class T, int R1, int R2>
@@ -350,8 +287,7 @@ __device__ __forceinline__ void tn_tr_body(const TnDev& a, char* smem, int L, in
             for (int r = 0; r < 4; ++r) {
                 const int n1 = n1_0 + (wv * RW + i) * 16 + (lane >> 4) * 4 + r, n2 = n2_0 + nt * 16 + (lane & 15);
                 if (n1 < a.N1 && n2 < a.N2) {
-                    if (a.cnt) tn_store_coherent(Cp + (long)n1 * a.N2 + n2, acc[i][nt][r]);
-                    else Cp[(long)n1 * a.N2 + n2] = acc[i][nt][r];
+                    Cp[(long)n1 * a.N2 + n2] = acc[i][nt][r];
                 }
             }
     if (do_cs && (lane & 15) == 0)
@@ -361,7 +297,6 @@ __device__ __forceinline__ void tn_tr_body(const TnDev& a, char* smem, int L, in
                 const int n1 = n1_0 + (wv * RW + i) * 16 + (lane >> 4) * 4 + r;
                 if (n1 < a.N1) a.colsum[((long)bz * a.nsplit + sp) * a.N1 + n1] = accs[i][r];
             }
-    tn_group_combine<256>(a, bz, sp, L, n1_0, n2_0, W1, W2);
 }
 
 template <class T, int W1, int W2>
@@ -560,12 +495,10 @@ __device__ __forceinline__ void tn_ring_body(const TnDev& a, char* smem, int L, 
         const int r = idx / CPR, c = (idx % CPR) * 4, n1 = n1_0 + r, n2 = n2_0 + c;
         if (n1 < a.N1 && n2 < a.N2) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * LDC + c);
-            if (a.cnt) tn_store_coherent4(Cp + (long)n1 * a.N2 + n2, v);
-            else *reinterpret_cast<f32x4*>(Cp + (long)n1 * a.N2 + n2) = v;
+            *reinterpret_cast<f32x4*>(Cp + (long)n1 * a.N2 + n2) = v;
         }
     }
     if (do_cs && tid < W1 && n1_0 + tid < a.N1) a.colsum[((long)bz * a.nsplit + sp) * a.N1 + n1_0 + tid] = Ss[tid];
-    tn_group_combine<512>(a, bz, sp, L, n1_0, n2_0, W1, W2);
 }
 
 template <class T, int W1, int W2> constexpr size_t tn_ring_lds() {
@@ -641,7 +574,7 @@ static int launch_tn(const TnDev& d, int batch, hipStream_t s) {
 
 extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride, const void* B, int64_t ldb, int64_t b_batch_stride,
                               float* Cpart, float* colsum_part, int64_t M, int32_t N1, int32_t N2, int32_t nsplit, int32_t batch, int32_t tile128,
-                              int32_t* group_counters, int dtype, void* stream) {
+                              int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(A && B && Cpart, "gemm_tn: null pointer");
@@ -652,8 +585,6 @@ extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride
     MPHSIR_REQUIRE(aligned16(A) && aligned16(B) && (lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0 &&
                        (a_batch_stride * esz) % 16 == 0 && (b_batch_stride * esz) % 16 == 0, "gemm_tn: 16-byte alignment required");
     TnDev d{A, (long)lda, (long)a_batch_stride, B, (long)ldb, (long)b_batch_stride, Cpart, colsum_part, (long)M, N1, N2, nsplit};
-    d.cnt = group_counters;
-    MPHSIR_REQUIRE(group_counters == nullptr || (tile128 > 0 && dtype != MPHSIR_F32), "gemm_tn: the in-kernel group sum exists in the 16-bit large-tile forms only");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool big = tile128 > 0;
     if (dtype == MPHSIR_F32) return big ? launch_tn<float, 2, 2>(d, batch, s) : launch_tn<float, 1, 1>(d, batch, s);
@@ -675,10 +606,6 @@ extern "C" int mphsir_gemm_tn(const void* A, int64_t lda, int64_t a_batch_stride
 #undef MPHSIR_TN_TR
 }
 
-extern "C" int64_t mphsir_gemm_tn_group_counters(int32_t N1, int32_t N2, int32_t nsplit, int32_t batch) {
-    return (int64_t)batch * ((N1 + 63) / 64) * ((N2 + 63) / 64) * ((nsplit + 7) / 8);
-}
-
 extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t n, int32_t form, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
@@ -697,7 +624,6 @@ extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t
                        "gemm_tn_group: bad problem %d", k);
         MPHSIR_REQUIRE(aligned16(q.A) && aligned16(q.B) && (q.lda * 2) % 16 == 0 && (q.ldb * 2) % 16 == 0, "gemm_tn_group: 16-byte alignment required");
         g.p[k] = TnDev{q.A, (long)q.lda, 0, q.B, (long)q.ldb, 0, q.Cpart, q.colsum_part, (long)q.M, q.N1, q.N2, q.nsplit};
-        g.p[k].cnt = q.group_counters;
         g.blk0[k] = blocks;
         const int ntiles = ((q.N1 + W1 - 1) / W1) * ((q.N2 + W2 - 1) / W2);
         blocks += ntiles * ((q.nsplit + 7) / 8 * 8);
@@ -721,7 +647,7 @@ extern "C" int mphsir_gemm_tn_group(const mphsir_gemm_tn_problem* probs, int32_t
 }
 
 extern "C" int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* Cpart, int32_t B, int32_t H, int32_t W,
-                                    int32_t Cout, int32_t Cin, int32_t nsplit, int32_t form, int32_t* group_counters, int dtype, void* stream) {
+                                    int32_t Cout, int32_t Cin, int32_t nsplit, int32_t form, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(dY && X && Cpart, "conv3x3_wgrad: null pointer");
@@ -730,7 +656,6 @@ extern "C" int mphsir_conv3x3_wgrad(const void* dY, int64_t lddy, const void* X,
                    "conv3x3_wgrad: bad shape (Cout, Cin must be multiples of 8)");
     MPHSIR_REQUIRE(aligned16(dY) && aligned16(X) && (lddy * 2) % 16 == 0 && (ldx * 2) % 16 == 0, "conv3x3_wgrad: 16-byte alignment required");
     TnDev d{dY, (long)lddy, 0, X, (long)ldx, 0, Cpart, nullptr, (long)B * H * W, Cout, 9 * Cin, nsplit, H, W, Cin};
-    d.cnt = group_counters;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define MPHSIR_CW_RING(T16) return Cout > 64 ? launch_tn_ring<T16, 128, 128>(d, 1, s) : launch_tn_ring<T16, 64, 128>(d, 1, s);
     if (form == 2) {

@@ -27,7 +27,6 @@ struct GemmDev {
     const void* SA; long ldsa;
     const float* gate; const float* keep;
     int H, Wimg, shift;
-    float* part;        // epi 3: [M/64][2][N] partials of d(LayerNorm weight), d(LayerNorm bias)
 };
 
 // Epilogue shared by both kernel forms: acc[w][mt] holds the TRANSPOSED 16x16 tiles (rows = output channels ntile + 64 w + ...,
@@ -40,104 +39,7 @@ __device__ __forceinline__ void gemm_tok_epilogue(const GemmDev& a, unsigned cha
     constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     constexpr int VEC = Vec16<T>::N;
     const int ntile = n0 + wv * 16;
-    if constexpr (EPI == 3) {
-        // ---- LayerNorm-backward epilogue: acc = d_xn (the data gradient of a Linear that reads LN(x), rows in WINDOW-token order:
-        // tile m0 / 64 is one 8x8 window) -> d_x = d_res + LN_backward(d_xn) written in IMAGE order (un-shift / un-window by address
-        // arithmetic), plus this window's partials of d(LN weight) / d(LN bias).  Replaces the store of d_xn, the ln_bwd_win launch and
-        // its re-read (ref: autograd of norm1 in PGSSTB, net/MP_HSIR.py:667; math of block_bwd.hip::ln_bwd_win_kernel, here on the
-        // unrounded fp32 accumulators).  The whole row must be in this tile: N <= 64 NW, one tile column.
-        constexpr int LDF = GT_BN * NW + 1;                                   // the pitch of ln_bwd_win's tile: scalar column accesses
-        float* Cf = reinterpret_cast<float*>(smem);                           // [64][LDF] d_xn, later d_xn * xhat
-        const int C = a.N;
-        sync();                                                               // every wave is done with the staging tiles
-    #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            if (ntile + w * 64 >= C) continue;
-            const int nl = wv * 16 + w * 64 + (lane >> 4) * 4;
-    #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                for (int r = 0; r < 4; ++r) Cf[(mt * 16 + (lane & 15)) * LDF + nl + r] = acc[w][mt][r];
-        }
-        sync();
-        const T* X = reinterpret_cast<const T*>(a.R);
-        const T* dRes = reinterpret_cast<const T*>(a.SA);
-        T* dX = reinterpret_cast<T*>(a.Y);
-        const float* lw = a.gate;
-        const int t = tid >> 2, q = tid & 3, nv = C / VEC;
-        const int nwx = a.Wimg >> 3, nWin = (a.H >> 3) * nwx, blk = m0 / 64;
-        const int b = blk / nWin, wi = blk % nWin, ys = (wi / nwx) * 8 + (t >> 3), xs = (wi % nwx) * 8 + (t & 7);
-        const long pix = ((long)b * a.H + (ys + a.shift) % a.H) * a.Wimg + (xs + a.shift) % a.Wimg;
-        constexpr int MAXV = (GT_BN * NW / VEC + 3) / 4;                      // 16-byte vectors of the row per lane (4 lanes per token)
-        Vec16<T> xv[MAXV], dr[MAXV];
-    #pragma unroll
-        for (int k = 0; k < MAXV; ++k) {
-            const int i = q + 4 * k;
-            if (i < nv) {
-                xv[k] = load16<T>(X + pix * a.ldr + i * VEC);
-                dr[k] = load16<T>(dRes + pix * a.ldsa + i * VEC);
-            }
-        }
-        float s_ = 0.f;
-    #pragma unroll
-        for (int k = 0; k < MAXV; ++k)
-            if (q + 4 * k < nv)
-                for (int e = 0; e < VEC; ++e) s_ += xv[k].get(e);
-        s_ += __shfl_xor(s_, 1); s_ += __shfl_xor(s_, 2);
-        const float mean = s_ / (float)C;
-        float d2 = 0.f;
-    #pragma unroll
-        for (int k = 0; k < MAXV; ++k)
-            if (q + 4 * k < nv)
-                for (int e = 0; e < VEC; ++e) { const float d = xv[k].get(e) - mean; d2 += d * d; }
-        d2 += __shfl_xor(d2, 1); d2 += __shfl_xor(d2, 2);
-        const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
-        float s1 = 0.f, s2 = 0.f;
-    #pragma unroll
-        for (int k = 0; k < MAXV; ++k) {
-            const int i = q + 4 * k;
-            if (i < nv)
-                for (int e = 0; e < VEC; ++e) {
-                    const int c = i * VEC + e;
-                    const float gw = Cf[t * LDF + c] * lw[c], xh = (xv[k].get(e) - mean) * rstd;
-                    s1 += gw; s2 += gw * xh;
-                }
-        }
-        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
-        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
-        s1 *= 1.0f / (float)C; s2 *= 1.0f / (float)C;
-    #pragma unroll
-        for (int k = 0; k < MAXV; ++k) {
-            const int i = q + 4 * k;
-            if (i < nv) {
-                Vec16<T> o;
-                for (int e = 0; e < VEC; ++e) {
-                    const int c = i * VEC + e;
-                    const float xh = (xv[k].get(e) - mean) * rstd;
-                    o.set(e, dr[k].get(e) + rstd * (Cf[t * LDF + c] * lw[c] - s1 - xh * s2));
-                }
-                store16<T>(dX + pix * a.ldy + i * VEC, o);
-            }
-        }
-        float* part = a.part + (long)blk * 2 * C;
-        for (int c = tid; c < C; c += 256) {                                  // d(LN bias): column sums of d_xn (nobody has overwritten it yet)
-            float sum = 0.f;
-            for (int tt = 0; tt < 64; ++tt) sum += Cf[tt * LDF + c];
-            part[C + c] = sum;
-        }
-        sync();
-    #pragma unroll
-        for (int k = 0; k < MAXV; ++k) {
-            const int i = q + 4 * k;
-            if (i < nv)
-                for (int e = 0; e < VEC; ++e) Cf[t * LDF + i * VEC + e] *= (xv[k].get(e) - mean) * rstd;
-        }
-        sync();
-        for (int c = tid; c < C; c += 256) {                                  // d(LN weight): column sums of d_xn * xhat
-            float sum = 0.f;
-            for (int tt = 0; tt < 64; ++tt) sum += Cf[tt * LDF + c];
-            part[c] = sum;
-        }
-    } else if constexpr (EPI == 0) {
+    if constexpr (EPI == 0) {
         // ---- epilogue: accumulators -> LDS (as [token][channel], reusing the staging tiles) -> whole 16-byte chunks of output
         // rows.  Storing straight from the transposed accumulators wrote 32-byte pieces of 16 different rows per instruction;
         // the write-heavy shapes (N = 3C from K = C) ran at 2.5 TB/s against 3.2-3.7 TB/s for the read-heavy ones.  Plain
@@ -374,7 +276,7 @@ __global__ __launch_bounds__(320) void gemm_tok_ring_kernel(GemmDev a) {
     typedef ElemTraits<T> TR;
     static_assert(sizeof(T) == 2, "ring form: 16-bit element types");
     constexpr int SLOT = 64 * 128;                                      // 64 tokens x 64 channels
-    constexpr int EPI_SYNCS = EPI == 3 ? 4 : (EPI == 0 || NW <= 2) ? 2 : 0;      // barriers inside gemm_tok_epilogue
+    constexpr int EPI_SYNCS = (EPI == 0 || NW <= 2) ? 2 : 0;      // barriers inside gemm_tok_epilogue
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     unsigned char* ring = reinterpret_cast<unsigned char*>(smem_v);      // [GR_RING][SLOT]
     unsigned char* stage = ring + GR_RING * SLOT;                        // the epilogue's staging tile
@@ -459,8 +361,7 @@ __global__ __launch_bounds__(320) void gemm_tok_ring_kernel(GemmDev a) {
 }
 
 template <class T, int EPI, int NW> constexpr size_t gemm_tok_ring_lds() {
-    constexpr size_t st = EPI == 3 ? 64 * (size_t)(GT_BN * NW + 1) * sizeof(float)
-                          : EPI == 0 ? 64 * (size_t)(GT_BN * NW + LDS_PAD_BYTES / sizeof(T)) * sizeof(T) : (NW <= 2 ? 64 * (size_t)(GT_BN * NW + 4) * sizeof(float) : 0);
+    constexpr size_t st = EPI == 0 ? 64 * (size_t)(GT_BN * NW + LDS_PAD_BYTES / sizeof(T)) * sizeof(T) : (NW <= 2 ? 64 * (size_t)(GT_BN * NW + 4) * sizeof(float) : 0);
     return (size_t)GR_RING * 64 * 128 + st;
 }
 
@@ -483,8 +384,7 @@ template <class T, int EPI, bool LN, int NW>
 static int launch_gemm_nw(const GemmDev& d, hipStream_t s) {
     dim3 grid(d.M / GT_BM, (d.N + GT_BN * NW - 1) / (GT_BN * NW));
     const size_t stage = 2 * 64 * (size_t)(GT_KC + LDS_PAD_BYTES / sizeof(T)) * sizeof(T) + 128 * sizeof(float);
-    const size_t epil = EPI == 3 ? 64 * (size_t)(GT_BN * NW + 1) * sizeof(float)
-                                 : EPI == 0 ? 64 * (size_t)(GT_BN * NW + LDS_PAD_BYTES / sizeof(T)) * sizeof(T)
+    const size_t epil = EPI == 0 ? 64 * (size_t)(GT_BN * NW + LDS_PAD_BYTES / sizeof(T)) * sizeof(T)
                                             : ((NW <= 2 && sizeof(T) == 2) ? 64 * (size_t)(GT_BN * NW + 4) * sizeof(float) : 0);
     const size_t shmem = stage > epil ? stage : epil;
     allow_big_lds(gemm_tok_kernel<T, EPI, LN, NW>, shmem);
@@ -505,19 +405,6 @@ static bool gemm_ring_applies(const GemmDev& d, int form) {
 
 template <class T, int EPI, bool LN>
 static int launch_gemm(const GemmDev& d, int form, hipStream_t s) {
-    if constexpr (EPI == 3) {          // the LayerNorm-backward epilogue needs the whole row in one tile (N <= 256, checked by the caller)
-        const bool ring = gemm_ring_applies<T, EPI, LN>(d, form);
-        if constexpr (!LN && sizeof(T) == 2) {
-            if (ring) {
-                if (d.N > 128) return launch_gemm_ring<T, EPI, 4>(d, s);
-                if (d.N > 64) return launch_gemm_ring<T, EPI, 2>(d, s);
-                return launch_gemm_ring<T, EPI, 1>(d, s);
-            }
-        }
-        if (d.N > 128) return launch_gemm_nw<T, EPI, LN, 4>(d, s);
-        if (d.N > 64) return launch_gemm_nw<T, EPI, LN, 2>(d, s);
-        return launch_gemm_nw<T, EPI, LN, 1>(d, s);
-    }
     if constexpr (!LN && sizeof(T) == 2) {
         if (gemm_ring_applies<T, EPI, LN>(d, form)) {
             if (d.N > 128) return launch_gemm_ring<T, EPI, 4>(d, s);
@@ -544,7 +431,6 @@ static int dispatch_gemm(const GemmDev& d, int epi, bool ln, int form, hipStream
         case 3: return launch_gemm<T, 1, true>(d, form, s);
         case 4: return launch_gemm<T, 2, false>(d, form, s);
         case 5: return launch_gemm<T, 2, true>(d, form, s);
-        case 6: return launch_gemm<T, 3, false>(d, form, s);
     }
     return MPHSIR_EINVAL;
 }
@@ -560,7 +446,7 @@ extern "C" int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* strea
     MPHSIR_REQUIRE(a->M > 0 && a->M % 64 == 0, "gemm_tok: M=%lld must be a positive multiple of 64", (long long)a->M);
     MPHSIR_REQUIRE(a->N > 0 && a->N % 16 == 0, "gemm_tok: N=%lld must be a multiple of 16", (long long)a->N);
     MPHSIR_REQUIRE(a->K > 0 && a->K % 32 == 0, "gemm_tok: K=%lld must be a multiple of 32", (long long)a->K);
-    MPHSIR_REQUIRE(a->epi >= 0 && a->epi <= 3, "gemm_tok: epi %d unknown", a->epi);
+    MPHSIR_REQUIRE(a->epi >= 0 && a->epi <= 2, "gemm_tok: epi %d unknown", a->epi);
     MPHSIR_REQUIRE(aligned16(a->X) && aligned16(a->W) && aligned16(a->Y) && (a->ldx * esz) % 16 == 0 &&
                        (a->ldy * esz) % 16 == 0, "gemm_tok: X/W/Y must be 16-byte aligned with 16-byte row pitch");
     MPHSIR_REQUIRE((a->ln_w == nullptr) == (a->ln_b == nullptr), "gemm_tok: ln_w and ln_b go together");
@@ -572,17 +458,11 @@ extern "C" int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* strea
                        "gemm_tok: epi 2 needs H,W multiples of 8 with M = B*H*W");
         MPHSIR_REQUIRE(a->shift == 0 || a->shift == 4, "gemm_tok: shift must be 0 or 4");
     }
-    if (a->epi == 3) {
-        MPHSIR_REQUIRE(a->SA && a->gate && a->part && aligned16(a->SA) && (a->ldsa * esz) % 16 == 0, "gemm_tok: epi 3 needs SA (d_res), gate (LN weight) and part");
-        MPHSIR_REQUIRE(a->N <= 256 && a->ln_w == nullptr && a->bias == nullptr, "gemm_tok: epi 3 needs the whole row in one tile (N <= 256), no bias, no LayerNorm prologue");
-        MPHSIR_REQUIRE(a->H > 0 && a->Wimg > 0 && a->H % 8 == 0 && a->Wimg % 8 == 0 && a->M % ((int64_t)a->H * a->Wimg) == 0 && (a->shift == 0 || a->shift == 4),
-                       "gemm_tok: epi 3 needs H,W multiples of 8 with M = B*H*W and shift 0 or 4");
-    }
     if (a->w_batch_stride)
         MPHSIR_REQUIRE(a->rows_per_batch > 0 && a->rows_per_batch % 64 == 0, "gemm_tok: rows_per_batch must be a multiple of 64");
     GemmDev d{a->X, (long)a->ldx, a->W, (long)a->w_batch_stride, (long)a->rows_per_batch, a->bias, a->ln_w, a->ln_b,
               a->Y, (long)a->ldy, (int)a->M, (int)a->N, (int)a->K, a->R, (long)a->ldr, a->SA, (long)a->ldsa,
-              a->gate, a->keep, a->H, a->Wimg, a->shift, a->part};
+              a->gate, a->keep, a->H, a->Wimg, a->shift};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     MPHSIR_REQUIRE(a->form >= 0 && a->form <= 2, "gemm_tok: form %d unknown", a->form);
     return MPHSIR_DISPATCH_T(dtype, (dispatch_gemm<T_>(d, a->epi, a->ln_w != nullptr, a->form, s)));

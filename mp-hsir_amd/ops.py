@@ -267,7 +267,7 @@ def _flush_gemms(gemms):
         for k, g in enumerate(chunk):
             q = arr[k]
             q.A, q.lda, q.B, q.ldb, q.Cpart, q.colsum_part = g["A"], g["lda"], g["B"], g["ldb"], g["Cpart"], g["cs"]
-            q.M, q.N1, q.N2, q.nsplit, q.group_counters = g["M"], g["N1"], g["N2"], g["nsplit"], g.get("cnt")
+            q.M, q.N1, q.N2, q.nsplit = g["M"], g["N1"], g["N2"], g["nsplit"]
         form = TN_FORM or (2 if all(g["form"] == 2 for g in chunk) else 1)
         _lib.check(lib.mphsir_gemm_tn_group(arr, len(chunk), form, _DT[chunk[0]["keep"][0].dtype], _stream(chunk[0]["keep"][0])), "gemm_tn_group")
 
@@ -492,41 +492,6 @@ def gemm_tok(x, w, bias=None, ln=None, epi=0, res=None, sa=None, gate=None, keep
 
 
 
-# norm1's backward as the epilogue of the d_xn GEMM (mphsir_gemm_tok epi 3) instead of gemm_tok -> ln_bwd_win.  Off: measured on the
-# MI355X the step is not faster with it (21.30-21.73 ms without, 21.80-21.84 with) -- the d_xn round trip it saves (2 C per token)
-# costs less than the four barriers and the fp32 staging tile it adds to every GEMM tile; ln_bwd_win alone streams at 5.5 TB/s
-LN_BWD_EPILOGUE = os.environ.get("MPHSIR_LN_BWD_EPILOGUE", "0") == "1"
-
-
-def gemm_tok_ln_bwd_fits(C):
-    return C <= 256 and C % 16 == 0
-
-
-def gemm_tok_ln_bwd(dyw, wT, x, dres, ln_w, shift):
-    """dx = dres + LN_backward(dyw @ wT^T) in ONE launch (mphsir_gemm_tok epi 3): dyw (M,K) rows in window-token order (the d[q|k|v] of
-    the window attention backward), wT (C,K) the transposed qkv weight, x / dres (B,H,W,C) in image order.
-    -> (dx (B,H,W,C), part (B*nW,2,C)) exactly as ln_bwd_win(x, gemm_tok(dyw, wT), dres, ln_w, shift) -- on the unrounded product."""
-    lib = _lib.load()
-    _check(dyw, wT, x, dres, ln_w)
-    B, H, W, C = x.shape
-    M, K = dyw.shape
-    assert M == B * H * W and wT.shape == (C, K) and wT.is_contiguous() and wT.dtype == dyw.dtype == x.dtype == dres.dtype
-    assert x.is_contiguous() and dres.is_contiguous() and dyw.stride(1) == 1 and gemm_tok_ln_bwd_fits(C) and ln_w.dtype == torch.float32
-    dx = torch.empty_like(x)
-    part = torch.empty((M // 64, 2, C), dtype=torch.float32, device=x.device)
-    a = _lib.GemmArgs()
-    a.X, a.ldx, a.W = _p(dyw), dyw.stride(0), _p(wT)
-    a.Y, a.ldy = _p(dx), C
-    a.M, a.N, a.K, a.epi = M, C, K, 3
-    a.R, a.ldr, a.SA, a.ldsa, a.gate = _p(x), C, _p(dres), C, _p(ln_w)
-    a.H, a.Wimg, a.shift = H, W, shift
-    a.form, a.part = TOK_FORM, _p(part)
-    _lib.check(lib.mphsir_gemm_tok(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gemm_tok")
-    es = x.element_size()
-    _acct("gemm_tok", 2.0 * M * C * K + 10.0 * M * C, (M * K + 3 * M * C) * es + wT.numel() * es)
-    return dx, part
-
-
 def layernorm_tok(x, ln_w, ln_b, out_dtype):
     """x (M,C) contiguous, fp32 or compute dtype -> LN(x) in out_dtype (statistics in fp32)."""
     lib = _lib.load()
@@ -599,12 +564,9 @@ def pack_gated_mlp(fc1_w, fc1_b, fc2_w, dtype):
     return W1, b1, W2
 
 
-# two-wave gated MLP kernels (32 tokens per workgroup) for launches of < 256 workgroups at C >= 192 (the latent level).  Off: measured
-# slower (natural step 22.05 -> 22.71 ms, remote-sensing step 28.55 -> 32.57): twice the workgroups stream twice the weights
+
+
 BASE_SKIP_FUSED = os.environ.get("MPHSIR_BASE_SKIP_FUSED", "1") == "1"     # BaseBlock's `+ x` inside its last gated-MLP launch (6 launches fewer per forward)
-MLP_SMALL_FORM = os.environ.get("MPHSIR_MLP_SMALL_FORM", "0") == "1"
-
-
 # hidden split of the gated MLP kernels for small launches (< 256 token tiles at C >= 192: the latent level): 0 = off, else the number of
 # workgroups per token tile is chosen so that about 256 workgroups exist
 MLP_HSPLIT = os.environ.get("MPHSIR_MLP_HSPLIT", "1") == "1"
@@ -636,8 +598,6 @@ def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, ou
     if res is not None:
         assert res.shape == x.shape and res.dtype == x.dtype
         a.R, a.ldr = _p(res), _rows(res)[1]
-    if tiles_per_wave == 0 and MLP_SMALL_FORM and x.dtype in _HALF and C >= 192 and M // 64 < 256:
-        tiles_per_wave = 5
     a.Y, a.ldy, a.M, a.C, a.HP, a.tiles_per_wave = _p(y), _rows(y)[1], M, C, HP, tiles_per_wave
     if hsplit is None:
         hsplit = mlp_hsplit(M, C, HP) if tiles_per_wave == 0 and (x.dtype in _HALF or C < 256) else 1
@@ -1101,13 +1061,11 @@ def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None,
     HP = W2T.shape[0]
     assert x.is_contiguous() and dy.is_contiguous() and (dm is None or dm.is_contiguous()) and W1T.shape == (C, 2 * HP) and W2T.shape == (HP, C)
     dev, dt = x.device, x.dtype
-    if variant == 0 and MLP_SMALL_FORM and dt in _HALF and C >= 192 and M // 64 < 256:
-        variant = 5           # fewer than one 64-token workgroup per CU, each streaming MBs of weights: 32-token workgroups
     dx = torch.empty_like(x)
     xn = torch.empty_like(x)
     h = torch.empty((M, HP), dtype=dt, device=dev) if operands else None
     dpre = torch.empty((M, 2 * HP), dtype=dt, device=dev) if operands else None
-    part = torch.empty((M // (32 if variant == 5 else 64), 2, C), dtype=torch.float32, device=dev)
+    part = torch.empty((M // 64, 2, C), dtype=torch.float32, device=dev)
     a = _lib.MlpBwdArgs()
     if keep is not None:
         _check(keep)
@@ -1276,27 +1234,6 @@ TN_BIG_TILES = True        # bf16 token-reduction GEMMs use the transposed-LDS-r
 # 0 = per problem: the ring form where it measured faster -- ONE output tile, unbatched, >= 65536 tokens (tools/bench/bench_tn.py) -- else 1
 TN_FORM = int(os.environ.get("MPHSIR_TN_FORM", "0"))
 TN_RING_WGS = 256          # ring form: workgroups per launch aimed at (one per CU)
-# first level of the ordered partial sum inside the GEMM launch (groups of 8 splits, see include/mphsir.h): the reduction launch then
-# reads an eighth of the partial bytes.  Counters: a zero-initialised ring per device; every launch takes its own range (concurrent
-# launches on the weight-gradient branch never share one) and leaves it zero.  Bitwise-correct on hardware and slower (21.3 -> 22.6 ms
-# per training step: the last workgroup of a group is a serial tail; csrc/gemm_tn.hip): off by default.
-TN_COMBINE = os.environ.get("MPHSIR_TN_COMBINE", "0") == "1"
-TN_GROUP = 8
-_TN_CNT = {}
-
-
-def _tn_counters(dev, N1, N2, nsplit, Bt):
-    n = Bt * ((N1 + 63) // 64) * ((N2 + 63) // 64) * ((nsplit + 7) // 8)
-    e = _TN_CNT.get(dev)
-    if e is None:
-        e = _TN_CNT[dev] = [torch.zeros(1 << 20, dtype=torch.int32, device=dev), 0]
-    if e[1] + n > e[0].numel():
-        e[1] = 0
-    c = e[0][e[1]:e[1] + n]
-    e[1] += (n + 3) // 4 * 4
-    return c
-
-
 TN_PART_CAP = float(os.environ.get("MPHSIR_TN_PART_CAP", "0.4"))    # 0 / 0.2 / 0.3 / 0.4 / 0.55: 21.59 / 21.82 / 21.47 / 21.43 / 21.45 ms per step (one box)
 TN_BIG_ROUNDS = float(os.environ.get("MPHSIR_TN_ROUNDS", "1.0"))        # ... and aim for this many full rounds of resident workgroups (re-measured with the partial sums deferred: 0.5 / 0.75 / 1 / 2 -> 22.48 / 22.33 / 22.37 / 22.47 ms per step)
 
@@ -1331,23 +1268,20 @@ def gemm_tn(a, b, nsplit=None, colsum=False, tile128=None, immediate=False, redu
             nsplit = max(1, (M + 4095) // 4096, min(nsplit, cap))
     part = torch.empty((Bt, nsplit, N1, N2), dtype=torch.float32, device=a.device)
     cs = torch.empty((Bt, nsplit, N1), dtype=torch.float32, device=a.device) if colsum else None
-    cnt = _tn_counters(a.device, N1, N2, nsplit, Bt) if (TN_COMBINE and tile128 and a.dtype in _HALF and nsplit > 1) else None
     if _SCOPE is not None and TN_GROUPED and not immediate and not batched and tile128 and a.dtype in _HALF:
         # nothing but the partial reduction at the end of the scope reads the result: issue it there, grouped
         _SCOPE.gemms.append(dict(A=a.data_ptr(), lda=a.stride(-2), B=b.data_ptr(), ldb=b.stride(-2), Cpart=part.data_ptr(),
                                  cs=cs.data_ptr() if colsum else None, M=M, N1=N1, N2=N2, nsplit=nsplit, form=form,
-                                 cnt=cnt.data_ptr() if cnt is not None else None, keep=(a, b, part, cs, cnt)))
+                                 keep=(a, b, part, cs)))
     else:
         _lib.check(lib.mphsir_gemm_tn(_p(a), a.stride(-2), a.stride(0) if batched else 0, _p(b), b.stride(-2),
                                       b.stride(0) if batched else 0, _p(part), _p(cs), M, N1, N2, nsplit, Bt,
-                                      (form if a.dtype in _HALF else 1) if tile128 else 0, _p(cnt),
+                                      (form if a.dtype in _HALF else 1) if tile128 else 0,
                                       _DT[a.dtype], _stream(a)),
                    "gemm_tn")
     # algorithmic bytes = the two token matrices, read once; the kernel's own split partials are overhead, accounted apart
     _acct("gemm_tn", 2.0 * Bt * M * N1 * N2, Bt * M * (N1 + N2) * a.element_size())
     _acct("gemm_tn:partials", 0.0, part.numel() * 4.0)
-    if cnt is not None:
-        part = part[:, ::TN_GROUP]             # the slots the in-kernel group sums were left in
     if not reduce:
         return (part, cs) if colsum else part
     out = reduce_parts(part, batched=True, immediate=immediate)
@@ -1504,13 +1438,10 @@ def conv3x3_wgrad(dy2, x, nsplit=None, cout=None, cin=None):
         tiles = ((Np + 127) // 128 if Np > 64 else 1) * ((9 * Cp + 127) // 128)
         nsplit = max(1, min(M // 256, 128, max(1, (TN_RING_WGS if TN_FORM == 2 else int(256 * 2 * TN_BIG_ROUNDS)) // tiles)))
     part = torch.empty((1, nsplit, Np, 9 * Cp), dtype=torch.float32, device=x.device)
-    cnt = _tn_counters(x.device, Np, 9 * Cp, nsplit, 1) if (TN_COMBINE and nsplit > 1) else None
-    _lib.check(lib.mphsir_conv3x3_wgrad(_p(dy2), dy2.stride(0), _p(x), Cp, _p(part), B, H, W, Np, Cp, nsplit, TN_FORM or 1, _p(cnt), _DT[x.dtype],
+    _lib.check(lib.mphsir_conv3x3_wgrad(_p(dy2), dy2.stride(0), _p(x), Cp, _p(part), B, H, W, Np, Cp, nsplit, TN_FORM or 1, _DT[x.dtype],
                                         _stream(x)), "conv3x3_wgrad")
     _acct("gemm_tn", 2.0 * M * Np * 9 * Cp, M * (Np + Cp) * x.element_size())
     _acct("gemm_tn:partials", 0.0, part.numel() * 4.0)
-    if cnt is not None:
-        part = part[:, ::TN_GROUP]
     if cout is None:
         return reduce_parts(part, batched=True, immediate=True)[0]
     assert cout <= Np and cin <= Cp

@@ -54,8 +54,8 @@ FULL_CASES = {
 # from the REFERENCE run in fp64: the loss, and per parameter gradient its norm + FULLGRAD_SAMPLES seeded samples (tensors up to
 # that many elements: in full), and the names of the parameters autograd leaves without gradient.
 FULLGRAD_CASES = {
-    "natural_b2": dict(cfg=NATURAL_CFG, shape=(2, 31, 64, 64), task=[0, 3], sigma=50.0),
-    "remote_b2": dict(cfg=REMOTE_CFG, shape=(2, 100, 64, 64), task=[4, 6], sigma=30.0),
+    "natural_b2": dict(cfg=NATURAL_CFG, shape=(2, 31, 64, 64), task=[0, 3], sigma=50.0, autocast=(torch.bfloat16, 1.0)),
+    "remote_b2": dict(cfg=REMOTE_CFG, shape=(2, 100, 64, 64), task=[4, 6], sigma=30.0, autocast=(torch.float16, 1024.0)),
 }
 FULLGRAD_SAMPLES = 4096
 

@@ -296,7 +296,30 @@ def gen_full_grad(which=None):
                 out["%s/samp/%s" % (name, k)] = to_np(g.flatten()[idx])
         out[name + "/none_keys"] = np.array(none_keys)
         print("full grad", name, "loss", float(loss), "none:", len(none_keys), "%.0f s" % (time.time() - t0), flush=True)
+        g64 = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        y64 = y.detach()
         del net, y, loss
+        # the reference's OWN mixed-precision deviation, per tensor: the same step under torch.autocast (train.py:118 trains in
+        # 16-mixed; bf16 for the natural case, fp16 with a fixed loss scale for the remote-sensing one) against its fp64 gradients.
+        # The tests hold the 16-bit HIP backward to a small multiple of THIS, tensor by tensor.
+        low, scale = c["autocast"]
+        net = build_ref_net(c["cfg"], torch.float32)
+        for p in net.parameters():
+            p.requires_grad_(True)
+        with torch.autocast(device_type="cpu", dtype=low):
+            ya = net(degraded, task_tensor(c["task"]))
+            la = F.l1_loss(torch.clamp(ya.float(), 0, 1), clean)
+        (la * scale).backward()
+        out[name + "/autocast_out_err"] = np.array(float((ya.detach().double() - y64).norm() / y64.norm()))
+        out[name + "/autocast_res_err"] = np.array(float((ya.detach().double() - y64).norm() / (y64 - degraded.double()).norm()))
+        for k, p in net.named_parameters():
+            if k in g64:
+                ga = p.grad.detach().double() / scale
+                out["%s/autocast_err/%s" % (name, k)] = np.array(float((ga - g64[k]).norm() / g64[k].norm()))
+        errs = sorted(float(out[k]) for k in out if k.startswith(name + "/autocast_err/"))
+        print("   autocast", low, "out err", float(out[name + "/autocast_out_err"]), "residual err", float(out[name + "/autocast_res_err"]),
+              "grad err median %.3g  90%% %.3g  max %.3g" % (errs[len(errs) // 2], errs[int(len(errs) * 0.9)], errs[-1]), flush=True)
+        del net
     np.savez_compressed(path, **out)
 
 

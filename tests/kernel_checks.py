@@ -86,36 +86,6 @@ def check_gemm_tok_ring(dev, dtype, M, N, K, epi, per_sample=0, ldx=None, ldy=No
             assert float(outs[1][:, N:].abs().max()) == 0.0
 
 
-def check_gemm_tok_ln_bwd(dev, dtype, C, shift, B=2, H=16, W=24):
-    """mphsir_gemm_tok epi 3 (LayerNorm backward as the epilogue of the d_xn GEMM) against gemm_tok + ln_bwd_win and against fp64:
-    both kernel forms, window / shift address arithmetic, widths of both nets that fit one tile."""
-    _use(dev)
-    from mp_hsir_amd import ops
-    M, K = B * H * W, 3 * C
-    dyw, wT = rnd((M, K), 31, dtype), rnd((C, K), 32, dtype, K ** -0.5)
-    x, dres = rnd((B, H, W, C), 33, dtype), rnd((B, H, W, C), 34, dtype)
-    lnw = 1 + 0.1 * rnd((C,), 35)
-    outs = []
-    for form in ((1, 2) if dtype != torch.float32 else (1,)):
-        with tok_form(form):
-            outs.append(ops.gemm_tok_ln_bwd(dyw, wT, x, dres, lnw, shift))
-    for dx_, part_ in outs[1:]:
-        assert torch.equal(dx_.cpu(), outs[0][0].cpu()) and torch.equal(part_.cpu(), outs[0][1].cpu())
-    dx, part = outs[0]
-    dx0, part0 = ops.ln_bwd_win(x, ops.gemm_tok(dyw, wT), dres, lnw, shift)
-    tol = 3e-6 if dtype == torch.float32 else TOL[dtype]
-    assert rel_l2(dx, dx0.double().cpu()) < tol and rel_l2(part, part0.double().cpu()) < tol
-    # fp64: d_xn in window order -> image order, LN backward
-    dxn_w = dyw.double().cpu() @ wT.double().cpu().t()
-    dxn = torch.roll(O.from_windows(dxn_w.reshape(-1, 64, C), B, H, W), shifts=(shift, shift), dims=(1, 2))
-    xd = x.double().cpu().requires_grad_(True)
-    wd = lnw.double().cpu().requires_grad_(True)
-    bd = torch.zeros(C, dtype=torch.float64, requires_grad=True)
-    O.layer_norm_c(xd, wd, bd).backward(dxn)
-    assert rel_l2(dx, xd.grad + dres.double().cpu()) < tol
-    assert rel_l2(part.sum(0)[0], wd.grad) < tol and rel_l2(part.sum(0)[1], bd.grad) < tol
-
-
 def check_gemm_tok(dev, dtype, M, N, K, ln, epi):
     _use(dev)
     from mp_hsir_amd import ops
@@ -703,40 +673,6 @@ def check_gemm_tn(dev, dtype, M, N1, N2, nsplit, batch, tile128=None):
     if not batch:
         c2 = ops.gemm_tn(wide[:, 8:8 + N1], b, nsplit=nsplit)
         assert rel_l2(c2, wide[:, 8:8 + N1].double().cpu().t() @ b.double().cpu()) < (3e-6 if dtype == torch.float32 else 1e-2)
-
-
-def check_gemm_tn_group_sum(dev, dt, M, N1, N2, nsplit, batch=0, form=1, repeats=3):
-    """the in-kernel first level of the ordered partial sum (include/mphsir.h, group_counters): for every group of 8 splits the
-    slot 8g holds ((p0 + p1) + p2) + ... of the partials a launch WITHOUT counters writes -- bitwise, whichever workgroup arrived
-    last (repeated launches agree bitwise) --, the counters are zero again afterwards, and the reduced result equals the ordered sum
-    of those group sums."""
-    _use(dev)
-    from mp_hsir_amd import ops
-    shape_a = (batch, M, N1) if batch else (M, N1)
-    shape_b = (batch, M, N2) if batch else (M, N2)
-    a, b = rnd(shape_a, 57, dt), rnd(shape_b, 58, dt)
-    old = ops.TN_COMBINE, ops.TN_FORM
-    try:
-        ops.TN_FORM = form
-        ops.TN_COMBINE = False
-        raw = ops.gemm_tn(a, b, nsplit=nsplit, reduce=False, tile128=True).clone()          # (Bt, nsplit, N1, N2)
-        ops.TN_COMBINE = True
-        got = [ops.gemm_tn(a, b, nsplit=nsplit, reduce=False, tile128=True).clone() for _ in range(repeats)]
-        full = ops.gemm_tn(a, b, nsplit=nsplit, tile128=True)
-    finally:
-        ops.TN_COMBINE, ops.TN_FORM = old
-    ng = (nsplit + 7) // 8
-    assert got[0].shape[1] == ng
-    for g in range(ng):
-        t = raw[:, 8 * g].clone()
-        for q in range(8 * g + 1, min(8 * g + 8, nsplit)):
-            t = t + raw[:, q]
-        for r in got:
-            assert torch.equal(r[:, g].cpu(), t.cpu()), "group %d" % g
-    for e in ops._TN_CNT.values():
-        assert int(e[0].abs().sum()) == 0, "group counters not left at zero"
-    ref = a.double().cpu().transpose(-1, -2) @ b.double().cpu()
-    assert rel_l2(full, ref) < 1e-2
 
 
 def check_conv3x3(dev, dtype, B, H, W, Cin, Cout):

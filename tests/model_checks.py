@@ -189,22 +189,34 @@ def fixture_grad_err(got, g, name, k):
     return max(e, rel_l2(got.flatten()[idx], g["%s/samp/%s" % (name, k)]))
 
 
-# bf16 / fp16 gradient bars (whole net): a parameter gradient has been through the forward's roundings once more on the way back, so
-# its bar is tied to the measured forward deviation e_fwd = rel-L2(y_16bit, y_fp32) of the SAME run instead of a flat number:
-# GRAD_BAR_FACTOR x e_fwd (measured on the MI355X: see DESIGN.md section 4), except the tensors listed in GRAD_BAR_LOOSE whose
-# gradients are residuals of cancelling sums (conditioning found in round 2: TVSP's rank-one text map through norm11; the
-# temperatures and the spectral-prompt gate see a handful of numbers per sample).
-GRAD_BAR_FACTOR = 6.0
-GRAD_BAR_LOOSE = (("cross_transformer.norm11", 30.0), ("text_prompt_learnable", 30.0), ("temperature", 20.0), ("local_spectral_attn", 20.0),
-                  ("relative_position_bias_table", 12.0), ("visual_prompt", 12.0))
+# 16-bit gradient bars (whole net).  The fixture holds, per parameter tensor, the deviation of the REFERENCE's own mixed-precision step
+# (torch.autocast, train.py:118 trains in 16-mixed) from its fp64 gradients: 2 % in the median for bf16, 8-10 % across the prompt
+# modules, 20-45 % for norm1.bias / prompt_param, and 100 % for the fp16 gradient of linear_prompt.weight (it underflows there).
+# The 16-bit HIP backward is held, tensor by tensor, to GRAD_BAR_FACTOR x that deviation plus GRAD_BAR_FLOOR x the median deviation
+# over all tensors (a tensor on which the reference was lucky must not fail ours for being average).
+# The parameters of the spectral-prompt gate (local_spectral_attn.*) are the exception to "tensor by tensor": their gradients are sums
+# over a handful of windows per sample (4 at the latent level) of products of small numbers, and which BLOCK's sum happens to cancel
+# is luck -- the reference's own deviation for kv.weight runs from 0.4 % to 17 % across the 22 blocks of one net.  They are held to
+# the reference's WORST block of the same tensor type instead of the same block.
+GRAD_BAR_FACTOR = 2.0
+GRAD_BAR_FLOOR = 2.0
 
 
-def grad_bar(k, e_fwd):
-    f = GRAD_BAR_FACTOR
-    for pat, ff in GRAD_BAR_LOOSE:
-        if pat in k:
-            f = max(f, ff)
-    return f * e_fwd
+def grad_bars(g, name):
+    import re
+    ref = {k.split("/autocast_err/")[1]: float(g[k]) for k in g.files if k.startswith(name + "/autocast_err/")}
+    med = sorted(ref.values())[len(ref) // 2]
+    worst_of_type = {}
+    for k, v in ref.items():
+        if ".local_spectral_attn." in k:
+            t = re.sub(r"^.*\.local_spectral_attn\.", "", k)
+            worst_of_type[t] = max(worst_of_type.get(t, 0.0), v)
+    bars = {}
+    for k, v in ref.items():
+        if ".local_spectral_attn." in k:
+            v = worst_of_type[re.sub(r"^.*\.local_spectral_attn\.", "", k)]
+        bars[k] = GRAD_BAR_FACTOR * v + GRAD_BAR_FLOOR * med
+    return bars, med
 
 
 def _hip_step_gradients(net, x, clean, task):
@@ -266,22 +278,25 @@ def check_full_gradients(dev, name, low=torch.bfloat16, oracle_threads=32):
     # (2) 16-bit storage
     net.set_compute_dtype(low)
     loss16, y16, g16 = _hip_step_gradients(net, x, cl, task)
-    e_fwd = rel_l2(y16, y32)
-    res["e_fwd"] = e_fwd
-    assert e_fwd < 4e-2 and abs(loss16 - loss64) < 4 * e_fwd * abs(loss64), (e_fwd, loss16, loss64)
+    bars, med = grad_bars(g, name)
+    res["e_fwd"] = rel_l2(y16, y32)
+    res["e_fwd_reference_autocast"] = float(g[name + "/autocast_out_err"])
+    assert res["e_fwd"] < 2.0 * res["e_fwd_reference_autocast"] + 1e-3 and abs(loss16 - loss64) < 2e-2 * abs(loss64), (res, loss16, loss64)
     ratios, bad = [], []
     for k, gr in g16.items():
         if k in none_keys:
             assert gr is None or float(gr.abs().max()) == 0.0, k
             continue
         e = rel_l2(gr, g64[k])
-        ratios.append((e / e_fwd, k, e))
-        if not e < grad_bar(k, e_fwd):
-            bad.append((k, e, grad_bar(k, e_fwd)))
+        ratios.append((e / bars[k], k, e))
+        if not e < bars[k]:
+            bad.append((k, e, bars[k]))
     ratios.sort(reverse=True)
-    res["low_worst_ratios"] = [(round(r, 2), k) for r, k, _ in ratios[:8]]
-    res["low_median_ratio"] = ratios[len(ratios) // 2][0]
-    assert not bad, (name, str(low), "e_fwd %g" % e_fwd, bad[:10])
+    errs = sorted(e for _, _, e in ratios)
+    res["low_closest_to_bar"] = [(round(r, 2), k, round(e, 4)) for r, k, e in ratios[:6]]
+    res["low_median_err"], res["reference_autocast_median_err"] = errs[len(errs) // 2], med
+    print(name, str(low), res)
+    assert not bad, (name, str(low), bad[:10])
     return res
 
 
@@ -311,16 +326,18 @@ def check_batch32_step(dev, low=torch.bfloat16, n_sampled=16, oracle_threads=64)
     finally:
         torch.set_num_threads(prev)
     res = {"e_fwd": e_fwd, "fwd_f32_vs_oracle": rel_l2(y32, y_o), "loss": (loss16, loss_o)}
-    assert res["fwd_f32_vs_oracle"] < 1e-4 and e_fwd < 4e-2 and abs(loss16 - loss_o) < 4 * e_fwd * abs(loss_o), res
+    g = np.load(os.path.join(GOLDEN, "full_grad.npz"))
+    bars, med = grad_bars(g, "natural_b2")            # the same net: the reference's own bf16 deviation per tensor, measured at batch 2
+    assert res["fwd_f32_vs_oracle"] < 1e-4 and e_fwd < 2.0 * float(g["natural_b2/autocast_out_err"]) + 1e-3 and abs(loss16 - loss_o) < 2e-2 * abs(loss_o), res
     names = sorted(k for k, v in g16.items() if v is not None)
     rng = torch.Generator().manual_seed(zlib.crc32(b"b32:params"))
     pick = [names[i] for i in torch.randperm(len(names), generator=rng)[:n_sampled].tolist()] + ["patch_embed.proj.weight", "output.weight"]
     worst = []
     for k in pick:
         e = rel_l2(g16[k], g_o[k])
-        worst.append((round(e / e_fwd, 2), k))
-        assert e < grad_bar(k, e_fwd), (k, e, grad_bar(k, e_fwd), e_fwd)
-    res["ratios"] = sorted(worst, reverse=True)[:6]
+        worst.append((round(e / bars[k], 2), k, round(e, 4)))
+        assert e < bars[k], (k, e, bars[k])
+    res["closest_to_bar"] = sorted(worst, reverse=True)[:6]
     return res
 
 

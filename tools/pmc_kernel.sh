@@ -1,5 +1,5 @@
 # per-wave issue / wait breakdown of ONE kernel from three rocprofv3 --pmc passes (GPU box):
-#     bash tools/pmc_kernel.sh <kernel-name substring> <python script> [args...]        e.g. gated_mlp_lds_kernel tools/pmc/run_mlp_once.py 128 340 131072
+#     bash tools/pmc_kernel.sh <kernel-name substring> <python script> [args...]        e.g. gated_mlp_lds_kernel tools/pmc/run_once.py mlp 128 340 131072
 # (counter values are quad-cycles / instruction counts summed over the sampled waves; the last launch of the kernel is reported)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 KN="$1"; shift
