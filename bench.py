@@ -321,10 +321,36 @@ def spawn_ranks(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].stdout.read().decode()
+    # rank 0's line is read on a thread while EVERY child is polled: a rank that dies early (bad device, out of memory, RCCL
+    # initialisation) would otherwise leave rank 0 in init_process_group / its first all-reduce and this process blocked in read()
+    # until the outer harness gives up.  One failed rank, or the overall limit, ends all of them.
+    import threading
+    import time
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    limit = float(os.environ.get("MPHSIR_BENCH_SPAWN_TIMEOUT", "3000"))
+    t0, failed = time.time(), False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() - t0 > limit:
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t1 = time.time()
+            while any(p.poll() is None for p in procs) and time.time() - t1 < 10:
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
     codes = [p.wait() for p in procs]
-    sys.stdout.write(out)
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(buf).decode())
     sys.stdout.flush()
+    if failed and all(c == 0 for c in codes):
+        codes[0] = 124                                   # the overall limit
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         print("bench.py: rank(s) failed: %s" % ", ".join("rank %d exit %d" % rc for rc in bad), file=sys.stderr, flush=True)
@@ -451,7 +477,10 @@ def main():
             ach, peak, unit, bound = nbytes / (ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
         # HBM bytes per launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) of the newest training profile
         # under profiles/ -- a file, not this run (PMC collection needs rocprofv3 around the process): `traffic_source` names it
-        traffic, traffic_source = None, None
+        # ... and the same kernel's average launch duration in that profile (rocprofv3 --kernel-trace of the REPLAYED step, where the
+        # parallel branches of the captured graph run beside each other): `frac_profile` prices the algorithmic work against it,
+        # `frac_inline` (= `frac`) against this run's HIP-event timing with the branches issued in line
+        traffic, traffic_source, prof_us = None, None, None
         try:
             import glob
             pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_train_b32_bf16_graph_pmc_summary.json")))
@@ -460,10 +489,14 @@ def main():
                 if "hbm_read_bytes_per_launch" in e:
                     traffic = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
                     traffic_source = "committed profile " + os.path.relpath(pm[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+                prof_us = e.get("avg_us")
         except Exception:
-            traffic, traffic_source = None, None
+            traffic, traffic_source, prof_us = None, None, None
+        per_launch = (flops if bound == "mfma" else nbytes) / launches
+        frac_profile = round(per_launch / (prof_us * 1e-6) / (1e12 if bound == "mfma" else 1e9) / peak, 4) if prof_us else None
         roofline = {"kernel": dom, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "algorithmic_per_launch": round((flops if bound == "mfma" else nbytes) / launches),
+                    "frac": round(ach / peak, 4), "frac_inline": round(ach / peak, 4), "frac_profile": frac_profile, "profile_avg_launch_us": prof_us,
+                    "traffic": traffic, "traffic_source": traffic_source, "algorithmic_per_launch": round(per_launch),
                     "launches_per_step": launches,
                     # bytes the kernel moves beyond its inputs (split-K partial sums): overhead, NOT part of `achieved`
                     "partials_bytes_per_step": acct.get(dom + ":partials", [0, 0.0, 0.0])[2],

@@ -371,7 +371,8 @@ __device__ __forceinline__ void tn_ring_body(const TnDev& a, char* smem, int L, 
     int row[CMAX];                  // row inside the slot
     bool colok[CMAX], isb[CMAX];
     unsigned ldsoff[CMAX];          // wave-uniform byte offset inside the slot
-    int cdy = 0, cdx = 0;           // conv weight gradient: the tap of this lane's 8 columns of B
+    int cdy[CMAX], cdx[CMAX];       // conv weight gradient: the tap of this lane's 8 columns of B, per DMA instruction (one shared pair
+                                    // was right only while every B instruction of a wave happened to land on the same tap)
     const int cHW = a.cH * a.cW;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
@@ -389,11 +390,12 @@ __device__ __forceinline__ void tn_ring_body(const TnDev& a, char* smem, int L, 
         colok[c] = q < NI && col < (b ? a.N2 : a.N1);
         const long ld = b ? a.ldb : a.lda;
         step[c] = (long)RG_ST * ld * 2;
-        if (b && a.cC) {
+        cdy[c] = cdx[c] = 0;
+        if (b && a.cC && q < NI) {
             const int tap = col / a.cC, ci = col - tap * a.cC;
-            cdy = tap / 3 - 1;
-            cdx = tap - (tap / 3) * 3 - 1;
-            src[c] = B + ((m_lo + r + (long)cdy * a.cW + cdx) * ld + ci) * 2;
+            cdy[c] = tap / 3 - 1;
+            cdx[c] = tap - (tap / 3) * 3 - 1;
+            src[c] = B + ((m_lo + r + (long)cdy[c] * a.cW + cdx[c]) * ld + ci) * 2;
         } else {
             src[c] = (b ? B : A) + ((m_lo + r) * ld + col) * 2;
         }
@@ -407,7 +409,7 @@ __device__ __forceinline__ void tn_ring_body(const TnDev& a, char* smem, int L, 
             bool ok = colok[c] && m < m_hi;
             if (isb[c] && a.cC) {                                        // wave-uniform
                 const unsigned p = (unsigned)m % (unsigned)cHW, py = p / (unsigned)a.cW;     // M < 2^31: 32-bit division
-                const int y = (int)py + cdy, x = (int)(p - py * (unsigned)a.cW) + cdx;
+                const int y = (int)py + cdy[c], x = (int)(p - py * (unsigned)a.cW) + cdx[c];
                 ok = ok && y >= 0 && y < a.cH && x >= 0 && x < a.cW;
             }
             const char* g = ok ? src[c] + (long)sidx * step[c] : zero;

@@ -35,12 +35,13 @@ namespace mphsir {
 
 constexpr int RW_SW = 32;                         // strip width in pixels
 constexpr int RW_RPX = RW_SW + 2;                 // ring row: left outer column | 32 pixels | right outer column
-constexpr int RW_RING = 8;                        // ring slots (rows)
+constexpr int RW_RING = 8;                        // ring slots (rows); C = 256: 4 (RwCfg::RING): eight 18 KB rows do not fit beside the row images
 constexpr int RW_LEAD = 2;                        // a row is first read one step before the taps run on it
 constexpr int RW_UNR = 1;                         // steady steps come in groups of RW_UNR with the low bits of the ring position static
 
 struct RowGramDev {
     const void* X; long ldx;
+    const float* ln_w; const float* ln_b;        // optional LayerNorm over C applied to every x row in the ring (LN builds)
     const void* Wqkv;                            // [3C][C]
     const float* w9; long ldw;                   // [9][ldw]: taps of q | k | v channels
     void* V; long ldvo;
@@ -71,7 +72,8 @@ template <class T, int C, int HD> struct RwCfg {
     static_assert(NDQ <= 2, "row ring: a wave issuing fewer than NDQ - 1 DMA instructions per row would wait on too large a count");
     static constexpr int OPE = 3 * CT + 8;                   // row image [q | k | v] + 16 B
     static constexpr int NT = HD / 16, NTW = HPG * NT * NT, TPW = (NTW + NW - 1) / NW;
-    static constexpr size_t ring_elems = (size_t)RW_RING * NCH * 8, img_elems = (size_t)2 * RW_SW * OPE;
+    static constexpr int RING = C > 192 ? RW_RING / 2 : RW_RING;      // ring slots
+    static constexpr size_t ring_elems = (size_t)RING * NCH * 8, img_elems = (size_t)2 * RW_SW * OPE;
     static constexpr size_t bytes(bool keep) { return (ring_elems + (keep ? 2 : 1) * img_elems) * sizeof(T); }
     static_assert(C % 32 == 0 && HD % 16 == 0 && CT % HD == 0 && CT % CW == 0 && NW <= 16, "shape");
 };
@@ -92,7 +94,11 @@ __device__ __forceinline__ float pick4(f32x4 v, int k) { return k == 0 ? v[0] : 
 // DBG builds only (mphsir_debug armed): shader-clock stamps of workgroup 0 / wave 0 at walk step 9
 #define RW_MARK(k) do { if (DBG && blockIdx.x == 0 && tid == 0 && i == 9) a.dbg[k] = __builtin_amdgcn_s_memtime(); } while (0)
 
-template <class T, int C, int HD, bool KEEP, bool DBG>
+// LN (round 5): the LayerNorm prologue of `Attention` (net/MP_HSIR.py:476 with its norm1, :289-322).  A row in the ring is normalised IN
+// PLACE, one lane per 16-byte chunk (C / 8 lanes per pixel: a 16- or 8-lane DPP/shuffle group holds a pixel's statistics), one walk
+// step after it has landed and one step before the matrix cores first read it -- the ring then keeps one row fewer in flight
+// (LEAD 3).  Same statistics as every other LayerNorm of the library: fp32, two passes, biased variance, eps 1e-5.
+template <class T, int C, int HD, bool KEEP, bool DBG, bool LN>
 __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void qkv_dwconv_gram_rows_kernel(RowGramDev a) {
     typedef ElemTraits<T> TR;
     typedef RwCfg<T, C, HD> CF;
@@ -100,6 +106,9 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
     constexpr int NBW = CF::NBW, CW = CF::CW, CT = CF::CT, HPG = CF::HPG, NKC = CF::NKC, XPE = CF::XPE, OPE = CF::OPE, WPT = CF::WPT, NW = CF::NW;
     constexpr int CH1 = CF::CH1, NCH = CF::NCH, NDQ = CF::NDQ, NT = CF::NT, NTW = CF::NTW, TPW = CF::TPW, THREADS = CF::THREADS;
     constexpr int HEADS = C / HD, SLOTE = NCH * 8;          // elements per ring slot
+    constexpr int LEAD = LN ? RW_LEAD + 1 : RW_LEAD;         // walk steps between "landed" and "first read by the matrix cores"
+    constexpr int RING = CF::RING;
+    static_assert(RING > LEAD && (RING & (RING - 1)) == 0, "ring");
     constexpr int IMG = RW_SW * OPE;                         // elements per row image
     static_assert(sizeof(T) == 2, "16-bit types only");
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
         if (dty >= 1 && dty <= a.H - 1) drow += drow_step;
     };
 #pragma unroll
-    for (int q = 0; q < RW_RING; ++q) dma_next(q);
+    for (int q = 0; q < RING; ++q) dma_next(q);
 
     // ---- per-wave constants: 1x1 weights as MFMA A fragments (rows = channels), depthwise taps of the lane's channels
     frag_t Wf[NBW][NKC];
@@ -221,6 +230,43 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
     wait_vmcnt<0>();
     lds_barrier();
 
+    // ---- LayerNorm of one ring slot in place (LN builds): lane = one 16-byte chunk of one of the 34 ring pixels
+    constexpr int CPP = C / 8;                               // chunks per pixel = lanes per pixel (8 or 16: one shuffle group)
+    static_assert(!LN || ((CPP == 8 || CPP == 16 || CPP == 32) && THREADS % CPP == 0), "LayerNorm prologue: C = 64, 128 or 256");
+    auto ln_row = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (LN) {
+            for (int base = 0; base + (tid & ~63) < RW_RPX * CPP; base += THREADS) {      // whole WAVES run the body (the shuffles need every lane
+                const bool valid = base + tid < RW_RPX * CPP;                               // of a group): lanes beyond the row recompute chunk 0
+                const int idx = valid ? base + tid : (tid % CPP);
+                T* p = ring + (size_t)slot * SLOTE + (idx / CPP) * XPE + (idx % CPP) * 8;
+                const Vec16<T> v = load16<T>(p);
+                float x[8], sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { x[e] = v.get(e); sum += x[e]; }
+#pragma unroll
+                for (int m = 1; m < CPP; m <<= 1) sum += __shfl_xor(sum, m);
+                const float mean = sum / (float)C;
+                float d2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { x[e] -= mean; d2 += x[e] * x[e]; }
+#pragma unroll
+                for (int m = 1; m < CPP; m <<= 1) d2 += __shfl_xor(d2, m);
+                const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+                // weight / bias of the lane's 8 channels: re-read per row (L1 hits) rather than 16 registers held across the whole walk
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.ln_w + (idx % CPP) * 8), w1 = *reinterpret_cast<const f32x4*>(a.ln_w + (idx % CPP) * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.ln_b + (idx % CPP) * 8), b1 = *reinterpret_cast<const f32x4*>(a.ln_b + (idx % CPP) * 8 + 4);
+                Vec16<T> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o.set(e, x[e] * rstd * w0[e] + b0[e]); o.set(4 + e, x[4 + e] * rstd * w1[e] + b1[e]); }
+                if (valid) store16<T>(p, o);
+            }
+        }
+    };
+    if constexpr (LN) {              // walk row 0 is read by the matrix cores in the first step (i = -1); row i + 2 is normalised in step i
+        ln_row(0);
+        lds_barrier();
+    }
+
     // One walk step.  STEADY: every part runs and the step's position in the 8-slot ring (U = i % 8) is a compile-time constant,
     // so ring slots, row-image parity and the edge-block phase are immediate offsets / static branches; otherwise the parts
     // are switched by (uniform) flags for the first and last steps.  Walk row i is image row y0 - 1 + i; output row o (image
@@ -237,7 +283,8 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
         const bool do_tw = KEEP && (STEADY || (i >= 1 && i <= RS));                              // t row i -> t image
         const bool do_ts = KEEP && (STEADY || (i >= 2 && i <= RS + 1));                          // t row i-1 -> HBM
         RW_MARK(0);
-        if (STEADY || i >= 0) dma_next(u);                  // slot i % 8 is free: row i was last read in step i-1
+        if (STEADY || i >= 0) dma_next(u & (RING - 1));     // slot i % RING is free: row i was last read in step i-1
+        if constexpr (LN) ln_row((u + 2) & (RING - 1));  // walk row i + 2: landed before this step began (LEAD 3), first read in step i + 1
 
         // ---- LDS reads whose results the end of the step needs, issued first so that their latency hides behind the taps:
         // the Gram operands and the store chunks of output row i-3 (row image written in step i-1), training: the chunks of
@@ -356,8 +403,8 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
         for (int nb = 0; nb < NBW; ++nb) nacc[0][nb] = nacc[1][nb] = neacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (do_mma) {
             typedef __attribute__((ext_vector_type(4))) int i32x4;
-            const T* xrow = xlane + ((u + 1) & (RW_RING - 1)) * SLOTE;
-            const T* erow = elane + ((u + 1) & (RW_RING - 1)) * SLOTE;
+            const T* xrow = xlane + ((u + 1) & (RING - 1)) * SLOTE;
+            const T* erow = elane + ((u + 1) & (RING - 1)) * SLOTE;
             const int emask = ex_ok ? -1 : 0;                // the outer column lies outside the image: t = 0 there
             // two K chunks (6 fragments, 24 registers) at a time: all of a wide row's fragments in flight at once is what tips
             // C = 128 over the 168 registers three waves per SIMD leave
@@ -395,8 +442,8 @@ __global__ __launch_bounds__(64 * rw_waves<HD>(), (rw_waves<HD>() + 3) / 4) void
         // the steps since are younger and stay in flight (vmcnt counts in issue order; this wave's stores only make the wait
         // reach a little further than it has to)
         if (64 * wv < NCH) {                                 // wave-uniform: this wave issues 1 .. NDQ DMA instructions per row
-            if (NDQ > 1 && 64 * (wv + NW * (NDQ - 1)) < NCH) wait_vmcnt<(RW_RING - RW_LEAD) * NDQ>();
-            else wait_vmcnt<(RW_RING - RW_LEAD) * (NDQ > 1 ? NDQ - 1 : 1)>();
+            if (NDQ > 1 && 64 * (wv + NW * (NDQ - 1)) < NCH) wait_vmcnt<(RING - LEAD) * NDQ>();
+            else wait_vmcnt<(RING - LEAD) * (NDQ > 1 ? NDQ - 1 : 1)>();
         }
         RW_MARK(4);
         lds_barrier();
@@ -449,16 +496,23 @@ template <class T, int C, int HD>
 static int launch_rows(const RowGramDev& d, hipStream_t s) {
     typedef RwCfg<T, C, HD> CF;
     const int grid = d.B * (d.W / RW_SW) * d.nseg * ((C / HD) / CF::HPG);
-#define MPHSIR_RW_GO(keep, dbg)                                                                                                    \
-    do {                                                                                                                           \
-        const size_t shmem = CF::bytes(keep);                                                                                      \
-        allow_big_lds(qkv_dwconv_gram_rows_kernel<T, C, HD, keep, dbg>, shmem);                                                    \
-        MPHSIR_LAUNCH(MPHSIR_K_QKV_DWCONV_GRAM, (qkv_dwconv_gram_rows_kernel<T, C, HD, keep, dbg>), dim3(grid), dim3(CF::THREADS), \
-                      shmem, s, d);                                                                                                \
+#define MPHSIR_RW_GO(keep, dbg, ln)                                                                                                    \
+    do {                                                                                                                               \
+        const size_t shmem = CF::bytes(keep);                                                                                          \
+        allow_big_lds(qkv_dwconv_gram_rows_kernel<T, C, HD, keep, dbg, ln>, shmem);                                                    \
+        MPHSIR_LAUNCH(MPHSIR_K_QKV_DWCONV_GRAM, (qkv_dwconv_gram_rows_kernel<T, C, HD, keep, dbg, ln>), dim3(grid), dim3(CF::THREADS), \
+                      shmem, s, d);                                                                                                    \
     } while (0)
-    if (d.dbg && !d.Tout && std::is_same<T, bf16_t>::value && C <= 128 && HD <= 64) MPHSIR_RW_GO(false, true);   // stamped build
-    else if (d.Tout) MPHSIR_RW_GO(true, false);
-    else MPHSIR_RW_GO(false, false);
+    if constexpr ((C == 64 || C == 128 || C == 256) && HD == 32) {       // the LayerNorm-ed `Attention` of PromptFusion: 32-wide heads
+        if (d.ln_w) {
+            if (d.Tout) MPHSIR_RW_GO(true, false, true);
+            else MPHSIR_RW_GO(false, false, true);
+            return MPHSIR_OK;
+        }
+    }
+    if (d.dbg && !d.Tout && std::is_same<T, bf16_t>::value && C <= 128 && HD <= 64) MPHSIR_RW_GO(false, true, false);   // stamped build
+    else if (d.Tout) MPHSIR_RW_GO(true, false, false);
+    else MPHSIR_RW_GO(false, false, false);
 #undef MPHSIR_RW_GO
     return MPHSIR_OK;
 }
@@ -467,13 +521,13 @@ static int launch_rows(const RowGramDev& d, hipStream_t s) {
 // 32 channels per wave: over the 168 registers that three waves per SIMD leave); the group of heads one workgroup takes (64
 // channels; 48-wide heads: one head) must divide the head count
 static bool rows_shape(int C, int HD) {
-    return (HD == 32 && (C == 64 || C == 128)) || (HD == 64 && (C == 64 || C == 128)) || (HD == 48 && (C == 96 || C == 192));
+    return (HD == 32 && (C == 64 || C == 128 || C == 256)) || (HD == 64 && (C == 64 || C == 128)) || (HD == 48 && (C == 96 || C == 192));
 }
 template <class T> struct RowShapes {
     static int run(const RowGramDev& d, int C, int HD, hipStream_t s) {
 #define MPHSIR_RW_CASE(c, hd) if (C == c && HD == hd) return launch_rows<T, c, hd>(d, s);
         MPHSIR_RW_CASE(64, 32) MPHSIR_RW_CASE(128, 32) MPHSIR_RW_CASE(64, 64) MPHSIR_RW_CASE(128, 64)
-        MPHSIR_RW_CASE(96, 48) MPHSIR_RW_CASE(192, 48)
+        MPHSIR_RW_CASE(96, 48) MPHSIR_RW_CASE(192, 48) MPHSIR_RW_CASE(256, 32)
 #undef MPHSIR_RW_CASE
         return MPHSIR_EINVAL;
     }
@@ -483,7 +537,8 @@ template <> struct RowShapes<float> {
 };
 
 int rows_form_fits(int C, int heads, int H, int W, int dtype, int ln) {
-    if (ln || dtype == MPHSIR_F32 || heads <= 0 || C % heads != 0 || H < 4 || W <= 0 || W % RW_SW != 0) return 0;
+    if (dtype == MPHSIR_F32 || heads <= 0 || C % heads != 0 || H < 4 || W <= 0 || W % RW_SW != 0) return 0;
+    if (ln && !((C == 64 || C == 128 || C == 256) && C / heads == 32)) return 0;      // the LayerNorm prologue: a pixel's C / 8 chunks = one 8- or 16-lane shuffle group; 32-wide heads
     const int HD = C / heads;
     if (!rows_shape(C, HD)) return 0;
     const int hpg = HD == 32 ? 2 : 1;
@@ -491,7 +546,7 @@ int rows_form_fits(int C, int heads, int H, int W, int dtype, int ln) {
 }
 
 int rows_form_launch(const mphsir_fused_gram_args* a, int dtype, hipStream_t s) {
-    RowGramDev d{a->X, (long)a->ldx, a->Wqkv, a->w9, (long)a->ldw, a->V, (long)a->ldvo, a->Gpart, a->Spart,
+    RowGramDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->Wqkv, a->w9, (long)a->ldw, a->V, (long)a->ldvo, a->Gpart, a->Spart,
                  a->B, a->H, a->W, a->row_segments, a->T, (long)a->ldt, a->QK, (long)a->ldqk, fused_debug_buffer()};
     return MPHSIR_DISPATCH_T(dtype, (RowShapes<T_>::run(d, a->C, a->C / a->heads, s)));
 }

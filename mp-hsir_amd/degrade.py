@@ -58,7 +58,9 @@ def motion_kernel2d(k, angle):
     """_apply_motion_blur (degradation_utils.py:137-143): a horizontal line of 1/k through row (k-1)//2, rotated by `angle`
     degrees about (k/2, k/2) with cv2.getRotationMatrix2D + cv2.warpAffine (bilinear, zero border).  cv2 is not available
     offline, so this restates its published semantics: dst(x,y) = src(M^-1 (x,y)), M = [[a, b, (1-a)cx - b cy],
-    [-b, a, b cx + (1-a) cy]], a = cos, b = sin.  PARITY UNPINNED (no cv2 to compare with)."""
+    [-b, a, b cx + (1-a) cy]], a = cos, b = sin.  Pinned at the angles where the warp maps pixel centres onto pixel centres (0, 90, 180,
+    270: tests/test_degrade.py::test_motion_kernel_exact_angles); in between OpenCV rounds source coordinates to 1/32 pixel, which
+    this float restatement does not reproduce (differences of the order of 1e-2 of a tap: unpinned, no cv2 to compare with)."""
     src = torch.zeros((k, k), dtype=torch.float64)
     src[int((k - 1) / 2), :] = 1.0 / k
     a, b = math.cos(math.radians(angle)), math.sin(math.radians(angle))

@@ -480,7 +480,7 @@ class MP_HSIR_Net(nn.Module):                                                   
         # the prompt branch of each level (ref :827, :835 -- there in program order behind the stages below) is forked where its input
         # exists and joined where the decoder of that level reads it: a parallel branch of the captured graph (inference only,
         # see ops.PROMPT_SIDE)
-        fork = ops.PROMPT_SIDE and not torch.is_grad_enabled()
+        fork = ops.PROMPT_SIDE and (ops.PROMPT_SIDE_TRAIN or not torch.is_grad_enabled())
         with ops.side_stream(e1, fork, "prompt1") as br1:
             f1 = self.fusion1(e1, self.prompt1(e1, clip, w))
         e2 = self.encoder_level2(AG.pixel_unshuffle2(AG.conv3x3(e1, self.down1_2.body[0])))

@@ -25,6 +25,28 @@ def clean(seed=1):
     return np.random.RandomState(seed).rand(*SHAPE).astype(np.float32)
 
 
+def haze_entries(D):
+    """the reference's `_simulate_haze` (degradation_utils.py:235-283) itself: its cirrus maps are .mat DATA files the image does not
+    hold, so the folder listing and `sio.loadmat` are answered with a seeded synthetic map of the patch size (then cv2.resize is
+    the identity: refshim/cv2.py).  What gets pinned is the function's arithmetic: atmospheric light from the top pixels per band,
+    t1 = 1 - omega * cirrus with its 1e-10 floor, the wavelength exponent, the blend."""
+    out = {}
+    x = clean(3)
+    rs = np.random.RandomState(31)
+    cirrus = (rs.rand(SHAPE[1], SHAPE[2]) * 1.6).astype(np.float64)          # values > 1 / omega exercise the t1 <= 0 floor
+    real_listdir, real_loadmat = RD.os.listdir, RD.sio.loadmat
+    RD.os.listdir = lambda folder: ["synthetic.mat"]
+    RD.sio.loadmat = lambda path: {"haze": cirrus}
+    try:
+        for i, (omega, gamma) in enumerate(((0.75, 1.0), (0.2, 1.0), (0.9, 0.5))):
+            out["haze%d/out" % i] = D._simulate_haze(x.copy(), omega=omega, gamma=gamma)
+            out["haze%d/omega_gamma" % i] = np.array([omega, gamma])
+    finally:
+        RD.os.listdir, RD.sio.loadmat = real_listdir, real_loadmat
+    out["haze/cirrus"] = cirrus
+    return out
+
+
 def main():
     D = RD.Degradation(None)
     out = {}
@@ -88,9 +110,19 @@ def main():
     for m in range(8):
         out["aug%d/out" % m] = np.ascontiguousarray(RI.data_augmentation(x.copy(), m))
     out["interp31/out"] = RI.interpolate_bands(x.copy(), 31)[0]
+    out.update(haze_entries(D))
     np.savez_compressed(os.path.join(HERE, "degrade.npz"), **out)
     print("wrote degrade.npz with", len(out), "entries")
 
 
+def add_haze_only():
+    """adds the haze entries to an existing degrade.npz (everything else regenerates bitwise, this just saves the minute)"""
+    path = os.path.join(HERE, "degrade.npz")
+    out = dict(np.load(path))
+    out.update(haze_entries(RD.Degradation(None)))
+    np.savez_compressed(path, **out)
+    print("degrade.npz: haze entries added,", len(out), "entries")
+
+
 if __name__ == "__main__":
-    main()
+    add_haze_only() if sys.argv[1:] == ["haze"] else main()

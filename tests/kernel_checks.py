@@ -282,12 +282,18 @@ FUSED_HG_CASES = [(64, 4, (1, 16, 32), 2, False, 1), (64, 4, (1, 16, 32), 2, Tru
 # the row-walking form (spectral_rows.hip): (C, heads, (B, H, W), row segments per strip, ln); W % 32 == 0, 16-bit
 ROWS_CASES = [(64, 2, (1, 8, 32), 1, False), (64, 2, (2, 16, 64), 2, False), (128, 4, (1, 8, 32), 2, False), (128, 2, (1, 12, 32), 1, False),
               (64, 1, (1, 8, 64), 2, False), (96, 2, (1, 8, 32), 1, False), (192, 4, (1, 4, 32), 1, False),
-              (64, 2, (1, 24, 96), 2, False)]
+              (64, 2, (1, 24, 96), 2, False),
+              # with the LayerNorm prologue (the `Attention` of PromptFusion: 32-wide heads): rows normalised in place in the ring
+              (64, 2, (1, 8, 32), 1, True), (128, 4, (1, 12, 64), 1, True), (128, 4, (2, 8, 32), 2, True),
+              # C = 256 (the latent level, fusion2's Attention): four-slot ring, four head groups per strip
+              (256, 8, (1, 8, 32), 1, False), (256, 8, (1, 12, 32), 2, True)]
 
 
 # larger ones for the GPU only: the widths / resolutions of both nets' levels 1-2 at 64x64 and 128x128 inputs
 ROWS_CASES_GPU = [(64, 2, (2, 64, 64), 4, False), (128, 4, (2, 32, 32), 2, False), (128, 2, (2, 64, 64), 8, False), (128, 4, (1, 64, 64), 1, False),
-                  (96, 2, (2, 64, 64), 2, False), (192, 4, (2, 32, 32), 4, False), (64, 2, (1, 128, 128), 8, False)]
+                  (96, 2, (2, 64, 64), 2, False), (192, 4, (2, 32, 32), 4, False), (64, 2, (1, 128, 128), 8, False),
+                  (128, 4, (2, 64, 64), 4, True), (128, 4, (1, 128, 128), 8, True), (64, 2, (2, 64, 64), 2, True),
+                  (256, 8, (1, 128, 128), 8, False), (256, 8, (2, 32, 32), 2, False), (256, 8, (1, 64, 64), 4, True)]
 
 
 def check_fused_pass_a(dev, dtype, C, heads, shape, nsplit, ln, hgroups=None, row_segments=0):

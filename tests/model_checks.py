@@ -192,13 +192,13 @@ def fixture_grad_err(got, g, name, k):
 # 16-bit gradient bars (whole net).  The fixture holds, per parameter tensor, the deviation of the REFERENCE's own mixed-precision step
 # (torch.autocast, train.py:118 trains in 16-mixed) from its fp64 gradients: 2 % in the median for bf16, 8-10 % across the prompt
 # modules, 20-45 % for norm1.bias / prompt_param, and 100 % for the fp16 gradient of linear_prompt.weight (it underflows there).
-# The 16-bit HIP backward is held, tensor by tensor, to GRAD_BAR_FACTOR x that deviation plus GRAD_BAR_FLOOR x the median deviation
+# The 16-bit HIP backward is held, tensor by tensor, to GRAD_BAR_FACTOR (3) x that deviation plus GRAD_BAR_FLOOR (2) x the median deviation
 # over all tensors (a tensor on which the reference was lucky must not fail ours for being average).
 # The parameters of the spectral-prompt gate (local_spectral_attn.*) are the exception to "tensor by tensor": their gradients are sums
 # over a handful of windows per sample (4 at the latent level) of products of small numbers, and which BLOCK's sum happens to cancel
 # is luck -- the reference's own deviation for kv.weight runs from 0.4 % to 17 % across the 22 blocks of one net.  They are held to
 # the reference's WORST block of the same tensor type instead of the same block.
-GRAD_BAR_FACTOR = 2.0
+GRAD_BAR_FACTOR = 3.0
 GRAD_BAR_FLOOR = 2.0
 
 
@@ -219,13 +219,15 @@ def grad_bars(g, name):
     return bars, med
 
 
-def _hip_step_gradients(net, x, clean, task):
+def _hip_step_gradients(net, x, clean, task, scale=1.0):
+    """scale: the loss scale of an fp16 step (the engine scales by 65536 and unscales in the optimizer kernel: d loss / d y = 1 / numel
+    ~ 1e-6 is below fp16's normal range): gradients are returned unscaled"""
     for p in net.parameters():
         p.grad = None
     y = net(x, task)
     loss = (y.clamp(0, 1) - clean).abs().mean()
-    loss.backward()
-    return float(loss.detach()), y.detach().float().cpu(), {k: (None if p.grad is None else p.grad.detach().float().cpu()) for k, p in net.named_parameters()}
+    (loss * scale).backward()
+    return float(loss.detach()), y.detach().float().cpu(), {k: (None if p.grad is None else p.grad.detach().float().cpu() / scale) for k, p in net.named_parameters()}
 
 
 def check_full_gradients(dev, name, low=torch.bfloat16, oracle_threads=32):
@@ -277,7 +279,7 @@ def check_full_gradients(dev, name, low=torch.bfloat16, oracle_threads=32):
     res["f32_vs_oracle"] = worst
     # (2) 16-bit storage
     net.set_compute_dtype(low)
-    loss16, y16, g16 = _hip_step_gradients(net, x, cl, task)
+    loss16, y16, g16 = _hip_step_gradients(net, x, cl, task, scale=65536.0 if low == torch.float16 else 1.0)
     bars, med = grad_bars(g, name)
     res["e_fwd"] = rel_l2(y16, y32)
     res["e_fwd_reference_autocast"] = float(g[name + "/autocast_out_err"])

@@ -127,6 +127,25 @@ def test_tiny_adamw_two_steps_vs_reference(use_graph):
     print("tiny AdamW worst relative error", M.check_tiny_adamw("cuda", use_graph=use_graph))
 
 
+@pytest.mark.xfail(strict=False, reason="round-4 finding, still open: with the prompt modules forked IN TRAINING (not the product's default) the "
+                   "captured step yields a wrong prompt1.text_prompt_learnable gradient; joining every side stream before the hand-over "
+                   "(ops._SIDE_USED, round 5) did not cure it")
+def test_tiny_adamw_graph_with_prompt_streams_in_training():
+    """the configuration that failed in round 4, kept as a test: captured step + weight-gradient branch + the prompt
+    modules forked on their own streams IN TRAINING (MPHSIR_PROMPT_SIDE_TRAIN, off by default: training gains nothing from it).
+    prompt1.text_prompt_learnable's gradient comes out wrong.  Round 5 joins every side stream a backward pass has forked before
+    gradients are handed over (ops._SIDE_USED) -- the cure the round-4 analysis called for -- and the check still fails (measured:
+    update norm 3.8 % off, sampled elements up to 49 %), so the missing ordering is not (only) at the hand-over."""
+    from mp_hsir_amd import ops
+    old = ops.PROMPT_SIDE_TRAIN, ops.DW_SIDE
+    ops.PROMPT_SIDE_TRAIN, ops.DW_SIDE = True, 2
+    try:
+        for _ in range(3):
+            M.check_tiny_adamw("cuda", use_graph=True)
+    finally:
+        ops.PROMPT_SIDE_TRAIN, ops.DW_SIDE = old
+
+
 def _spawn_ranks(mode, steps, out, world=2, port=29541, backend="gloo"):
     import os
     import subprocess
