@@ -184,7 +184,7 @@ extern "C" int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, 
                          g.src_batch_stride % 4 == 0 && g.dst_batch_stride % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0;
         const long nitems = (long)g.nbatch * rows * ((g.n + 3) / 4);
         int lg = 0;                        // lanes per item: keep <= 32 splits per lane, and small segments still fill waves
-        while (lg < 6 && (g.nsplit >> lg) > 32) ++lg;
+        while (lg < 6 && (g.nsplit >> lg) > 32) ++lg;      // (<= 8 / <= 4 per lane measured in round 5: 21.10 / 21.29 against 21.09 ms per step)
         while (lg < 6 && (nitems << lg) < 8192 && (g.nsplit >> lg) > 4) ++lg;      // (32 k / 64 k / 128 k threads measured: no difference)
         d.s[k] = RedSegDev{g.src, g.dst, (long)g.n, (long)g.stride, (long)g.src_batch_stride, (long)g.dst_batch_stride, threads, nitems,
                            src_ld, dst_ld, g.nsplit, vec ? 1 : 0, lg, rows, dcs};

@@ -198,11 +198,19 @@ def _dw_side(scope):
         g["keep"] = (g["keep"][0], g["keep"][1].detach())
     _poison(scope.segs)
     if DW_SIDE >= 2:
-        st.wait_stream(main)
-        with torch.cuda.stream(st):
-            _flush_calls(scope.calls)
-            _flush_gemms(scope.gemms)
-            _flush(scope.segs)
+        # Small backward functions (the lower pyramid levels: a few MB of operands, launches that cost their 15-30 us floor whatever
+        # they move) are BATCHED: their problems wait until DW_BATCH_BYTES of operands, a full grouped launch (8 problems) or 32 sum
+        # segments have come together, and go out as ONE grouped GEMM launch + ONE ordered-sum launch; a big function flushes at once
+        # (with whatever is pending, in issue order).  The operands stay referenced (pending list, then _DW_KEEP).
+        nbytes = sum(g["M"] * (g["N1"] + g["N2"]) * 2 for g in scope.gemms)
+        pend = _DW_PENDING.setdefault(dev, [[], [], [], 0])
+        pend[0] += scope.gemms
+        pend[1] += scope.calls
+        pend[2] += scope.segs
+        pend[3] += nbytes
+        if scope.calls or pend[3] >= DW_BATCH_BYTES or len(pend[0]) + 3 > _lib.TN_GROUP_MAX or len(pend[2]) + 17 > _lib.REDUCE_MAX_SEGS:
+            _dw_flush_pending(dev)
+        return True
     else:
         _flush_calls(scope.calls)
         _flush_gemms(scope.gemms)
@@ -213,10 +221,31 @@ def _dw_side(scope):
     return True
 
 
+DW_BATCH_BYTES = int(float(os.environ.get("MPHSIR_DW_BATCH_MB", "48")) * (1 << 20))
+_DW_PENDING = {}
+
+
+def _dw_flush_pending(dev):
+    pend = _DW_PENDING.get(dev)
+    if not pend or not (pend[0] or pend[1] or pend[2]):
+        return
+    gemms, calls, segs = pend[0], pend[1], pend[2]
+    _DW_PENDING[dev] = [[], [], [], 0]
+    st = _DW_STREAM[dev]
+    st.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(st):
+        _flush_calls(calls)
+        _flush_gemms(gemms)
+        _flush(segs)
+    _DW_KEEP.append((dev, [g["keep"] for g in gemms] + [c["keep"] for c in calls], [g["keep"] for g in segs]))
+
+
 def _dw_join(final=True):
     """the stream that reads gradients waits for the weight-gradient branch.  Only the FINAL join (the end of the backward pass, on
     the stream backward() was called from) releases the tensors and forgets the branch: a join in the middle -- a backward function
     that has to read a sum, possibly running on a prompt module's own stream -- makes ITS stream wait and leaves the rest as it is."""
+    for dev in list(_DW_PENDING):
+        _dw_flush_pending(dev)
     if _DW_KEEP:
         for dev in {k[0] for k in _DW_KEEP}:
             torch.cuda.current_stream(dev).wait_stream(_DW_STREAM[dev])
@@ -1103,11 +1132,15 @@ def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None,
 MLP_WGRAD = os.environ.get("MPHSIR_MLP_WGRAD", "1") == "1"      # parameter gradients of the gated MLP by recomputation (no h / dpre in HBM)
 MLP_WGRAD_NCH = int(os.environ.get("MPHSIR_MLP_WGRAD_NCH", "0"))  # chunks of 32 hidden units per workgroup: 0 = per shape, 1, 2
 MLP_WGRAD_WGS = int(os.environ.get("MPHSIR_MLP_WGRAD_WGS", "512"))
+MLP_WGRAD_MAXC = int(os.environ.get("MPHSIR_MLP_WGRAD_MAXC", "128"))
 MLP_WGRAD_CAP = float(os.environ.get("MPHSIR_MLP_WGRAD_CAP", "1.0"))   # partial bytes <= this x the bytes of the two token matrices
 
 
 def gated_mlp_wgrad_fits(M, C, HP, dtype):
-    return (MLP_WGRAD and dtype in _HALF and M % 64 == 0 and HP % 32 == 0 and M >= 16384
+    """where the library takes the recomputing weight-gradient kernel: 16-bit types, >= 16384 tokens (below, the partials of a range
+    outweigh the token matrices), C <= 128 -- at C = 192 the kernel has no registers left for the tile in flight (19 spilled) and
+    measured slower than the operand path: remote-sensing fp16 step 27.0 against 26.2 ms, 195-210 against 120 us per launch"""
+    return (MLP_WGRAD and dtype in _HALF and M % 64 == 0 and HP % 32 == 0 and M >= 16384 and C <= MLP_WGRAD_MAXC
             and bool(_lib.load().mphsir_gated_mlp_wgrad_fits(C, 1, _DT[dtype])))
 
 
