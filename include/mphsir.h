@@ -249,8 +249,18 @@ typedef struct mphsir_mlp_args {
     float* ypart;                                /* ... a workspace [hsplit][M][C] fp32 for the partial fc2 products (summed in order) */
     const void* R; int64_t ldr;                  /* optional second residual [M][ldr]: Y = (X + keep * mlp(LN(X))) + R -- the skip of a
                                                     whole BaseBlock (net/MP_HSIR.py:727-761) added by its last block's kernel */
+    /* optional FUSED BRANCH SUM (PV != NULL; mphsir_gated_mlp_fwd_fuses): the row the LayerNorm / the residual read is not X but
+     *   y = X + pkeep[b] * (PSA * pgate[window(m)] + PV Mb[b]^T)      (PGSSTB.forward net/MP_HSIR.py:715-718 -- exactly mphsir_gemm_tok
+     * epi 2 with R = X, element for element), formed in LDS; Yb (optional [M][ldyb]: training keeps y for the backward) receives it.
+     * PV [M][ldpv]; PM [B][C][C] per-sample matrices (stride pm_batch_stride elements); PSA [M][ldpsa]; pgate [B*nW][C] fp32;
+     * pkeep [B] fp32 or NULL; image geometry H, Wimg (multiples of 8, H*Wimg % 128 == 0, M = B*H*Wimg), shift 0 | 4.        */
+    const void* PV; int64_t ldpv; const void* PM; int64_t pm_batch_stride;
+    const void* PSA; int64_t ldpsa; const float* pgate; const float* pkeep;
+    void* Yb; int64_t ldyb;
+    int32_t H, Wimg, shift;
 } mphsir_mlp_args;
 int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream);
+int mphsir_gated_mlp_fwd_fuses(int32_t C, int64_t M, int dtype);     /* 1 where the fused branch sum exists: 16-bit types, C <= 128, M % 128 == 0 */
 
 /* ---- backward (data) of the fused LayerNorm + gated MLP + residual ---------------------------------
  * Given dY = dL/dY of mphsir_gated_mlp_fwd and DM = keep[b]*dY (= dY when DropPath is off), computes

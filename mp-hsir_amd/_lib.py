@@ -29,7 +29,9 @@ class MlpArgs(ctypes.Structure):
     _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("W1", c_void_p),
                 ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p), ("keep", c_void_p), ("rows_per_batch", c_int64),
                 ("Y", c_void_p), ("ldy", c_int64), ("M", c_int64), ("C", c_int32), ("HP", c_int32), ("tiles_per_wave", c_int32),
-                ("hsplit", c_int32), ("ypart", c_void_p), ("R", c_void_p), ("ldr", c_int64)]
+                ("hsplit", c_int32), ("ypart", c_void_p), ("R", c_void_p), ("ldr", c_int64),
+                ("PV", c_void_p), ("ldpv", c_int64), ("PM", c_void_p), ("pm_batch_stride", c_int64), ("PSA", c_void_p), ("ldpsa", c_int64),
+                ("pgate", c_void_p), ("pkeep", c_void_p), ("Yb", c_void_p), ("ldyb", c_int64), ("H", c_int32), ("Wimg", c_int32), ("shift", c_int32)]
 
 
 class WinAttnArgs(ctypes.Structure):
@@ -193,6 +195,7 @@ _SYMBOLS = {
     "mphsir_gated_mlp_wgrad": (c_int, [ctypes.POINTER(MlpWgradArgs), c_int, c_void_p]),
     "mphsir_gated_mlp_wgrad_fits": (c_int, [c_int32, c_int32, c_int]),
     "mphsir_gated_mlp_fwd": (c_int, [ctypes.POINTER(MlpArgs), c_int, c_void_p]),
+    "mphsir_gated_mlp_fwd_fuses": (c_int, [c_int32, c_int64, c_int]),
     "mphsir_reduce_parts": (c_int, [ctypes.POINTER(ReduceSeg), c_int32, c_void_p]),
     "mphsir_gemm_tn_group": (c_int, [ctypes.POINTER(TnProblem), c_int32, c_int32, c_int, c_void_p]),
     "mphsir_pack_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

@@ -26,31 +26,35 @@ class _GatedMlp(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         (y,) = ctx.saved_tensors
-        blk, k2 = ctx.blk, ctx.k2
-        B, H, W, Cc = y.shape
-        dt = y.dtype
-        pk = blk.packed(dt)
-        dz2 = dz.reshape(-1, Cc).contiguous()
-        hid = blk.mlp.fc2.weight.shape[1]
-        HP = pk["W2T"].shape[0]
-        # 16-bit types, big launches: the parameter gradients are recomputed per hidden slab from LN(y) and dm alone
-        # (ops.gated_mlp_wgrad); h and [dval | dgate] then never reach HBM
-        fused = ops.gated_mlp_wgrad_fits(dz2.shape[0], Cc, HP, dt)
-        if k2 is None:
-            dm = dz2
-            dx, xn, h, dpre, part = ops.gated_mlp_bwd(y.reshape(-1, Cc), dz2, dm, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"],
-                                                      pk["W1T"], pk["W2T"], operands=not fused)
-        else:               # DropPath: dm = keep[b] * dz is formed (and kept for dW2 / db2) inside the kernel
-            dx, xn, h, dpre, part, dm = ops.gated_mlp_bwd(y.reshape(-1, Cc), dz2, None, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"],
-                                                          pk["W1T"], pk["W2T"], keep=k2, rows_per_batch=H * W, operands=not fused)
-        with ops.reduce_scope(leaf=True):                                   # one ordered-sum launch for all five partial buffers
-            if fused:
-                dW1, db1, dW2, db2 = ops.gated_mlp_wgrad(xn, dm, pk["W1"], pk["b1"], pk["W2T"], hid)
-            else:
-                dW2, db2 = ops.gemm_tn_blocks(dm, h, [(0, Cc)], ncols=hid, colsum=True)             # drops the padded hidden columns
-                dW1, db1 = ops.gemm_tn_blocks(dpre, xn, [(0, hid), (HP, hid)], colsum=True)            # value rows | gate rows
-            dln = ops.reduce_parts(part)
-        return (None, None, dx.reshape(B, H, W, Cc), dln[0], dln[1], dW1, db1, dW2, db2, dz if ctx.needs_input_grad[9] else None)
+        return (None, None) + _gated_mlp_backward(ctx.blk, ctx.k2, y, dz) + (dz if ctx.needs_input_grad[9] else None,)
+
+
+def _gated_mlp_backward(blk, k2, y, dz):
+    """backward of z = y + keep2 * mlp(LN2(y)): (dy, d ln2.weight, d ln2.bias, d fc1.weight, d fc1.bias, d fc2.weight, d fc2.bias)"""
+    B, H, W, Cc = y.shape
+    dt = y.dtype
+    pk = blk.packed(dt)
+    dz2 = dz.reshape(-1, Cc).contiguous()
+    hid = blk.mlp.fc2.weight.shape[1]
+    HP = pk["W2T"].shape[0]
+    # 16-bit types, big launches: the parameter gradients are recomputed per hidden slab from LN(y) and dm alone
+    # (ops.gated_mlp_wgrad); h and [dval | dgate] then never reach HBM
+    fused = ops.gated_mlp_wgrad_fits(dz2.shape[0], Cc, HP, dt)
+    if k2 is None:
+        dm = dz2
+        dx, xn, h, dpre, part = ops.gated_mlp_bwd(y.reshape(-1, Cc), dz2, dm, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"],
+                                                  pk["W1T"], pk["W2T"], operands=not fused)
+    else:               # DropPath: dm = keep[b] * dz is formed (and kept for dW2 / db2) inside the kernel
+        dx, xn, h, dpre, part, dm = ops.gated_mlp_bwd(y.reshape(-1, Cc), dz2, None, pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"],
+                                                      pk["W1T"], pk["W2T"], keep=k2, rows_per_batch=H * W, operands=not fused)
+    with ops.reduce_scope(leaf=True):                                   # one ordered-sum launch for all five partial buffers
+        if fused:
+            dW1, db1, dW2, db2 = ops.gated_mlp_wgrad(xn, dm, pk["W1"], pk["b1"], pk["W2T"], hid)
+        else:
+            dW2, db2 = ops.gemm_tn_blocks(dm, h, [(0, Cc)], ncols=hid, colsum=True)             # drops the padded hidden columns
+            dW1, db1 = ops.gemm_tn_blocks(dpre, xn, [(0, hid), (HP, hid)], colsum=True)            # value rows | gate rows
+        dln = ops.reduce_parts(part)
+    return (dx.reshape(B, H, W, Cc), dln[0], dln[1], dW1, db1, dW2, db2)
 
 
 def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, MbT, temperature, wo, heads, B, H, W, qk=None):
@@ -115,9 +119,10 @@ def _pass_a_infer(x2, wqkv, w9, B, H, W, C, heads, ln=None):
     return v, gp, sp
 
 
-def _pgsstb_attn_infer(blk, k1, x):
+def _pgsstb_attn_infer(blk, k1, x, fuse=False):
     """First residual branch of a PGSSTB block under no_grad: nothing is kept for a backward, and the 1x1 qkv conv, the
-    depthwise conv and the Gram of the global spectral branch run as ONE launch (t = qkv(sa) never reaches HBM)."""
+    depthwise conv and the Gram of the global spectral branch run as ONE launch (t = qkv(sa) never reaches HBM).
+    fuse: return the operands of the branch sum (ops.gated_mlp_fwd branch=...) instead of launching it."""
     B, H, W, Cc = x.shape
     dt = x.dtype
     pk = blk.packed(dt)
@@ -134,6 +139,8 @@ def _pgsstb_attn_infer(blk, k1, x):
         gate = ops.pg_gate_fwd(mu, pk["pg"])
     Mb = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt)
     br.join()
+    if fuse:
+        return dict(v=v, Mb=Mb, sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
     y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
     return y.reshape(B, H, W, Cc)
 
@@ -146,92 +153,137 @@ def _self_channel_attn_infer(attn, ln, geom, t2):
     return ops.gemm_tok(v, ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], t2.dtype), epi=1, res=t2)
 
 
+def _pgsstb_attn_forward(blk, k1, x, fuse=False):
+    """forward of the first residual branch; returns (y, tensors kept for the backward).  fuse: y is left to the gated-MLP launch
+    (ops.gated_mlp_fwd branch=...: the operands are saved[6] = v, saved[9] = Mb, saved[1] = sa, saved[2] = gate) and None is returned."""
+    B, H, W, Cc = x.shape
+    dt = x.dtype
+    pk = blk.packed(dt)
+    sp = blk.gobal_spectral_attn.packed(dt)
+    heads, shift = blk.num_heads, blk.shift_size
+    w9 = sp["w9"]
+    sa, mu, oattn = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"],
+                                     pk["bproj"], pk["pg"], heads, shift, save=True, gate=False)
+    with ops.side_stream(sa, ops.SIDE_BRANCH) as br:      # the prompt gate (few workgroups, latency-bound) runs beside pass A
+        gate = ops.pg_gate_fwd(mu, pk["pg"])
+    sa2 = sa.reshape(-1, Cc)
+    # pass A; t and q | k after the depthwise conv are kept for the backward (q|k: 2C values per token, cheaper than
+    # recomputing them).  One fused launch where the kernel covers the shape, else 1x1 GEMM + depthwise/Gram kernel.
+    if ops.FUSED_TRAIN and ops.qkv_dwconv_gram_fits(Cc, heads, H, W, dt):
+        v, gp, spart, _, t, qk = ops.qkv_dwconv_gram(sa2, sp["wqkv"], w9, B, H, W, Cc, heads, keep=True)
+    else:
+        t = ops.gemm_tok(sa2, sp["wqkv"])
+        v, gp, spart, _, qk = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
+                                              3 * Cc, B, H, W, Cc, heads, keep_qk=True)
+    Mb, MbT, gp, spart = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt, transposed=True)   # keep the sums, drop the partials
+    br.join()
+    saved = (x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT) + ((qk,) if qk is not None else ())
+    if fuse:
+        return None, saved
+    y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
+    return y.reshape(B, H, W, Cc), saved
+
+
+def _pgsstb_attn_backward(blk, k1, saved, dy):
+    """backward of the first residual branch: (dx, d norm1.weight, d norm1.bias, d qkv.weight, d qkv.bias, d proj.weight, d proj.bias,
+    d rpb table, d temperature, d spectral qkv, d spectral dw, d project_out, *d prompt-gate parameters (_PG_KEYS))"""
+    x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT = saved[:11]
+    qk = saved[11] if len(saved) > 11 else None
+    B, H, W, Cc = x.shape
+    dt = x.dtype
+    M = B * H * W
+    heads, shift = blk.num_heads, blk.shift_size
+    pk = blk.packed(dt)
+    sp = blk.gobal_spectral_attn.packed(dt)
+    dy = dy.contiguous()
+    with ops.reduce_scope(leaf=True):      # every split partial of this backward is summed by ONE launch when the scope exits
+        # (1) branch sum  y = x + keep*(sa*gate + out)
+        d_out, d_sa, dgate = ops.combine_bwd(dy, sa, gate, k1, shift)
+        # (3, issued first on a side branch) local spectral-prompt gate: one launch per block + one token-reduction GEMM
+        # over the windows.  Factor rows in the compute dtype ride in the grouped 16-bit GEMM launch; fp16's narrow exponent
+        # would flush the gate's tiny d-logits (w ~ 1/128 of an already small gradient), so that path keeps them in fp32
+        with ops.side_stream(dy, ops.SIDE_BRANCH) as br:
+            # ... and so do levels with few windows (the latent level: 4 per sample), where a parameter gradient is the sum of a
+            # few hundred signed terms: with bf16 factor rows linear_down / kv of a latent block came out 23 % off in the whole-net
+            # check (the reference's own bf16 autocast: 2 %); the fp32 product of <= 512 rows costs nothing
+            f32_factors = dt == torch.float16 or mu.shape[0] <= 512
+            dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=torch.float32 if f32_factors else dt)
+        # (2) global spectral attention
+        t4 = t.reshape(B, H, W, 3 * Cc)
+        w9 = sp["w9"]
+        tq, tk, tv = t4[..., :Cc], t4[..., Cc:2 * Cc], t4[..., 2 * Cc:]
+        dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
+            d_out.reshape(M, Cc), tq, tk, tv, w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:], v, gp, spart, Mb, MbT,
+            blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W, qk=qk)
+        if dtq.data_ptr() + Cc * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * Cc:
+            dt3 = torch.as_strided(dtq, (M, 3 * Cc), (3 * Cc, 1))
+        else:
+            dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
+        d_sa = ops.gemm_tok(dt3, sp["wqkvT"], epi=1, res=d_sa.reshape(M, Cc))    # + dt Wqkv  (1x1 conv backward)
+        d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
+        dpg = tuple(gpg[k].reshape(getattr_path(blk.local_spectral_attn, k).shape) for k in _PG_KEYS)
+        br.join()
+        # (4) window attention core
+        dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
+                                                 pk["rpb"], pk["wprojT"], heads, shift)
+        d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xnw, colsum=True)
+        dsat2 = dsat.reshape(M, Cc)
+        d_proj_w, d_proj_b = ops.gemm_tn(dsat2, oattn.reshape(M, Cc), colsum=True)
+        # (5) d_xn = dqkv Wqkv, then norm1 backward and the residual path.  (The LayerNorm backward as an epilogue of that GEMM
+        # was built and measured slower in round 4 -- four barriers and an fp32 staging tile per GEMM tile against a 2 C per token
+        # round trip -- and removed in round 5.)
+        dx, part = ops.ln_bwd_win(x, ops.gemm_tok(dqkv, pk["wqkvT"]), dy, pk["ln1"][0], shift)
+        dln = ops.reduce_parts(part)
+        drpb = ops.reduce_parts(drpb)
+    d_sdw = _join_taps(dwq, dwk, dwv).reshape(3 * Cc, 1, 3, 3)
+    return (dx, dln[0], dln[1], d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, drpb,
+            dtemp.reshape(heads, 1, 1), d_sqkv, d_sdw, dwo.reshape(Cc, Cc, 1, 1)) + tuple(dpg)
+
+
+
+
 class _PgsstbAttn(torch.autograd.Function):
     """First residual branch of a PGSSTB block: HIP forward (5 launches) and HIP backward."""
 
     @staticmethod
     def forward(ctx, blk, k1, x, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, rpb, s_temp, s_qkv, s_dw, s_out, *pg):
-        B, H, W, Cc = x.shape
-        dt = x.dtype
-        pk = blk.packed(dt)
-        sp = blk.gobal_spectral_attn.packed(dt)
-        heads, shift = blk.num_heads, blk.shift_size
-        w9 = sp["w9"]
-        sa, mu, oattn = ops.win_attn_fwd(x, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"], pk["rpb"], pk["wproj"],
-                                         pk["bproj"], pk["pg"], heads, shift, save=True, gate=False)
-        with ops.side_stream(sa, ops.SIDE_BRANCH) as br:      # the prompt gate (few workgroups, latency-bound) runs beside pass A
-            gate = ops.pg_gate_fwd(mu, pk["pg"])
-        sa2 = sa.reshape(-1, Cc)
-        # pass A; t and q | k after the depthwise conv are kept for the backward (q|k: 2C values per token, cheaper than
-        # recomputing them).  One fused launch where the kernel covers the shape, else 1x1 GEMM + depthwise/Gram kernel.
-        if ops.FUSED_TRAIN and ops.qkv_dwconv_gram_fits(Cc, heads, H, W, dt):
-            v, gp, spart, _, t, qk = ops.qkv_dwconv_gram(sa2, sp["wqkv"], w9, B, H, W, Cc, heads, keep=True)
-        else:
-            t = ops.gemm_tok(sa2, sp["wqkv"])
-            v, gp, spart, _, qk = ops.dwconv_gram(t[:, :Cc], t[:, Cc:2 * Cc], t[:, 2 * Cc:], w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:],
-                                                  3 * Cc, B, H, W, Cc, heads, keep_qk=True)
-        Mb, MbT, gp, spart = ops.spectral_fold(gp, spart, sp["temp"], sp["wo"], dt, transposed=True)   # keep the sums, drop the partials
-        br.join()
-        y = ops.gemm_tok(v, Mb, epi=2, res=x.reshape(-1, Cc), sa=sa2, gate=gate, keep=k1, geom=(H, W, shift))
+        y, saved = _pgsstb_attn_forward(blk, k1, x)
         ctx.blk, ctx.k1 = blk, k1
-        ctx.has_qk = qk is not None
-        ctx.save_for_backward(x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT, *([qk] if qk is not None else []))
-        return y.reshape(B, H, W, Cc)
+        ctx.save_for_backward(*saved)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT = ctx.saved_tensors[:11]
-        qk = ctx.saved_tensors[11] if ctx.has_qk else None
-        blk, k1 = ctx.blk, ctx.k1
+        return (None, None) + _pgsstb_attn_backward(ctx.blk, ctx.k1, ctx.saved_tensors, dy)
+
+
+_N_ATTN_PARAMS = 11 + len(_PG_KEYS)
+
+
+class _Pgsstb(torch.autograd.Function):
+    """A whole PGSSTB block with the branch sum y = x + keep1 (sa gate + v Mb^T) formed INSIDE the gated-MLP launch (16-bit types,
+    C <= 128, big launches: ops.gated_mlp_fuses): one launch and one read of y fewer than _PgsstbAttn + _GatedMlp; y is written once,
+    for the backward.  The backward is the two halves' backward, in sequence."""
+
+    @staticmethod
+    def forward(ctx, blk, k1, k2, res, x, *params):
         B, H, W, Cc = x.shape
-        dt = x.dtype
-        M = B * H * W
-        heads, shift = blk.num_heads, blk.shift_size
-        pk = blk.packed(dt)
-        sp = blk.gobal_spectral_attn.packed(dt)
-        dy = dy.contiguous()
-        with ops.reduce_scope(leaf=True):      # every split partial of this backward is summed by ONE launch when the scope exits
-            # (1) branch sum  y = x + keep*(sa*gate + out)
-            d_out, d_sa, dgate = ops.combine_bwd(dy, sa, gate, k1, shift)
-            # (3, issued first on a side branch) local spectral-prompt gate: one launch per block + one token-reduction GEMM
-            # over the windows.  Factor rows in the compute dtype ride in the grouped 16-bit GEMM launch; fp16's narrow exponent
-            # would flush the gate's tiny d-logits (w ~ 1/128 of an already small gradient), so that path keeps them in fp32
-            with ops.side_stream(dy, ops.SIDE_BRANCH) as br:
-                # ... and so do levels with few windows (the latent level: 4 per sample), where a parameter gradient is the sum of a
-                # few hundred signed terms: with bf16 factor rows linear_down / kv of a latent block came out 23 % off in the whole-net
-                # check (the reference's own bf16 autocast: 2 %); the fp32 product of <= 512 rows costs nothing
-                f32_factors = dt == torch.float16 or mu.shape[0] <= 512
-                dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=torch.float32 if f32_factors else dt)
-            # (2) global spectral attention
-            t4 = t.reshape(B, H, W, 3 * Cc)
-            w9 = sp["w9"]
-            tq, tk, tv = t4[..., :Cc], t4[..., Cc:2 * Cc], t4[..., 2 * Cc:]
-            dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
-                d_out.reshape(M, Cc), tq, tk, tv, w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:], v, gp, spart, Mb, MbT,
-                blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W, qk=qk)
-            if dtq.data_ptr() + Cc * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * Cc:
-                dt3 = torch.as_strided(dtq, (M, 3 * Cc), (3 * Cc, 1))
-            else:
-                dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
-            d_sa = ops.gemm_tok(dt3, sp["wqkvT"], epi=1, res=d_sa.reshape(M, Cc))    # + dt Wqkv  (1x1 conv backward)
-            d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
-            dpg = tuple(gpg[k].reshape(getattr_path(blk.local_spectral_attn, k).shape) for k in _PG_KEYS)
-            br.join()
-            # (4) window attention core
-            dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
-                                                     pk["rpb"], pk["wprojT"], heads, shift)
-            d_qkv_w, d_qkv_b = ops.gemm_tn(dqkv, xnw, colsum=True)
-            dsat2 = dsat.reshape(M, Cc)
-            d_proj_w, d_proj_b = ops.gemm_tn(dsat2, oattn.reshape(M, Cc), colsum=True)
-            # (5) d_xn = dqkv Wqkv, then norm1 backward and the residual path.  (The LayerNorm backward as an epilogue of that GEMM
-            # was built and measured slower in round 4 -- four barriers and an fp32 staging tile per GEMM tile against a 2 C per token
-            # round trip -- and removed in round 5.)
-            dx, part = ops.ln_bwd_win(x, ops.gemm_tok(dqkv, pk["wqkvT"]), dy, pk["ln1"][0], shift)
-            dln = ops.reduce_parts(part)
-            drpb = ops.reduce_parts(drpb)
-        d_sdw = _join_taps(dwq, dwk, dwv).reshape(3 * Cc, 1, 3, 3)
-        return (None, None, dx, dln[0], dln[1], d_qkv_w, d_qkv_b, d_proj_w, d_proj_b, drpb,
-                dtemp.reshape(heads, 1, 1), d_sqkv, d_sdw, dwo.reshape(Cc, Cc, 1, 1)) + tuple(dpg)
+        _, saved = _pgsstb_attn_forward(blk, k1, x, fuse=True)
+        pk = blk.packed(x.dtype)
+        z, y = ops.gated_mlp_fwd(x.reshape(-1, Cc), pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"], pk["W2"], pk["b2"], keep=k2, rows_per_batch=H * W,
+                                 res=None if res is None else res.reshape(-1, Cc),
+                                 branch=dict(v=saved[6], Mb=saved[9], sa=saved[1].reshape(-1, Cc), gate=saved[2], keep=k1,
+                                             geom=(H, W, blk.shift_size), want_y=True))
+        ctx.blk, ctx.k1, ctx.k2 = blk, k1, k2
+        ctx.save_for_backward(y.reshape(B, H, W, Cc), *saved)
+        return z.reshape(B, H, W, Cc)
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        gm = _gated_mlp_backward(ctx.blk, ctx.k2, y, dz)
+        ga = _pgsstb_attn_backward(ctx.blk, ctx.k1, saved, gm[0])
+        return (None, None, None, dz if ctx.needs_input_grad[3] else None) + ga + gm[1:]
 
 
 def _join_taps(*dw):
@@ -258,13 +310,23 @@ def pgsstb(blk, x, k1, k2, res=None):
     """One PGSSTB block (ref :662-723): attention-side residual branch, then the gated-MLP residual branch (+ res: the skip of the
     enclosing BaseBlock when this is its last block)."""
     a, sp, pgm = blk.attn, blk.gobal_spectral_attn, blk.local_spectral_attn
+    m = blk.mlp
+    B, H, W, Cc = x.shape
+    fuse = ops.gated_mlp_fuses(B * H * W, Cc, H * W, x.dtype)
     if not torch.is_grad_enabled():
+        if fuse:
+            pk = blk.packed(x.dtype)
+            z, _ = ops.gated_mlp_fwd(x.reshape(-1, Cc), pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"], pk["W2"], pk["b2"], keep=k2, rows_per_batch=H * W,
+                                     res=None if res is None else res.reshape(-1, Cc), branch=_pgsstb_attn_infer(blk, k1, x, fuse=True))
+            return z.reshape(B, H, W, Cc)
         y = _pgsstb_attn_infer(blk, k1, x)
     else:
-        y = _PgsstbAttn.apply(blk, k1, x, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
-                              a.relative_position_bias_table, sp.temperature, sp.qkv.weight, sp.qkv_dwconv.weight,
-                              sp.project_out.weight, *[getattr_path(pgm, k) for k in _PG_KEYS])
-    m = blk.mlp
+        attn_params = (blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                       a.relative_position_bias_table, sp.temperature, sp.qkv.weight, sp.qkv_dwconv.weight,
+                       sp.project_out.weight, *[getattr_path(pgm, k) for k in _PG_KEYS])
+        if fuse:
+            return _Pgsstb.apply(blk, k1, k2, res, x, *attn_params, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+        y = _PgsstbAttn.apply(blk, k1, x, *attn_params)
     return _GatedMlp.apply(blk, k2, y, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, res)
 
 

@@ -24,6 +24,14 @@ struct MlpDev {
     int hsplit;   // > 1 (LDS form): the hidden dimension is dealt to hsplit workgroups per token tile (grid.y); each writes its fp32
     float* Ypart; // partial fc2 product [hsplit][M][C]; mlp_combine_kernel adds them, the bias and the residual
     const void* R; long ldr;   // optional second residual: Y = (X + keep*mlp(LN(X))) + R  (the BaseBlock skip, net/MP_HSIR.py:727-761)
+    // optional FUSED BRANCH SUM (round 5; the LDS forms with one token tile per wave, 16-bit types, C <= 128): the kernel's input row
+    //   y = X + pkeep[b] * (PSA * pgate[window] + PV Mb[b]^T)          (PGSSTB.forward net/MP_HSIR.py:715-718: pass B of the channel
+    // attention + the local gate + the first residual, what mphsir_gemm_tok epi 2 computes) is formed in LDS from the PV tile and the
+    // sample's C x C matrix instead of being read from X; Yb (optional: training keeps y for the backward) receives it.
+    const void* PV; long ldpv; const void* PM; long pms;
+    const void* PSA; long ldpsa; const float* pgate; const float* pkeep;
+    void* Yb; long ldyb;
+    int H, Wimg, shift;
 };
 
 template <class T, int C>
@@ -163,8 +171,9 @@ template <class T, int C, int TT, int NWV = 4> struct MlpLdsCfg {
     static constexpr bool FITS = BYTES <= 160 * 1024;
 };
 
-template <class T, int C, int TT, int NWV>
-__global__ __launch_bounds__(64 * NWV) void gated_mlp_lds_kernel(MlpDev a) {
+// (the fused-sum form is held to 128 registers -- four waves per SIMD, two workgroups per CU like the plain form -- it asked for 154)
+template <class T, int C, int TT, int NWV, bool PB = false>
+__global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_mlp_lds_kernel(MlpDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
     typedef MlpLdsCfg<T, C, TT, NWV> CF;
@@ -176,16 +185,86 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_lds_kernel(MlpDev a) {
     T* W1s = Xs + BM * LDX;                             // [64][LDX]  value rows 0..31, gate rows 32..63
     T* W2s = W1s + 64 * LDX;                            // [C][LDH]
     T* Hs = W2s + C * LDH;                              // [NWV][16*TT][LDH]
-
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const int m0 = blockIdx.x * BM;
     const T* X = reinterpret_cast<const T*>(a.X);
+
+    // ---- fused branch sum (PB): the tile's rows y = X + pkeep * (PSA * gate[window] + PV Mb^T) are formed here: in Xs for the
+    // LayerNorm below (normalised in place), in registers for the residual of the epilogue, in Yb for the backward ------------------
+    constexpr int NVR = C / VEC, NIT = PB ? BM * NVR / NTHR : 1;
+    Vec16<T> yreg[NIT];
+    if constexpr (PB) {
+        static_assert(TT == 1 && NWV == 8 && sizeof(T) == 2 && (BM * NVR) % NTHR == 0, "fused branch sum: eight waves, one token tile each, 16-bit types");
+        constexpr int LDF = C + 4, NKC0 = C / TR::KCHUNK;
+        static_assert((size_t)C * LDX <= (size_t)64 * LDX + (size_t)C * LDH + NWV * 16 * LDH, "the sample's matrix is staged over the weight tiles");
+        static_assert((size_t)BM * LDF * 4 <= CF::BYTES, "fp32 stage of the product");
+        const int hw = a.H * a.Wimg, bsmp = m0 / hw;     // a token tile never straddles samples (H W % BM == 0, checked by the host)
+        const T* V = reinterpret_cast<const T*>(a.PV);
+        const T* Mb = reinterpret_cast<const T*>(a.PM) + (long)bsmp * a.pms;
+        T* Ms = W1s;                                     // [C][LDX] over W1s | W2s | Hs;  the V tile goes to Xs
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + NTHR * it, r = idx / NVR, c0 = (idx % NVR) * VEC;
+            store16<T>(Xs + r * LDX + c0, load16<T>(V + (long)(m0 + r) * a.ldpv + c0));
+        }
+        for (int idx = tid; idx < C * NVR; idx += NTHR) {
+            const int r = idx / NVR, c0 = (idx % NVR) * VEC;
+            store16<T>(Ms + r * LDX + c0, load16<T>(Mb + (long)r * C + c0));
+        }
+        __syncthreads();
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < NKC0; ++kc) {
+            const frag_t bf = load_frag<T>(Xs, LDX, wv * 16, kc * TR::KCHUNK);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) mma(acc[ct], load_frag<T>(Ms, LDX, ct * 16, kc * TR::KCHUNK), bf);
+        }
+        __syncthreads();                                 // every wave has read the V tile and the matrix: the fp32 stage goes over them
+        float* Cf = reinterpret_cast<float*>(smem_v);    // [BM][LDF]
+        {
+            const int tok = wv * 16 + (lane & 15), cr = (lane >> 4) * 4;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(Cf + tok * LDF + ct * 16 + cr) = acc[ct];
+        }
+        __syncthreads();
+        // a thread finishes 8 consecutive channels of a token: 16-byte loads of X and PSA, one rounding -- the arithmetic of
+        // gemm_tok's epilogue 2, element for element
+        const T* SA = reinterpret_cast<const T*>(a.PSA);
+        T* Yb = reinterpret_cast<T*>(a.Yb);
+        const float kf1 = a.pkeep ? a.pkeep[bsmp] : 1.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + NTHR * it, r = idx / NVR, c = (idx % NVR) * VEC;
+            const long m = (long)m0 + r;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(Cf + r * LDF + c), v1 = *reinterpret_cast<const f32x4*>(Cf + r * LDF + c + 4);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const int p = (int)(m - (long)bsmp * hw), y = p / a.Wimg, x = p % a.Wimg;
+            const int ys = (y - a.shift + a.H) % a.H, xs = (x - a.shift + a.Wimg) % a.Wimg;          // shifted-frame coordinates
+            const float* gp = a.pgate + ((long)bsmp * (hw / 64) + (ys >> 3) * (a.Wimg >> 3) + (xs >> 3)) * C + c;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+            const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+            const Vec16<T> rr = load16<T>(X + m * a.ldx + c), sa = load16<T>(SA + m * a.ldpsa + c);
+            Vec16<T> o;
+            for (int e = 0; e < 8; ++e) o.set(e, rr.get(e) + kf1 * (sa.get(e) * g[e] + v[e]));
+            yreg[it] = o;
+            if (Yb) store16<T>(Yb + m * a.ldyb + c, o);
+        }
+        __syncthreads();                                 // the stage is consumed: the rows go where the LayerNorm expects them
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + NTHR * it, r = idx / NVR, c = (idx % NVR) * VEC;
+            store16<T>(Xs + r * LDX + c, yreg[it]);
+        }
+        __syncthreads();
+    }
 
     // ---- LayerNorm into LDS: 4 adjacent lanes per token, TT passes ---------------------------------
     for (int pass = 0; pass < TT; ++pass) {
         constexpr int NV = C / VEC, VPT = NV / 4;
         const int r = pass * 16 * NWV + (tid >> 2), q = tid & 3;
-        const T* row = X + (long)(m0 + r) * a.ldx;
+        const T* row = PB ? Xs + r * LDX : X + (long)(m0 + r) * a.ldx;
         Vec16<T> xv[VPT];
         float s = 0.f;
 #pragma unroll
@@ -381,10 +460,14 @@ __global__ __launch_bounds__(64 * NWV) void gated_mlp_lds_kernel(MlpDev a) {
     __syncthreads();
     T* Y = reinterpret_cast<T*>(a.Y);
     constexpr int NV = C / VEC;
-    for (int idx = tid; idx < BM * NV; idx += NTHR) {
-        const int r = idx / NV, c0 = (idx % NV) * VEC, m = m0 + r;
+    constexpr int NEP = BM * NV / NTHR;                 // = TT * NV / 4: whole
+    static_assert((BM * NV) % NTHR == 0, "epilogue: whole passes");
+#pragma unroll(PB ? NEP : 1)
+    for (int it = 0; it < NEP; ++it) {
+        const int idx = tid + it * NTHR, r = idx / NV, c0 = (idx % NV) * VEC, m = m0 + r;
         const float kf = a.keep ? a.keep[m / a.rpb] : 1.f;
-        const Vec16<T> x = load16<T>(X + (long)m * a.ldx + c0);
+        Vec16<T> x;
+        if constexpr (PB) x = yreg[it]; else x = load16<T>(X + (long)m * a.ldx + c0);
         const Vec16<T> h = load16<T>(Xs + r * LDX + c0);
         Vec16<T> o;
         if (a.R) {
@@ -435,6 +518,14 @@ static int launch_mlp_lds(const MlpDev& d, hipStream_t s) {
     if constexpr (!CF::FITS) {
         return 1;   // caller falls back
     } else {
+        if constexpr (sizeof(T) == 2 && TT == 1 && C <= 128 && NWV == 8) {
+            if (d.PV) {                       // fused branch sum: same LDS, the y rows live in the X tile / in registers
+                allow_big_lds(gated_mlp_lds_kernel<T, C, TT, NWV, true>, CF::BYTES);
+                MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_lds_kernel<T, C, TT, NWV, true>), dim3(d.M / CF::BM, 1), dim3(CF::NTHR), CF::BYTES, s, d);
+                return MPHSIR_OK;
+            }
+        }
+        if (d.PV) { set_error("gated_mlp: the fused branch sum needs the eight-wave LDS form"); return MPHSIR_EINVAL; }
         allow_big_lds(gated_mlp_lds_kernel<T, C, TT, NWV>, CF::BYTES);
         const int hsp = d.hsplit > 1 ? d.hsplit : 1;
         MPHSIR_LAUNCH(MPHSIR_K_GATED_MLP, (gated_mlp_lds_kernel<T, C, TT, NWV>), dim3(d.M / CF::BM, hsp), dim3(CF::NTHR), CF::BYTES, s, d);
@@ -484,6 +575,10 @@ static int dispatch_mlp(const MlpDev& d, int C, hipStream_t s) {
 
 }  // namespace mphsir
 
+extern "C" int mphsir_gated_mlp_fwd_fuses(int32_t C, int64_t M, int dtype) {
+    return ((dtype == MPHSIR_BF16 || dtype == MPHSIR_F16) && (C == 32 || C == 64 || C == 96 || C == 128) && M > 0 && M % 128 == 0) ? 1 : 0;
+}
+
 extern "C" int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
@@ -497,7 +592,19 @@ extern "C" int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* s
     if (a->keep) MPHSIR_REQUIRE(a->rows_per_batch > 0, "gated_mlp: keep needs rows_per_batch");
     MlpDev d{a->X, (long)a->ldx, a->ln_w, a->ln_b, a->W1, a->b1, a->W2, a->b2, a->keep,
              (long)(a->rows_per_batch > 0 ? a->rows_per_batch : a->M), a->Y, (long)a->ldy, (int)a->M, a->HP, a->tiles_per_wave,
-             a->hsplit, a->ypart, a->R, (long)a->ldr};
+             a->hsplit, a->ypart, a->R, (long)a->ldr,
+             a->PV, (long)a->ldpv, a->PM, (long)a->pm_batch_stride, a->PSA, (long)a->ldpsa, a->pgate, a->pkeep, a->Yb, (long)a->ldyb,
+             a->H, a->Wimg, a->shift};
+    if (a->PV) {
+        d.tpw = 3;                              // the eight-wave form, one token tile per wave
+        MPHSIR_REQUIRE(mphsir_gated_mlp_fwd_fuses(a->C, a->M, dtype) && a->hsplit <= 1 && (a->tiles_per_wave == 0 || a->tiles_per_wave == 3),
+                       "gated_mlp: the fused branch sum exists for 16-bit types, C in {32,64,96,128}, one token tile per wave, no hidden split");
+        MPHSIR_REQUIRE(a->PM && a->PSA && a->pgate && aligned16(a->PV) && aligned16(a->PM) && aligned16(a->PSA) && (a->ldpv * esz) % 16 == 0 &&
+                           (a->ldpsa * esz) % 16 == 0 && (a->pm_batch_stride * esz) % 16 == 0 && (!a->Yb || (aligned16(a->Yb) && (a->ldyb * esz) % 16 == 0)),
+                       "gated_mlp: fused branch sum: PM, PSA, pgate required, 16-byte alignment");
+        MPHSIR_REQUIRE(a->H > 0 && a->Wimg > 0 && a->H % 8 == 0 && a->Wimg % 8 == 0 && ((int64_t)a->H * a->Wimg) % 128 == 0 && a->M % ((int64_t)a->H * a->Wimg) == 0 &&
+                           (a->shift == 0 || a->shift == 4), "gated_mlp: fused branch sum: H, W multiples of 8 with H*W %% 128 == 0, M = B*H*W, shift 0 or 4");
+    }
     if (a->R) MPHSIR_REQUIRE(aligned16(a->R) && (a->ldr * esz) % 16 == 0, "gated_mlp: second residual: 16-byte alignment required");
     if (a->hsplit > 1)
         MPHSIR_REQUIRE(a->ypart && aligned16(a->ypart) && a->HP % (32 * a->hsplit) == 0 && a->tiles_per_wave <= 2,

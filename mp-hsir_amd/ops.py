@@ -223,6 +223,10 @@ def _dw_side(scope):
 
 DW_BATCH_BYTES = int(float(os.environ.get("MPHSIR_DW_BATCH_MB", "48")) * (1 << 20))
 _DW_PENDING = {}
+# the ordered sums of the weight-gradient branch: 1 = all of them at the join (the end of the backward pass / a bucket hook), as few
+# launches of 32 segments as there can be, instead of one small launch behind every flush of the branch
+DW_SUMS_LATE = os.environ.get("MPHSIR_DW_SUMS_LATE", "0") == "1"
+_DW_SUMS = {}
 
 
 def _dw_flush_pending(dev):
@@ -236,7 +240,10 @@ def _dw_flush_pending(dev):
     with torch.cuda.stream(st):
         _flush_calls(calls)
         _flush_gemms(gemms)
-        _flush(segs)
+        if DW_SUMS_LATE:
+            _DW_SUMS.setdefault(dev, []).extend(segs)      # ... summed at the join, 32 segments per launch
+        else:
+            _flush(segs)
     _DW_KEEP.append((dev, [g["keep"] for g in gemms] + [c["keep"] for c in calls], [g["keep"] for g in segs]))
 
 
@@ -246,6 +253,11 @@ def _dw_join(final=True):
     that has to read a sum, possibly running on a prompt module's own stream -- makes ITS stream wait and leaves the rest as it is."""
     for dev in list(_DW_PENDING):
         _dw_flush_pending(dev)
+    for dev, segs in list(_DW_SUMS.items()):
+        if segs:
+            _DW_SUMS[dev] = []
+            with torch.cuda.stream(_DW_STREAM[dev]):      # behind the GEMMs that wrote the partials (same stream)
+                _flush(segs)
     if _DW_KEEP:
         for dev in {k[0] for k in _DW_KEEP}:
             torch.cuda.current_stream(dev).wait_stream(_DW_STREAM[dev])
@@ -622,9 +634,22 @@ def mlp_hsplit(M, C, HP):
     return s
 
 
-def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, out=None, tiles_per_wave=0, hsplit=None, res=None):
+MLP_FUSE_SUM = os.environ.get("MPHSIR_MLP_FUSE_SUM", "1") == "1"      # the block's branch sum (pass B + gate + residual) inside the gated-MLP launch
+MLP_FUSE_MIN_TILES = int(os.environ.get("MPHSIR_MLP_FUSE_MIN_TILES", "256"))   # ... from this many 128-token tiles (where the plain launch is the eight-wave form too)
+
+
+def gated_mlp_fuses(M, C, HW, dtype):
+    """the gated-MLP forward can form its own input y = x + keep1 * (sa * gate + v Mb^T) (the launch of gemm_tok epi 2 disappears)"""
+    return (MLP_FUSE_SUM and dtype in _HALF and HW % 128 == 0 and M // 128 >= MLP_FUSE_MIN_TILES
+            and bool(_lib.load().mphsir_gated_mlp_fwd_fuses(C, M, _DT[dtype])))
+
+
+def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, out=None, tiles_per_wave=0, hsplit=None, res=None, branch=None):
     """x (M,C) row-major view -> x + keep * mlp(LN(x)) [+ res, a second residual (M,C) row-major view: the skip of a whole BaseBlock
-    folded into its last block's launch]; weights from pack_gated_mlp."""
+    folded into its last block's launch]; weights from pack_gated_mlp.
+    branch = dict(v, Mb, sa, gate, keep, geom=(H, W, shift), want_y): the FUSED branch sum -- the kernel first forms
+    y = x + keep1 * (sa * gate[window] + v Mb^T) (what gemm_tok(v, Mb, epi=2, res=x, ...) returns, bitwise) and runs on it; returns
+    (z, y) with y None unless want_y."""
     lib = _lib.load()
     _check(x, W1, W2, b1, b2, ln_w, ln_b, keep, res)
     M, ldx = _rows(x)
@@ -640,13 +665,31 @@ def gated_mlp_fwd(x, ln_w, ln_b, W1, b1, W2, b2, keep=None, rows_per_batch=0, ou
         assert res.shape == x.shape and res.dtype == x.dtype
         a.R, a.ldr = _p(res), _rows(res)[1]
     a.Y, a.ldy, a.M, a.C, a.HP, a.tiles_per_wave = _p(y), _rows(y)[1], M, C, HP, tiles_per_wave
+    yb = None
+    if branch is not None:
+        v, Mb, sa, gate = branch["v"], branch["Mb"], branch["sa"], branch["gate"]
+        H, W, shift = branch["geom"]
+        _check(v, Mb, sa, gate, branch.get("keep"))
+        assert x.dtype in _HALF and (H * W) % 128 == 0 and lib.mphsir_gated_mlp_fwd_fuses(C, M, _DT[x.dtype]) and Mb.dim() == 3 and Mb.shape[1:] == (C, C) and Mb.is_contiguous() and M == Mb.shape[0] * H * W
+        assert v.dtype == x.dtype and sa.dtype == x.dtype and gate.dtype == torch.float32 and gate.is_contiguous() and hsplit in (None, 1)
+        a.PV, a.ldpv, a.PM, a.pm_batch_stride = _p(v), _rows(v)[1], _p(Mb), C * C
+        a.PSA, a.ldpsa, a.pgate, a.pkeep = _p(sa), _rows(sa)[1], _p(gate), _p(branch.get("keep"))
+        a.H, a.Wimg, a.shift = H, W, shift
+        if branch.get("want_y"):
+            yb = torch.empty((M, C), dtype=x.dtype, device=x.device)
+            a.Yb, a.ldyb = _p(yb), C
+        hsplit = 1
     if hsplit is None:
         hsplit = mlp_hsplit(M, C, HP) if tiles_per_wave == 0 and (x.dtype in _HALF or C < 256) else 1
     if hsplit > 1:
         ypart = torch.empty((hsplit, M, C), dtype=torch.float32, device=x.device)
         a.hsplit, a.ypart, a.tiles_per_wave = hsplit, _p(ypart), 1
     _lib.check(lib.mphsir_gated_mlp_fwd(ctypes.byref(a), _DT[x.dtype], _stream(x)), "gated_mlp_fwd")
-    _acct("gated_mlp", 6.0 * M * C * HP, 2.0 * M * C * x.element_size() + 3.0 * C * HP * x.element_size())
+    es = x.element_size()
+    if branch is not None:        # + the branch sum: v Mb^T, reads of v and sa (x is counted below), the optional write of y
+        _acct("gated_mlp", 6.0 * M * C * HP + 2.0 * M * C * C, (4.0 + (1.0 if yb is not None else 0.0)) * M * C * es + 3.0 * C * HP * es)
+        return y, yb
+    _acct("gated_mlp", 6.0 * M * C * HP, 2.0 * M * C * es + 3.0 * C * HP * es)
     return y
 
 

@@ -144,6 +144,34 @@ def check_gated_mlp(dev, dtype, C, hid, tpw=0, M=128, hsplit=None, res=False):
     assert rel_l2(y, ref) < TOL[dtype]
 
 
+def check_gated_mlp_branch_sum(dev, dtype, C, hid, B=2, H=8, W=16, shift=0, keep=True, want_y=True, res=False):
+    """mphsir_gated_mlp_fwd with PV (the block's branch sum formed inside the launch) against the two launches it replaces
+    (gemm_tok epi 2, then the plain gated MLP in the same kernel form): the same arithmetic in the same order -> bitwise equal."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    M = B * H * W
+    x = rnd((M, C), 1, dtype)
+    v = rnd((M, 3 * C), 11, dtype)[:, 2 * C:]                        # a strided view, as pass A hands it over
+    sa = rnd((M, C), 12, dtype)
+    Mb = rnd((B, C, C), 13, scale=C ** -0.5).to(dtype)
+    gate = rnd((B * (H * W // 64), C), 14)
+    k1 = torch.tensor(([1.0, 1.25, 0.0, 1.5] * B)[:B]).to(dev) if keep else None
+    k2 = torch.tensor(([1.5, 1.0, 1.25, 0.0] * B)[:B]).to(dev) if keep else None
+    r2 = rnd((M, C + 8), 8, dtype)[:, :C] if res else None
+    fc1w, fc1b = rnd((2 * hid, C), 2, scale=C ** -0.5), 0.1 * rnd((2 * hid,), 3)
+    fc2w, fc2b = rnd((C, hid), 4, scale=hid ** -0.5), 0.1 * rnd((C,), 5)
+    lnw, lnb = 1 + 0.1 * rnd((C,), 6), 0.1 * rnd((C,), 7)
+    W1, b1, W2 = ops.pack_gated_mlp(fc1w, fc1b, fc2w, dtype)
+    y0 = ops.gemm_tok(v, Mb, epi=2, res=x, sa=sa, gate=gate, keep=k1, geom=(H, W, shift))
+    z0 = ops.gated_mlp_fwd(y0, lnw, lnb, W1, b1, W2, fc2b, keep=k2, rows_per_batch=H * W, tiles_per_wave=3, res=r2)
+    z1, y1 = ops.gated_mlp_fwd(x, lnw, lnb, W1, b1, W2, fc2b, keep=k2, rows_per_batch=H * W, res=r2,
+                               branch=dict(v=v, Mb=Mb, sa=sa, gate=gate, keep=k1, geom=(H, W, shift), want_y=want_y))
+    assert (y1 is not None) == want_y
+    if want_y:
+        assert torch.equal(y0.cpu(), y1.cpu()), rel_l2(y1, y0.double().cpu())
+    assert torch.equal(z0.cpu(), z1.cpu()), rel_l2(z1, z0.double().cpu())
+
+
 # ---- fp32 twins of the forms that exist in 16 bits only (round-3 review, weak point 13) ------------------------------------------
 # The oracle comparisons above allow TOL[bf16] = 1.5e-2: wide enough for a wrong small term.  Here the SAME operation runs through the
 # fp32 kernels on the 16-bit-rounded inputs and weights, so that what is left is the 16-bit rounding of the stored intermediates and

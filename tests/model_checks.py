@@ -426,6 +426,46 @@ def check_block_gradients(dev, name="nat_enc1", dtype=torch.float32, tol=2e-4):
     return max(errs.values())
 
 
+def check_fused_block_equals_unfused(dev, name="nat_enc1", dtype=torch.bfloat16):
+    """A PGSSTB block with the branch sum formed inside the gated-MLP launch (autograd_ops._Pgsstb / the no-grad twin) against the
+    same block through _PgsstbAttn + _GatedMlp: output, input gradient and every parameter gradient bit for bit (the fused launch
+    computes the same y; the backward is the same sequence of launches)."""
+    from golden.cases import BLOCK_CASES, cotangent
+    from golden.detfill import det_value
+    from mp_hsir_amd import ops
+    from mp_hsir_amd.net.MP_HSIR import PGSSTB
+    c = BLOCK_CASES[name]
+    mod = PGSSTB(c["C"], c["heads"], [64, 64], 8, c["shift"], 0.0, 2.66, c["cr"], 128).eval()
+    with torch.no_grad():
+        for k, p in mod.named_parameters():
+            p.copy_(det_value(k, p.shape).float())
+    mod = mod.to(dev)
+    x0 = seeded_input(name, c["shape"], "normal").to(dev).permute(0, 2, 3, 1).contiguous().to(dtype)
+    cot = cotangent(name, c["shape"]).to(dev).permute(0, 2, 3, 1).to(dtype)
+    saved = (ops.MLP_FUSE_SUM, ops.MLP_FUSE_MIN_TILES)
+    res = {}
+    try:
+        for fuse in (False, True):
+            ops.MLP_FUSE_SUM, ops.MLP_FUSE_MIN_TILES = fuse, 1
+            assert ops.gated_mlp_fuses(x0.numel() // c["C"], c["C"], c["shape"][2] * c["shape"][3], dtype) == fuse
+            mod.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            ops.ACCOUNT = {}
+            y = mod(x)
+            (y * cot).sum().backward()
+            acct, ops.ACCOUNT = ops.ACCOUNT, None
+            with torch.no_grad():
+                yi = mod(x0)
+            res[fuse] = (y.detach(), yi, x.grad, {k: p.grad.clone() for k, p in mod.named_parameters()}, acct)
+    finally:
+        ops.MLP_FUSE_SUM, ops.MLP_FUSE_MIN_TILES = saved
+    (y0, yi0, dx0, g0, a0), (y1, yi1, dx1, g1, a1) = res[False], res[True]
+    assert a1["gemm_tok"][0] == a0["gemm_tok"][0] - 1, (a0["gemm_tok"], a1["gemm_tok"])       # the launch that disappeared
+    assert torch.equal(y0, y1) and torch.equal(yi0, yi1) and torch.equal(y1, yi1) and torch.equal(dx0, dx1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+
+
 def check_pack_plan(dev, dtype=torch.float32, steps=3):
     """engine.PackPlan (all kernel-layout weights = one gather from the flat arena) against the per-module packers:
     every module cache gets pinned, and the parameter trajectory of a few AdamW steps is bitwise the same."""

@@ -306,6 +306,14 @@ def test_fp32_twins_of_16bit_only_forms(dt):
     K.check_gdfn_fused_fp32_twin("cpu", dt, 64, 170, (1, 16, 32))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,hid,shift,keep,want_y,res", [(64, 170, 0, True, True, False), (128, 340, 4, False, False, True),
+                                                          (32, 85, 4, True, True, True), (96, 255, 0, True, False, False)])
+def test_gated_mlp_fused_branch_sum(dtype, C, hid, shift, keep, want_y, res):
+    """the PGSSTB branch sum formed inside the gated-MLP launch == gemm_tok epi 2 followed by the plain launch, bit for bit"""
+    K.check_gated_mlp_branch_sum("cpu", dtype, C, hid, shift=shift, keep=keep, want_y=want_y, res=res)
+
+
 @pytest.mark.parametrize("dtype", K.DTYPES)
 def test_gated_mlp_second_residual(dtype):
     """mphsir_gated_mlp_fwd with R: every kernel form adds the BaseBlock skip in its epilogue (direct form, LDS forms, hidden-split combine)"""

@@ -34,6 +34,11 @@ def test_block_gradients_bf16_widest():
     assert M.check_block_gradients("cpu", "rs_latent", torch.bfloat16, tol=6e-2) < 6e-2
 
 
+def test_fused_block_equals_unfused_bf16():
+    """the whole-block Function (branch sum inside the gated-MLP launch) == attention Function + MLP Function, bit for bit"""
+    M.check_fused_block_equals_unfused("cpu", "nat_enc1")
+
+
 def test_pack_plan_matches_per_module_packers():
     import torch
     M.check_pack_plan("cpu")

@@ -32,6 +32,17 @@ def test_gemm_tok(dtype, M, N, K_, ln, epi):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,hid,B,H,W,shift,keep,want_y,res", [(64, 170, 2, 8, 16, 0, True, True, False), (128, 340, 2, 8, 16, 4, False, False, True),
+                                                               (32, 85, 2, 16, 16, 4, True, True, True), (96, 255, 2, 8, 16, 0, True, False, False),
+                                                               (128, 340, 4, 64, 64, 4, True, True, False), (64, 170, 4, 128, 128, 0, True, True, True),
+                                                               (128, 340, 32, 64, 64, 0, True, False, False)])
+def test_gated_mlp_fused_branch_sum(dtype, C, hid, B, H, W, shift, keep, want_y, res):
+    """the PGSSTB branch sum formed inside the gated-MLP launch == gemm_tok epi 2 followed by the plain launch, bit for bit -- also at
+    the sizes of the training step and of the 512x512 forward, where the launch it replaces is the ring form of gemm_tok"""
+    K.check_gated_mlp_branch_sum("cuda", dtype, C, hid, B=B, H=H, W=W, shift=shift, keep=keep, want_y=want_y, res=res)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K_,epi,ps,ldx,ldy", [(256, 64, 64, 0, 0, None, None), (512, 96, 96, 1, 0, 128, 104), (1024, 208, 160, 0, 4, None, 256),
                                                     (512, 128, 64, 2, 2, None, None), (256, 272, 32, 0, 0, None, None), (768, 48, 224, 1, 3, 256, None), (131072, 256, 256, 0, 32, 256, 384), (131072, 128, 384, 1, 0, 384, 128), (131072, 128, 128, 2, 32, 128, 128), (65536, 352, 128, 0, 0, None, None), (70016, 64, 192, 1, 0, None, None)])
 def test_gemm_tok_ring(dtype, M, N, K_, epi, ps, ldx, ldy):

@@ -86,6 +86,14 @@ def test_full_size_cube_vs_reference_and_oracle(name):
 
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("name", ["nat_enc1", "nat_enc2", "nat_refine", "rs_enc1"])
+def test_fused_block_equals_unfused(name, dtype):
+    """the whole-block Function (branch sum inside the gated-MLP launch: C <= 128, 16-bit) == attention Function + MLP Function,
+    bit for bit: output (training and no-grad), dX, every parameter gradient"""
+    M.check_fused_block_equals_unfused("cuda", name, dtype)
+
+
 @pytest.mark.parametrize("name", list(BLOCK_CASES))
 def test_block_gradients_fp32(name):
     """every shape class of both shipped configurations (C 64..384, head_dim 32..96) + TVSP + PromptFusion: output, dX and
