@@ -202,10 +202,16 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
         const T* V = reinterpret_cast<const T*>(a.PV);
         const T* Mb = reinterpret_cast<const T*>(a.PM) + (long)bsmp * a.pms;
         T* Ms = W1s;                                     // [C][LDX] over W1s | W2s | Hs;  the V tile goes to Xs
+        // the epilogue's rows of X and PSA are requested now (registers are free until the hidden loop): their round trip runs
+        // under the staging, the product and its barriers instead of behind them
+        const T* SA = reinterpret_cast<const T*>(a.PSA);
+        Vec16<T> xr[NIT], sr[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + NTHR * it, r = idx / NVR, c0 = (idx % NVR) * VEC;
             store16<T>(Xs + r * LDX + c0, load16<T>(V + (long)(m0 + r) * a.ldpv + c0));
+            xr[it] = load16<T>(X + (long)(m0 + r) * a.ldx + c0);
+            sr[it] = load16<T>(SA + (long)(m0 + r) * a.ldpsa + c0);
         }
         for (int idx = tid; idx < C * NVR; idx += NTHR) {
             const int r = idx / NVR, c0 = (idx % NVR) * VEC;
@@ -231,7 +237,6 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
         __syncthreads();
         // a thread finishes 8 consecutive channels of a token: 16-byte loads of X and PSA, one rounding -- the arithmetic of
         // gemm_tok's epilogue 2, element for element
-        const T* SA = reinterpret_cast<const T*>(a.PSA);
         T* Yb = reinterpret_cast<T*>(a.Yb);
         const float kf1 = a.pkeep ? a.pkeep[bsmp] : 1.f;
 #pragma unroll
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
             const float* gp = a.pgate + ((long)bsmp * (hw / 64) + (ys >> 3) * (a.Wimg >> 3) + (xs >> 3)) * C + c;
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
             const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-            const Vec16<T> rr = load16<T>(X + m * a.ldx + c), sa = load16<T>(SA + m * a.ldpsa + c);
+            const Vec16<T> rr = xr[it], sa = sr[it];
             Vec16<T> o;
             for (int e = 0; e < 8; ++e) o.set(e, rr.get(e) + kf1 * (sa.get(e) * g[e] + v[e]));
             yreg[it] = o;
