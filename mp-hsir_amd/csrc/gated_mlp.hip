@@ -467,7 +467,7 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
     constexpr int NV = C / VEC;
     constexpr int NEP = BM * NV / NTHR;                 // = TT * NV / 4: whole
     static_assert((BM * NV) % NTHR == 0, "epilogue: whole passes");
-#pragma unroll(PB ? NEP : 1)
+#pragma unroll PB ? NEP : 1
     for (int it = 0; it < NEP; ++it) {
         const int idx = tid + it * NTHR, r = idx / NV, c0 = (idx % NV) * VEC, m = m0 + r;
         const float kf = a.keep ? a.keep[m / a.rpb] : 1.f;

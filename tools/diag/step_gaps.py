@@ -42,3 +42,13 @@ print("idle gaps:", {k: (v[0], round(v[1] / 1e6, 3)) for k, v in hist.items()})
 q = "Queue_Id"
 for g, a, b in sorted(gaps, key=lambda x: -x[0])[:top]:
     print("%7.1f us   after q=%s %-48s before q=%s %s" % (g / 1e3, a[q] if a else "-", (a["Kernel_Name"] if a else "-")[8:56], b[q], b["Kernel_Name"][8:60]))
+# optional 4th argument: write every launch of that step in issue order (kernel, duration, grid, workgroup, LDS) to a CSV -- with the
+# serial trace (tools/lab/step_sweeps.sh serial) this is the per-launch cost table
+if len(sys.argv) > 4:
+    import re
+    with open(sys.argv[4], "w") as out:
+        out.write("index,kernel,us,grid,workgroup,lds_bytes\n")
+        for i, r in enumerate(step):
+            n = re.sub(r"^_ZN6mphsir\d+|^void mphsir::|^mphsir::", "", r["Kernel_Name"])[:70].replace(",", ";")
+            out.write("%d,%s,%.2f,%s,%s,%s\n" % (i, n, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size", ""),
+                                                r.get("Workgroup_Size", ""), r.get("LDS_Block_Size", r.get("LDS_Block_Size_v", ""))))
