@@ -325,6 +325,9 @@ def _flush_gemms(gemms):
         _lib.check(lib.mphsir_gemm_tn_group(arr, len(chunk), form, _DT[chunk[0]["keep"][0].dtype], _stream(chunk[0]["keep"][0])), "gemm_tn_group")
 
 
+LOG_SEGS = os.environ.get("MPHSIR_LOG_SEGS", "0") == "1"
+
+
 def _flush(segs):
     """segs: dicts with the fields of mphsir_reduce_seg + the tensors that keep the memory alive until the launch."""
     lib = _lib.load()
@@ -341,6 +344,8 @@ def _flush(segs):
             nbytes += 4.0 * g["nbatch"] * max(1, g["rows"]) * g["n"] * (g["nsplit"] + 1)
         _lib.check(lib.mphsir_reduce_parts(arr, len(chunk), _stream(chunk[0]["keep"][0])), "reduce_parts")
         _acct("reduce_parts", nbytes / 4.0, nbytes)
+        if LOG_SEGS:       # diagnostics: one line per launch -- (n, rows, nsplit, nbatch, dst column stride, 16-byte aligned source) per segment
+            print("reduce_parts %.1f MB:" % (nbytes / 1e6), [(g["n"], g["rows"], g["nsplit"], g["nbatch"], g["dcs"], g["src"] % 16 == 0 and g["stride"] % 4 == 0) for g in chunk], flush=True)
 
 
 def _submit(seg, immediate):
