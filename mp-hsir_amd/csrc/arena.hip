@@ -42,10 +42,12 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(RedDev a) {
     const int ne = (s.n - i4) < 4 ? (int)(s.n - i4) : 4;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (live) {
-        if (s.vec) {
-            // 8 independent 16-byte loads in flight per lane (the kernel is a latency chain of strided L2 reads), summed in
-            // split order
-            int sp = g;
+        // 8 independent loads (16-byte ones where the source allows: bit 0 of `vec`) in flight per lane -- the kernel is a latency
+        // chain of strided L2 reads -- summed in split order.  (Until round 5 only the all-vector segments did this; the others -- tap
+        // gradients written transposed, the 450-wide relative-position-bias rows with 2048 splits -- walked their splits one by one
+        // and set the time of the launch: 60 us for 69 MB.)
+        int sp = g;
+        if (s.vec & 1) {
             for (; sp + 7 * G < s.nsplit; sp += 8 * G) {
                 f32x4 v[8];
 #pragma unroll
@@ -55,7 +57,15 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(RedDev a) {
             }
             for (; sp < s.nsplit; sp += G) acc += *reinterpret_cast<const f32x4*>(src + (long)sp * s.stride);
         } else {
-            for (int sp = g; sp < s.nsplit; sp += G)
+            for (; sp + 7 * G < s.nsplit; sp += 8 * G) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    for (int e = 0; e < 4; ++e) v[u][e] = e < ne ? src[(long)(sp + u * G) * s.stride + e] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; sp < s.nsplit; sp += G)
                 for (int e = 0; e < ne; ++e) acc[e] += src[(long)sp * s.stride + e];
         }
     }
@@ -64,7 +74,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(RedDev a) {
         for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], m);
     if (live && g == 0) {
         float* dst = s.dst + b * s.dbs + r * s.dst_ld + i4 * s.dcs;
-        if (s.vec) *reinterpret_cast<f32x4*>(dst) = acc;
+        if (s.vec & 2) *reinterpret_cast<f32x4*>(dst) = acc;
         else
             for (int e = 0; e < ne; ++e) dst[(long)e * s.dcs] = acc[e];
     }
@@ -180,14 +190,14 @@ extern "C" int mphsir_reduce_parts(const mphsir_reduce_seg* segs, int32_t nseg, 
         MPHSIR_REQUIRE(g.src && g.dst && g.n > 0 && g.nsplit > 0 && g.nbatch > 0, "reduce_parts: bad segment %d", k);
         const int rows = g.rows > 1 ? g.rows : 1, dcs = g.dst_col_stride > 0 ? g.dst_col_stride : 1;
         const long src_ld = rows > 1 ? (long)g.src_ld : 0, dst_ld = rows > 1 ? (long)g.dst_ld : 0;
-        const bool vec = aligned16(g.src) && aligned16(g.dst) && g.n % 4 == 0 && g.stride % 4 == 0 && dcs == 1 &&
-                         g.src_batch_stride % 4 == 0 && g.dst_batch_stride % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0;
+        const bool vload = aligned16(g.src) && g.n % 4 == 0 && g.stride % 4 == 0 && g.src_batch_stride % 4 == 0 && src_ld % 4 == 0;
+        const bool vstore = vload && aligned16(g.dst) && dcs == 1 && g.dst_batch_stride % 4 == 0 && dst_ld % 4 == 0;
         const long nitems = (long)g.nbatch * rows * ((g.n + 3) / 4);
         int lg = 0;                        // lanes per item: keep <= 32 splits per lane, and small segments still fill waves
         while (lg < 6 && (g.nsplit >> lg) > 32) ++lg;      // (<= 8 / <= 4 per lane measured in round 5: 21.10 / 21.29 against 21.09 ms per step)
         while (lg < 6 && (nitems << lg) < 8192 && (g.nsplit >> lg) > 4) ++lg;      // (32 k / 64 k / 128 k threads measured: no difference)
         d.s[k] = RedSegDev{g.src, g.dst, (long)g.n, (long)g.stride, (long)g.src_batch_stride, (long)g.dst_batch_stride, threads, nitems,
-                           src_ld, dst_ld, g.nsplit, vec ? 1 : 0, lg, rows, dcs};
+                           src_ld, dst_ld, g.nsplit, (vload ? 1 : 0) | (vstore ? 2 : 0), lg, rows, dcs};
         threads += ((nitems << lg) + 63) / 64 * 64;
     }
     d.threads = threads;
