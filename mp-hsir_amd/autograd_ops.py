@@ -572,6 +572,14 @@ def _packed_conv3x3(conv, w, dtype):
                                                            bwd=ops.pack_conv3x3(w, dtype, flip_transpose=True)))
 
 
+def _row_major(t):
+    """a 2-D view the token kernels can read as it is (unit column stride, 16-byte aligned rows), else one contiguous copy"""
+    es = t.element_size()
+    if t.dim() == 2 and t.stride(1) == 1 and (t.stride(0) * es) % 16 == 0 and t.data_ptr() % 16 == 0 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.contiguous()
+
+
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, conv):
@@ -588,13 +596,14 @@ class _Conv1x1(torch.autograd.Function):
         N, K = w.shape[0], w.shape[1]
         dy2, x2 = dy.reshape(-1, N), x.reshape(-1, K)
         pk = _packed_conv1x1(ctx.conv, w, x.dtype)
+        dy2 = _row_major(dy2)            # a channel slice of a wider gradient (the split of a `cat`) is read in place through its row pitch
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_tok(dy2.contiguous(), pk["wT"]).reshape(x.shape)
+            dx = ops.gemm_tok(dy2, pk["wT"]).reshape(x.shape)
         dw = None
         if ctx.needs_input_grad[1]:
             with ops.reduce_scope(leaf=True):          # w is a leaf: the sum joins the deferred parameter-gradient sums
-                dw = ops.gemm_tn(dy2.contiguous(), x2).reshape(w.shape)
+                dw = ops.gemm_tn(dy2, x2).reshape(w.shape)
         return dx, dw, None
 
 
