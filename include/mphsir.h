@@ -359,6 +359,7 @@ typedef struct mphsir_fold_bwd_args {
     const float* Gpart; const float* Spart; const float* temperature; const float* Wo; const float* dM;
     void* W2; float* dWo; float* dtemp;
     int32_t B, C, heads, nsplit;
+    int32_t dM_nsplit;          /* <= 1: dM is [B][C][C]; > 1: dM is [B][dM_nsplit][C][C], the split partials of mphsir_gemm_tn, summed here in split order */
 } mphsir_fold_bwd_args;
 int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype, void* stream);
 typedef struct mphsir_pg_bwd_args {

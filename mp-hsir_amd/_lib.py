@@ -104,7 +104,7 @@ class WinAttnBwdArgs(ctypes.Structure):
 class FoldBwdArgs(ctypes.Structure):
     """mirror of struct mphsir_fold_bwd_args"""
     _fields_ = [(n, c_void_p) for n in ("Gpart", "Spart", "temperature", "Wo", "dM", "W2", "dWo", "dtemp")] + \
-               [(n, c_int32) for n in ("B", "C", "heads", "nsplit")]
+               [(n, c_int32) for n in ("B", "C", "heads", "nsplit", "dM_nsplit")]
 
 
 class PgBwdArgs(ctypes.Structure):

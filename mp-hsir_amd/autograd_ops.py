@@ -69,7 +69,7 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     N = H * W
     M = B * N
     dt = v.dtype
-    dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), immediate=True)      # (B,C,C) fp32, read right below
+    dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), reduce=False)        # (B, splits, C, C) fp32 partials: summed by the fold backward as it stages them
     W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temperature.detach().reshape(heads).float().contiguous(),
                                                wo.detach().reshape(C, C).float().contiguous(), dM, dt, reduce=False)
     # q, k of the forward: either kept by it (qk) or recomputed by the depthwise kernel; when q|k|v are adjacent channel

@@ -18,7 +18,8 @@ namespace mphsir {
 struct FoldBwdDev {
     const float* Gpart; const float* Spart; int nsplit;
     const float* temperature; const float* Wo;
-    const float* dM;            // [B][C][C] fp32
+    const float* dM;            // [B][C][C] fp32, or [B][dm_nsplit][C][C]: the split partials of the token-reduction GEMM that produced it
+    int dm_nsplit;              // (summed in split order while they are staged: the ordered-sum launch between the two kernels is gone)
     void* W2;                   // [B][2C][2C] compute dtype
     float* dWo;                 // [B][C][C] fp32 per-sample partial (column block of this head written by its WG)
     float* dtemp;               // [B][HEADS]
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
         const float inv = 1.0f / den;
         if (on) for (int j = qd; j < HD; j += 4) A[row * LD + j] *= inv;
     }
-    const float* dM = a.dM + (long)b * C * C;
+    const int nsp = a.dm_nsplit > 1 ? a.dm_nsplit : 1;
+    const long CC = (long)C * C;
+    const float* dM = a.dM + (long)b * nsp * CC;
     float* dWo = a.dWo + (long)b * C * C;
     constexpr int NS = (36 + FB_WAVES - 1) / FB_WAVES;   // dA tiles per wave: t = wv + FB_WAVES*s < NT*NT <= 36 (head_dim <= 96)
     f32x4 accA[NS];
@@ -106,7 +109,17 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
             const int rr = idx / HD, cc = idx % HD;
             const bool in = c0 + rr < C;
             Ws[rr * LD + cc] = in ? a.Wo[(long)(c0 + rr) * C + h * HD + cc] : 0.f;
-            Ms[rr * LD + cc] = in ? dM[(long)(c0 + rr) * C + h * HD + cc] : 0.f;
+            float m = 0.f;
+            if (in) {
+                const float* mp = dM + (long)(c0 + rr) * C + h * HD + cc;
+                int sp = 0;
+                for (; sp + 4 <= nsp; sp += 4) {          // four loads in flight, summed in split order (what reduce_parts did)
+                    const float t0 = mp[sp * CC], t1 = mp[(sp + 1) * CC], t2 = mp[(sp + 2) * CC], t3 = mp[(sp + 3) * CC];
+                    m += t0; m += t1; m += t2; m += t3;
+                }
+                for (; sp < nsp; ++sp) m += mp[sp * CC];
+            }
+            Ms[rr * LD + cc] = m;
         }
         __syncthreads();
 #pragma unroll
@@ -221,7 +234,7 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold_bwd: bad shape");
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 96, "spectral_fold_bwd: head_dim %d > 96", HD);
-    FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->W2, a->dWo, a->dtemp, a->B, a->C, HD};
+    FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->dM_nsplit, a->W2, a->dWo, a->dtemp, a->B, a->C, HD};
     MPHSIR_REQUIRE(HD % 16 == 0, "spectral_fold_bwd: head_dim %d must be a multiple of 16", HD);
     const size_t shmem = ((3 * (size_t)HD + 2 * fb_co(HD)) * (HD + 8) + 9 * (size_t)HD) * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -221,7 +221,7 @@ def _dw_side(scope):
     return True
 
 
-DW_BATCH_BYTES = int(float(os.environ.get("MPHSIR_DW_BATCH_MB", "48")) * (1 << 20))
+DW_BATCH_BYTES = int(float(os.environ.get("MPHSIR_DW_BATCH_MB", "256")) * (1 << 20))      # 0 / 24 / 48 / 128 / 256 / 512 MB: 20.90 / 20.82 / 20.75 / 20.67 / 20.60 / 20.63 ms per step (one box, pairs)
 _DW_PENDING = {}
 # the ordered sums of the weight-gradient branch: 1 = all of them at the join (the end of the backward pass / a bucket hook), as few
 # launches of 32 segments as there can be, instead of one small launch behind every flush of the branch
@@ -304,6 +304,9 @@ def flush_deferred():
     _dw_join(final=False)
 
 
+LOG_SEGS = os.environ.get("MPHSIR_LOG_SEGS", "0") == "1"      # diagnostics: print the problems / segments of every grouped launch
+
+
 def _flush_calls(calls):
     """calls: deferred weight-gradient launches other than the grouped token-reduction GEMMs (dicts: `run` = the launch on the
     stream that is current NOW, `keep` = the tensors it reads / writes)."""
@@ -322,10 +325,9 @@ def _flush_gemms(gemms):
             q.A, q.lda, q.B, q.ldb, q.Cpart, q.colsum_part = g["A"], g["lda"], g["B"], g["ldb"], g["Cpart"], g["cs"]
             q.M, q.N1, q.N2, q.nsplit = g["M"], g["N1"], g["N2"], g["nsplit"]
         form = TN_FORM or (2 if all(g["form"] == 2 for g in chunk) else 1)
+        if LOG_SEGS:       # diagnostics: (M, N1, N2, nsplit, column sums) per problem of the grouped launch
+            print("gemm_tn_group form %d:" % form, [(g["M"], g["N1"], g["N2"], g["nsplit"], g["cs"] is not None) for g in chunk], flush=True)
         _lib.check(lib.mphsir_gemm_tn_group(arr, len(chunk), form, _DT[chunk[0]["keep"][0].dtype], _stream(chunk[0]["keep"][0])), "gemm_tn_group")
-
-
-LOG_SEGS = os.environ.get("MPHSIR_LOG_SEGS", "0") == "1"
 
 
 def _flush(segs):
@@ -1181,7 +1183,7 @@ MLP_WGRAD = os.environ.get("MPHSIR_MLP_WGRAD", "1") == "1"      # parameter grad
 MLP_WGRAD_NCH = int(os.environ.get("MPHSIR_MLP_WGRAD_NCH", "0"))  # chunks of 32 hidden units per workgroup: 0 = per shape, 1, 2
 MLP_WGRAD_WGS = int(os.environ.get("MPHSIR_MLP_WGRAD_WGS", "512"))
 MLP_WGRAD_MAXC = int(os.environ.get("MPHSIR_MLP_WGRAD_MAXC", "128"))
-MLP_WGRAD_CAP = float(os.environ.get("MPHSIR_MLP_WGRAD_CAP", "1.0"))   # partial bytes <= this x the bytes of the two token matrices
+MLP_WGRAD_CAP = float(os.environ.get("MPHSIR_MLP_WGRAD_CAP", "4.0"))   # partial bytes <= this x the bytes of the two token matrices (1 / 2 / 4: 21.04-21.09 / 20.98-20.99 / 20.95-20.97 ms per step: at M = 32768 a full round of workgroups -- 40 ranges instead of 24 -- is worth more than the 9 MB of partials it adds)
 
 
 def gated_mlp_wgrad_fits(M, C, HP, dtype):
@@ -1439,14 +1441,17 @@ def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True):
     _check(gp, sp, temperature, Wo, dM)
     B, nsplit, heads, hd, _ = gp.shape
     C = heads * hd
-    assert dM.shape == (B, C, C) and dM.dtype == torch.float32 and dM.is_contiguous()
+    # dM (B, C, C), or (B, splits, C, C): the raw split partials of the token-reduction GEMM (gemm_tn(..., reduce=False)) -- the kernel
+    # sums them in split order while it stages them, so no ordered-sum launch sits between the two
+    dm_nsplit = dM.shape[1] if dM.dim() == 4 else 1
+    assert dM.shape[0] == B and dM.shape[-2:] == (C, C) and dM.dtype == torch.float32 and dM.is_contiguous()
     W2 = torch.empty((B, 2 * C, 2 * C), dtype=dtype, device=gp.device)
     dWo = torch.empty((B, C, C), dtype=torch.float32, device=gp.device)
     dtemp = torch.empty((B, heads), dtype=torch.float32, device=gp.device)
     a = _lib.FoldBwdArgs()
     a.Gpart, a.Spart, a.temperature, a.Wo, a.dM = _p(gp), _p(sp), _p(temperature), _p(Wo), _p(dM)
     a.W2, a.dWo, a.dtemp = _p(W2), _p(dWo), _p(dtemp)
-    a.B, a.C, a.heads, a.nsplit = B, C, heads, nsplit
+    a.B, a.C, a.heads, a.nsplit, a.dM_nsplit = B, C, heads, nsplit, dm_nsplit
     _lib.check(lib.mphsir_spectral_fold_bwd(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold_bwd")
     _acct("spectral_fold_bwd", 4.0 * B * C * C * hd, 3.0 * B * C * C * 4)
     if not reduce:

@@ -962,6 +962,26 @@ def check_pg_gate_fwd(dev, C, cr, nW=20):
     assert rel_l2(gate, want) < 2e-5, rel_l2(gate, want)
 
 
+def check_fold_bwd_split_dm(dev, dtype, C=64, heads=2, B=2, nsp=5):
+    """mphsir_spectral_fold_bwd with dM handed over as the SPLIT PARTIALS of the token-reduction GEMM (B, splits, C, C): the kernel's
+    in-order sum while staging against the ordered-sum launch (reduce_parts) followed by the plain call"""
+    _use(dev)
+    from mp_hsir_amd import ops
+    hd = C // heads
+    gp = rnd((B, 1, heads, hd, hd), 601)
+    sp = rnd((B, 1, 2, C), 602).abs() + 0.5
+    temp = (1 + 0.3 * rnd((heads,), 603)).contiguous()
+    wo = rnd((C, C), 604, scale=C ** -0.5)
+    part = rnd((B, nsp, C, C), 605)
+    dm = ops.reduce_parts(part, batched=True)
+    a = ops.spectral_fold_bwd(gp, sp, temp, wo, dm, dtype, reduce=False)
+    b = ops.spectral_fold_bwd(gp, sp, temp, wo, part, dtype, reduce=False)
+    # (the same partials summed in a different fixed order -- reduce_parts deals the splits to lanes -- so fp32 reassociation, not bits)
+    for x, y in zip(a, b):
+        tol = 1e-6 if x.dtype == torch.float32 else 2e-3
+        assert rel_l2(y, x.double().cpu()) < tol, rel_l2(y, x.double().cpu())
+
+
 def check_channel_attention_bwd(dev, dtype, C, heads, shape, cross=False):
     """The channel ("spectral") attention backward chain -- gemm_tn (dM), spectral_fold_bwd, the [dq|dk] / dv token GEMMs,
     depthwise backward + tap gradients -- as the prompt modules use it (self: TransformerBlock :289-322; cross:

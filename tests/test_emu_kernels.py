@@ -212,6 +212,12 @@ def test_pg_gate_bwd():
     K.check_pg_gate_bwd("cpu", 192, 8, nW=6)
 
 
+@pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,heads,nsp", [(64, 2, 5), (128, 4, 12), (96, 2, 3)])
+def test_fold_bwd_takes_split_partials_of_dm(dtype, C, heads, nsp):
+    K.check_fold_bwd_split_dm("cpu", dtype, C, heads, nsp=nsp)
+
+
 @pytest.mark.parametrize("dtype,C,heads,shape,cross", [(torch.float32, 64, 2, (1, 16, 16), False), (torch.bfloat16, 128, 2, (2, 8, 16), True)])
 def test_channel_attention_bwd(dtype, C, heads, shape, cross):
     K.check_channel_attention_bwd("cpu", dtype, C, heads, shape, cross)

@@ -309,6 +309,12 @@ def test_pg_gate_bwd(factor_dtype, C, cr):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
+@pytest.mark.parametrize("C,heads,nsp", [(64, 2, 5), (128, 4, 12), (96, 2, 3)])
+def test_fold_bwd_takes_split_partials_of_dm(dtype, C, heads, nsp):
+    K.check_fold_bwd_split_dm("cuda", dtype, C, heads, nsp=nsp)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
 @pytest.mark.parametrize("C,heads,shape,cross", [(64, 2, (2, 64, 64), True), (128, 2, (2, 32, 32), True), (128, 4, (2, 64, 64), False),
                                                  (256, 8, (2, 32, 32), False), (96, 2, (1, 64, 64), True), (192, 4, (1, 64, 64), False),
                                                  (384, 8, (1, 32, 32), False), (192, 2, (1, 32, 32), True)])

@@ -1,6 +1,7 @@
 #!/bin/bash
 # lab (GPU box): whole-step experiments of round 5, one mode per call.  Each prints the bench line's value / ms_per_step per setting.
 #   tools/lab/step_sweeps.sh ab NAME A B [bench flags]   A/B of one environment knob, twice each, on the training step
+#   tools/lab/step_sweeps.sh sweep "K=V [K=V]" ...          each environment setting (plus the default, first and last) twice round-robin: ms per step
 #   tools/lab/step_sweeps.sh side                         what each captured side branch buys (step, 512x512 forward, batch-16 forward)
 #   tools/lab/step_sweeps.sh graphenv                     HIP runtime knobs for graph replay (branch queues, packet capture), with lab chains
 #   tools/lab/step_sweeps.sh procs                        two / four bench processes on one GPU against one
@@ -14,6 +15,9 @@ case $mode in
 ab)
   N=$1; A=$2; B=$3; shift 3; X="$*"
   for i in 1 2; do for v in $A $B; do echo "$N=$v: $(line $N=$v)"; done; done ;;
+sweep)
+  ms() { env "$@" python3 bench.py $F 2>&1 | tail -1 | grep -o '"ms_per_step": [0-9.]*'; }
+  for i in 1 2; do echo "default: $(ms X=1)"; for e in "$@"; do echo "$e: $(ms $e)"; done; echo "default: $(ms X=1)"; done ;;
 side)
   for X in "" "--forward-only --patch 512 --batch 1" "--forward-only --batch 16"; do
     echo "### $X"
