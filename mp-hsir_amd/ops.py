@@ -215,6 +215,9 @@ def _dw_side(scope):
         _flush_calls(scope.calls)
         _flush_gemms(scope.gemms)
         st.wait_stream(main)
+        for d2, s2 in list(_SIDE_USED):      # (as in _dw_flush_pending)
+            if d2 == dev and s2 != st:
+                st.wait_stream(s2)
         with torch.cuda.stream(st):
             _flush(scope.segs)
     _DW_KEEP.append((dev, [g["keep"] for g in scope.gemms] + [c["keep"] for c in scope.calls], [g["keep"] for g in scope.segs]))
@@ -237,6 +240,11 @@ def _dw_flush_pending(dev):
     _DW_PENDING[dev] = [[], [], [], 0]
     st = _DW_STREAM[dev]
     st.wait_stream(torch.cuda.current_stream(dev))
+    # a batch may hold problems whose operands were produced on another stream than the one that flushes it (a prompt module's own
+    # stream, MPHSIR_PROMPT_SIDE_TRAIN): the branch is ordered behind every side stream this pass has forked, not only the current one
+    for d2, s2 in list(_SIDE_USED):
+        if d2 == dev and s2 != st:
+            st.wait_stream(s2)
     with torch.cuda.stream(st):
         _flush_calls(calls)
         _flush_gemms(gemms)
