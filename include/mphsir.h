@@ -56,6 +56,7 @@ int mphsir_device_arch(char* buf, int n);
  * M % 64 == 0, N % 16 == 0, K % 32 == 0; ldx/ldy/ldr/ldsa in elements, multiples of 16 bytes.
  * w_batch_stride (elements) != 0 selects W + (m / rows_per_batch) * w_batch_stride per sample.   */
 typedef struct mphsir_gemm_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const void* X; int64_t ldx;
     const void* W; int64_t w_batch_stride; int64_t rows_per_batch;
     const float* bias;
@@ -91,6 +92,7 @@ int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* stream);
  * The spectral-prompt weights are the fp32 parameters as stored: Wprompt [128][C], prompt_param [128][r], Wq [r][r],
  * Wkv [2r][r], Wdown [r][C], Wpproj [r][r] + bpproj [r], Wup [C][r]; C % 16 == 0, r <= 32.                          */
 typedef struct mphsir_win_attn_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const void* X;
     const float* ln_w; const float* ln_b;
     const void* Wqkv; const float* bqkv;
@@ -102,6 +104,7 @@ typedef struct mphsir_win_attn_args {
     int32_t B, H, W, C, heads, shift;
 } mphsir_win_attn_args;
 typedef struct mphsir_pg_fwd_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const float* mu;
     const float* Wprompt; const float* prompt_param; const float* Wq; const float* Wkv; const float* Wdown;
     const float* Wpproj; const float* bpproj; const float* Wup;
@@ -128,6 +131,7 @@ int mphsir_win_attn_hdp(int head_dim, int dtype);
  * M[b] = Wo * blockdiag_h(softmax(...)), written as [B][C][C] in the compute dtype -- the per-sample
  * weight of the pass-B mphsir_gemm_tok over V.  (C, C/heads) as for win_attn plus (32,16),(64,16),(128,16). */
 typedef struct mphsir_gram_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const void* Tq; int64_t ldq; const void* Tk; int64_t ldk; const void* Tv; int64_t ldv;
     const float* wq; const float* wk; const float* wv; int64_t ldw;
     void* V; int64_t ldvo;
@@ -148,6 +152,7 @@ int mphsir_dwconv_gram_keeps_qk(int32_t C, int32_t W, int dtype);     /* 1 if QK
  * mphsir_spectral_fold and pass B follow unchanged.  Training passes T and QK to keep what its backward needs.
  * mphsir_qkv_dwconv_gram_fits: 1 if (C, heads, H, W, dtype) is covered (H % 8 == 0, W % 16 == 0, instantiated width). */
 typedef struct mphsir_fused_gram_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const void* X; int64_t ldx;
     const float* ln_w; const float* ln_b;   /* both or neither: LayerNorm over C (eps 1e-5) applied to X first */
     const void* Wqkv;
@@ -175,6 +180,7 @@ int mphsir_qkv_dwconv_gram_rows_fits(int32_t C, int32_t heads, int32_t H, int32_
 enum { MPHSIR_DEBUG_PG_GATE = 0, MPHSIR_DEBUG_WIN_ATTN = 1, MPHSIR_DEBUG_FUSED_PASS_A = 2 };
 int mphsir_debug(int kind, void* stamps);
 typedef struct mphsir_fold_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const float* Gpart; const float* Spart;
     const float* temperature;   /* [heads] */
     const float* Wo;            /* project_out.weight [C][C] fp32 */
@@ -192,6 +198,7 @@ int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* stream);
  * gelu on the FIRST half).  T [B*H*W][2*HP] (ldt), w9 fp32 [9][2*HP] (ldw), U [B*H*W][HP] (ldu);
  * HP = hidden width zero-padded to a multiple of 32 on both halves.                                */
 typedef struct mphsir_gate_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const void* T; int64_t ldt;
     const float* w9; int64_t ldw;
     void* U; int64_t ldu;
@@ -213,6 +220,7 @@ int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* stream);
  * workgroups per sample walk (H/8)*(W/tw)/nsplit pixel tiles of 8 x tw pixels each,
  * tw = mphsir_gdfn_fused_tile_width(D) (16 up to D = 128, 8 above).                                    */
 typedef struct mphsir_gdfn_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const void* X; int64_t ldx;
     const float* ln_w; const float* ln_b;
     const void* Win; const float* w9; int64_t ldw;
@@ -235,6 +243,7 @@ int mphsir_gdfn_fused_tile_width(int32_t D);
  * HP = hid rounded up to a multiple of 32.  C in {32,64,96,128,192,256,384}; M % 64 == 0.
  * Y may alias X.                                                                                 */
 typedef struct mphsir_mlp_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const void* X; int64_t ldx;
     const float* ln_w; const float* ln_b;
     const void* W1; const float* b1;
@@ -271,6 +280,7 @@ int mphsir_gated_mlp_fwd_fuses(int32_t C, int64_t M, int dtype);     /* 1 where 
  * W1/b1 as for the forward; W1T = W1 transposed [C][2*HP]; W2T = fc2.weight^T zero-padded [HP][C].
  * fp32 supports C <= 256.  Autograd of train.py:58-67 for net/MP_HSIR.py:719.                       */
 typedef struct mphsir_mlp_bwd_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const void* X; const void* dY; const void* DM;
     const float* ln_w; const float* ln_b;
     const void* W1; const float* b1; const void* W1T; const void* W2T;
@@ -297,6 +307,7 @@ int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream);
  * (zeros).  W1 / b1 / W2T as for mphsir_gated_mlp_bwd.  mphsir_gated_mlp_wgrad_fits: which (C, chunks_per_wg, dtype) exist.
  * Autograd of train.py:58-67 for net/MP_HSIR.py:66-82 (fc1, fc2 of GatedMlp).                                            */
 typedef struct mphsir_mlp_wgrad_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const void* XN; const void* DM;
     const void* W1; const float* b1; const void* W2T;
     float* dW1p; float* dW2p; float* db1p; float* db2p;
@@ -326,6 +337,7 @@ int mphsir_gated_mlp_wgrad_fits(int32_t C, int32_t chunks_per_wg, int dtype);
 int mphsir_combine_bwd(const void* dY, const void* SA, const float* gate, const float* keep, void* dOut, void* dSA,
                        float* dgate, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
 typedef struct mphsir_win_attn_bwd_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const void* X; const void* dSA; const float* dmu;
     const float* ln_w; const float* ln_b;
     const void* Wqkv; const float* bqkv; const float* rpb; const void* WprojT;
@@ -356,6 +368,7 @@ int mphsir_layernorm_tok(const void* X, int x_dtype, const float* ln_w, const fl
  *   (KL >= C+5r+256, KR >= 5r+1+C, multiples of 4): L^T R over the windows (mphsir_gemm_tn, fp32) holds every
  *   parameter gradient of PG_Spectral_Attention (net/MP_HSIR.py:122-129) as a sub-block.                        */
 typedef struct mphsir_fold_bwd_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const float* Gpart; const float* Spart; const float* temperature; const float* Wo; const float* dM;
     void* W2; float* dWo; float* dtemp;
     int32_t B, C, heads, nsplit;
@@ -363,6 +376,7 @@ typedef struct mphsir_fold_bwd_args {
 } mphsir_fold_bwd_args;
 int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype, void* stream);
 typedef struct mphsir_pg_bwd_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
     const float* mu; const float* dgate;
     const float* Wprompt; const float* prompt_param; const float* Wq; const float* Wkv; const float* Wdown;
     const float* Wpproj; const float* bpproj; const float* Wup;

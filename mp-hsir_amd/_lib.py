@@ -15,18 +15,30 @@ c_void_p, c_int64, c_int32, c_int, c_float_p = (ctypes.c_void_p, ctypes.c_int64,
                                                 ctypes.POINTER(ctypes.c_float))
 
 
-class GemmArgs(ctypes.Structure):
+class _Args(ctypes.Structure):
+    """base of every mphsir_*_args mirror: the first member, struct_size, is filled in on construction (the library refuses a struct
+    of another size: include/mphsir.h)"""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(self)
+
+
+_SZ = [("struct_size", ctypes.c_uint32)]
+
+
+class GemmArgs(_Args):
     """mirror of struct mphsir_gemm_args"""
-    _fields_ = [("X", c_void_p), ("ldx", c_int64), ("W", c_void_p), ("w_batch_stride", c_int64),
+    _fields_ = _SZ + [("X", c_void_p), ("ldx", c_int64), ("W", c_void_p), ("w_batch_stride", c_int64),
                 ("rows_per_batch", c_int64), ("bias", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p),
                 ("Y", c_void_p), ("ldy", c_int64), ("M", c_int64), ("N", c_int64), ("K", c_int64),
                 ("epi", c_int), ("R", c_void_p), ("ldr", c_int64), ("SA", c_void_p), ("ldsa", c_int64),
                 ("gate", c_void_p), ("keep", c_void_p), ("H", c_int32), ("Wimg", c_int32), ("shift", c_int32), ("form", c_int32)]
 
 
-class MlpArgs(ctypes.Structure):
+class MlpArgs(_Args):
     """mirror of struct mphsir_mlp_args"""
-    _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("W1", c_void_p),
+    _fields_ = _SZ + [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("W1", c_void_p),
                 ("b1", c_void_p), ("W2", c_void_p), ("b2", c_void_p), ("keep", c_void_p), ("rows_per_batch", c_int64),
                 ("Y", c_void_p), ("ldy", c_int64), ("M", c_int64), ("C", c_int32), ("HP", c_int32), ("tiles_per_wave", c_int32),
                 ("hsplit", c_int32), ("ypart", c_void_p), ("R", c_void_p), ("ldr", c_int64),
@@ -34,82 +46,82 @@ class MlpArgs(ctypes.Structure):
                 ("pgate", c_void_p), ("pkeep", c_void_p), ("Yb", c_void_p), ("ldyb", c_int64), ("H", c_int32), ("Wimg", c_int32), ("shift", c_int32)]
 
 
-class WinAttnArgs(ctypes.Structure):
+class WinAttnArgs(_Args):
     """mirror of struct mphsir_win_attn_args"""
-    _fields_ = [(n, c_void_p) for n in ("X", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "Wproj", "bproj", "SA", "mu", "Oattn")] + \
+    _fields_ = _SZ + [(n, c_void_p) for n in ("X", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "Wproj", "bproj", "SA", "mu", "Oattn")] + \
                [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift")]
 
 
-class PgFwdArgs(ctypes.Structure):
+class PgFwdArgs(_Args):
     """mirror of struct mphsir_pg_fwd_args"""
-    _fields_ = [(n, c_void_p) for n in ("mu", "Wprompt", "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup", "gate")] + \
+    _fields_ = _SZ + [(n, c_void_p) for n in ("mu", "Wprompt", "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup", "gate")] + \
                [(n, c_int32) for n in ("nW", "C", "r")]
 
 
-class GramArgs(ctypes.Structure):
+class GramArgs(_Args):
     """mirror of struct mphsir_gram_args"""
-    _fields_ = [("Tq", c_void_p), ("ldq", c_int64), ("Tk", c_void_p), ("ldk", c_int64), ("Tv", c_void_p), ("ldv", c_int64),
+    _fields_ = _SZ + [("Tq", c_void_p), ("ldq", c_int64), ("Tk", c_void_p), ("ldk", c_int64), ("Tv", c_void_p), ("ldv", c_int64),
                 ("wq", c_void_p), ("wk", c_void_p), ("wv", c_void_p), ("ldw", c_int64), ("V", c_void_p), ("ldvo", c_int64),
                 ("Gpart", c_void_p), ("Spart", c_void_p)] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nsplit")] + \
                [("QK", c_void_p), ("ldqk", c_int64)]
 
 
-class FusedGramArgs(ctypes.Structure):
+class FusedGramArgs(_Args):
     """mirror of struct mphsir_fused_gram_args"""
-    _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("Wqkv", c_void_p), ("w9", c_void_p),
+    _fields_ = _SZ + [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("Wqkv", c_void_p), ("w9", c_void_p),
                 ("ldw", c_int64), ("V", c_void_p), ("ldvo", c_int64), ("Gpart", c_void_p), ("Spart", c_void_p)] + \
                [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nsplit", "head_groups")] + \
                [("T", c_void_p), ("ldt", c_int64), ("QK", c_void_p), ("ldqk", c_int64), ("row_segments", c_int32)]
 
 
-class FoldArgs(ctypes.Structure):
+class FoldArgs(_Args):
     """mirror of struct mphsir_fold_args"""
-    _fields_ = [("Gpart", c_void_p), ("Spart", c_void_p), ("temperature", c_void_p), ("Wo", c_void_p), ("M", c_void_p),
+    _fields_ = _SZ + [("Gpart", c_void_p), ("Spart", c_void_p), ("temperature", c_void_p), ("Wo", c_void_p), ("M", c_void_p),
                 ("MT", c_void_p)] + \
                [(n, c_int32) for n in ("B", "C", "heads", "nsplit")] + [("Gsum", c_void_p), ("Ssum", c_void_p)]
 
 
-class GateArgs(ctypes.Structure):
+class GateArgs(_Args):
     """mirror of struct mphsir_gate_args"""
-    _fields_ = [("T", c_void_p), ("ldt", c_int64), ("w9", c_void_p), ("ldw", c_int64), ("U", c_void_p), ("ldu", c_int64)] + \
+    _fields_ = _SZ + [("T", c_void_p), ("ldt", c_int64), ("w9", c_void_p), ("ldw", c_int64), ("U", c_void_p), ("ldu", c_int64)] + \
                [(n, c_int32) for n in ("B", "H", "W", "HP")]
 
 
-class GdfnArgs(ctypes.Structure):
+class GdfnArgs(_Args):
     """mirror of struct mphsir_gdfn_args"""
-    _fields_ = [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("Win", c_void_p), ("w9", c_void_p),
+    _fields_ = _SZ + [("X", c_void_p), ("ldx", c_int64), ("ln_w", c_void_p), ("ln_b", c_void_p), ("Win", c_void_p), ("w9", c_void_p),
                 ("ldw", c_int64), ("Wout", c_void_p), ("Y", c_void_p), ("ldy", c_int64)] + \
                [(n, c_int32) for n in ("B", "H", "W", "D", "HP", "nsplit")] + [("T", c_void_p), ("ldt", c_int64)]
 
 
-class MlpBwdArgs(ctypes.Structure):
+class MlpBwdArgs(_Args):
     """mirror of struct mphsir_mlp_bwd_args"""
-    _fields_ = [(n, c_void_p) for n in ("X", "dY", "DM", "ln_w", "ln_b", "W1", "b1", "W1T", "W2T", "dX", "XN", "H", "DPRE", "part")] + \
+    _fields_ = _SZ + [(n, c_void_p) for n in ("X", "dY", "DM", "ln_w", "ln_b", "W1", "b1", "W1T", "W2T", "dX", "XN", "H", "DPRE", "part")] + \
                [("M", c_int64), ("C", c_int32), ("HP", c_int32), ("variant", c_int32), ("keep", c_void_p), ("rows_per_batch", c_int64),
                 ("hsplit", c_int32), ("dxn_part", c_void_p)]
 
 
-class MlpWgradArgs(ctypes.Structure):
+class MlpWgradArgs(_Args):
     """mirror of struct mphsir_mlp_wgrad_args"""
-    _fields_ = [(n, c_void_p) for n in ("XN", "DM", "W1", "b1", "W2T", "dW1p", "dW2p", "db1p", "db2p")] + \
+    _fields_ = _SZ + [(n, c_void_p) for n in ("XN", "DM", "W1", "b1", "W2T", "dW1p", "dW2p", "db1p", "db2p")] + \
                [("M", c_int64), ("C", c_int32), ("HP", c_int32), ("ranges", c_int32), ("chunks_per_wg", c_int32)]
 
 
-class WinAttnBwdArgs(ctypes.Structure):
+class WinAttnBwdArgs(_Args):
     """mirror of struct mphsir_win_attn_bwd_args"""
-    _fields_ = [(n, c_void_p) for n in ("X", "dSA", "dmu", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "WprojT", "dQKV", "XNw",
+    _fields_ = _SZ + [(n, c_void_p) for n in ("X", "dSA", "dmu", "ln_w", "ln_b", "Wqkv", "bqkv", "rpb", "WprojT", "dQKV", "XNw",
                                          "dSAt", "drpb")] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "shift", "head_split")]
 
 
-class FoldBwdArgs(ctypes.Structure):
+class FoldBwdArgs(_Args):
     """mirror of struct mphsir_fold_bwd_args"""
-    _fields_ = [(n, c_void_p) for n in ("Gpart", "Spart", "temperature", "Wo", "dM", "W2", "dWo", "dtemp")] + \
+    _fields_ = _SZ + [(n, c_void_p) for n in ("Gpart", "Spart", "temperature", "Wo", "dM", "W2", "dWo", "dtemp")] + \
                [(n, c_int32) for n in ("B", "C", "heads", "nsplit", "dM_nsplit")]
 
 
-class PgBwdArgs(ctypes.Structure):
+class PgBwdArgs(_Args):
     """mirror of struct mphsir_pg_bwd_args"""
-    _fields_ = [(n, c_void_p) for n in ("mu", "dgate", "Wprompt", "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup",
+    _fields_ = _SZ + [(n, c_void_p) for n in ("mu", "dgate", "Wprompt", "prompt_param", "Wq", "Wkv", "Wdown", "Wpproj", "bpproj", "Wup",
                                          "dmu", "L", "R")] + [(n, c_int32) for n in ("nW", "C", "r", "KL", "KR", "lr_bf16")]
 
 

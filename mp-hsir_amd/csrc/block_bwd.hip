@@ -644,6 +644,7 @@ extern "C" int mphsir_combine_bwd(const void* dY, const void* SA, const float* g
 extern "C" int mphsir_win_attn_bwd(const mphsir_win_attn_bwd_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "win_attn_bwd");
     MPHSIR_REQUIRE(a && a->X && a->dSA && a->dmu && a->ln_w && a->ln_b && a->Wqkv && a->bqkv && a->rpb && a->WprojT && a->dQKV &&
                        a->XNw && a->dSAt && a->drpb, "win_attn_bwd: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "win_attn_bwd: dtype %d unsupported", dtype);

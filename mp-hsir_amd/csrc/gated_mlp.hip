@@ -191,8 +191,11 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
 
     // ---- fused branch sum (PB): the tile's rows y = X + pkeep * (PSA * gate[window] + PV Mb^T) are formed here: in Xs for the
     // LayerNorm below (normalised in place), in registers for the residual of the epilogue, in Yb for the backward ------------------
+    // (the rows y are NOT kept in registers for the epilogue's residual -- 16 registers across the whole hidden loop pushed this form
+    // 18 registers over the 128 that two workgroups per CU leave: it spilled -- but re-read there by the thread that stored them, from
+    // Yb, or, when the caller keeps no y, from the output rows Y, which receive y first and z later)
     constexpr int NVR = C / VEC, NIT = PB ? BM * NVR / NTHR : 1;
-    Vec16<T> yreg[NIT];
+    T* Ykeep = nullptr;
     if constexpr (PB) {
         static_assert(TT == 1 && NWV == 8 && sizeof(T) == 2 && (BM * NVR) % NTHR == 0, "fused branch sum: eight waves, one token tile each, 16-bit types");
         constexpr int LDF = C + 4, NKC0 = C / TR::KCHUNK;
@@ -202,16 +205,13 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
         const T* V = reinterpret_cast<const T*>(a.PV);
         const T* Mb = reinterpret_cast<const T*>(a.PM) + (long)bsmp * a.pms;
         T* Ms = W1s;                                     // [C][LDX] over W1s | W2s | Hs;  the V tile goes to Xs
-        // the epilogue's rows of X and PSA are requested now (registers are free until the hidden loop): their round trip runs
-        // under the staging, the product and its barriers instead of behind them
+        // (requesting the epilogue's rows of X and PSA here, under the staging and the product, measured level in round 5 and held 32
+        // registers across the product: they are read where they are used)
         const T* SA = reinterpret_cast<const T*>(a.PSA);
-        Vec16<T> xr[NIT], sr[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + NTHR * it, r = idx / NVR, c0 = (idx % NVR) * VEC;
             store16<T>(Xs + r * LDX + c0, load16<T>(V + (long)(m0 + r) * a.ldpv + c0));
-            xr[it] = load16<T>(X + (long)(m0 + r) * a.ldx + c0);
-            sr[it] = load16<T>(SA + (long)(m0 + r) * a.ldpsa + c0);
         }
         for (int idx = tid; idx < C * NVR; idx += NTHR) {
             const int r = idx / NVR, c0 = (idx % NVR) * VEC;
@@ -237,7 +237,9 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
         __syncthreads();
         // a thread finishes 8 consecutive channels of a token: 16-byte loads of X and PSA, one rounding -- the arithmetic of
         // gemm_tok's epilogue 2, element for element
-        T* Yb = reinterpret_cast<T*>(a.Yb);
+        Ykeep = a.Yb ? reinterpret_cast<T*>(a.Yb) : reinterpret_cast<T*>(a.Y);
+        const long ldk = a.Yb ? a.ldyb : a.ldy;
+        Vec16<T> yreg[NIT];
         const float kf1 = a.pkeep ? a.pkeep[bsmp] : 1.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -250,11 +252,11 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
             const float* gp = a.pgate + ((long)bsmp * (hw / 64) + (ys >> 3) * (a.Wimg >> 3) + (xs >> 3)) * C + c;
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
             const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-            const Vec16<T> rr = xr[it], sa = sr[it];
+            const Vec16<T> rr = load16<T>(X + m * a.ldx + c), sa = load16<T>(SA + m * a.ldpsa + c);
             Vec16<T> o;
             for (int e = 0; e < 8; ++e) o.set(e, rr.get(e) + kf1 * (sa.get(e) * g[e] + v[e]));
             yreg[it] = o;
-            if (Yb) store16<T>(Yb + m * a.ldyb + c, o);
+            store16<T>(Ykeep + m * ldk + c, o);
         }
         __syncthreads();                                 // the stage is consumed: the rows go where the LayerNorm expects them
 #pragma unroll
@@ -358,29 +360,9 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
 #pragma unroll
         for (int t = 0; t < TT; ++t)
             for (int u = 0; u < 2; ++u) { vv[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; gg[t][u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        // PIPE (eight waves, one token tile per wave, C <= 128: registers to spare at two waves per SIMD): the four weight fragments of
-        // K chunk kc + 1 are requested before the MFMAs of chunk kc and the scheduler is kept from sinking each read down to its use
-        // (left alone it serialises read -> wait -> MFMA with one or two reads in flight: the LDS latency in front of most MFMAs).
-        constexpr bool PIPE = false && NWV == 8 && TT == 1 && C <= 256 && sizeof(T) == 2;   // measured SLOWER on the MI355X (M = 131072, C = 128: 65.8 -> 72.7 us; M = 262144: 120 -> 141): off
-        if constexpr (PIPE) {
-            frag_t wq[2][4];
-            auto fetch = [&](int kc) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wq[kc & 1][i] = load_frag<T>(W1s, LDX, 16 * i, kc * TR::KCHUNK);
-            };
-            fetch(0);
-#pragma unroll
-            for (int kc = 0; kc < NKC; ++kc) {
-                const int b = kc & 1;
-                if (kc + 1 < NKC) fetch(kc + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(vv[0][0], wq[b][0], bx[0][kc]);
-                mma(vv[0][1], wq[b][1], bx[0][kc]);
-                mma(gg[0][0], wq[b][2], bx[0][kc]);
-                mma(gg[0][1], wq[b][3], bx[0][kc]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
+        // (requesting the four weight fragments of K chunk kc + 1 before the MFMAs of chunk kc, with scheduling barriers, was measured
+        // SLOWER here -- M = 131072, C = 128: 65.8 -> 72.7 us -- and is gone; the backward and the weight-gradient kernel keep it)
+        {
 #pragma unroll
             for (int kc = 0; kc < NKC; ++kc) {
                 const int kk = kc * TR::KCHUNK;
@@ -405,25 +387,7 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
                 store4<T>(Hw + (t * 16 + (lane & 15)) * LDH + u * 16 + hr, h);
             }
         wave_barrier();                                    // Hw is wave-private
-        if constexpr (PIPE) {
-            constexpr int GW = NCT % 4 == 0 ? 4 : 2, NG = NCT / GW;      // fc2 fragments in groups, the next group requested a group ahead
-            static_assert(32 == TR::KCHUNK && NCT % GW == 0, "one K chunk per hidden chunk");
-            const frag_t bh = load_frag<T>(Hw, LDH, 0, 0);
-            frag_t w2q[2][GW];
-            auto fetch = [&](int g) {
-#pragma unroll
-                for (int i = 0; i < GW; ++i) w2q[g & 1][i] = load_frag<T>(W2s, LDH, (g * GW + i) * 16, 0);
-            };
-            fetch(0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) fetch(g + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < GW; ++i) mma(out[0][g * GW + i], w2q[g & 1][i], bh);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
+        {
 #pragma unroll
             for (int kk = 0; kk < 32; kk += TR::KCHUNK) {
                 frag_t bh[TT];
@@ -467,12 +431,13 @@ __global__ __launch_bounds__(64 * NWV, PB ? 4 : (NWV == 8 ? 2 : 1)) void gated_m
     constexpr int NV = C / VEC;
     constexpr int NEP = BM * NV / NTHR;                 // = TT * NV / 4: whole
     static_assert((BM * NV) % NTHR == 0, "epilogue: whole passes");
-#pragma unroll PB ? NEP : 1
+#pragma unroll PB ? 2 : 1
     for (int it = 0; it < NEP; ++it) {
         const int idx = tid + it * NTHR, r = idx / NV, c0 = (idx % NV) * VEC, m = m0 + r;
         const float kf = a.keep ? a.keep[m / a.rpb] : 1.f;
         Vec16<T> x;
-        if constexpr (PB) x = yreg[it]; else x = load16<T>(X + (long)m * a.ldx + c0);
+        if constexpr (PB) x = load16<T>(Ykeep + (long)m * (a.Yb ? a.ldyb : a.ldy) + c0);      // this thread's own store of the prologue
+        else x = load16<T>(X + (long)m * a.ldx + c0);
         const Vec16<T> h = load16<T>(Xs + r * LDX + c0);
         Vec16<T> o;
         if (a.R) {
@@ -587,6 +552,7 @@ extern "C" int mphsir_gated_mlp_fwd_fuses(int32_t C, int64_t M, int dtype) {
 extern "C" int mphsir_gated_mlp_fwd(const mphsir_mlp_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "gated_mlp_fwd");
     MPHSIR_REQUIRE(a && a->X && a->Y && a->W1 && a->W2 && a->b1 && a->b2 && a->ln_w && a->ln_b, "gated_mlp: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "gated_mlp: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2;

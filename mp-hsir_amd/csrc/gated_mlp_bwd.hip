@@ -775,6 +775,7 @@ static int dispatch_mlp_bwd(const MlpBwdDev& d, int C, int variant, hipStream_t 
 extern "C" int mphsir_gated_mlp_bwd(const mphsir_mlp_bwd_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "gated_mlp_bwd");
     MPHSIR_REQUIRE(a && a->X && a->dY && a->DM && a->ln_w && a->ln_b && a->W1 && a->b1 && a->W1T && a->W2T && a->dX && a->XN &&
                        a->part && (!a->H == !a->DPRE), "gated_mlp_bwd: null pointer (H and DPRE: both or neither)");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "gated_mlp_bwd: dtype %d unsupported", dtype);

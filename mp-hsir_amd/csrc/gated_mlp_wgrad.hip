@@ -293,6 +293,7 @@ extern "C" int mphsir_gated_mlp_wgrad_fits(int32_t C, int32_t chunks_per_wg, int
 extern "C" int mphsir_gated_mlp_wgrad(const mphsir_mlp_wgrad_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "gated_mlp_wgrad");
     MPHSIR_REQUIRE(a && a->XN && a->DM && a->W1 && a->b1 && a->W2T && a->dW1p && a->dW2p && a->db1p && a->db2p, "gated_mlp_wgrad: null pointer");
     MPHSIR_REQUIRE(dtype == MPHSIR_BF16 || dtype == MPHSIR_F16, "gated_mlp_wgrad: 16-bit element types only (dtype %d)", dtype);
     MPHSIR_REQUIRE(a->M > 0 && a->M % 64 == 0 && a->HP > 0 && a->HP % 32 == 0, "gated_mlp_wgrad: M %% 64 and HP %% 32 must be 0");

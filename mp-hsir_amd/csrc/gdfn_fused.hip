@@ -373,6 +373,7 @@ extern "C" int mphsir_gdfn_fused_fits(int32_t D, int32_t HP, int32_t H, int32_t 
 extern "C" int mphsir_gdfn_fused(const mphsir_gdfn_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "gdfn_fused");
     MPHSIR_REQUIRE(a && a->X && a->ln_w && a->ln_b && a->Win && a->w9 && a->Wout && a->Y, "gdfn_fused: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "gdfn_fused: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->B > 0 && mphsir_gdfn_fused_fits(a->D, a->HP, a->H, a->W, dtype),

@@ -440,6 +440,7 @@ static int dispatch_gemm(const GemmDev& d, int epi, bool ln, int form, hipStream
 extern "C" int mphsir_gemm_tok(const mphsir_gemm_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "gemm_tok");
     MPHSIR_REQUIRE(a && a->X && a->W && a->Y, "gemm_tok: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "gemm_tok: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2;

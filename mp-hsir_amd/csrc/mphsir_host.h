@@ -29,6 +29,16 @@ bool diag_skip(int kid);
         }                                  \
     } while (0)
 
+// Every mphsir_*_args struct starts with struct_size = sizeof(the struct as the CALLER compiled it): a caller built against an
+// older include/mphsir.h (the structs grow at the end) is refused instead of having fields read past the end of its struct.
+#define MPHSIR_CHECK_ARGS(a, fn)                                                                                          \
+    do {                                                                                                                  \
+        MPHSIR_REQUIRE((a) != nullptr, "%s: null pointer (args)", fn);                                                     \
+        MPHSIR_REQUIRE((a)->struct_size == (uint32_t)sizeof(*(a)),                                                         \
+                       "%s: args struct_size %u, this library expects %u (built against another include/mphsir.h?)", fn,   \
+                       (unsigned)(a)->struct_size, (unsigned)sizeof(*(a)));                                                \
+    } while (0)
+
 // Launches `kern` (a __global__ function, already instantiated) and reports launch errors.
 #define MPHSIR_LAUNCH(kid, kern, grid, block, shmem, stream, ...)                                   \
     do {                                                                                            \

@@ -513,6 +513,7 @@ void pg_debug_buffer(unsigned long long* p) { g_pg_dbg = p; }
 extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "pg_gate_fwd");
     MPHSIR_REQUIRE(a && a->mu && a->Wprompt && a->prompt_param && a->Wq && a->Wkv && a->Wdown && a->Wpproj && a->bpproj && a->Wup && a->gate,
                    "pg_gate_fwd: null pointer");
     MPHSIR_REQUIRE(a->nW > 0 && a->C > 0 && a->C % 16 == 0 && a->r > 0 && a->r <= PG_RMAX, "pg_gate_fwd: need C %% 16 == 0 and 0 < r <= 32");
@@ -539,6 +540,7 @@ extern "C" int mphsir_pg_gate_fwd(const mphsir_pg_fwd_args* a, void* stream) {
 extern "C" int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "pg_gate_bwd");
     MPHSIR_REQUIRE(a && a->mu && a->dgate && a->Wprompt && a->prompt_param && a->Wq && a->Wkv && a->Wdown && a->Wpproj && a->bpproj &&
                        a->Wup && a->dmu && a->L && a->R, "pg_gate_bwd: null pointer");
     MPHSIR_REQUIRE(a->nW > 0 && a->C > 0 && a->C % 16 == 0 && a->r > 0 && a->r <= PG_RMAX, "pg_gate_bwd: need C %% 16 == 0 and 0 < r <= 32");

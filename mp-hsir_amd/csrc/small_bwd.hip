@@ -229,6 +229,7 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
 extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "spectral_fold_bwd");
     MPHSIR_REQUIRE(a && a->Gpart && a->Spart && a->temperature && a->Wo && a->dM && a->W2 && a->dWo && a->dtemp, "spectral_fold_bwd: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "spectral_fold_bwd: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold_bwd: bad shape");

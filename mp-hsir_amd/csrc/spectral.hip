@@ -623,6 +623,7 @@ static int dispatch_gram(const GramDev& d, int C, int HD, hipStream_t s) {
 extern "C" int mphsir_dwconv_gram(const mphsir_gram_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "dwconv_gram");
     MPHSIR_REQUIRE(a && a->Tq && a->Tk && a->Tv && a->wq && a->wk && a->wv && a->V && a->Gpart && a->Spart, "dwconv_gram: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "dwconv_gram: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2;
@@ -650,6 +651,7 @@ extern "C" int mphsir_dwconv_gram_keeps_qk(int32_t C, int32_t W, int dtype) {
 extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "spectral_fold");
     MPHSIR_REQUIRE(a && a->Gpart && a->Spart && a->temperature && a->Wo && a->M, "spectral_fold: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "spectral_fold: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold: bad shape");
@@ -687,6 +689,7 @@ extern "C" int mphsir_spectral_fold(const mphsir_fold_args* a, int dtype, void* 
 extern "C" int mphsir_dwconv_gate(const mphsir_gate_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "dwconv_gate");
     MPHSIR_REQUIRE(a && a->T && a->w9 && a->U, "dwconv_gate: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "dwconv_gate: dtype %d unsupported", dtype);
     const int esz = dtype == MPHSIR_F32 ? 4 : 2;

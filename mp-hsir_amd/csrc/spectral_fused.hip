@@ -462,6 +462,7 @@ extern "C" int mphsir_qkv_dwconv_gram_fits(int32_t C, int32_t heads, int32_t H, 
 extern "C" int mphsir_qkv_dwconv_gram(const mphsir_fused_gram_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "qkv_dwconv_gram");
     MPHSIR_REQUIRE(a && a->X && a->Wqkv && a->w9 && a->V && a->Gpart && a->Spart, "qkv_dwconv_gram: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "qkv_dwconv_gram: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C > 0 && a->C % a->heads == 0, "qkv_dwconv_gram: bad shape");

@@ -443,6 +443,7 @@ namespace mphsir { void win_debug_buffer(unsigned long long* p) { g_win_dbg = p;
 extern "C" int mphsir_win_attn_fwd(const mphsir_win_attn_args* a, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
+    MPHSIR_CHECK_ARGS(a, "win_attn_fwd");
     MPHSIR_REQUIRE(a && a->X && a->SA && a->mu && a->Wqkv && a->bqkv && a->rpb && a->Wproj && a->bproj && a->ln_w && a->ln_b,
                    "win_attn: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "win_attn: dtype %d unsupported", dtype);

@@ -480,11 +480,11 @@ class MP_HSIR_Net(nn.Module):                                                   
         # the prompt branch of each level (ref :827, :835 -- there in program order behind the stages below) is forked where its input
         # exists and joined where the decoder of that level reads it: a parallel branch of the captured graph (inference only,
         # see ops.PROMPT_SIDE)
-        fork = ops.PROMPT_SIDE and (ops.PROMPT_SIDE_TRAIN or not torch.is_grad_enabled())
-        with ops.side_stream(e1, fork, "prompt1") as br1:
+        fork = ops.PROMPT_SIDE and not torch.is_grad_enabled()
+        with ops.side_stream(e1, fork, "prompt1", track=False) as br1:
             f1 = self.fusion1(e1, self.prompt1(e1, clip, w))
         e2 = self.encoder_level2(AG.pixel_unshuffle2(AG.conv3x3(e1, self.down1_2.body[0])))
-        with ops.side_stream(e2, fork, "prompt2") as br2:
+        with ops.side_stream(e2, fork, "prompt2", track=False) as br2:
             f2 = self.fusion2(e2, self.prompt2(e2, clip, w))
         lat = self.latent(AG.pixel_unshuffle2(AG.conv3x3(e2, self.down2_3.body[0])))
         d2_in = AG.pixel_shuffle2(AG.conv3x3(lat, self.up3_2.body[0]))

@@ -58,19 +58,16 @@ _SIDE = {}
 SIDE_BRANCH = os.environ.get("MPHSIR_SIDE_BRANCH", "1") == "1"
 # the prompt modules of a pyramid level (TVSP + PromptFusion: prompt1 / fusion1 on e1, prompt2 / fusion2 on e2) feed the DECODER of that
 # level only: issued on streams of their own they run beside the encoder / latent / decoder stages below them, whose launches leave
-# part of the chip idle.  Inference only (512x512 forward 7.32 -> 6.97 ms, batch-16 forward 3.70 -> 3.38 ms): in training the branches
-# bought nothing (21.5 ms either way) and, together with the weight-gradient branch below, a two-step AdamW check against the
-# reference failed in graph mode on prompt1.text_prompt_learnable: its gradient comes out of the LAST kernels of the prompt stream's
-# backward (plain torch ops behind the stream's last weight-gradient fork), and in the captured step nothing made the launch stream
-# wait for that tail before the gradient hand-over -- with the sums issued in line the launch stream is merely late enough.  (Making
-# the weight-gradient stream wait for the prompt1 stream at every fork, and with it the final join, makes the check pass 3 / 3; waiting
-# for the gate or the prompt2 stream does not.)  Round 5: every side stream a backward pass has used is now joined explicitly where
-# gradients are handed over (_SIDE_USED, _dw_join) -- the join that analysis called for -- and the failing configuration is kept as a
-# test (tests/test_gpu_model.py::test_tiny_adamw_graph_with_prompt_streams_in_training, MPHSIR_PROMPT_SIDE_TRAIN=1): it STILL fails
-# (expected-failure), so the missing ordering is not only at the hand-over.  Training does not fork the prompt modules (no gain).
+# part of the chip idle.  NO-GRAD FORWARD ONLY (512x512 forward 7.32 -> 6.97 ms, batch-16 forward 3.70 -> 3.38 ms).  In training the
+# branches bought nothing (21.5 ms either way), and under capture together with the weight-gradient branch below they produced a wrong
+# prompt1.text_prompt_learnable gradient twice (rounds 4 and 5: plain autograd ops on the prompt stream behind its last explicit join;
+# one ordering hole was found and closed, a second configuration stayed 4 % off): round 6 removed the training switch
+# (MPHSIR_PROMPT_SIDE_TRAIN) instead of shipping a knob known to yield wrong gradients -- the module forks them under no_grad only.
 PROMPT_SIDE = os.environ.get("MPHSIR_PROMPT_SIDE", "1") == "1"
-PROMPT_SIDE_TRAIN = os.environ.get("MPHSIR_PROMPT_SIDE_TRAIN", "0") == "1"
-_SIDE_USED = set()        # (device, stream) of every side stream forked since the last final join
+# (device, stream) of every TRACKED side stream forked since the backward pass began: the gradient hand-over waits for them (_dw_join).
+# Only streams a backward pass can have work on are tracked (the prompt gate's); the no-grad prompt-module streams are not -- a captured
+# training step must never wait on a stream that was last used outside its capture.
+_SIDE_USED = set()
 
 
 class side_stream:
@@ -79,9 +76,10 @@ class side_stream:
     (record_stream).  Works under hipGraph capture (fork/join from the capturing stream = parallel graph branches).
     No-op on CPU tensors (emulator) or when disabled."""
 
-    def __init__(self, like, enabled=True, name="gate"):
+    def __init__(self, like, enabled=True, name="gate", track=True):
         self.on = enabled and like.is_cuda
         self.ctx = None
+        self.track = track
         if self.on:
             dev = like.device
             self.main = torch.cuda.current_stream(dev)
@@ -92,7 +90,8 @@ class side_stream:
     def __enter__(self):
         if self.on:
             self.side.wait_stream(self.main)
-            _SIDE_USED.add((self.main.device, self.side))
+            if self.track:
+                _SIDE_USED.add((self.main.device, self.side))
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
         return self
@@ -240,8 +239,8 @@ def _dw_flush_pending(dev):
     _DW_PENDING[dev] = [[], [], [], 0]
     st = _DW_STREAM[dev]
     st.wait_stream(torch.cuda.current_stream(dev))
-    # a batch may hold problems whose operands were produced on another stream than the one that flushes it (a prompt module's own
-    # stream, MPHSIR_PROMPT_SIDE_TRAIN): the branch is ordered behind every side stream this pass has forked, not only the current one
+    # a batch may hold problems whose operands were produced on another stream than the one that flushes it: the branch is ordered
+    # behind every (tracked) side stream this pass has forked, not only the current one
     for d2, s2 in list(_SIDE_USED):
         if d2 == dev and s2 != st:
             st.wait_stream(s2)
@@ -271,9 +270,8 @@ def _dw_join(final=True):
             torch.cuda.current_stream(dev).wait_stream(_DW_STREAM[dev])
         if final:
             del _DW_KEEP[:]
-    # ... and for every other side stream this backward pass has forked (the prompt gate's, the prompt modules'): work that autograd
-    # issued on one of them behind its last explicit join -- the tail of a module's backward -- is ordered before the hand-over
-    # here, not by luck (the round-4 failure recorded at PROMPT_SIDE)
+    # ... and for every other tracked side stream this backward pass has forked (the prompt gate's): work that autograd issued on one
+    # of them behind its last explicit join is ordered before the hand-over here, not by luck
     for dev, st in list(_SIDE_USED):
         torch.cuda.current_stream(dev).wait_stream(st)
     if final:
@@ -291,6 +289,8 @@ class deferred_reductions:
         global _DEFERRED
         self.prev = _DEFERRED
         _DEFERRED = []
+        if self.prev is None:
+            _SIDE_USED.clear()      # streams forked before this backward pass (an earlier no-grad forward, another capture) are not its business
         return self
 
     def __exit__(self, *exc):

@@ -135,32 +135,23 @@ def test_tiny_adamw_two_steps_vs_reference(use_graph):
     print("tiny AdamW worst relative error", M.check_tiny_adamw("cuda", use_graph=use_graph))
 
 
-def _prompt_streams_in_training(side_branch):
+def test_eval_forward_with_prompt_streams_then_captured_training_step():
+    """a no-grad forward forks the prompt modules on their own streams (ops.PROMPT_SIDE); the captured training step that
+    follows must not wait on streams last used outside its capture (they are not tracked, and the set of tracked streams is reset
+    where a backward pass begins) -- and must still reproduce the reference's two AdamW steps."""
     from mp_hsir_amd import ops
-    old = ops.PROMPT_SIDE_TRAIN, ops.DW_SIDE, ops.SIDE_BRANCH
-    ops.PROMPT_SIDE_TRAIN, ops.DW_SIDE, ops.SIDE_BRANCH = True, 2, side_branch
-    try:
-        for _ in range(3):
-            M.check_tiny_adamw("cuda", use_graph=True)
-    finally:
-        ops.PROMPT_SIDE_TRAIN, ops.DW_SIDE, ops.SIDE_BRANCH = old
-
-
-def test_tiny_adamw_graph_with_prompt_streams_in_training():
-    """the configuration that failed in round 4, kept as a test: captured step + weight-gradient branch + the prompt
-    modules forked on their own streams IN TRAINING (MPHSIR_PROMPT_SIDE_TRAIN, off by default: training gains nothing from it).
-    Round 5 found the ordering that was missing: a batch of the weight-gradient branch can hold problems whose operands were produced
-    on a prompt module's stream while another stream flushes it -- the branch now waits for every side stream the pass has forked
-    (ops._dw_flush_pending), and this passes."""
-    _prompt_streams_in_training(True)
-
-
-@pytest.mark.xfail(strict=False, reason="still open: the same configuration WITHOUT the prompt-gate branch (MPHSIR_SIDE_BRANCH=0) yields a wrong "
-                   "prompt1.text_prompt_learnable gradient under capture (update norm 4 % off) whenever the weight-gradient branch is on "
-                   "(DW_SIDE 1 or 2; eager launches and DW_SIDE=0 are right): a gradient that plain autograd ops produce on the prompt "
-                   "module's stream.  Not a product configuration (two non-default switches)")
-def test_tiny_adamw_graph_with_prompt_streams_in_training_without_gate_branch():
-    _prompt_streams_in_training(False)
+    from golden.cases import TINY_CFG
+    from golden.detfill import det_fill_, seeded_input, surrogate_clip_prompt
+    from mp_hsir_amd.net.MP_HSIR import MP_HSIR_Net
+    assert ops.PROMPT_SIDE and not hasattr(ops, "PROMPT_SIDE_TRAIN")
+    net = MP_HSIR_Net(**TINY_CFG, clip_prompt=surrogate_clip_prompt(6)).eval()
+    det_fill_(net)
+    net = net.cuda().set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        net(seeded_input("smoke", (2, 8, 32, 32)).cuda(), torch.tensor([1, 4]).cuda())
+    assert not any(st in (ops._SIDE.get((d, "prompt1")), ops._SIDE.get((d, "prompt2"))) for d, st in ops._SIDE_USED)
+    for _ in range(2):
+        M.check_tiny_adamw("cuda", use_graph=True)
 
 
 def _spawn_ranks(mode, steps, out, world=2, port=29541, backend="gloo"):
