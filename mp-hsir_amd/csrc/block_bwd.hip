@@ -698,8 +698,13 @@ extern "C" int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dR
     if (vpt <= 4) { MPHSIR_LNB(4); }
     if (vpt <= 8) { MPHSIR_LNB(8); }
     if (vpt <= 12) { MPHSIR_LNB(12); }
-    if (vpt <= 32) { MPHSIR_LNB(32); }
+    if (vpt <= 16) { MPHSIR_LNB(16); }
 #undef MPHSIR_LNB
+    if (dtype == MPHSIR_F32 && vpt <= 32) {       // C = 512 in fp32 only (a 16-bit row of 512 channels is 16 vectors per lane): the 32-vector
+        allow_big_lds(ln_bwd_win_kernel<float, 32>, shmem);      // form of the 16-bit types kept 96 vectors live and spilled 1356 registers
+        MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_kernel<float, 32>), dim3(nblk), dim3(256), shmem, s, d);
+        return MPHSIR_OK;
+    }
     set_error("ln_bwd_win: C=%d too wide", C);
     return MPHSIR_EINVAL;
 }

@@ -203,6 +203,76 @@ def gen_blocks():
     np.savez_compressed(os.path.join(HERE, "blocks.npz"), **out)
 
 
+def _block_module(name, c):
+    """the reference module of a BLOCK_CASES entry with detfill weights, fp32, plus a function that runs it on fresh leaf inputs"""
+    kind = c["kind"]
+    if kind == "pgsstb":
+        m = ref.PGSSTB(dim=c["C"], num_heads=c["heads"], input_resolution=[64, 64], window_size=8, shift_size=c["shift"], mlp_ratio=2.66,
+                       compress_ratio=c["cr"], prompt_len=128, drop_path=0.0, qkv_bias=True, bias=False).eval()
+        det_fill_(m)
+
+        def run(mod, dt):
+            x = seeded_input(name, c["shape"], "normal").to(dt).requires_grad_(True)
+            return mod(x), {"dx": x}
+    elif kind == "tvsp":
+        m = ref.TVSP(task_classes=c["T"], prompt_size=c["ps"], prompt_dim=c["D"], out_dim=c["D"]).eval()
+        det_fill_(m)
+
+        def run(mod, dt):
+            x = seeded_input(name, c["shape"], "normal").to(dt)
+            w = F.one_hot(task_tensor(c["task"]), c["T"])
+            clip = (w.unsqueeze(-1) * surrogate_clip_prompt(c["T"]).to(dt).unsqueeze(0)).mean(1)
+            return mod(x, clip, w), {}
+    else:
+        m = ref.PromptFusion(dim=c["D"] * 2, out_dim=c["D"], head=c["heads"]).eval()
+        det_fill_(m)
+
+        def run(mod, dt):
+            x = seeded_input(name + ":x", c["shape"], "normal").to(dt).requires_grad_(True)
+            p = seeded_input(name + ":p", c["shape"], "normal").to(dt).requires_grad_(True)
+            return mod(x, p), {"dx": x, "dprompt": p}
+    return m, run
+
+
+def gen_block_autocast():
+    """blocks_autocast.npz: per gradient tensor of every BLOCK_CASES entry with gradients, the deviation of the REFERENCE's OWN
+    mixed-precision backward (torch.autocast bf16 / fp16: train.py:118 trains in 16-mixed) from its fp64 gradients -- the yardstick
+    the 16-bit HIP block gradients are held to, tensor by tensor (tests/model_checks.py::block_grad_bars), instead of one flat bar."""
+    import copy
+    out = {}
+    for name, c in BLOCK_CASES.items():
+        if c["kind"] == "pgsstb" and not c.get("grad", False):
+            continue
+        m32, run = _block_module(name, c)
+        m64 = copy.deepcopy(m32).double()
+        for mod in (m32, m64):
+            for p in mod.parameters():
+                p.requires_grad_(True)
+        y64, ins64 = run(m64, torch.float64)
+        cot = cotangent(name, y64.shape)
+        (y64 * cot.double()).sum().backward()
+        g64 = {"dparam/" + k: p.grad for k, p in m64.named_parameters() if p.grad is not None}
+        g64.update({k: t.grad for k, t in ins64.items()})
+        for tag, low, scale in (("bf16", torch.bfloat16, 1.0),):      # (fp16 autocast of a stand-alone block overflows in fc2.bias without a tuned loss scale: the fp16 block bar stays flat)
+            for p in m32.parameters():
+                p.grad = None
+            with torch.autocast(device_type="cpu", dtype=low):
+                ya, insa = run(m32, torch.float32)
+                loss = (ya.float() * cot).sum() * scale
+            loss.backward()
+            ga = {"dparam/" + k: p.grad for k, p in m32.named_parameters() if p.grad is not None}
+            ga.update({k: t.grad for k, t in insa.items()})
+            errs = []
+            for k, g in g64.items():
+                e = float((ga[k].double() / scale - g).norm() / (g.norm() + 1e-300))
+                out["%s/%s/%s" % (name, tag, k)] = np.array(e)
+                errs.append(e)
+            out["%s/%s/out" % (name, tag)] = np.array(float((ya.detach().double() - y64.detach()).norm() / y64.detach().norm()))
+            errs.sort()
+            print("block autocast", name, tag, "out", float(out["%s/%s/out" % (name, tag)]), "median", errs[len(errs) // 2], "max", errs[-1], flush=True)
+    np.savez_compressed(os.path.join(HERE, "blocks_autocast.npz"), **out)
+
+
 def psnr_ref(restored, clean):
     """Band-wise PSNR as utils/val_utils.py:49-69 defines it (skimage absent: data_range=1 form)."""
     r = np.clip(restored, 0, 1).astype(np.float64)
@@ -367,6 +437,8 @@ if __name__ == "__main__":
         gen_tiny_grad()
     if "blocks" in which:
         gen_blocks()
+    if "block_autocast" in which:
+        gen_block_autocast()
     if "full" in which:
         gen_full()
     if "schedule" in which:

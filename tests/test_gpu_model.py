@@ -75,6 +75,13 @@ def test_batch_coupling_and_large_cube():
 from golden.cases import BLOCK_CASES, CUBE_CASES
 
 
+@pytest.mark.timeout(1800)
+def test_b16_forward_vs_oracle_at_real_width():
+    """BASELINE configs[1] (natural net, batch 16, bf16 forward) against the oracle on this host as full tensors, fp32 and bf16 --
+    until round 6 that configuration was only property-checked at real width (finite, batch-coupled)."""
+    print(M.check_b16_forward("cuda"))
+
+
 @pytest.mark.timeout(2400)
 @pytest.mark.parametrize("name", list(CUBE_CASES))
 def test_full_size_cube_vs_reference_and_oracle(name):
@@ -103,9 +110,11 @@ def test_block_gradients_fp32(name):
 
 @pytest.mark.parametrize("name", list(BLOCK_CASES))
 def test_block_gradients_bf16(name):
-    """same at the benchmark's compute dtype: bf16 storage, fp32 accumulation (the reference's own bf16 autocast deviates
-    1e-2 from its fp32 forward; gradients through 6 fused stages: bar 6e-2 per tensor)."""
-    print("bf16 block-gradient worst rel-L2", name, M.check_block_gradients("cuda", name, torch.bfloat16, tol=6e-2))
+    """same at the benchmark's compute dtype: bf16 storage, fp32 accumulation.  Bars tensor by tensor: 3 x the deviation of the
+    reference's own bf16 autocast backward for that tensor + 2 x the block's median (model_checks.block_grad_bars; 2-7 % -- until
+    round 6 a flat 6e-2)."""
+    worst, worst_ratio, med = M.check_block_gradients("cuda", name, torch.bfloat16, tol=None)
+    print("bf16 block gradients %s: worst rel-L2 %.3g, worst error / bar %.2f, reference's median deviation %.3g" % (name, worst, worst_ratio, med))
 
 
 @pytest.mark.timeout(1800)
