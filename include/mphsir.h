@@ -386,6 +386,35 @@ typedef struct mphsir_pg_bwd_args {
 } mphsir_pg_bwd_args;
 int mphsir_pg_gate_bwd(const mphsir_pg_bwd_args* a, void* stream);
 
+/* ---- backward of the channel attention between the fold and the 1x1 conv, one launch ------------------------------------------
+ * autograd of Spectral_Attention.forward net/MP_HSIR.py:96-113 (== Attention :301-322) through train.py:58-67, in the folded form
+ * (SURVEY Appendix A):   dv = d_out M_b,   [dq | dk] = [q | k] W2_b^T,   dt = depthwise3x3^T([dq | dk | dv]),
+ *                        d taps[c][tap] = sum_p t[c][p + tap] [dq | dk | dv][c][p].
+ * Replaces mphsir_gemm_tok (x2, per-sample weights) + mphsir_dwconv3x3_bwd: [dq | dk | dv] (3C values per token) never reaches HBM --
+ * a workgroup produces the halo tile of its channel slab on the matrix cores (fp32, in LDS) and runs the depthwise backward on it.
+ * QK  [B*H*W][ldqk >= 2C]  q | k after the depthwise conv, as mphsir_qkv_dwconv_gram / mphsir_dwconv_gram keep them;
+ * DO  [B*H*W][lddo >= C]   d_out;      T  [B*H*W][ldt >= 3C]  t = qkv(x) (the depthwise conv's input);
+ * W2  [B][2C][2C]          per-sample matrix of mphsir_spectral_fold_bwd;      MbT [B][C][C]  M_b^T of mphsir_spectral_fold;
+ * w9  fp32 [9][ldw >= 3C]  taps of q | k | v;      dT [B*H*W][lddt >= 3C];
+ * part fp32 [nblk][9][3C]  tap-gradient partials, one per tile range (ordered sum by mphsir_reduce_parts): nblk ranges x
+ *                          mphsir_spectral_dqkv_bwd_slabs(C, heads) channel slabs = the workgroups of the launch.
+ * round_dall != 0 (tests): [dq | dk | dv] is rounded to the storage type before the depthwise pass -- dT is then bitwise what the
+ * three-launch path produces (head widths 32 / 64).  16-bit dtypes; H % 8 == 0, W % 16 == 0; (C, C/heads) as mphsir_..._fits says.  */
+typedef struct mphsir_spectral_bwd_args {
+    uint32_t struct_size;       /* = sizeof(this struct), set by the caller: any other value is rejected with MPHSIR_EINVAL */
+    const void* QK; int64_t ldqk;
+    const void* DO; int64_t lddo;
+    const void* T; int64_t ldt;
+    const void* W2; const void* MbT;
+    const float* w9; int64_t ldw;
+    void* dT; int64_t lddt;
+    float* part;
+    int32_t B, H, W, C, heads, nblk, round_dall;
+} mphsir_spectral_bwd_args;
+int mphsir_spectral_dqkv_bwd(const mphsir_spectral_bwd_args* a, int dtype, void* stream);
+int mphsir_spectral_dqkv_bwd_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype);
+int mphsir_spectral_dqkv_bwd_slabs(int32_t C, int32_t heads);
+
 /* ---- dense 3x3 convolution (implicit GEMM) -----------------------------------------------------------
  * Y[p][n] = sum_tap sum_ci X[p+tap][ci] * W[n][tap*Cin + ci]   stride 1, zero padding, no bias, channels-last.
  * Replaces OverlapPatchEmbed.proj (net/MP_HSIR.py:458), Downsample/Upsample convs (:436,:446), TVSP.conv_last
@@ -569,6 +598,7 @@ int mphsir_l1_clamp_loss(const float* y, const float* clean, float* grad, float*
 #define MPHSIR_K_MULTI_COPY 27
 #define MPHSIR_K_L1_LOSS 28
 #define MPHSIR_K_GATED_MLP_WGRAD 29
+#define MPHSIR_K_SPECTRAL_DQKV_BWD 30
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

@@ -125,6 +125,13 @@ class PgBwdArgs(_Args):
                                          "dmu", "L", "R")] + [(n, c_int32) for n in ("nW", "C", "r", "KL", "KR", "lr_bf16")]
 
 
+class SpectralBwdArgs(_Args):
+    """mirror of struct mphsir_spectral_bwd_args"""
+    _fields_ = _SZ + [("QK", c_void_p), ("ldqk", c_int64), ("DO", c_void_p), ("lddo", c_int64), ("T", c_void_p), ("ldt", c_int64),
+                      ("W2", c_void_p), ("MbT", c_void_p), ("w9", c_void_p), ("ldw", c_int64), ("dT", c_void_p), ("lddt", c_int64),
+                      ("part", c_void_p)] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nblk", "round_dall")]
+
+
 class TnProblem(ctypes.Structure):
     """mirror of struct mphsir_gemm_tn_problem"""
     _fields_ = [("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64), ("Cpart", c_void_p), ("colsum_part", c_void_p),
@@ -198,6 +205,9 @@ _SYMBOLS = {
                                c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_spectral_fold_bwd": (c_int, [ctypes.POINTER(FoldBwdArgs), c_int, c_void_p]),
     "mphsir_pg_gate_bwd": (c_int, [ctypes.POINTER(PgBwdArgs), c_void_p]),
+    "mphsir_spectral_dqkv_bwd": (c_int, [ctypes.POINTER(SpectralBwdArgs), c_int, c_void_p]),
+    "mphsir_spectral_dqkv_bwd_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int]),
+    "mphsir_spectral_dqkv_bwd_slabs": (c_int, [c_int32, c_int32]),
     "mphsir_conv3x3_tok": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_int, c_void_p]),
     "mphsir_conv3x3_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),

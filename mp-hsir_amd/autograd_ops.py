@@ -63,8 +63,9 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     d_out (M,C); t_q/t_k/t_v: (B,H,W,*) views of the 1x1-conv outputs that fed dwconv_gram (channels-last,
     C channels each); w9*: fp32 tap-major dw weights [9][C] views; v, gp, sp, Mb, MbT as saved by the forward.
     Returns d(t_q), d(t_k), d(t_v) (B,H,W,C each), d(dw taps) (C,9) x3, d temperature (heads,), d Wo (C,C).
-    All HIP: dM = d_out^T v (gemm_tn), fold backward (one launch), [dq|dk] and dv as per-sample token GEMMs,
-    depthwise backward (data + taps)."""
+    All HIP: dM = d_out^T v (gemm_tn), fold backward (one launch), then [dq|dk], dv and the depthwise backward (data + taps) in ONE
+    launch (ops.spectral_dqkv_bwd, 16-bit types, self-attention: q|k|v adjacent slices of one t) -- else per-sample token GEMMs +
+    the depthwise backward kernels."""
     C = v.shape[1]
     N = H * W
     M = B * N
@@ -77,13 +78,22 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     joint = (t_q.data_ptr() + C * t_q.element_size() == t_k.data_ptr() and t_k.data_ptr() + C * t_k.element_size() == t_v.data_ptr()
              and t_q.stride() == t_k.stride() == t_v.stride() and w9q.data_ptr() + 4 * C == w9k.data_ptr()
              and w9k.data_ptr() + 4 * C == w9v.data_ptr())
-    dall = torch.empty((M, 3 * C), dtype=dt, device=v.device)
     if qk is not None:
         pass                                                    # kept by the forward (dwconv_gram keep_qk)
     elif joint:
         qk = ops.dwconv3x3(torch.as_strided(t_q, (B, H, W, 2 * C), t_q.stride()), torch.as_strided(w9q, (9, 2 * C), w9q.stride()))
     else:
         qk = torch.cat([ops.dwconv3x3(t_q, w9q), ops.dwconv3x3(t_k, w9k)], dim=-1)
+    if joint and t_q.stride(2) == 3 * C and w9q.stride(0) == 3 * C and ops.spectral_dqkv_bwd_fits(C, heads, H, W, dt):
+        # ONE launch from the fold backward's matrix to dt: dv = d_out M_b and [dq | dk] = [q | k] W2^T are formed per halo tile on the
+        # matrix cores and fed to the depthwise backward in LDS -- [dq | dk | dv] (3C per token) is neither written nor read back
+        dwo, dtemp = ops.reduce_parts(dwo_p), ops.reduce_parts(dtemp_p)
+        t_all = torch.as_strided(t_q, (M, 3 * C), (3 * C, 1))
+        w9_all = torch.as_strided(w9q, (9, 3 * C), w9q.stride())
+        dt_all, dw_all = ops.spectral_dqkv_bwd(qk.reshape(M, 2 * C), d_out, t_all, W2, MbT, w9_all, B, H, W, C, heads)
+        dt_all = dt_all.reshape(B, H, W, 3 * C)
+        return (dt_all[..., :C], dt_all[..., C:2 * C], dt_all[..., 2 * C:], dw_all[:C], dw_all[C:2 * C], dw_all[2 * C:], dtemp, dwo)
+    dall = torch.empty((M, 3 * C), dtype=dt, device=v.device)
     ops.gemm_tok(d_out, MbT, out=dall[:, 2 * C:])                                     # dv = d_out M_b
     dwo, dtemp = ops.reduce_parts(dwo_p), ops.reduce_parts(dtemp_p)
     ops.gemm_tok(qk.reshape(M, 2 * C), W2, out=dall[:, :2 * C])                       # [dq | dk]

@@ -1150,6 +1150,46 @@ def dwconv3x3_bwd(x, dy, w9, col_ranges=None):
     return dx, out
 
 
+# ---- backward of the channel attention between the fold and the 1x1 conv in one launch (csrc/spectral_bwd.hip) ----------------
+SPECTRAL_BWD_FUSED = os.environ.get("MPHSIR_SPECTRAL_BWD_FUSED", "1") == "1"     # 0: the three launches it replaces (gemm_tok x2 + dwconv3x3_bwd)
+SPECTRAL_BWD_WGS = int(os.environ.get("MPHSIR_SPECTRAL_BWD_WGS", "512"))          # workgroups per launch aimed at (two per CU)
+
+
+def spectral_dqkv_bwd_fits(C, heads, H, W, dtype):
+    return SPECTRAL_BWD_FUSED and dtype in _HALF and bool(_lib.load().mphsir_spectral_dqkv_bwd_fits(C, heads, H, W, _DT[dtype]))
+
+
+def spectral_dqkv_bwd(qk, d_out, t, W2, MbT, w9, B, H, W, C, heads, nblk=None, round_dall=False):
+    """dt (M, 3C) and the tap gradients (3C, 9) of the channel attention from q|k (M, 2C), d_out (M, C), t (M, 3C), the per-sample
+    matrices W2 (B, 2C, 2C) / MbT (B, C, C) and the taps w9 fp32 [9][3C]:  dv = d_out M_b, [dq|dk] = [q|k] W2^T, then both gradients of
+    the depthwise conv -- [dq|dk|dv] stays on the chip (include/mphsir.h).  nblk: tile ranges (x channel slabs = workgroups)."""
+    lib = _lib.load()
+    _check(qk, d_out, t, W2, MbT, w9)
+    M = B * H * W
+    for x_, n in ((qk, 2 * C), (d_out, C), (t, 3 * C)):
+        assert x_.dim() == 2 and x_.shape == (M, n) and x_.stride(1) == 1, (tuple(x_.shape), tuple(x_.stride()), n)
+    assert W2.is_contiguous() and MbT.is_contiguous() and W2.shape == (B, 2 * C, 2 * C) and MbT.shape == (B, C, C)
+    assert w9.dtype == torch.float32 and w9.shape == (9, 3 * C) and w9.stride(1) == 1
+    nslab = lib.mphsir_spectral_dqkv_bwd_slabs(C, heads)
+    tiles = B * (H // 8) * (W // 16)
+    if nblk is None:
+        nblk = max(1, min(tiles, SPECTRAL_BWD_WGS // nslab))
+        if nblk >= 8:
+            nblk = nblk // 8 * 8          # grid a multiple of 8: the slabs of a tile range then share an XCD (xcd_contiguous_block)
+    dt = torch.empty((M, 3 * C), dtype=qk.dtype, device=qk.device)
+    part = torch.empty((nblk, 9, 3 * C), dtype=torch.float32, device=qk.device)
+    a = _lib.SpectralBwdArgs()
+    a.QK, a.ldqk, a.DO, a.lddo, a.T, a.ldt = _p(qk), qk.stride(0), _p(d_out), d_out.stride(0), _p(t), t.stride(0)
+    a.W2, a.MbT, a.w9, a.ldw, a.dT, a.lddt, a.part = _p(W2), _p(MbT), _p(w9), w9.stride(0), _p(dt), 3 * C, _p(part)
+    a.B, a.H, a.W, a.C, a.heads, a.nblk, a.round_dall = B, H, W, C, heads, nblk, int(round_dall)
+    _lib.check(lib.mphsir_spectral_dqkv_bwd(ctypes.byref(a), _DT[qk.dtype], _stream(qk)), "spectral_dqkv_bwd")
+    hd = C // heads
+    _acct("spectral_dqkv_bwd", M * (2.0 * C * C + 8.0 * C * hd + 108.0 * C), 10.0 * M * C * qk.element_size() + part.numel() * 4)
+    dw = torch.empty((3 * C, 9), dtype=torch.float32, device=qk.device)
+    reduce_block(part, 0, 9, 0, 3 * C, dw, transpose=True)
+    return dt, dw
+
+
 def gated_mlp_bwd(x, dy, dm, ln_w, ln_b, W1, b1, W1T, W2T, variant=0, keep=None, rows_per_batch=0, hsplit=None, operands=True):
     """-> dx, xn, h, dpre, part (see include/mphsir.h).  x, dy, dm: contiguous (M,C).  With keep (DropPath factors, one
     per rows_per_batch rows) dm is ignored as input: the kernel computes keep*dy itself and it is returned as a 6th value.

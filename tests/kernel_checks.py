@@ -982,6 +982,69 @@ def check_fold_bwd_split_dm(dev, dtype, C=64, heads=2, B=2, nsp=5):
         assert rel_l2(y, x.double().cpu()) < tol, rel_l2(y, x.double().cpu())
 
 
+def check_spectral_dqkv_bwd(dev, dtype, C, heads, shape, nblk=None):
+    """mphsir_spectral_dqkv_bwd (dv, [dq | dk], depthwise backward + tap gradients in one launch) against the three launches it replaces
+    -- gemm_tok(d_out, M_b^T), gemm_tok([q | k], W2), dwconv3x3_bwd -- on the same operands:
+      * round_dall=1: [dq | dk | dv] rounded to the storage type as the three-launch path stores it -> dt BITWISE equal (head widths whose
+        K chunks align with the token GEMM's: 32 / 64), tap gradients within fp32 summation order;
+      * the product form (fp32 [dq | dk | dv] in LDS): within the storage type's rounding of the three-launch path, and closer to an fp64
+        evaluation of the same formula than it."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    M, hd = B * H * W, C // heads
+    assert ops.spectral_dqkv_bwd_fits(C, heads, H, W, dtype), (C, heads, shape)
+    qk, d_out, t = rnd((M, 2 * C), 901, dtype), rnd((M, C), 902, dtype), rnd((M, 3 * C), 903, dtype)
+    W2 = torch.zeros((B, 2 * C, 2 * C), dtype=torch.float32, device=dev)          # the block structure spectral_fold_bwd emits
+    full = rnd((B, 2 * C, 2 * C), 904, scale=(2 * hd) ** -0.5)
+    for h in range(heads):
+        qs, ks = slice(h * hd, (h + 1) * hd), slice(C + h * hd, C + (h + 1) * hd)
+        W2[:, qs, ks] = full[:, qs, ks]
+        W2[:, ks, qs] = full[:, ks, qs]
+    idx = torch.arange(2 * C, device=dev)
+    W2[:, idx, idx] = full[:, idx, idx]
+    W2 = W2.to(dtype).contiguous()
+    MbT = rnd((B, C, C), 905, dtype, scale=C ** -0.5)
+    w9 = rnd((9, 3 * C), 906, scale=1 / 3)
+    # the three launches
+    dall = torch.empty((M, 3 * C), dtype=dtype, device=dev)
+    ops.gemm_tok(d_out, MbT, out=dall[:, 2 * C:])
+    ops.gemm_tok(qk, W2, out=dall[:, :2 * C])
+    with ops.reduce_scope():
+        dt_ref, dw_ref = ops.dwconv3x3_bwd(t.reshape(B, H, W, 3 * C), dall.reshape(B, H, W, 3 * C), w9, col_ranges=[(0, 3 * C)])
+    dt_ref = dt_ref.reshape(M, 3 * C)
+    res = {}
+    for nb in ([nblk] if nblk else [None, 1, 3]):
+        with ops.reduce_scope():
+            dt_r, dw_r = ops.spectral_dqkv_bwd(qk, d_out, t, W2, MbT, w9, B, H, W, C, heads, nblk=nb, round_dall=True)
+        if hd in (32, 64):
+            assert torch.equal(dt_r, dt_ref), ("dt not bitwise the three-launch path's", C, heads, shape, nb, rel_l2(dt_r, dt_ref))
+        else:
+            assert rel_l2(dt_r, dt_ref) < 3e-3
+        res["dw_round_%s" % nb] = rel_l2(dw_r, dw_ref)
+        assert res["dw_round_%s" % nb] < (1e-5 if hd in (32, 64) else 3e-3), res
+    with ops.reduce_scope():
+        dt_f, dw_f = ops.spectral_dqkv_bwd(qk, d_out, t, W2, MbT, w9, B, H, W, C, heads, nblk=nblk)
+    # fp64 evaluation of the same formula on the same (rounded) operands
+    qk64, do64, t64, w964 = qk.double().cpu(), d_out.double().cpu(), t.double().cpu(), w9.double().cpu()
+    d64 = torch.empty((M, 3 * C), dtype=torch.float64)
+    for b in range(B):
+        rows = slice(b * H * W, (b + 1) * H * W)
+        d64[rows, :2 * C] = qk64[rows] @ W2[b].double().cpu().t()
+        d64[rows, 2 * C:] = do64[rows] @ MbT[b].double().cpu().t()
+    dy = d64.reshape(B, H, W, 3 * C).permute(0, 3, 1, 2)
+    wk = w964.t().reshape(3 * C, 1, 3, 3)
+    tt = t64.reshape(B, H, W, 3 * C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wk = wk.clone().requires_grad_(True)
+    (torch.nn.functional.conv2d(tt, wk, padding=1, groups=3 * C) * dy).sum().backward()
+    dt64 = tt.grad.permute(0, 2, 3, 1).reshape(M, 3 * C)
+    dw64 = wk.grad.reshape(3 * C, 9)
+    res.update(dt=rel_l2(dt_f, dt64), dt_three=rel_l2(dt_ref, dt64), dw=rel_l2(dw_f, dw64), dw_three=rel_l2(dw_ref, dw64))
+    tol = TOL[dtype]
+    assert res["dt"] < tol and res["dw"] < tol and res["dt"] <= res["dt_three"] * 1.05 and res["dw"] <= res["dw_three"] * 1.05 + 1e-6, res
+    return res
+
+
 def check_channel_attention_bwd(dev, dtype, C, heads, shape, cross=False):
     """The channel ("spectral") attention backward chain -- gemm_tn (dM), spectral_fold_bwd, the [dq|dk] / dv token GEMMs,
     depthwise backward + tap gradients -- as the prompt modules use it (self: TransformerBlock :289-322; cross:

@@ -223,6 +223,22 @@ def test_channel_attention_bwd(dtype, C, heads, shape, cross):
     K.check_channel_attention_bwd("cpu", dtype, C, heads, shape, cross)
 
 
+@pytest.mark.parametrize("dtype,C,heads,shape", [(torch.bfloat16, 32, 1, (2, 8, 16)), (torch.bfloat16, 64, 2, (1, 16, 32)), (torch.float16, 128, 2, (1, 8, 16)),
+                                                 (torch.bfloat16, 96, 2, (1, 8, 16))])
+def test_spectral_dqkv_bwd_against_the_three_launches(dtype, C, heads, shape):
+    print(K.check_spectral_dqkv_bwd("cpu", dtype, C, heads, shape))
+
+
+def test_channel_attention_bwd_self_16bit_takes_the_fused_launch():
+    from mp_hsir_amd import ops
+    ops.ACCOUNT = {}
+    try:
+        K.check_channel_attention_bwd("cpu", torch.bfloat16, 64, 2, (1, 16, 16), False)
+        assert "spectral_dqkv_bwd" in ops.ACCOUNT and "dwconv3x3_bwd" not in ops.ACCOUNT, sorted(ops.ACCOUNT)
+    finally:
+        ops.ACCOUNT = None
+
+
 # ---- fp16 storage (dtype code 2, the reference's 16-mixed precision): same kernels, v_mfma_f32_16x16x32_f16 ------------------
 F16 = torch.float16
 

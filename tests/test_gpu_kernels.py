@@ -323,6 +323,19 @@ def test_channel_attention_bwd(dtype, C, heads, shape, cross):
     K.check_channel_attention_bwd("cuda", dtype, C, heads, shape, cross)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,heads,shape", [(64, 2, (2, 64, 64)), (128, 2, (2, 64, 64)), (128, 4, (3, 32, 32)), (256, 8, (4, 16, 16)), (96, 2, (1, 64, 64)),
+                                           (192, 4, (2, 32, 32)), (192, 2, (1, 64, 64)), (384, 8, (2, 16, 16)), (32, 1, (1, 8, 16))])
+def test_spectral_dqkv_bwd_against_the_three_launches(dtype, C, heads, shape):
+    """every (C, head width) of both configurations: dt bitwise the three-launch path's with its rounding switched on (head widths 32 / 64),
+    the product form within rounding of it and no further from fp64 than it"""
+    print(K.check_spectral_dqkv_bwd("cuda", dtype, C, heads, shape))
+
+
+def test_spectral_dqkv_bwd_at_the_training_shape():
+    print(K.check_spectral_dqkv_bwd("cuda", torch.bfloat16, 128, 2, (32, 64, 64), nblk=80))
+
+
 # ---- fp16 storage (dtype code 2; BASELINE configs[4]: remote-sensing training in fp16 + loss scaling) ------------------------
 F16 = torch.float16
 
