@@ -105,21 +105,37 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
     const int lr = lane & 15, lk = 4 * (lane >> 4);
     for (int c0 = 0; c0 < C; c0 += FB_CO) {
         __syncthreads();                              // previous chunk consumed (first time: A complete)
-        for (int idx = tid; idx < FB_CO * HD; idx += FB_THREADS) {
-            const int rr = idx / HD, cc = idx % HD;
+        // Ws / Ms rows of this chunk: 16-byte vectors along the head's columns.  The dM rows are the ordered sum of the token-reduction
+        // GEMM's split partials: ALL the splits of a vector are requested before the first is added (in split order, eight at a time) --
+        // until round 6 a thread walked its elements one after the other with four loads in flight, 24 dependent round trips at the
+        // level-1 shape (12 splits): most of the launch's 36 us.
+        for (int idx = tid; idx < FB_CO * (HD / 4); idx += FB_THREADS) {
+            const int rr = idx / (HD / 4), cc = (idx % (HD / 4)) * 4;
             const bool in = c0 + rr < C;
-            Ws[rr * LD + cc] = in ? a.Wo[(long)(c0 + rr) * C + h * HD + cc] : 0.f;
-            float m = 0.f;
+            f32x4 wv4 = f32x4{0.f, 0.f, 0.f, 0.f}, m = f32x4{0.f, 0.f, 0.f, 0.f};
             if (in) {
+                wv4 = *reinterpret_cast<const f32x4*>(a.Wo + (long)(c0 + rr) * C + h * HD + cc);
                 const float* mp = dM + (long)(c0 + rr) * C + h * HD + cc;
                 int sp = 0;
-                for (; sp + 4 <= nsp; sp += 4) {          // four loads in flight, summed in split order (what reduce_parts did)
-                    const float t0 = mp[sp * CC], t1 = mp[(sp + 1) * CC], t2 = mp[(sp + 2) * CC], t3 = mp[(sp + 3) * CC];
-                    m += t0; m += t1; m += t2; m += t3;
+                for (; sp + 8 <= nsp; sp += 8) {
+                    f32x4 tv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) tv[u] = *reinterpret_cast<const f32x4*>(mp + (sp + u) * CC);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) m += tv[u];
                 }
-                for (; sp < nsp; ++sp) m += mp[sp * CC];
+                if (sp + 4 <= nsp) {
+                    f32x4 tv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) tv[u] = *reinterpret_cast<const f32x4*>(mp + (sp + u) * CC);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) m += tv[u];
+                    sp += 4;
+                }
+                for (; sp < nsp; ++sp) m += *reinterpret_cast<const f32x4*>(mp + sp * CC);
             }
-            Ms[rr * LD + cc] = m;
+            *reinterpret_cast<f32x4*>(Ws + rr * LD + cc) = wv4;
+            *reinterpret_cast<f32x4*>(Ms + rr * LD + cc) = m;
         }
         __syncthreads();
 #pragma unroll
