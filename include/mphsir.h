@@ -172,11 +172,11 @@ typedef struct mphsir_fused_gram_args {
 int mphsir_qkv_dwconv_gram(const mphsir_fused_gram_args* a, int dtype, void* stream);
 int mphsir_qkv_dwconv_gram_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype);
 int mphsir_qkv_dwconv_gram_rows_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype, int32_t with_ln);   /* row-walking
-                                           form: 16-bit dtypes, W % 32 == 0, H >= 4, (C, head width) in {64,128}x{32,64},
-                                           {96,192}x48; with the LayerNorm prologue: C in {64,128} with 32-wide heads */
+                                           form: 16-bit dtypes, W % 32 == 0, H >= 4, (C, head width) in {64,128}x{32,64}, {96,192}x48 and
+                                           (256,32) (four-slot ring); with the LayerNorm prologue: C in {64,128,256} with 32-wide heads
+                                           (spectral_rows.hip: rows_shape / rows_form_fits) */
 /* Diagnostics, one entry point: arm (stamps = device buffer of >= 32 uint64) or disarm (NULL) the shader-clock phase stamps
- * that workgroup 0 of the next launches of one kernel family writes (tools/bench_pg.py, bench_win.py, bench_fused.py,
- * bench_rows.py).  The only mutable global state of the library besides the launch timer (mphsir_prof_*).               */
+ * that workgroup 0 of the next launches of one kernel family writes (tools/bench/bench_win.py [pg], tools/bench/bench_rows.py).  The only mutable global state of the library besides the launch timer (mphsir_prof_*).               */
 enum { MPHSIR_DEBUG_PG_GATE = 0, MPHSIR_DEBUG_WIN_ATTN = 1, MPHSIR_DEBUG_FUSED_PASS_A = 2 };
 int mphsir_debug(int kind, void* stamps);
 typedef struct mphsir_fold_args {

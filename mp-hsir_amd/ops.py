@@ -327,6 +327,9 @@ def _flush_gemms(gemms):
     lib = _lib.load()
     for i in range(0, len(gemms), _lib.TN_GROUP_MAX):
         chunk = gemms[i:i + _lib.TN_GROUP_MAX]
+        # one launch = one element type on one device (a batch of the weight-gradient branch can mix backward functions: ADVICE r05)
+        k0 = chunk[0]["keep"][0]
+        assert all(g["keep"][0].dtype == k0.dtype and g["keep"][0].device == k0.device for g in chunk), "grouped token-reduction GEMMs of mixed dtype / device"
         arr = (_lib.TnProblem * len(chunk))()
         for k, g in enumerate(chunk):
             q = arr[k]

@@ -437,7 +437,7 @@ def check_block_gradients(dev, name="nat_enc1", dtype=torch.float32, tol=2e-4):
     if kind == "pgsstb":
         ins["dx"] = nhwc(seeded_input(name, c["shape"], "normal")).requires_grad_(True)
         run = lambda: mod(ins["dx"])
-        want_kernels = ("win_attn", "win_attn_bwd", "combine_bwd", "ln_bwd_win", "gated_mlp_bwd", "dwconv3x3_bwd|dwconv3x3_wgrad", "pg_gate_bwd",
+        want_kernels = ("win_attn", "win_attn_bwd", "combine_bwd", "ln_bwd_win", "gated_mlp_bwd", "dwconv3x3_bwd|dwconv3x3_wgrad|spectral_dqkv_bwd", "pg_gate_bwd",
                         "spectral_fold_bwd", "gemm_tn")
     elif kind == "tvsp":
         x = nhwc(seeded_input(name, c["shape"], "normal"))

@@ -25,7 +25,7 @@ HOT = [
     r"gemm_tok_kernelIDF16[b_]", r"gemm_tok_ring_kernelIDF16[b_]", r"gemm_tn_tr_kernelIDF16[b_]", r"gemm_tn_tr_group_kernelIDF16[b_]",
     r"gemm_tn_ring", r"dwconv3x3_bwd_tile_kernelIDF16[b_]", r"dwconv3x3_tile_kernelIDF16[b_]", r"dwconv_gate_tile_kernel",
     r"combine_bwd_kernelIDF16[b_]", r"ln_bwd_win_kernelIDF16[b_]Li(4|8)E", r"reduce_parts_kernel", r"pg_gate_(fwd|bwd)_kernel",
-    r"spectral_fold_kernelIDF16[b_]", r"spectral_fold_bwd_kernelIDF16[b_]", r"conv3x3_pipe_kernel", r"spectral_dqkv_bwd_kernelIDF16[b_]",
+    r"spectral_fold_kernelIDF16[b_]", r"spectral_fold_bwd_kernelIDF16[b_]", r"conv3x3_pipe_kernel", r"spectral_dqkv_bwd_kernelIDF16[b_]Li(32|64|128|256)E",
     r"flat_adamw_kernel", r"multi_copy_kernel", r"pack_gather_kernel", r"l1_clamp_loss_kernel",
 ]
 # cold instantiations of the 16-bit paths at the natural widths that spill today: (pattern, ceiling).  Remote-sensing widths
