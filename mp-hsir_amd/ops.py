@@ -202,6 +202,17 @@ def _dw_side(scope):
         # segments have come together, and go out as ONE grouped GEMM launch + ONE ordered-sum launch; a big function flushes at once
         # (with whatever is pending, in issue order).  The operands stay referenced (pending list, then _DW_KEEP).
         nbytes = sum(g["M"] * (g["N1"] + g["N2"]) * 2 for g in scope.gemms)
+        rows = max([g["M"] for g in scope.gemms] + [c["keep"][0].shape[0] for c in scope.calls if c["keep"][0].dim() == 2] + [0])
+        if DW_DEFER and rows >= DW_DEFER_ROWS:
+            # a BIG backward function (the full-resolution level: 131072 token rows at batch 32): its weight-gradient work is HELD, not
+            # issued -- beside the equally big data-gradient kernels of the next block it only shares the CUs and HBM with them.  It goes
+            # out when the backward pass reaches the lower pyramid levels (below), whose launches are latency-bound and leave most of the
+            # chip idle: the branch then fills that idle time.  What the last big functions of a pass hold (encoder level 1) is issued
+            # by the join.  Operands stay referenced (held list, then _DW_KEEP).
+            _DW_HELD.setdefault(dev, []).append((scope.gemms, scope.calls, scope.segs))
+            return True
+        if DW_DEFER and rows > 0:
+            _dw_release_held(dev)           # a small function: the held work of the big ones starts now, ahead of this function's own
         pend = _DW_PENDING.setdefault(dev, [[], [], [], 0])
         pend[0] += scope.gemms
         pend[1] += scope.calls
@@ -225,10 +236,30 @@ def _dw_side(scope):
 
 DW_BATCH_BYTES = int(float(os.environ.get("MPHSIR_DW_BATCH_MB", "256")) * (1 << 20))      # 0 / 24 / 48 / 128 / 256 / 512 MB: 20.90 / 20.82 / 20.75 / 20.67 / 20.60 / 20.63 ms per step (one box, pairs)
 _DW_PENDING = {}
+# MPHSIR_DW_DEFER=1 (round-6 experiment, OFF): the weight-gradient work of the big (full-resolution) backward functions is held back until
+# the pass reaches the lower pyramid levels, whose latency-bound launches leave most of the chip idle.  Measured SLOWER (20.31-20.35
+# against 20.07-20.09 ms per step, two pairs on one box; with the 32768-row level held too: 20.45-20.50): beside a grouped GEMM that
+# fills every CU the small launches of the main chain wait for workgroup slots -- the chain loses more than the branch hides.
+DW_DEFER = os.environ.get("MPHSIR_DW_DEFER", "0") == "1"
+DW_DEFER_ROWS = int(os.environ.get("MPHSIR_DW_DEFER_ROWS", "65536"))
+_DW_HELD = {}
 # the ordered sums of the weight-gradient branch: 1 = all of them at the join (the end of the backward pass / a bucket hook), as few
 # launches of 32 segments as there can be, instead of one small launch behind every flush of the branch
 DW_SUMS_LATE = os.environ.get("MPHSIR_DW_SUMS_LATE", "0") == "1"
 _DW_SUMS = {}
+
+
+def _dw_release_held(dev):
+    """issue the held weight-gradient work of the big backward functions on the branch: function by function in the order they ran
+    (a grouped GEMM launch + an ordered-sum launch each time DW_BATCH_BYTES of operands have come together)"""
+    held = _DW_HELD.get(dev)
+    if not held:
+        return
+    _dw_flush_pending(dev)                  # what was pending before goes first
+    _DW_HELD[dev] = []
+    for gemms, calls, segs in held:         # one batch per function: its sums follow its GEMMs while the partials are on the die
+        _DW_PENDING[dev] = [list(gemms), list(calls), list(segs), 0]
+        _dw_flush_pending(dev)
 
 
 def _dw_flush_pending(dev):
@@ -258,6 +289,8 @@ def _dw_join(final=True):
     """the stream that reads gradients waits for the weight-gradient branch.  Only the FINAL join (the end of the backward pass, on
     the stream backward() was called from) releases the tensors and forgets the branch: a join in the middle -- a backward function
     that has to read a sum, possibly running on a prompt module's own stream -- makes ITS stream wait and leaves the rest as it is."""
+    for dev in list(_DW_HELD):
+        _dw_release_held(dev)
     for dev in list(_DW_PENDING):
         _dw_flush_pending(dev)
     for dev, segs in list(_DW_SUMS.items()):

@@ -1,7 +1,9 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
-timeout 2400 python -m pytest tests/ -q -m gpu > gpurun_out/r06d_fulltests.log 2>&1; echo "rc=$?" >> gpurun_out/r06d_fulltests.log
-tail -5 gpurun_out/r06d_fulltests.log
-R="python3 bench.py --model remote_sensing --dtype f16 --batch 16 --warmup 5 --no-cpu-baseline --no-roofline --no-spectral --no-extra --steps 40"
-$R 2>/dev/null | tail -1 | cut -c50-140 > gpurun_out/r06d_rs.log
-MPHSIR_SPECTRAL_BWD_FUSED=0 $R 2>/dev/null | tail -1 | cut -c50-140 >> gpurun_out/r06d_rs.log
-cat gpurun_out/r06d_rs.log
+F="--no-cpu-baseline --no-extra --no-spectral --no-roofline --steps 40 --warmup 5"
+for i in 1 2; do
+  for e in "MPHSIR_DW_DEFER=1" "MPHSIR_DW_DEFER=0" "MPHSIR_DW_DEFER=1 MPHSIR_DW_DEFER_ROWS=30000"; do
+    echo "$e: $(env $e python bench.py $F 2>/dev/null | tail -1 | cut -c50-140)"
+  done
+done > gpurun_out/r06e_defer.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_model.py -q -x -m gpu -k "deferred or tiny_adamw or graph_replay or no_parameter_gradient or data_parallel_world2_on_one" > gpurun_out/r06e_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r06e_tests.log
+cat gpurun_out/r06e_defer.log; tail -3 gpurun_out/r06e_tests.log
