@@ -82,8 +82,10 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
         pass                                                    # kept by the forward (dwconv_gram keep_qk)
     elif joint:
         qk = ops.dwconv3x3(torch.as_strided(t_q, (B, H, W, 2 * C), t_q.stride()), torch.as_strided(w9q, (9, 2 * C), w9q.stride()))
-    else:
-        qk = torch.cat([ops.dwconv3x3(t_q, w9q), ops.dwconv3x3(t_k, w9k)], dim=-1)
+    else:                                                       # cross attention: q and k come from different tensors -- both
+        qk = torch.empty((B, H, W, 2 * C), dtype=dt, device=v.device)      # depthwise outputs go straight into the halves of [q | k]
+        ops.dwconv3x3(t_q, w9q, out=qk[..., :C])
+        ops.dwconv3x3(t_k, w9k, out=qk[..., C:])
     if joint and t_q.stride(2) == 3 * C and w9q.stride(0) == 3 * C and ops.spectral_dqkv_bwd_fits(C, heads, H, W, dt):
         # ONE launch from the fold backward's matrix to dt: dv = d_out M_b and [dq | dk] = [q | k] W2^T are formed per halo tile on the
         # matrix cores and fed to the depthwise backward in LDS -- [dq | dk | dv] (3C per token) is neither written nor read back
@@ -109,7 +111,9 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     # the three tap gradients are row ranges of ONE buffer: the callers join them as a view (a cat would READ sums that may
     # not have been launched yet, ops.deferred_reductions)
     dw3 = torch.empty((3 * C, 9), dtype=torch.float32, device=v.device)
-    return (ops.dwconv3x3(dq4, w9q, flip=True), ops.dwconv3x3(dk4, w9k, flip=True), ops.dwconv3x3(dv4, w9v, flip=True),
+    # d(t_k), d(t_v) as the halves of ONE buffer: the cross attention's caller takes them as [d t_k | d t_v] without a cat
+    dkv = torch.empty((B, H, W, 2 * C), dtype=dt, device=v.device)
+    return (ops.dwconv3x3(dq4, w9q, flip=True), ops.dwconv3x3(dk4, w9k, flip=True, out=dkv[..., :C]), ops.dwconv3x3(dv4, w9v, flip=True, out=dkv[..., C:]),
             ops.dwconv3x3_wgrad(t_q, dq4, col_ranges=[(0, C)], out=dw3[:C]), ops.dwconv3x3_wgrad(t_k, dk4, col_ranges=[(0, C)], out=dw3[C:2 * C]),
             ops.dwconv3x3_wgrad(t_v, dv4, col_ranges=[(0, C)], out=dw3[2 * C:]), dtemp, dwo)
 
@@ -489,7 +493,10 @@ class _CrossChannelAttnRes(torch.autograd.Function):
                 da, tq4, tkv4[..., :D], tkv4[..., D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], v, gp, sp, Mb, MbT,
                 attn.temperature, attn.project_out.weight, attn.num_heads, B, H, W)
             dtq2 = dtq.reshape(M, D).contiguous()
-            dkv = torch.cat([dtk, dtv], dim=-1).reshape(M, 2 * D)
+            if dtk.data_ptr() + D * dtk.element_size() == dtv.data_ptr() and dtk.stride(2) == 2 * D:      # halves of one buffer
+                dkv = torch.as_strided(dtk, (M, 2 * D), (2 * D, 1))
+            else:
+                dkv = torch.cat([dtk, dtv], dim=-1).reshape(M, 2 * D)
             n11w, n11b = ct.norm11.pair()
             n12w, n12b = ct.norm12.pair()
             # norm11 backward in fp32 on the fp32 text map (see the class docstring); dres = the residual path of `a`

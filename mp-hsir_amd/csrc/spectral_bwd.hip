@@ -47,11 +47,18 @@ template <class T, int C, int HD> struct SbCfg {
     static constexpr int KQ = 2 * HD, KV = C, KMAX = KQ > KV ? KQ : KV;
     static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     static constexpr int LDW = KMAX + PAD;           // weight rows [CS][K]: conflict-free ds_read_b128 fragments
-    static constexpr int LDT = CS + 4;               // fp32 tile pitch: = 4 (mod 8) floats -- the accumulator stores (16 pixels x 16 B) and the
-                                                     // window reads (strips 8 pixels apart: 32 banks apart) both cover the 64 banks once
-    static constexpr size_t t_floats = (size_t)SB_MB * 16 * LDT;
+    // pixels per window-pass thread: 8, as in the depthwise kernels -- but a 32-channel slab then keeps only 128 of the 256 threads busy
+    // in that pass (8 channel quads x 16 strips): those slabs use strips of 4 pixels (32 strips: every thread busy, 4.5 instead of 3.75
+    // LDS reads per output)
+    static constexpr int SPX = CS == 32 ? 4 : 8, SPR = SB_TW / SPX, NST = SB_TH * SPR;
+    // fp32 tile pitch.  8-pixel strips: = 4 (mod 8) floats -- the accumulator stores (16 pixels x 16 B) and the window reads (the two
+    // strips of a 16-lane group are 8 pixels apart: 32 banks) both cover the 64 banks once.  4-pixel strips: = 8 (mod 16) floats -- the
+    // two strips of a group are 4 pixels apart: 32 banks again (the accumulator stores of 16 pixels then collide pairwise: six per tile)
+    static constexpr int LDT = SPX == 4 ? CS + 8 : CS + 4;
+    static constexpr size_t t_floats0 = (size_t)SB_MB * 16 * LDT, red_floats = (size_t)NST * 9 * CS;
+    static constexpr size_t t_floats = t_floats0 > red_floats ? t_floats0 : red_floats;      // the strip sums reuse the tile
     static constexpr size_t bytes = t_floats * sizeof(float) + (size_t)CS * LDW * sizeof(T);
-    static_assert(HD % CS == 0 && C % CS == 0 && KQ % 32 == 0 && KV % 32 == 0 && (size_t)16 * 9 * CS <= t_floats, "shape");
+    static_assert(HD % CS == 0 && C % CS == 0 && KQ % 32 == 0 && KV % 32 == 0 && QPR * NST <= SB_THREADS, "shape");
 };
 
 template <class T, int C, int HD>
@@ -61,6 +68,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void spectral_dqkv_bwd_kernel(SpecBw
     typedef typename TR::vec4_t v4_t;
     typedef SbCfg<T, C, HD> CF;
     constexpr int CS = CF::CS, NB = CF::NB, NSLT = CF::NSLT, NSLAB = CF::NSLAB, QPR = CF::QPR, LDW = CF::LDW, LDT = CF::LDT;
+    constexpr int SPX = CF::SPX, SPR = CF::SPR, NST = CF::NST;
     static_assert(sizeof(T) == 2, "16-bit types only");
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     float* Ts = reinterpret_cast<float*>(smem_v);                       // [192][LDT] fp32 [dq | dk | dv] of the halo tile, this slab; at the end: strip sums
@@ -72,8 +80,8 @@ __global__ __launch_bounds__(SB_THREADS, 2) void spectral_dqkv_bwd_kernel(SpecBw
     const long total = (long)a.B * tiles, per = (total + a.nblk - 1) / a.nblk;
     const long t_begin = (long)rg * per, t_end = t_begin + per < total ? t_begin + per : total;
     const int tcol = type * C + c0;                                     // column of T / dT / w9 / part
-    const bool on = tid < QPR * 16;
-    const int c4 = tid % QPR, st = tid / QPR, iy = st >> 1, ix0 = (st & 1) * 8;
+    const bool on = tid < QPR * NST;
+    const int c4 = tid % QPR, st = tid / QPR, iy = st / SPR, ix0 = (st % SPR) * SPX;      // 4 channels x a strip of SPX pixels of tile row iy
 
     auto body = [&](auto isv_c) __attribute__((always_inline)) {
         constexpr bool ISV = decltype(isv_c)::value;
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void spectral_dqkv_bwd_kernel(SpecBw
             return z;
         };
         frag_t xf[SB_MBW][GP];          // the first GP K chunks of the tile's input fragments, requested a tile ahead
-        v4_t xy[8];                     // t of this thread's 8 pixels x 4 channels
+        v4_t xy[SPX];                   // t of this thread's SPX pixels x 4 channels
         auto gload = [&](long t) __attribute__((always_inline)) {
 #pragma unroll
             for (int mb = 0; mb < SB_MBW; ++mb) {
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void spectral_dqkv_bwd_kernel(SpecBw
                 const int ty0 = (tile / tilesx) * SB_TH, tx0 = (tile % tilesx) * SB_TW;
                 const T* ts = reinterpret_cast<const T*>(a.T) + ((long)b * a.H * a.W + (long)(ty0 + iy) * a.W + tx0 + ix0) * a.ldt + tcol + c4 * 4;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xy[i] = *reinterpret_cast<const v4_t*>(ts + (long)i * a.ldt);
+                for (int i = 0; i < SPX; ++i) xy[i] = *reinterpret_cast<const v4_t*>(ts + (long)i * a.ldt);
             }
         };
         // window position (r, c) holds dY[p + (r-1, c-1)] = dY[p - tap] for tap (1-r, 1-c): it meets the flipped tap 8 - (3r + c)
@@ -183,9 +191,9 @@ __global__ __launch_bounds__(SB_THREADS, 2) void spectral_dqkv_bwd_kernel(SpecBw
                     *reinterpret_cast<f32x4*>(trow + nb * 16) = o;
                 }
             }
-            f32x4 xin[8];
+            f32x4 xin[SPX];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xin[i] = f32x4{to_f32(xy[i][0]), to_f32(xy[i][1]), to_f32(xy[i][2]), to_f32(xy[i][3])};
+            for (int i = 0; i < SPX; ++i) xin[i] = f32x4{to_f32(xy[i][0]), to_f32(xy[i][1]), to_f32(xy[i][2]), to_f32(xy[i][3])};
             __syncthreads();            // the tile is complete (and every wave is done with Ws for this tile)
             if (t + 1 < t_end) gload(t + 1);
             if (on) {
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void spectral_dqkv_bwd_kernel(SpecBw
 #pragma unroll
                 for (int r = 0; r < 3; ++r) { cl[r] = tvec(r, 0); cm[r] = tvec(r, 1); }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < SPX; ++i) {
 #pragma unroll
                     for (int r = 0; r < 3; ++r) cr[r] = tvec(r, i + 2);
                     f32x4 o = cl[0] * w[0];      // the order of dwconv3x3_bwd_tile_kernel (bitwise the same dt for the same window)
@@ -221,9 +229,9 @@ __global__ __launch_bounds__(SB_THREADS, 2) void spectral_dqkv_bwd_kernel(SpecBw
             }
             __syncthreads();            // the tile is free for the next one (and, after the last, for the strip sums)
         }
-        // ---- the nine tap sums of the slab's channels: ordered sum over the 16 strips -> this range's partial, tap-major in the
+        // ---- the nine tap sums of the slab's channels: ordered sum over the NST strips -> this range's partial, tap-major in the
         // parameter's tap order (ranges without tiles write zeros: every partial is summed)
-        float* red = Ts;                // [16][9][CS]
+        float* red = Ts;                // [NST][9][CS]
         if (on)
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) *reinterpret_cast<f32x4*>(red + (st * 9 + tp) * CS + c4 * 4) = acc9[8 - tp];
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void spectral_dqkv_bwd_kernel(SpecBw
         for (int i = tid; i < 9 * CS; i += SB_THREADS) {
             const int tp = i / CS, c = i % CS;
             float s = 0.f;
-            for (int k = 0; k < 16; ++k) s += red[(k * 9 + tp) * CS + c];
+            for (int k = 0; k < NST; ++k) s += red[(k * 9 + tp) * CS + c];
             a.part[((long)rg * 9 + tp) * (3 * C) + tcol + c] = s;
         }
     };

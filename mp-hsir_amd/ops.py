@@ -1113,14 +1113,16 @@ def scaled_adamw_step(p, g, m, v, scaler, lr, beta1=0.9, beta2=0.999, eps=1e-8, 
     bump_weight_epoch()
 
 
-def dwconv3x3(x, w9, flip=False):
-    """x (B,H,W,C) channels-last (last dim contiguous, row pitch = stride of W axis); w9 fp32 [9][C] view."""
+def dwconv3x3(x, w9, flip=False, out=None):
+    """x (B,H,W,C) channels-last (last dim contiguous, row pitch = stride of W axis); w9 fp32 [9][C] view.
+    out: optional (B,H,W,C) view to write (a channel slice of a wider buffer: its pixel pitch is passed on) instead of a new tensor."""
     lib = _lib.load()
     _check(x, w9)
     B, H, W, C = x.shape
     assert x.stride(3) == 1 and x.stride(1) == W * x.stride(2) and x.stride(0) == H * x.stride(1)
-    y = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
-    _lib.check(lib.mphsir_dwconv3x3(_p(x), x.stride(2), _p(w9), w9.stride(0), _p(y), C, B, H, W, C, int(flip),
+    y = out if out is not None else torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    assert y.shape == x.shape and y.dtype == x.dtype and y.stride(3) == 1 and y.stride(1) == W * y.stride(2) and y.stride(0) == H * y.stride(1)
+    _lib.check(lib.mphsir_dwconv3x3(_p(x), x.stride(2), _p(w9), w9.stride(0), _p(y), y.stride(2), B, H, W, C, int(flip),
                                     _DT[x.dtype], _stream(x)), "dwconv3x3")
     _acct("dwconv3x3", 18.0 * B * H * W * C, 2.0 * B * H * W * C * x.element_size())
     return y
