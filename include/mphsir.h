@@ -373,6 +373,10 @@ typedef struct mphsir_fold_bwd_args {
     void* W2; float* dWo; float* dtemp;
     int32_t B, C, heads, nsplit;
     int32_t dM_nsplit;          /* <= 1: dM is [B][C][C]; > 1: dM is [B][dM_nsplit][C][C], the split partials of mphsir_gemm_tn, summed here in split order */
+    /* N > 0 (16-bit dtypes, head width 32 / 48 / 64; meant for small images: N <= 1024 tokens per sample): dM is not read (may be
+     * NULL) but FORMED in the kernel, dM_b = d_out_b^T v_b over the sample's N tokens -- DO [B*N][lddo >= C] = d_out, V [B*N][ldv >= C]
+     * = v of the forward (16-byte aligned rows): the token-reduction GEMM in front of this launch disappears */
+    const void* DO; int64_t lddo; const void* V; int64_t ldv; int32_t N;
 } mphsir_fold_bwd_args;
 int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype, void* stream);
 typedef struct mphsir_pg_bwd_args {

@@ -116,7 +116,8 @@ class WinAttnBwdArgs(_Args):
 class FoldBwdArgs(_Args):
     """mirror of struct mphsir_fold_bwd_args"""
     _fields_ = _SZ + [(n, c_void_p) for n in ("Gpart", "Spart", "temperature", "Wo", "dM", "W2", "dWo", "dtemp")] + \
-               [(n, c_int32) for n in ("B", "C", "heads", "nsplit", "dM_nsplit")]
+               [(n, c_int32) for n in ("B", "C", "heads", "nsplit", "dM_nsplit")] + \
+               [("DO", c_void_p), ("lddo", c_int64), ("V", c_void_p), ("ldv", c_int64), ("N", c_int32)]
 
 
 class PgBwdArgs(_Args):

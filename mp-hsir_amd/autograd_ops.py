@@ -70,9 +70,13 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     N = H * W
     M = B * N
     dt = v.dtype
-    dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), reduce=False)        # (B, splits, C, C) fp32 partials: summed by the fold backward as it stages them
-    W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temperature.detach().reshape(heads).float().contiguous(),
-                                               wo.detach().reshape(C, C).float().contiguous(), dM, dt, reduce=False)
+    temp32, wo32 = temperature.detach().reshape(heads).float().contiguous(), wo.detach().reshape(C, C).float().contiguous()
+    if ops.fold_bwd_forms_dm(N, C, heads, dt):
+        # small images (the lower pyramid levels): dM = d_out^T v is formed INSIDE the fold backward -- one launch fewer on the chain
+        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temp32, wo32, None, dt, reduce=False, d_out=d_out.reshape(M, C), v=v.reshape(M, C))
+    else:
+        dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), reduce=False)    # (B, splits, C, C) fp32 partials: summed by the fold backward as it stages them
+        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temp32, wo32, dM, dt, reduce=False)
     # q, k of the forward: either kept by it (qk) or recomputed by the depthwise kernel; when q|k|v are adjacent channel
     # slices of one tensor (self-attention) every depthwise pass runs once over the joint channel range.
     joint = (t_q.data_ptr() + C * t_q.element_size() == t_k.data_ptr() and t_k.data_ptr() + C * t_k.element_size() == t_v.data_ptr()

@@ -20,6 +20,8 @@ struct FoldBwdDev {
     const float* temperature; const float* Wo;
     const float* dM;            // [B][C][C] fp32, or [B][dm_nsplit][C][C]: the split partials of the token-reduction GEMM that produced it
     int dm_nsplit;              // (summed in split order while they are staged: the ordered-sum launch between the two kernels is gone)
+    const void* DO; long lddo; const void* V; long ldv; int N;      // N > 0 (16-bit types, small images): dM is not read but FORMED here -- dM_b =
+                                                                      // d_out_b^T v_b over the sample's N tokens (rows b N .. of DO [.][lddo], V [.][ldv])
     void* W2;                   // [B][2C][2C] compute dtype
     float* dWo;                 // [B][C][C] fp32 per-sample partial (column block of this head written by its WG)
     float* dtemp;               // [B][HEADS]
@@ -49,6 +51,11 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
     float* sq = rn + 2 * HD;                          // [2*HD] raw sums of squares
     float* dn = sq + 2 * HD;                          // [2*HD] d nq | d nk
     float* red = dn + 2 * HD;                         // [HD] per-row d temperature terms
+    // in-kernel dM (a.N > 0): token tiles of d_out[:, c0 .. c0 + FB_CO) and v[:, head] in the storage type, 64 tokens per stage
+    constexpr int FB_TK = 64, FB_PAD = 8;
+    const int LDD = FB_CO + FB_PAD, LDV = HD + FB_PAD;
+    T* Dt = reinterpret_cast<T*>(red + ((HD + 3) & ~3));          // [FB_TK][LDD]
+    T* Vt = Dt + FB_TK * LDD;                                      // [FB_TK][LDV]
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
     const float temp = a.temperature[h];
 
@@ -105,6 +112,63 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
     const int lr = lane & 15, lk = 4 * (lane >> 4);
     for (int c0 = 0; c0 < C; c0 += FB_CO) {
         __syncthreads();                              // previous chunk consumed (first time: A complete)
+        bool formed = false;
+        if constexpr (sizeof(T) == 2 && HDT > 0 && HDT <= 64) {
+            if (a.N > 0) {
+                // ---- dM rows c0 .. c0 + FB_CO of this head, formed here: Ms[rr][cc] = sum_tok d_out[tok][c0 + rr] v[tok][h HD + cc].  Both
+                // operands are token-major (K-strided): 64-token tiles go through LDS and are read as MFMA fragments by the transposed
+                // reads; the next tile's rows are requested from L2 before this tile's barrier.  (The lower pyramid levels -- 256 / 1024
+                // tokens per sample -- where the token-reduction GEMM this replaces was a 15-22 us launch on the critical path.)
+                typedef typename ElemTraits<T>::frag_t frag_t;
+                const T* DOb = reinterpret_cast<const T*>(a.DO) + (long)b * a.N * a.lddo + c0;
+                const T* Vb = reinterpret_cast<const T*>(a.V) + (long)b * a.N * a.ldv + h * HD;
+                const int cw = (C - c0) < FB_CO ? (C - c0) : FB_CO;       // valid rows of this chunk
+                const int dvr = FB_CO / 8, vvr = HD / 8;                   // 16-byte vectors per token row
+                constexpr int NTM = (fb_co(HDT) / 16) * (HDT / 16), TPWM = (NTM + FB_WAVES - 1) / FB_WAVES;
+                f32x4 accM[TPWM];
+#pragma unroll
+                for (int q = 0; q < TPWM; ++q) accM[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                Vec16<T> dreg, vreg;
+                const int dtok = tid / dvr, dcol = (tid % dvr) * 8, vtok = tid / vvr, vcol = (tid % vvr) * 8;
+                const bool don = tid < FB_TK * dvr, von = tid < FB_TK * vvr;
+                auto tload = [&](int t0) __attribute__((always_inline)) {
+                    if (don) { if (dcol < cw && t0 + dtok < a.N) dreg = load16<T>(DOb + (long)(t0 + dtok) * a.lddo + dcol); else dreg = Vec16<T>{}; }
+                    if (von) { if (t0 + vtok < a.N) vreg = load16<T>(Vb + (long)(t0 + vtok) * a.ldv + vcol); else vreg = Vec16<T>{}; }
+                };
+                tload(0);
+                for (int t0 = 0; t0 < a.N; t0 += FB_TK) {
+                    if (don) store16<T>(Dt + dtok * LDD + dcol, dreg);
+                    if (von) store16<T>(Vt + vtok * LDV + vcol, vreg);
+                    __syncthreads();
+                    if (t0 + FB_TK < a.N) tload(t0 + FB_TK);
+#pragma unroll
+                    for (int q = 0; q < TPWM; ++q) {
+                        const int tt = wv + FB_WAVES * q;              // wave-uniform: output tile (16 rows of the chunk, 16 head columns)
+                        if (tt < (FB_CO / 16) * NT) {
+                            const int ti = tt / NT, tj = tt % NT;
+#pragma unroll
+                            for (int k0 = 0; k0 < FB_TK; k0 += 32)
+                                mma(accM[q], load_frag_tr<T>(Dt, LDD, ti * 16, k0), load_frag_tr<T>(Vt, LDV, tj * 16, k0));
+                        }
+                    }
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int q = 0; q < TPWM; ++q) {
+                    const int tt = wv + FB_WAVES * q;
+                    if (tt < (FB_CO / 16) * NT) {
+                        const int ti = tt / NT, tj = tt % NT;
+                        for (int r = 0; r < 4; ++r) Ms[(ti * 16 + (lane >> 4) * 4 + r) * LD + tj * 16 + (lane & 15)] = accM[q][r];
+                    }
+                }
+                for (int idx = tid; idx < FB_CO * (HD / 4); idx += FB_THREADS) {
+                    const int rr = idx / (HD / 4), cc = (idx % (HD / 4)) * 4;
+                    *reinterpret_cast<f32x4*>(Ws + rr * LD + cc) = c0 + rr < C ? *reinterpret_cast<const f32x4*>(a.Wo + (long)(c0 + rr) * C + h * HD + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                formed = true;
+            }
+        }
+        if (!formed)
         // Ws / Ms rows of this chunk: 16-byte vectors along the head's columns.  The dM rows are the ordered sum of the token-reduction
         // GEMM's split partials: ALL the splits of a vector are requested before the first is added (in split order, eight at a time) --
         // until round 6 a thread walked its elements one after the other with four loads in flight, 24 dependent round trips at the
@@ -246,14 +310,19 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
     using namespace mphsir;
     clear_error();
     MPHSIR_CHECK_ARGS(a, "spectral_fold_bwd");
-    MPHSIR_REQUIRE(a && a->Gpart && a->Spart && a->temperature && a->Wo && a->dM && a->W2 && a->dWo && a->dtemp, "spectral_fold_bwd: null pointer");
+    MPHSIR_REQUIRE(a && a->Gpart && a->Spart && a->temperature && a->Wo && (a->dM || a->N > 0) && a->W2 && a->dWo && a->dtemp, "spectral_fold_bwd: null pointer");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(dtype), "spectral_fold_bwd: dtype %d unsupported", dtype);
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold_bwd: bad shape");
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 96, "spectral_fold_bwd: head_dim %d > 96", HD);
-    FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->dM_nsplit, a->W2, a->dWo, a->dtemp, a->B, a->C, HD};
+    FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->dM_nsplit, a->DO, (long)a->lddo, a->V, (long)a->ldv, a->N, a->W2, a->dWo, a->dtemp, a->B, a->C, HD};
+    if (a->N > 0)
+        MPHSIR_REQUIRE(dtype != MPHSIR_F32 && (HD == 32 || HD == 48 || HD == 64) && a->DO && a->V && aligned16(a->DO) && aligned16(a->V) &&
+                           (a->lddo * 2) % 16 == 0 && (a->ldv * 2) % 16 == 0 && a->lddo >= a->C && a->ldv >= a->C,
+                       "spectral_fold_bwd: forming dM in the kernel (N > 0) needs a 16-bit type, a head width of 32 / 48 / 64 and 16-byte aligned DO / V rows");
     MPHSIR_REQUIRE(HD % 16 == 0, "spectral_fold_bwd: head_dim %d must be a multiple of 16", HD);
-    const size_t shmem = ((3 * (size_t)HD + 2 * fb_co(HD)) * (HD + 8) + 9 * (size_t)HD) * sizeof(float);
+    const size_t shmem = ((3 * (size_t)HD + 2 * fb_co(HD)) * (HD + 8) + 9 * (size_t)HD + 4) * sizeof(float) +
+                         (a->N > 0 ? (size_t)64 * (fb_co(HD) + 8 + HD + 8) * 2 : 0);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define MPHSIR_FB_LAUNCH(T_, HD_)                                                                                                       \
     do {                                                                                                                              \

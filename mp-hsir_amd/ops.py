@@ -1520,13 +1520,42 @@ def dwconv_gate_bwd(t, w9, du, B, H, W):
     return u, dt_
 
 
-def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True):
+FOLD_BWD_DM_MAX_TOKENS = int(os.environ.get("MPHSIR_FOLD_BWD_DM_TOKENS", "1024"))      # per sample; 0: always the token-reduction GEMM
+
+
+def fold_bwd_forms_dm(N, C, heads, dtype):
+    """the fold backward can form dM = d_out^T v itself (small images: the lower pyramid levels, where the token-reduction GEMM in
+    front of it is a 15-22 us launch on the critical path for 4-8 MB of operands)"""
+    return dtype in _HALF and 0 < N <= FOLD_BWD_DM_MAX_TOKENS and N % 64 == 0 and (C // heads) in (32, 48, 64)      # (96-wide heads: the token tiles do not fit beside the 150 KB the kernel already takes)
+
+
+def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True, d_out=None, v=None):
     """-> W2 (B,2C,2C) in `dtype`, dWo (C,C) fp32, dtemp (heads,) fp32 (reduce=False: the per-sample partials
-    (B,C,C) / (B,heads) instead, for the caller to pass to reduce_parts)."""
+    (B,C,C) / (B,heads) instead, for the caller to pass to reduce_parts).  dM=None with d_out, v (B*N, C) in `dtype`: dM is formed in
+    the kernel (fold_bwd_forms_dm)."""
     lib = _lib.load()
-    _check(gp, sp, temperature, Wo, dM)
     B, nsplit, heads, hd, _ = gp.shape
     C = heads * hd
+    if dM is None:
+        _check(gp, sp, temperature, Wo, d_out, v)
+        N = d_out.shape[0] // B
+        assert d_out.shape == (B * N, C) and v.shape == (B * N, C) and d_out.dtype == dtype and v.dtype == dtype and d_out.stride(1) == 1 and v.stride(1) == 1
+        assert fold_bwd_forms_dm(N, C, heads, dtype)
+        W2 = torch.empty((B, 2 * C, 2 * C), dtype=dtype, device=gp.device)
+        dWo = torch.empty((B, C, C), dtype=torch.float32, device=gp.device)
+        dtemp = torch.empty((B, heads), dtype=torch.float32, device=gp.device)
+        a = _lib.FoldBwdArgs()
+        a.Gpart, a.Spart, a.temperature, a.Wo = _p(gp), _p(sp), _p(temperature), _p(Wo)
+        a.W2, a.dWo, a.dtemp = _p(W2), _p(dWo), _p(dtemp)
+        a.B, a.C, a.heads, a.nsplit, a.dM_nsplit = B, C, heads, nsplit, 0
+        a.DO, a.lddo, a.V, a.ldv, a.N = _p(d_out), d_out.stride(0), _p(v), v.stride(0), N
+        _lib.check(lib.mphsir_spectral_fold_bwd(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold_bwd")
+        _acct("spectral_fold_bwd", 4.0 * B * C * C * hd + 2.0 * B * N * C * C, 3.0 * B * C * C * 4 + 2.0 * B * N * C * d_out.element_size())
+        _acct("spectral_fold_bwd:dm", 0.0, 0.0)
+        if not reduce:
+            return W2, dWo, dtemp
+        return W2, reduce_parts(dWo), reduce_parts(dtemp)
+    _check(gp, sp, temperature, Wo, dM)
     # dM (B, C, C), or (B, splits, C, C): the raw split partials of the token-reduction GEMM (gemm_tn(..., reduce=False)) -- the kernel
     # sums them in split order while it stages them, so no ordered-sum launch sits between the two
     dm_nsplit = dM.shape[1] if dM.dim() == 4 else 1

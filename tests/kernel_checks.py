@@ -982,6 +982,32 @@ def check_fold_bwd_split_dm(dev, dtype, C=64, heads=2, B=2, nsp=5):
         assert rel_l2(y, x.double().cpu()) < tol, rel_l2(y, x.double().cpu())
 
 
+def check_fold_bwd_forms_dm(dev, dtype, C=64, heads=2, B=3, N=256):
+    """mphsir_spectral_fold_bwd forming dM = d_out^T v itself (N > 0: the lower pyramid levels) against the token-reduction GEMM followed
+    by the plain call, and dM against an fp64 product of the same operands"""
+    _use(dev)
+    from mp_hsir_amd import ops
+    hd = C // heads
+    assert ops.fold_bwd_forms_dm(N, C, heads, dtype)
+    gp = rnd((B, 1, heads, hd, hd), 611)
+    sp = rnd((B, 1, 2, C), 612).abs() + 0.5
+    temp = (1 + 0.3 * rnd((heads,), 613)).contiguous()
+    wo = rnd((C, C), 614, scale=C ** -0.5)
+    d_out, v = rnd((B * N, C), 615, dtype), rnd((B * N, C), 616, dtype)
+    dm = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), reduce=False)
+    a = ops.spectral_fold_bwd(gp, sp, temp, wo, dm, dtype, reduce=False)
+    b = ops.spectral_fold_bwd(gp, sp, temp, wo, None, dtype, reduce=False, d_out=d_out, v=v)
+    # fp64 reference of W2 / dWo / dtemp through the plain call on an fp64-accurate dM
+    dm64 = torch.einsum("bnc,bnd->bcd", d_out.double().cpu().reshape(B, N, C), v.double().cpu().reshape(B, N, C)).float().to(dev)
+    c = ops.spectral_fold_bwd(gp, sp, temp, wo, dm64.contiguous(), dtype, reduce=False)
+    res = {}
+    for name, x, y, z in zip(("W2", "dWo", "dtemp"), a, b, c):
+        tol = 1e-5 if x.dtype == torch.float32 else 4e-3
+        res[name] = (rel_l2(y, x.double().cpu()), rel_l2(y, z.double().cpu()))
+        assert res[name][0] < tol and res[name][1] < tol, res
+    return res
+
+
 def check_spectral_dqkv_bwd(dev, dtype, C, heads, shape, nblk=None):
     """mphsir_spectral_dqkv_bwd (dv, [dq | dk], depthwise backward + tap gradients in one launch) against the three launches it replaces
     -- gemm_tok(d_out, M_b^T), gemm_tok([q | k], W2), dwconv3x3_bwd -- on the same operands:

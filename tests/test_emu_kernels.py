@@ -223,6 +223,11 @@ def test_channel_attention_bwd(dtype, C, heads, shape, cross):
     K.check_channel_attention_bwd("cpu", dtype, C, heads, shape, cross)
 
 
+@pytest.mark.parametrize("dtype,C,heads,N", [(torch.bfloat16, 64, 2, 256), (torch.float16, 128, 2, 128), (torch.bfloat16, 96, 2, 64)])
+def test_fold_bwd_forms_dm_itself(dtype, C, heads, N):
+    print(K.check_fold_bwd_forms_dm("cpu", dtype, C, heads, B=2, N=N))
+
+
 @pytest.mark.parametrize("dtype,C,heads,shape", [(torch.bfloat16, 32, 1, (2, 8, 16)), (torch.bfloat16, 64, 2, (1, 16, 32)), (torch.float16, 128, 2, (1, 8, 16)),
                                                  (torch.bfloat16, 96, 2, (1, 8, 16))])
 def test_spectral_dqkv_bwd_against_the_three_launches(dtype, C, heads, shape):

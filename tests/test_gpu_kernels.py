@@ -332,6 +332,13 @@ def test_spectral_dqkv_bwd_against_the_three_launches(dtype, C, heads, shape):
     print(K.check_spectral_dqkv_bwd("cuda", dtype, C, heads, shape))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,heads,N", [(128, 4, 1024), (256, 8, 256), (64, 2, 1024), (192, 4, 1024), (384, 8, 256), (128, 2, 1024)])
+def test_fold_bwd_forms_dm_itself(dtype, C, heads, N):
+    """the fold backward with dM = d_out^T v formed inside (the lower pyramid levels of both configurations, batch 32)"""
+    print(K.check_fold_bwd_forms_dm("cuda", dtype, C, heads, B=32, N=N))
+
+
 def test_spectral_dqkv_bwd_at_the_training_shape():
     print(K.check_spectral_dqkv_bwd("cuda", torch.bfloat16, 128, 2, (32, 64, 64), nblk=80))
 
