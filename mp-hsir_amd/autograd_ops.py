@@ -461,34 +461,38 @@ class _CrossChannelAttnRes(torch.autograd.Function):
     norm11 residuals of large cancelling sums -- rounding it to bf16 before the LayerNorm changes d(norm11.weight) and
     d(q.weight) by 15 % (csrc/layernorm.hip).  So norm11 runs on the fp32 input (layernorm_tok, fp32 statistics, output
     in the compute dtype) and its backward in fp32, as the reference's autocast does; everything after it is the
-    compute-dtype path."""
+    compute-dtype path.
+
+    x_kv is TVSP's visual prompt, ONE (ps, ps, D) map shared by the whole batch (the reference expands it to B copies, :578): vis1 is
+    that one map (ps*ps, D).  norm12 and the kv 1x1 conv run on it once (their B results are identical) and only t_kv is repeated for
+    the depthwise / Gram kernel; the backward sums d t_kv over the batch first and runs the kv / norm12 backward on ps*ps tokens."""
 
     @staticmethod
-    def forward(ctx, ct, geom, dt, text32, vis2, n11w, n11b, n12w, n12b, w_q, w_kv, w_qdw, w_kvdw, w_out, temp):
+    def forward(ctx, ct, geom, dt, text32, vis1, n11w, n11b, n12w, n12b, w_q, w_kv, w_qdw, w_kvdw, w_out, temp):
         B, H, W = geom
         D = text32.shape[1]
         pa = ct.attn.packed(dt)
         lw, lb = ct.norm11.pair()
         xq = ops.layernorm_tok(text32, lw, lb, dt)
         tq = ops.gemm_tok(xq, pa["wq"])
-        tkv = ops.gemm_tok(vis2, pa["wkv"], ln=ct.norm12.pair())
+        tkv = ops.gemm_tok(vis1, pa["wkv"], ln=ct.norm12.pair()).repeat(B, 1)      # (B ps ps, 2D): the same rows for every sample
         w9 = pa["w9"]
         v, gp, sp, _ = ops.dwconv_gram(tq, tkv[:, :D], tkv[:, D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
                                        B, H, W, D, ct.attn.num_heads)
         Mb, MbT, gp, sp = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
         a = ops.gemm_tok(v, Mb, epi=1, res=text32.to(dt))
         ctx.ct, ctx.geom = ct, geom
-        ctx.save_for_backward(text32, vis2, xq, tq, tkv, v, gp, sp, Mb, MbT)
+        ctx.save_for_backward(text32, vis1, xq, tq, tkv, v, gp, sp, Mb, MbT)
         return a
 
     @staticmethod
     def backward(ctx, da):
-        text32, vis2, xq, tq, tkv, v, gp, sp, Mb, MbT = ctx.saved_tensors
+        text32, vis1, xq, tq, tkv, v, gp, sp, Mb, MbT = ctx.saved_tensors
         ct, (B, H, W) = ctx.ct, ctx.geom
         attn = ct.attn
         D = text32.shape[1]
         M = text32.shape[0]
-        pa = attn.packed(vis2.dtype)
+        pa = attn.packed(vis1.dtype)
         w9 = pa["w9"]
         da = da.contiguous()
         tq4, tkv4 = tq.reshape(B, H, W, D), tkv.reshape(B, H, W, 2 * D)
@@ -505,9 +509,12 @@ class _CrossChannelAttnRes(torch.autograd.Function):
             n12w, n12b = ct.norm12.pair()
             # norm11 backward in fp32 on the fp32 text map (see the class docstring); dres = the residual path of `a`
             dtext, d11w, d11b, _ = ops.ln_bwd_tok(text32, ops.gemm_tok(dtq2, pa["wqT"]).float(), da.float(), n11w, n11b)
-            dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis2, ops.gemm_tok(dkv, pa["wkvT"]), torch.zeros_like(vis2), n12w, n12b)
+            # the kv side is batch-invariant up to t_kv: its gradient is summed over the batch (fp32 accumulation) and everything behind it
+            # -- the 1x1 conv's data gradient, norm12's backward, both parameter gradients -- runs on the ps*ps tokens of the one map
+            dkv1 = dkv.reshape(B, H * W, 2 * D).sum(dim=0)
+            dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis1, ops.gemm_tok(dkv1, pa["wkvT"]), torch.zeros_like(vis1), n12w, n12b)
             d_wq = ops.gemm_tn(dtq2, xq).reshape(D, D, 1, 1)
-            d_wkv = ops.gemm_tn(dkv, xv).reshape(2 * D, D, 1, 1)
+            d_wkv = ops.gemm_tn(dkv1, xv).reshape(2 * D, D, 1, 1)
         return (None, None, None, dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.reshape(D, 1, 3, 3),
                 _join_taps(dwk, dwv).reshape(2 * D, 1, 3, 3), dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1))
 
@@ -548,10 +555,10 @@ def tvsp(mod, x, clip_prompt, prompt_weights):
     learn = mod.text_prompt_learnable[0, :, :, 0, 0]                                   # (T,D)
     L = (prompt_weights.to(torch.float32).unsqueeze(-1) * learn.unsqueeze(0)).mean(dim=1)      # (B,D)
     text = _TextMap.apply(L, clip_prompt, ps)                                          # fp32: see _CrossChannelAttnRes
-    vis = mod.visual_prompt.permute(0, 2, 3, 1).expand(B, ps, ps, D).to(dt).contiguous()
+    vis1 = mod.visual_prompt[0].permute(1, 2, 0).to(dt).contiguous().reshape(ps * ps, D)      # the one visual prompt map (ref :578 expands it to B copies)
     ct = mod.cross_transformer
     at = ct.attn
-    a = _CrossChannelAttnRes.apply(ct, (B, ps, ps), dt, text.reshape(-1, D), vis.reshape(-1, D), ct.norm11.body.weight,
+    a = _CrossChannelAttnRes.apply(ct, (B, ps, ps), dt, text.reshape(-1, D), vis1, ct.norm11.body.weight,
                                    ct.norm11.body.bias, ct.norm12.body.weight, ct.norm12.body.bias, at.q.weight, at.kv.weight,
                                    at.q_dwconv.weight, at.kv_dwconv.weight, at.project_out.weight, at.temperature)
     y = _gdfn_res_ag(ct.ffn, ct.norm2, a, B, ps, ps).reshape(B, ps, ps, D)
