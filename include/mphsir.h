@@ -352,6 +352,14 @@ int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const f
                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, const float* ln_b, void* XN, int32_t linear,
                       int dtype, void* stream);
 
+/* The same with the d_xn GEMM inside: d_xn = dQKV WqkvT^T is formed per window on the matrix cores (dQKV [B*nW*64][3C] in window-token
+ * order as mphsir_win_attn_bwd writes it, WqkvT = the [C][3C] weight mphsir_gemm_tok would take for that data gradient) and fed to the
+ * LayerNorm backward in LDS: replaces mphsir_gemm_tok + mphsir_ln_bwd_win (autograd of net/MP_HSIR.py:667 norm1 and :193-196 qkv);
+ * d_xn never reaches HBM.  dX = dRes + LN_backward(d_xn) in image order; part [B*nW][2][C] as mphsir_ln_bwd_win.  16-bit dtypes. */
+int mphsir_ln_bwd_win_dxn(const void* X, const void* dQKV, const void* WqkvT, const void* dRes, const float* ln_w, void* dX, float* part,
+                          int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
+int mphsir_ln_bwd_win_dxn_fits(int32_t C, int dtype);
+
 /* ---- stand-alone LayerNorm over channels (SURVEY 8b `layernorm_nhwc`; net/MP_HSIR.py:341-370) ---------------------------
  * Y[m][:] = LN(X[m][:]) * ln_w + ln_b, biased variance, eps 1e-5, statistics in fp32.  X and Y may have different element
  * types (x_dtype / y_dtype): TVSP's norm11 (:282) reads the fp32 rank-one text map and writes the compute dtype.        */

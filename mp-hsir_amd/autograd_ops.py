@@ -250,7 +250,10 @@ def _pgsstb_attn_backward(blk, k1, saved, dy):
         # (5) d_xn = dqkv Wqkv, then norm1 backward and the residual path.  (The LayerNorm backward as an epilogue of that GEMM
         # was built and measured slower in round 4 -- four barriers and an fp32 staging tile per GEMM tile against a 2 C per token
         # round trip -- and removed in round 5.)
-        dx, part = ops.ln_bwd_win(x, ops.gemm_tok(dqkv, pk["wqkvT"]), dy, pk["ln1"][0], shift)
+        if ops.ln_bwd_win_dxn_fits(M, Cc, dt):      # d_xn = dqkv Wqkv formed inside the LayerNorm-backward launch
+            dx, part = ops.ln_bwd_win_dxn(x, dqkv, pk["wqkvT"], dy, pk["ln1"][0], shift)
+        else:
+            dx, part = ops.ln_bwd_win(x, ops.gemm_tok(dqkv, pk["wqkvT"]), dy, pk["ln1"][0], shift)
         dln = ops.reduce_parts(part)
         drpb = ops.reduce_parts(drpb)
     d_sdw = _join_taps(dwq, dwk, dwv).reshape(3 * Cc, 1, 3, 3)

@@ -1394,6 +1394,32 @@ def ln_bwd_win(x, dxn_w, dres, ln_w, shift):
     return dx, part
 
 
+LN_BWD_DXN = os.environ.get("MPHSIR_LN_BWD_DXN", "1") == "1"      # d_xn = dQKV Wqkv formed inside the LayerNorm-backward launch (0: gemm_tok + ln_bwd_win)
+LN_BWD_DXN_MAX_ROWS = int(os.environ.get("MPHSIR_LN_BWD_DXN_ROWS", "0"))      # 0: every size; else only launches of at most this many token rows
+
+
+def ln_bwd_win_dxn_fits(M, C, dtype):
+    return (LN_BWD_DXN and dtype in _HALF and (LN_BWD_DXN_MAX_ROWS == 0 or M <= LN_BWD_DXN_MAX_ROWS)
+            and bool(_lib.load().mphsir_ln_bwd_win_dxn_fits(C, _DT[dtype])))
+
+
+def ln_bwd_win_dxn(x, dqkv, wqkvT, dres, ln_w, shift):
+    """dx = dres + LN_backward(dqkv wqkvT^T) with the token GEMM inside the launch (dqkv (M, 3C) in window-token order, wqkvT (C, 3C))
+    -> (dx (B,H,W,C), part (B*nW,2,C))."""
+    lib = _lib.load()
+    _check(x, dqkv, wqkvT, dres, ln_w)
+    B, H, W, C = x.shape
+    assert x.is_contiguous() and dqkv.is_contiguous() and dres.is_contiguous() and wqkvT.is_contiguous()
+    assert dqkv.shape == (B * H * W, 3 * C) and wqkvT.shape == (C, 3 * C) and wqkvT.dtype == x.dtype
+    dx = torch.empty_like(x)
+    part = torch.empty((B * H * W // 64, 2, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mphsir_ln_bwd_win_dxn(_p(x), _p(dqkv), _p(wqkvT), _p(dres), _p(ln_w), _p(dx), _p(part), B, H, W, C, shift,
+                                         _DT[x.dtype], _stream(x)), "ln_bwd_win_dxn")
+    _acct("ln_bwd_win", 10.0 * x.numel() + 6.0 * x.numel() * C, 6.0 * x.numel() * x.element_size())
+    _acct("ln_bwd_win:dxn", 0.0, 0.0)
+    return dx, part
+
+
 def ln_bwd_tok(x2, dxn, dres, ln_w, ln_b):
     """plain token order: (dx = dres + LN_backward(dxn), d ln weight, d ln bias, LN(x)) for x2 (M,C), M % 64 == 0."""
     lib = _lib.load()

@@ -982,6 +982,40 @@ def check_fold_bwd_split_dm(dev, dtype, C=64, heads=2, B=2, nsp=5):
         assert rel_l2(y, x.double().cpu()) < tol, rel_l2(y, x.double().cpu())
 
 
+def check_ln_bwd_win_dxn(dev, dtype, C=64, shape=(2, 16, 16), shift=4):
+    """mphsir_ln_bwd_win_dxn (d_xn = dQKV Wqkv formed inside the LayerNorm-backward launch) against gemm_tok + ln_bwd_win on the same
+    operands, and both against an fp64 evaluation (the fused form keeps d_xn in fp32: it must be no further from fp64 than the pair)"""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    M = B * H * W
+    assert ops.ln_bwd_win_dxn_fits(M, C, dtype)
+    x, dres = rnd((B, H, W, C), 921, dtype), rnd((B, H, W, C), 922, dtype)
+    dqkv = rnd((M, 3 * C), 923, dtype)
+    wT = rnd((C, 3 * C), 924, dtype, scale=(3 * C) ** -0.5)
+    ln_w = (1 + 0.2 * rnd((C,), 925)).contiguous()
+    dx_a, part_a = ops.ln_bwd_win(x, ops.gemm_tok(dqkv, wT), dres, ln_w, shift)
+    dx_b, part_b = ops.ln_bwd_win_dxn(x, dqkv, wT, dres, ln_w, shift)
+    # fp64: d_xn in window order -> image order through the same index map the oracle's window partition uses
+    x64, dr64 = x.double().cpu(), dres.double().cpu()
+    dxn_w = (dqkv.double().cpu() @ wT.double().cpu().t()).reshape(B, H // 8, W // 8, 8, 8, C)          # (b, wy, wx, ty, tx, c) in the SHIFTED frame
+    dxn_s = dxn_w.permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+    dxn = torch.roll(dxn_s, shifts=(shift, shift), dims=(1, 2))                                            # back to the image frame
+    xr = x64.clone().requires_grad_(True)
+    lw = ln_w.double().cpu().clone().requires_grad_(True)
+    lb = torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.layer_norm(xr, (C,), lw, lb, 1e-5)
+    (y * dxn).sum().backward()
+    dx64 = xr.grad + dr64
+    pa, pb = part_a.double().cpu().sum(0), part_b.double().cpu().sum(0)
+    res = dict(dx_pair=rel_l2(dx_a, dx64), dx=rel_l2(dx_b, dx64), dgamma_pair=rel_l2(pa[0], lw.grad), dgamma=rel_l2(pb[0], lw.grad),
+               dbeta_pair=rel_l2(pa[1], lb.grad), dbeta=rel_l2(pb[1], lb.grad))
+    tol = TOL[dtype]
+    assert res["dx"] < tol and res["dgamma"] < tol and res["dbeta"] < tol, res
+    assert res["dx"] <= res["dx_pair"] * 1.05 + 1e-7 and res["dgamma"] <= res["dgamma_pair"] * 1.05 + 1e-6 and res["dbeta"] <= res["dbeta_pair"] * 1.05 + 1e-6, res
+    return res
+
+
 def check_fold_bwd_forms_dm(dev, dtype, C=64, heads=2, B=3, N=256):
     """mphsir_spectral_fold_bwd forming dM = d_out^T v itself (N > 0: the lower pyramid levels) against the token-reduction GEMM followed
     by the plain call, and dM against an fp64 product of the same operands"""

@@ -223,6 +223,12 @@ def test_channel_attention_bwd(dtype, C, heads, shape, cross):
     K.check_channel_attention_bwd("cpu", dtype, C, heads, shape, cross)
 
 
+@pytest.mark.parametrize("dtype,C,shape,shift", [(torch.bfloat16, 64, (2, 16, 16), 4), (torch.float16, 128, (1, 8, 16), 0), (torch.bfloat16, 96, (1, 16, 8), 4),
+                                                 (torch.bfloat16, 256, (1, 8, 8), 4)])
+def test_ln_bwd_win_with_the_dxn_gemm_inside(dtype, C, shape, shift):
+    print(K.check_ln_bwd_win_dxn("cpu", dtype, C, shape, shift))
+
+
 @pytest.mark.parametrize("dtype,C,heads,N", [(torch.bfloat16, 64, 2, 256), (torch.float16, 128, 2, 128), (torch.bfloat16, 96, 2, 64)])
 def test_fold_bwd_forms_dm_itself(dtype, C, heads, N):
     print(K.check_fold_bwd_forms_dm("cpu", dtype, C, heads, B=2, N=N))

@@ -333,6 +333,13 @@ def test_spectral_dqkv_bwd_against_the_three_launches(dtype, C, heads, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,shape,shift", [(64, (4, 64, 64), 4), (128, (32, 64, 64), 0), (128, (32, 32, 32), 4), (256, (32, 16, 16), 4), (96, (2, 64, 64), 0),
+                                           (192, (16, 32, 32), 4), (32, (1, 8, 8), 0)])
+def test_ln_bwd_win_with_the_dxn_gemm_inside(dtype, C, shape, shift):
+    print(K.check_ln_bwd_win_dxn("cuda", dtype, C, shape, shift))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("C,heads,N", [(128, 4, 1024), (256, 8, 256), (64, 2, 1024), (192, 4, 1024), (384, 8, 256), (128, 2, 1024)])
 def test_fold_bwd_forms_dm_itself(dtype, C, heads, N):
     """the fold backward with dM = d_out^T v formed inside (the lower pyramid levels of both configurations, batch 32)"""
