@@ -359,6 +359,12 @@ int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const f
 int mphsir_ln_bwd_win_dxn(const void* X, const void* dQKV, const void* WqkvT, const void* dRes, const float* ln_w, void* dX, float* part,
                           int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
 int mphsir_ln_bwd_win_dxn_fits(int32_t C, int dtype);
+/* ... and in plain token order for the prompt modules' pre-norm 1x1 convs (autograd of `self.ffn(self.norm2(x))` / `self.attn(self.norm1(x))`,
+ * net/MP_HSIR.py:286,476-477 with :256,:303): d_xn = dY WT^T with dY [M][K] (the gradient of the 1x1 conv's output, K = its output
+ * channels, K % 32 == 0), WT [C][K] = the conv weight transposed; dX = dRes + LN_backward(d_xn); XN (optional, needs ln_b) = LN(X), the
+ * operand of the conv's weight gradient; part [M/64][2][C].  M % 64 == 0; (C, dtype) as mphsir_ln_bwd_win_dxn_fits.                 */
+int mphsir_ln_bwd_tok_dxn(const void* X, const void* dY, const void* WT, const void* dRes, const float* ln_w, const float* ln_b, void* dX,
+                          void* XN, float* part, int64_t M, int32_t C, int32_t K, int dtype, void* stream);
 
 /* ---- stand-alone LayerNorm over channels (SURVEY 8b `layernorm_nhwc`; net/MP_HSIR.py:341-370) ---------------------------
  * Y[m][:] = LN(X[m][:]) * ln_w + ln_b, biased variance, eps 1e-5, statistics in fp32.  X and Y may have different element

@@ -204,6 +204,7 @@ _SYMBOLS = {
     "mphsir_ln_bwd_win": (c_int, [c_void_p] * 6 + [c_int32] * 5 + [c_void_p, c_void_p, c_int32, c_int, c_void_p]),
     "mphsir_ln_bwd_win_dxn": (c_int, [c_void_p] * 7 + [c_int32] * 5 + [c_int, c_void_p]),
     "mphsir_ln_bwd_win_dxn_fits": (c_int, [c_int32, c_int]),
+    "mphsir_ln_bwd_tok_dxn": (c_int, [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_gemm_tn": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_spectral_fold_bwd": (c_int, [ctypes.POINTER(FoldBwdArgs), c_int, c_void_p]),

@@ -391,7 +391,10 @@ class _GdfnRes(torch.autograd.Function):
             dt_, d_dw = ops.dwconv3x3_bwd(t4, dtdw4, pf["w9"], col_ranges=[(0, hid), (HP, hid)])
             dt_, d_dw = dt_.reshape(-1, 2 * HP), d_dw.reshape(2 * hid, 1, 3, 3)
             lw, lb = ln.pair()
-            da, dlw, dlb, xn = ops.ln_bwd_tok(a2, ops.gemm_tok(dt_, pf["w_inT"]), dy, lw, lb)
+            if ops.ln_bwd_win_dxn_fits(a2.shape[0], D, a2.dtype):        # project_in's data gradient formed inside the LayerNorm-backward launch
+                da, dlw, dlb, xn = ops.ln_bwd_tok_dxn(a2, dt_, pf["w_inT"], dy, lw, lb)
+            else:
+                da, dlw, dlb, xn = ops.ln_bwd_tok(a2, ops.gemm_tok(dt_, pf["w_inT"]), dy, lw, lb)
             d_in_w = ops.gemm_tn_blocks(dt_, xn, [(0, hid), (HP, hid)]).reshape(2 * hid, D, 1, 1)
         return None, None, None, da, dlw, dlb, d_in_w, d_dw, d_out_w
 
@@ -451,7 +454,10 @@ class _SelfChannelAttnRes(torch.autograd.Function):
             else:
                 dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * D)
             lw, lb = ln.pair()
-            dt_in, dlw, dlb, xn = ops.ln_bwd_tok(t2, ops.gemm_tok(dt3, pa["wqkvT"]), da, lw, lb)
+            if ops.ln_bwd_win_dxn_fits(M, D, t2.dtype) and dt3.is_contiguous():      # the qkv conv's data gradient inside the LayerNorm-backward launch
+                dt_in, dlw, dlb, xn = ops.ln_bwd_tok_dxn(t2, dt3, pa["wqkvT"], da, lw, lb)
+            else:
+                dt_in, dlw, dlb, xn = ops.ln_bwd_tok(t2, ops.gemm_tok(dt3, pa["wqkvT"]), da, lw, lb)
             d_qkv = ops.gemm_tn(dt3, xn).reshape(3 * D, D, 1, 1)
         d_dw = _join_taps(dwq, dwk, dwv).reshape(3 * D, 1, 3, 3)
         return None, None, None, dt_in, dlw, dlb, d_qkv, d_dw, dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1)

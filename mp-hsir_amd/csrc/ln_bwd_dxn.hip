@@ -24,20 +24,23 @@ struct LnDxnDev {
     const void* X; const void* dQKV; const void* WT; const void* dRes; const float* ln_w;
     void* dX; float* part;
     int B, H, W, shift;
+    int K;                       // reduction width of the GEMM (3C for the window attention's qkv; 2 HP / 3 D for the prompt modules), % 32 == 0
+    int linear;                  // 1: rows in plain token order (the prompt modules' LayerNorms): row = 64 blockIdx + t, no window gather
+    const float* ln_b; void* XN; // optional (linear form): also emit LN(x), the operand of the 1x1 conv's weight gradient
 };
 
 template <class T, int C> struct LnDxnCfg {
-    static constexpr int K = 3 * C, NB = C / 16, NKC = K / 32;
+    static constexpr int NB = C / 16;
     static constexpr int PAD = LDS_PAD_BYTES / sizeof(T);
     // K chunks (of 32) per weight stage: the stage [C][32 KGC + pad] next to the fp32 tile [64][C + 1] must leave two workgroups per CU
     // where it can (C <= 192)
     static constexpr int KGC = C <= 192 ? 3 : (C <= 256 ? 2 : 1);
-    static constexpr int NGRP = NKC / KGC, LDW = 32 * KGC + PAD, LDF = C + 1;
+    static constexpr int LDW = 32 * KGC + PAD, LDF = C + 1;
     static constexpr int MAXV = C / 32;                               // 16-byte vectors of a token row per lane (4 lanes per token)
     static constexpr size_t f_floats = ((size_t)64 * LDF + 3) & ~(size_t)3;
     static constexpr size_t bytes = f_floats * 4 + (size_t)C * LDW * sizeof(T);
     static constexpr int NWV = (C * KGC * 4 + 255) / 256;             // 16-byte weight vectors per thread and stage
-    static_assert(C % 32 == 0 && NKC % KGC == 0 && bytes <= 160 * 1024, "shape");
+    static_assert(C % 32 == 0 && bytes <= 160 * 1024, "shape");
 };
 
 template <class T, int C>
@@ -45,7 +48,8 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
     typedef LnDxnCfg<T, C> CF;
-    constexpr int VEC = 8, K = CF::K, NB = CF::NB, KGC = CF::KGC, NGRP = CF::NGRP, LDW = CF::LDW, LDF = CF::LDF, MAXV = CF::MAXV, NWV = CF::NWV;
+    constexpr int VEC = 8, NB = CF::NB, KGC = CF::KGC, LDW = CF::LDW, LDF = CF::LDF, MAXV = CF::MAXV, NWV = CF::NWV;
+    const int K = a.K, NKC = K / 32, NGRP = (NKC + KGC - 1) / KGC;
     static_assert(sizeof(T) == 2, "16-bit types only");
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     float* Fs = reinterpret_cast<float*>(smem_v);                      // [64][LDF] d_xn, then d_xn * xhat
@@ -59,14 +63,16 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
     // token t of this window in image order (cyclic shift + window partition as address arithmetic, net/MP_HSIR.py:672-677)
     const int nwx = a.W >> 3, nW = (a.H >> 3) * nwx;
     const int b = blockIdx.x / nW, wi = blockIdx.x % nW, wy = wi / nwx, wx = wi % nwx;
-    const long pix = ((long)b * a.H + (wy * 8 + (t >> 3) + a.shift) % a.H) * a.W + (wx * 8 + (t & 7) + a.shift) % a.W;
+    const long pix = a.linear ? (long)blockIdx.x * 64 + t
+                              : ((long)b * a.H + (wy * 8 + (t >> 3) + a.shift) % a.H) * a.W + (wx * 8 + (t & 7) + a.shift) % a.W;
 
     // ---- the lane's share of the token row (x, d_res): requested now, used after the GEMM
+    constexpr bool DR_LATE = C >= 256;       // wide rows: d_res is requested after the GEMM (32 registers fewer held across it: no spills)
     Vec16<T> xv[MAXV], dr[MAXV];
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
         xv[k] = load16<T>(X + pix * C + (q + 4 * k) * VEC);
-        dr[k] = load16<T>(dRes + pix * C + (q + 4 * k) * VEC);
+        if (!DR_LATE) dr[k] = load16<T>(dRes + pix * C + (q + 4 * k) * VEC);
     }
 
     // ---- (a) d_xn = dQKV Wqkv: wave wv owns window rows 16 wv .. 16 wv + 15
@@ -76,7 +82,10 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < C * KGC * 4) wreg[i] = load16<T>(WT + (long)(idx / (KGC * 4)) * K + g * 32 * KGC + (idx % (KGC * 4)) * VEC);
+            if (idx < C * KGC * 4) {
+                const int col = g * 32 * KGC + (idx % (KGC * 4)) * VEC;
+                if (col < K) wreg[i] = load16<T>(WT + (long)(idx / (KGC * 4)) * K + col);
+            }
         }
     };
     auto wstore = [&]() __attribute__((always_inline)) {
@@ -94,15 +103,18 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
     for (int g = 0; g < NGRP; ++g) {
         frag_t xf[KGC];
 #pragma unroll
-        for (int kc = 0; kc < KGC; ++kc) xf[kc] = *reinterpret_cast<const frag_t*>(drow + (g * KGC + kc) * 32);
+        for (int kc = 0; kc < KGC; ++kc)
+            if (g * KGC + kc < NKC) xf[kc] = *reinterpret_cast<const frag_t*>(drow + (g * KGC + kc) * 32);
         __syncthreads();                                   // the previous group's fragments have been read
         wstore();
         __syncthreads();
         if (g + 1 < NGRP) wload(g + 1);
 #pragma unroll
         for (int kc = 0; kc < KGC; ++kc)
+            if (g * KGC + kc < NKC) {                      // (uniform) the last group of a K that is not a multiple of 32 KGC is short
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) mma(acc[nb], load_frag<T>(Ws, LDW, nb * 16, kc * 32), xf[kc]);
+                for (int nb = 0; nb < NB; ++nb) mma(acc[nb], load_frag<T>(Ws, LDW, nb * 16, kc * 32), xf[kc]);
+            }
     }
     {
         float* frow = Fs + (wv * 16 + (lane & 15)) * LDF + (lane >> 4) * 4;
@@ -114,6 +126,10 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
     __syncthreads();
 
     // ---- (b) LayerNorm backward on the tile (ln_bwd_win_kernel's arithmetic, d_xn read from the fp32 tile)
+    if (DR_LATE) {
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) dr[k] = load16<T>(dRes + pix * C + (q + 4 * k) * VEC);
+    }
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k)
@@ -147,6 +163,11 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
             o.set(e, dr[k].get(e) + rstd * (dxn * a.ln_w[c0 + e] - s1 - xh * s2));
         }
         store16<T>(dX + pix * C + c0, o);
+        if (a.XN) {
+            Vec16<T> n;
+            for (int e = 0; e < VEC; ++e) n.set(e, (xv[k].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
+            store16<T>(reinterpret_cast<T*>(a.XN) + pix * C + c0, n);
+        }
     }
     __syncthreads();
     float* part = a.part + (long)blockIdx.x * 2 * C;
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
 
 template <class T> struct LnDxnShapes {
     static int run(const LnDxnDev& d, int C, hipStream_t s) {
-        const int nblk = d.B * (d.H / 8) * (d.W / 8);
+        const int nblk = d.linear ? d.B : d.B * (d.H / 8) * (d.W / 8);      // linear: B = number of 64-row blocks
 #define MPHSIR_LD_CASE(c)                                                                                                 \
     if (C == c) {                                                                                                          \
         constexpr size_t shmem = LnDxnCfg<T, c>::bytes;                                                                     \
@@ -202,7 +223,20 @@ extern "C" int mphsir_ln_bwd_win_dxn(const void* X, const void* dQKV, const void
     MPHSIR_REQUIRE(mphsir_ln_bwd_win_dxn_fits(C, dtype), "ln_bwd_win_dxn: (C=%d, dtype=%d) not covered (16-bit types; ask mphsir_ln_bwd_win_dxn_fits)", C, dtype);
     MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && (shift == 0 || shift == 4), "ln_bwd_win_dxn: bad geometry");
     MPHSIR_REQUIRE(aligned16(X) && aligned16(dQKV) && aligned16(WqkvT) && aligned16(dRes) && aligned16(dX), "ln_bwd_win_dxn: 16-byte alignment required");
-    LnDxnDev d{X, dQKV, WqkvT, dRes, ln_w, dX, part, B, H, W, shift};
+    LnDxnDev d{X, dQKV, WqkvT, dRes, ln_w, dX, part, B, H, W, shift, 3 * C, 0, nullptr, nullptr};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return MPHSIR_DISPATCH_T(dtype, (LnDxnShapes<T_>::run(d, C, s)));
+}
+
+extern "C" int mphsir_ln_bwd_tok_dxn(const void* X, const void* dY, const void* WT, const void* dRes, const float* ln_w, const float* ln_b, void* dX,
+                                     void* XN, float* part, int64_t M, int32_t C, int32_t K, int dtype, void* stream) {
+    using namespace mphsir;
+    clear_error();
+    MPHSIR_REQUIRE(X && dY && WT && dRes && ln_w && dX && part && (!XN || ln_b), "ln_bwd_tok_dxn: null pointer (XN needs ln_b)");
+    MPHSIR_REQUIRE(mphsir_ln_bwd_win_dxn_fits(C, dtype), "ln_bwd_tok_dxn: (C=%d, dtype=%d) not covered (16-bit types; ask mphsir_ln_bwd_win_dxn_fits)", C, dtype);
+    MPHSIR_REQUIRE(M > 0 && M % 64 == 0 && K > 0 && K % 32 == 0, "ln_bwd_tok_dxn: M %% 64 == 0 and K %% 32 == 0 required (M=%ld, K=%d)", (long)M, K);
+    MPHSIR_REQUIRE(aligned16(X) && aligned16(dY) && aligned16(WT) && aligned16(dRes) && aligned16(dX) && (!XN || aligned16(XN)), "ln_bwd_tok_dxn: 16-byte alignment required");
+    LnDxnDev d{X, dY, WT, dRes, ln_w, dX, part, (int)(M / 64), 8, 8, 0, K, 1, ln_b, XN};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return MPHSIR_DISPATCH_T(dtype, (LnDxnShapes<T_>::run(d, C, s)));
 }

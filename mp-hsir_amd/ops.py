@@ -1420,6 +1420,25 @@ def ln_bwd_win_dxn(x, dqkv, wqkvT, dres, ln_w, shift):
     return dx, part
 
 
+def ln_bwd_tok_dxn(x2, dy, wT, dres, ln_w, ln_b):
+    """ln_bwd_tok with the 1x1 conv's data gradient inside: d_xn = dy wT^T (dy (M, K), wT (C, K)) is formed per 64 rows on the matrix cores
+    -> (dx = dres + LN_backward(d_xn), d ln weight, d ln bias, LN(x)) for x2 (M, C), M % 64 == 0."""
+    lib = _lib.load()
+    _check(x2, dy, wT, dres, ln_w, ln_b)
+    M, C = x2.shape
+    K = dy.shape[1]
+    assert x2.is_contiguous() and dy.is_contiguous() and dres.is_contiguous() and wT.is_contiguous() and M % 64 == 0 and K % 32 == 0
+    assert dy.shape == (M, K) and wT.shape == (C, K) and wT.dtype == x2.dtype and dy.dtype == x2.dtype
+    dx, xn = torch.empty_like(x2), torch.empty_like(x2)
+    part = torch.empty((M // 64, 2, C), dtype=torch.float32, device=x2.device)
+    _lib.check(lib.mphsir_ln_bwd_tok_dxn(_p(x2), _p(dy), _p(wT), _p(dres), _p(ln_w), _p(ln_b), _p(dx), _p(xn), _p(part), M, C, K,
+                                         _DT[x2.dtype], _stream(x2)), "ln_bwd_tok_dxn")
+    _acct("ln_bwd_win", 12.0 * x2.numel() + 2.0 * M * C * K, (5.0 * C + K) * M * x2.element_size())
+    _acct("ln_bwd_win:dxn", 0.0, 0.0)
+    g = reduce_parts(part)
+    return dx, g[0], g[1], xn
+
+
 def ln_bwd_tok(x2, dxn, dres, ln_w, ln_b):
     """plain token order: (dx = dres + LN_backward(dxn), d ln weight, d ln bias, LN(x)) for x2 (M,C), M % 64 == 0."""
     lib = _lib.load()

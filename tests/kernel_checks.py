@@ -1016,6 +1016,32 @@ def check_ln_bwd_win_dxn(dev, dtype, C=64, shape=(2, 16, 16), shift=4):
     return res
 
 
+def check_ln_bwd_tok_dxn(dev, dtype, C=64, K=384, M=256):
+    """mphsir_ln_bwd_tok_dxn (token order, any K % 32 == 0, LN(x) as a second output) against gemm_tok + ln_bwd_tok on the same operands"""
+    _use(dev)
+    from mp_hsir_amd import ops
+    assert ops.ln_bwd_win_dxn_fits(M, C, dtype)
+    x, dres = rnd((M, C), 931, dtype), rnd((M, C), 932, dtype)
+    dy = rnd((M, K), 933, dtype)
+    wT = rnd((C, K), 934, dtype, scale=K ** -0.5)
+    ln_w, ln_b = (1 + 0.2 * rnd((C,), 935)).contiguous(), (0.1 * rnd((C,), 936)).contiguous()
+    with ops.reduce_scope():
+        a = ops.ln_bwd_tok(x, ops.gemm_tok(dy, wT), dres, ln_w, ln_b)
+        b = ops.ln_bwd_tok_dxn(x, dy, wT, dres, ln_w, ln_b)
+    dxn = dy.double().cpu() @ wT.double().cpu().t()
+    xr = x.double().cpu().clone().requires_grad_(True)
+    lw, lb = ln_w.double().cpu().clone().requires_grad_(True), ln_b.double().cpu().clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (C,), lw, lb, 1e-5)
+    (y * dxn).sum().backward()
+    want = (xr.grad + dres.double().cpu(), lw.grad, lb.grad, y.detach())
+    res = {}
+    for name, pa, pb, w in zip(("dx", "dgamma", "dbeta", "xn"), a, b, want):
+        res[name] = (rel_l2(pa, w), rel_l2(pb, w))
+        assert res[name][1] < TOL[dtype] and res[name][1] <= res[name][0] * 1.05 + 1e-6, res
+    assert rel_l2(b[3], a[3].double().cpu()) < TOL[dtype] / 4      # LN(x): the same formula (the compiler contracts its fmas differently in the two kernels)
+    return res
+
+
 def check_fold_bwd_forms_dm(dev, dtype, C=64, heads=2, B=3, N=256):
     """mphsir_spectral_fold_bwd forming dM = d_out^T v itself (N > 0: the lower pyramid levels) against the token-reduction GEMM followed
     by the plain call, and dM against an fp64 product of the same operands"""

@@ -229,6 +229,11 @@ def test_ln_bwd_win_with_the_dxn_gemm_inside(dtype, C, shape, shift):
     print(K.check_ln_bwd_win_dxn("cpu", dtype, C, shape, shift))
 
 
+@pytest.mark.parametrize("dtype,C,Kd,M", [(torch.bfloat16, 64, 384, 128), (torch.float16, 128, 704, 64), (torch.bfloat16, 256, 160, 64), (torch.bfloat16, 96, 96, 64)])
+def test_ln_bwd_tok_with_the_conv_gradient_inside(dtype, C, Kd, M):
+    print(K.check_ln_bwd_tok_dxn("cpu", dtype, C, Kd, M))
+
+
 @pytest.mark.parametrize("dtype,C,heads,N", [(torch.bfloat16, 64, 2, 256), (torch.float16, 128, 2, 128), (torch.bfloat16, 96, 2, 64)])
 def test_fold_bwd_forms_dm_itself(dtype, C, heads, N):
     print(K.check_fold_bwd_forms_dm("cpu", dtype, C, heads, B=2, N=N))

@@ -340,6 +340,12 @@ def test_ln_bwd_win_with_the_dxn_gemm_inside(dtype, C, shape, shift):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,Kd,M", [(128, 704, 131072), (64, 384, 131072), (256, 1408, 32768), (128, 384, 131072), (256, 768, 32768), (192, 1024, 4096), (96, 512, 65536)])
+def test_ln_bwd_tok_with_the_conv_gradient_inside(dtype, C, Kd, M):
+    print(K.check_ln_bwd_tok_dxn("cuda", dtype, C, Kd, M))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("C,heads,N", [(128, 4, 1024), (256, 8, 256), (64, 2, 1024), (192, 4, 1024), (384, 8, 256), (128, 2, 1024)])
 def test_fold_bwd_forms_dm_itself(dtype, C, heads, N):
     """the fold backward with dM = d_out^T v formed inside (the lower pyramid levels of both configurations, batch 32)"""

@@ -1,9 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -q -m gpu -k "ln_bwd_win_with or pgsstb_backward or block_gradients or whole_net or tiny_net or fused_block" > gpurun_out/r06k_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r06k_tests.log
-tail -3 gpurun_out/r06k_tests.log
-F="--no-cpu-baseline --no-extra --no-spectral --no-roofline --steps 40 --warmup 5"
-for i in 1 2; do
-  for e in "MPHSIR_LN_BWD_DXN=1" "MPHSIR_LN_BWD_DXN=0" "MPHSIR_LN_BWD_DXN_ROWS=32768"; do
-    echo "$e: $(env $e python bench.py $F 2>/dev/null | tail -1 | cut -c50-140)"
-  done
-done
+timeout 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "ln_bwd_tok_with" > gpurun_out/r06l_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r06l_tests.log
+tail -3 gpurun_out/r06l_tests.log
