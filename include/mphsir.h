@@ -391,6 +391,8 @@ typedef struct mphsir_fold_bwd_args {
      * NULL) but FORMED in the kernel, dM_b = d_out_b^T v_b over the sample's N tokens -- DO [B*N][lddo >= C] = d_out, V [B*N][ldv >= C]
      * = v of the forward (16-byte aligned rows): the token-reduction GEMM in front of this launch disappears */
     const void* DO; int64_t lddo; const void* V; int64_t ldv; int32_t N;
+    const float* dm_scale;      /* optional [B]: dM_b (given or formed) is multiplied by dm_scale[b] -- the DropPath factor, when d_out is handed over
+                                   as the block's incoming gradient without it */
 } mphsir_fold_bwd_args;
 int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype, void* stream);
 typedef struct mphsir_pg_bwd_args {
@@ -428,6 +430,7 @@ typedef struct mphsir_spectral_bwd_args {
     void* dT; int64_t lddt;
     float* part;
     int32_t B, H, W, C, heads, nblk, round_dall;
+    const float* vscale;        /* optional [B]: dv_b = vscale[b] * DO_b M_b (DO handed over without its DropPath factor) */
 } mphsir_spectral_bwd_args;
 int mphsir_spectral_dqkv_bwd(const mphsir_spectral_bwd_args* a, int dtype, void* stream);
 int mphsir_spectral_dqkv_bwd_fits(int32_t C, int32_t heads, int32_t H, int32_t W, int dtype);

@@ -117,7 +117,7 @@ class FoldBwdArgs(_Args):
     """mirror of struct mphsir_fold_bwd_args"""
     _fields_ = _SZ + [(n, c_void_p) for n in ("Gpart", "Spart", "temperature", "Wo", "dM", "W2", "dWo", "dtemp")] + \
                [(n, c_int32) for n in ("B", "C", "heads", "nsplit", "dM_nsplit")] + \
-               [("DO", c_void_p), ("lddo", c_int64), ("V", c_void_p), ("ldv", c_int64), ("N", c_int32)]
+               [("DO", c_void_p), ("lddo", c_int64), ("V", c_void_p), ("ldv", c_int64), ("N", c_int32), ("dm_scale", c_void_p)]
 
 
 class PgBwdArgs(_Args):
@@ -130,7 +130,7 @@ class SpectralBwdArgs(_Args):
     """mirror of struct mphsir_spectral_bwd_args"""
     _fields_ = _SZ + [("QK", c_void_p), ("ldqk", c_int64), ("DO", c_void_p), ("lddo", c_int64), ("T", c_void_p), ("ldt", c_int64),
                       ("W2", c_void_p), ("MbT", c_void_p), ("w9", c_void_p), ("ldw", c_int64), ("dT", c_void_p), ("lddt", c_int64),
-                      ("part", c_void_p)] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nblk", "round_dall")]
+                      ("part", c_void_p)] + [(n, c_int32) for n in ("B", "H", "W", "C", "heads", "nblk", "round_dall")] + [("vscale", c_void_p)]
 
 
 class TnProblem(ctypes.Structure):

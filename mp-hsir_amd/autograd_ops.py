@@ -57,11 +57,13 @@ def _gated_mlp_backward(blk, k2, y, dz):
     return (dx.reshape(B, H, W, Cc), dln[0], dln[1], dW1, db1, dW2, db2)
 
 
-def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, MbT, temperature, wo, heads, B, H, W, qk=None):
+def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, MbT, temperature, wo, heads, B, H, W, qk=None, keep=None):
     """Backward of the folded channel attention  out = M_b v,  M_b = Wo blockdiag(softmax(normalised Gram)).
 
     d_out (M,C); t_q/t_k/t_v: (B,H,W,*) views of the 1x1-conv outputs that fed dwconv_gram (channels-last,
     C channels each); w9*: fp32 tap-major dw weights [9][C] views; v, gp, sp, Mb, MbT as saved by the forward.
+    keep (optional, (B,) fp32): d_out is handed over WITHOUT the DropPath factor of its block -- the fold backward scales dM and the fused
+    launch scales dv by keep[b] (both are linear in d_out), so nothing has to form keep * d_out first (fused path only).
     Returns d(t_q), d(t_k), d(t_v) (B,H,W,C each), d(dw taps) (C,9) x3, d temperature (heads,), d Wo (C,C).
     All HIP: dM = d_out^T v (gemm_tn), fold backward (one launch), then [dq|dk], dv and the depthwise backward (data + taps) in ONE
     launch (ops.spectral_dqkv_bwd, 16-bit types, self-attention: q|k|v adjacent slices of one t) -- else per-sample token GEMMs +
@@ -73,10 +75,10 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     temp32, wo32 = temperature.detach().reshape(heads).float().contiguous(), wo.detach().reshape(C, C).float().contiguous()
     if ops.fold_bwd_forms_dm(N, C, heads, dt):
         # small images (the lower pyramid levels): dM = d_out^T v is formed INSIDE the fold backward -- one launch fewer on the chain
-        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temp32, wo32, None, dt, reduce=False, d_out=d_out.reshape(M, C), v=v.reshape(M, C))
+        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temp32, wo32, None, dt, reduce=False, d_out=d_out.reshape(M, C), v=v.reshape(M, C), dm_scale=keep)
     else:
         dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), reduce=False)    # (B, splits, C, C) fp32 partials: summed by the fold backward as it stages them
-        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temp32, wo32, dM, dt, reduce=False)
+        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temp32, wo32, dM, dt, reduce=False, dm_scale=keep)
     # q, k of the forward: either kept by it (qk) or recomputed by the depthwise kernel; when q|k|v are adjacent channel
     # slices of one tensor (self-attention) every depthwise pass runs once over the joint channel range.
     joint = (t_q.data_ptr() + C * t_q.element_size() == t_k.data_ptr() and t_k.data_ptr() + C * t_k.element_size() == t_v.data_ptr()
@@ -96,9 +98,10 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
         dwo, dtemp = ops.reduce_parts(dwo_p), ops.reduce_parts(dtemp_p)
         t_all = torch.as_strided(t_q, (M, 3 * C), (3 * C, 1))
         w9_all = torch.as_strided(w9q, (9, 3 * C), w9q.stride())
-        dt_all, dw_all = ops.spectral_dqkv_bwd(qk.reshape(M, 2 * C), d_out, t_all, W2, MbT, w9_all, B, H, W, C, heads)
+        dt_all, dw_all = ops.spectral_dqkv_bwd(qk.reshape(M, 2 * C), d_out, t_all, W2, MbT, w9_all, B, H, W, C, heads, vscale=keep)
         dt_all = dt_all.reshape(B, H, W, 3 * C)
         return (dt_all[..., :C], dt_all[..., C:2 * C], dt_all[..., 2 * C:], dw_all[:C], dw_all[C:2 * C], dw_all[2 * C:], dtemp, dwo)
+    assert keep is None, "the unscaled d_out form needs the fused launch (ops.spectral_dqkv_bwd_fits)"
     dall = torch.empty((M, 3 * C), dtype=dt, device=v.device)
     ops.gemm_tok(d_out, MbT, out=dall[:, 2 * C:])                                     # dv = d_out M_b
     dwo, dtemp = ops.reduce_parts(dwo_p), ops.reduce_parts(dtemp_p)
@@ -120,6 +123,14 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     return (ops.dwconv3x3(dq4, w9q, flip=True), ops.dwconv3x3(dk4, w9k, flip=True, out=dkv[..., :C]), ops.dwconv3x3(dv4, w9v, flip=True, out=dkv[..., C:]),
             ops.dwconv3x3_wgrad(t_q, dq4, col_ranges=[(0, C)], out=dw3[:C]), ops.dwconv3x3_wgrad(t_k, dk4, col_ranges=[(0, C)], out=dw3[C:2 * C]),
             ops.dwconv3x3_wgrad(t_v, dv4, col_ranges=[(0, C)], out=dw3[2 * C:]), dtemp, dwo)
+
+
+import os
+# MPHSIR_COMBINE_SIDE=1 (round-6 experiment, OFF): the branch sum's backward leaves the chain -- the spectral kernels take dy itself (the fold
+# backward scales dM, the fused launch scales dv by the DropPath factor: keep * dy is never formed) and combine_bwd runs on the prompt gate's
+# side branch.  Measured level to slower (19.50-19.60 against 19.44-19.46 ms, three pairs on one box): like every other branch of the captured
+# step it hides nothing, and the d_out store it saves was hidden already.
+COMBINE_SIDE = os.environ.get("MPHSIR_COMBINE_SIDE", "0") == "1"
 
 
 _PG_KEYS = ("linear_down.weight", "linear_up.weight", "linear_prompt.weight", "prompt_param", "q.weight", "kv.weight",
@@ -215,32 +226,46 @@ def _pgsstb_attn_backward(blk, k1, saved, dy):
     sp = blk.gobal_spectral_attn.packed(dt)
     dy = dy.contiguous()
     with ops.reduce_scope(leaf=True):      # every split partial of this backward is summed by ONE launch when the scope exits
-        # (1) branch sum  y = x + keep*(sa*gate + out)
-        d_out, d_sa, dgate = ops.combine_bwd(dy, sa, gate, k1, shift)
-        # (3, issued first on a side branch) local spectral-prompt gate: one launch per block + one token-reduction GEMM
-        # over the windows.  Factor rows in the compute dtype ride in the grouped 16-bit GEMM launch; fp16's narrow exponent
-        # would flush the gate's tiny d-logits (w ~ 1/128 of an already small gradient), so that path keeps them in fp32
-        with ops.side_stream(dy, ops.SIDE_BRANCH) as br:
-            # ... and so do levels with few windows (the latent level: 4 per sample), where a parameter gradient is the sum of a
-            # few hundred signed terms: with bf16 factor rows linear_down / kv of a latent block came out 23 % off in the whole-net
-            # check (the reference's own bf16 autocast: 2 %); the fp32 product of <= 512 rows costs nothing
-            f32_factors = dt == torch.float16 or mu.shape[0] <= 512
-            dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=torch.float32 if f32_factors else dt)
+        # (1) branch sum  y = x + keep*(sa*gate + out).  Where the fused spectral backward applies, the branch sum's backward leaves the
+        # chain: the spectral kernels take dy itself (the fold backward scales dM, the fused launch scales dv by keep[b]: d_out = keep * dy
+        # is never formed), and combine_bwd -- now only d_sa = keep dy gate and the gate's gradient -- runs on the side branch in front of
+        # the prompt gate's backward, joined where the 1x1 conv's data gradient adds to d_sa.
+        f32_factors = dt == torch.float16 or mu.shape[0] <= 512
+        lean = COMBINE_SIDE and ops.spectral_dqkv_bwd_fits(Cc, heads, H, W, dt) and sp["w9"].stride(0) == 3 * Cc and t.is_contiguous()
+        if lean:
+            with ops.side_stream(dy, ops.SIDE_BRANCH) as br:
+                _, d_sa, dgate = ops.combine_bwd(dy, sa, gate, k1, shift, want_dout=False)
+                dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=torch.float32 if f32_factors else dt)
+            d_out, keep_s = dy, k1
+        else:
+            d_out, d_sa, dgate = ops.combine_bwd(dy, sa, gate, k1, shift)
+            keep_s = None
+            # (3, issued first on a side branch) local spectral-prompt gate: one launch per block + one token-reduction GEMM
+            # over the windows.  Factor rows in the compute dtype ride in the grouped 16-bit GEMM launch; fp16's narrow exponent
+            # would flush the gate's tiny d-logits (w ~ 1/128 of an already small gradient), so that path keeps them in fp32
+            with ops.side_stream(dy, ops.SIDE_BRANCH) as br:
+                # ... and so do levels with few windows (the latent level: 4 per sample), where a parameter gradient is the sum of a
+                # few hundred signed terms: with bf16 factor rows linear_down / kv of a latent block came out 23 % off in the whole-net
+                # check (the reference's own bf16 autocast: 2 %); the fp32 product of <= 512 rows costs nothing
+                dmu, gpg = ops.pg_gate_bwd(mu, dgate, pk["pg"], factor_dtype=torch.float32 if f32_factors else dt)
         # (2) global spectral attention
         t4 = t.reshape(B, H, W, 3 * Cc)
         w9 = sp["w9"]
         tq, tk, tv = t4[..., :Cc], t4[..., Cc:2 * Cc], t4[..., 2 * Cc:]
         dtq, dtk, dtv, dwq, dwk, dwv, dtemp, dwo = channel_attention_bwd(
             d_out.reshape(M, Cc), tq, tk, tv, w9[:, :Cc], w9[:, Cc:2 * Cc], w9[:, 2 * Cc:], v, gp, spart, Mb, MbT,
-            blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W, qk=qk)
+            blk.gobal_spectral_attn.temperature, blk.gobal_spectral_attn.project_out.weight, heads, B, H, W, qk=qk, keep=keep_s)
         if dtq.data_ptr() + Cc * dtq.element_size() == dtk.data_ptr() and dtq.stride(2) == 3 * Cc:
             dt3 = torch.as_strided(dtq, (M, 3 * Cc), (3 * Cc, 1))
         else:
             dt3 = torch.cat([dtq, dtk, dtv], dim=-1).reshape(M, 3 * Cc)
+        if lean:
+            br.join()                     # d_sa = keep dy gate comes from the side branch
         d_sa = ops.gemm_tok(dt3, sp["wqkvT"], epi=1, res=d_sa.reshape(M, Cc))    # + dt Wqkv  (1x1 conv backward)
         d_sqkv = ops.gemm_tn(dt3, sa.reshape(M, Cc)).reshape(3 * Cc, Cc, 1, 1)
         dpg = tuple(gpg[k].reshape(getattr_path(blk.local_spectral_attn, k).shape) for k in _PG_KEYS)
-        br.join()
+        if not lean:
+            br.join()
         # (4) window attention core
         dqkv, xnw, dsat, drpb = ops.win_attn_bwd(x, d_sa.reshape(B, H, W, Cc), dmu, pk["ln1"][0], pk["ln1"][1], pk["wqkv"], pk["bqkv"],
                                                  pk["rpb"], pk["wprojT"], heads, shift)

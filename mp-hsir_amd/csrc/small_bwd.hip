@@ -20,6 +20,7 @@ struct FoldBwdDev {
     const float* temperature; const float* Wo;
     const float* dM;            // [B][C][C] fp32, or [B][dm_nsplit][C][C]: the split partials of the token-reduction GEMM that produced it
     int dm_nsplit;              // (summed in split order while they are staged: the ordered-sum launch between the two kernels is gone)
+    const float* dm_scale;      // optional [B]: dM_b is multiplied by dm_scale[b] (the DropPath factor of a d_out that was handed over unscaled)
     const void* DO; long lddo; const void* V; long ldv; int N;      // N > 0 (16-bit types, small images): dM is not read but FORMED here -- dM_b =
                                                                       // d_out_b^T v_b over the sample's N tokens (rows b N .. of DO [.][lddo], V [.][ldv])
     void* W2;                   // [B][2C][2C] compute dtype
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
     T* Vt = Dt + FB_TK * LDD;                                      // [FB_TK][LDV]
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform(), b = blockIdx.x / HEADS, h = blockIdx.x % HEADS;
     const float temp = a.temperature[h];
+    const float dms = a.dm_scale ? a.dm_scale[b] : 1.f;
 
     for (int i = tid; i < HD * HD; i += FB_THREADS) {        // ordered sum over the splits (1 when the forward saved the sums)
         const float* gp = a.Gpart + ((long)b * a.nsplit * HEADS + h) * HD * HD + i;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
                     const int tt = wv + FB_WAVES * q;
                     if (tt < (FB_CO / 16) * NT) {
                         const int ti = tt / NT, tj = tt % NT;
-                        for (int r = 0; r < 4; ++r) Ms[(ti * 16 + (lane >> 4) * 4 + r) * LD + tj * 16 + (lane & 15)] = accM[q][r];
+                        for (int r = 0; r < 4; ++r) Ms[(ti * 16 + (lane >> 4) * 4 + r) * LD + tj * 16 + (lane & 15)] = accM[q][r] * dms;
                     }
                 }
                 for (int idx = tid; idx < FB_CO * (HD / 4); idx += FB_THREADS) {
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
                 for (; sp < nsp; ++sp) m += *reinterpret_cast<const f32x4*>(mp + sp * CC);
             }
             *reinterpret_cast<f32x4*>(Ws + rr * LD + cc) = wv4;
-            *reinterpret_cast<f32x4*>(Ms + rr * LD + cc) = m;
+            *reinterpret_cast<f32x4*>(Ms + rr * LD + cc) = m * dms;
         }
         __syncthreads();
 #pragma unroll
@@ -315,7 +317,7 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold_bwd: bad shape");
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 96, "spectral_fold_bwd: head_dim %d > 96", HD);
-    FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->dM_nsplit, a->DO, (long)a->lddo, a->V, (long)a->ldv, a->N, a->W2, a->dWo, a->dtemp, a->B, a->C, HD};
+    FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->dM_nsplit, a->dm_scale, a->DO, (long)a->lddo, a->V, (long)a->ldv, a->N, a->W2, a->dWo, a->dtemp, a->B, a->C, HD};
     if (a->N > 0)
         MPHSIR_REQUIRE(dtype != MPHSIR_F32 && (HD == 32 || HD == 48 || HD == 64) && a->DO && a->V && aligned16(a->DO) && aligned16(a->V) &&
                            (a->lddo * 2) % 16 == 0 && (a->ldv * 2) % 16 == 0 && a->lddo >= a->C && a->ldv >= a->C,

@@ -39,6 +39,7 @@ struct SpecBwdDev {
     const float* w9; long ldw;
     void* dT; long lddt; float* part;
     int B, H, W, nblk, round_dall;
+    const float* vscale;        // optional [B]: dv_b is multiplied by vscale[b] (DO handed over without its DropPath factor)
 };
 
 template <class T, int C, int HD> struct SbCfg {
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(SB_THREADS, 2) void spectral_dqkv_bwd_kernel(SpecBw
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     f32x4 o = acc[mb][nb];
+                    if (ISV && a.vscale) o *= a.vscale[b];
                     if (a.round_dall) {      // tests: the values the three-launch path would have read back from its 16-bit [dq | dk | dv]
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = to_f32(from_f32<T>(o[e]));
@@ -302,7 +304,7 @@ extern "C" int mphsir_spectral_dqkv_bwd(const mphsir_spectral_bwd_args* a, int d
     MPHSIR_REQUIRE(a->ldqk >= 2 * a->C && a->lddo >= a->C && a->ldt >= 3 * a->C && a->lddt >= 3 * a->C && a->ldw >= 3 * a->C, "spectral_dqkv_bwd: row pitch");
     MPHSIR_REQUIRE(a->dT != a->T, "spectral_dqkv_bwd: dT must not alias T");
     SpecBwdDev d{a->QK, (long)a->ldqk, a->DO, (long)a->lddo, a->T, (long)a->ldt, a->W2, a->MbT, a->w9, (long)a->ldw, a->dT, (long)a->lddt, a->part,
-                 a->B, a->H, a->W, a->nblk, a->round_dall};
+                 a->B, a->H, a->W, a->nblk, a->round_dall, a->vscale};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return MPHSIR_DISPATCH_T(dtype, (SpecBwdShapes<T_>::run(d, a->C, a->C / a->heads, s)));
 }

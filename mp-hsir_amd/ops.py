@@ -1197,7 +1197,7 @@ def spectral_dqkv_bwd_fits(C, heads, H, W, dtype):
     return SPECTRAL_BWD_FUSED and dtype in _HALF and bool(_lib.load().mphsir_spectral_dqkv_bwd_fits(C, heads, H, W, _DT[dtype]))
 
 
-def spectral_dqkv_bwd(qk, d_out, t, W2, MbT, w9, B, H, W, C, heads, nblk=None, round_dall=False):
+def spectral_dqkv_bwd(qk, d_out, t, W2, MbT, w9, B, H, W, C, heads, nblk=None, round_dall=False, vscale=None):
     """dt (M, 3C) and the tap gradients (3C, 9) of the channel attention from q|k (M, 2C), d_out (M, C), t (M, 3C), the per-sample
     matrices W2 (B, 2C, 2C) / MbT (B, C, C) and the taps w9 fp32 [9][3C]:  dv = d_out M_b, [dq|dk] = [q|k] W2^T, then both gradients of
     the depthwise conv -- [dq|dk|dv] stays on the chip (include/mphsir.h).  nblk: tile ranges (x channel slabs = workgroups)."""
@@ -1220,6 +1220,7 @@ def spectral_dqkv_bwd(qk, d_out, t, W2, MbT, w9, B, H, W, C, heads, nblk=None, r
     a.QK, a.ldqk, a.DO, a.lddo, a.T, a.ldt = _p(qk), qk.stride(0), _p(d_out), d_out.stride(0), _p(t), t.stride(0)
     a.W2, a.MbT, a.w9, a.ldw, a.dT, a.lddt, a.part = _p(W2), _p(MbT), _p(w9), w9.stride(0), _p(dt), 3 * C, _p(part)
     a.B, a.H, a.W, a.C, a.heads, a.nblk, a.round_dall = B, H, W, C, heads, nblk, int(round_dall)
+    a.vscale = _p(vscale)
     _lib.check(lib.mphsir_spectral_dqkv_bwd(ctypes.byref(a), _DT[qk.dtype], _stream(qk)), "spectral_dqkv_bwd")
     hd = C // heads
     _acct("spectral_dqkv_bwd", M * (2.0 * C * C + 8.0 * C * hd + 108.0 * C), 10.0 * M * C * qk.element_size() + part.numel() * 4)
@@ -1340,16 +1341,17 @@ def gated_mlp_wgrad(xn, dm, W1, b1, W2T, hid, nch=None, ranges=None):
     return dW1, db1[0], dW2, db2
 
 
-def combine_bwd(dy, sa, gate, keep, shift):
-    """dy, sa (B,H,W,C) -> (d_out (= dy when keep is None), d_sa, dgate (B*nW,C) fp32)."""
+def combine_bwd(dy, sa, gate, keep, shift, want_dout=True):
+    """dy, sa (B,H,W,C) -> (d_out (= dy when keep is None; None with want_dout=False: the consumers apply keep themselves), d_sa,
+    dgate (B*nW,C) fp32)."""
     lib = _lib.load()
     _check(dy, sa, gate, keep)
     B, H, W, C = dy.shape
     assert dy.is_contiguous() and sa.is_contiguous()
-    d_out = torch.empty_like(dy) if keep is not None else dy
+    d_out = (torch.empty_like(dy) if want_dout else None) if keep is not None else dy
     d_sa = torch.empty_like(dy)
     dgate = torch.empty_like(gate)
-    _lib.check(lib.mphsir_combine_bwd(_p(dy), _p(sa), _p(gate), _p(keep), _p(d_out) if keep is not None else None, _p(d_sa),
+    _lib.check(lib.mphsir_combine_bwd(_p(dy), _p(sa), _p(gate), _p(keep), _p(d_out) if (keep is not None and want_dout) else None, _p(d_sa),
                                       _p(dgate), B, H, W, C, shift, _DT[dy.dtype], _stream(dy)), "combine_bwd")
     _acct("combine_bwd", 4.0 * dy.numel(), 4.0 * dy.numel() * dy.element_size())
     return d_out, d_sa, dgate
@@ -1574,7 +1576,7 @@ def fold_bwd_forms_dm(N, C, heads, dtype):
     return dtype in _HALF and 0 < N <= FOLD_BWD_DM_MAX_TOKENS and N % 64 == 0 and (C // heads) in (32, 48, 64)      # (96-wide heads: the token tiles do not fit beside the 150 KB the kernel already takes)
 
 
-def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True, d_out=None, v=None):
+def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True, d_out=None, v=None, dm_scale=None):
     """-> W2 (B,2C,2C) in `dtype`, dWo (C,C) fp32, dtemp (heads,) fp32 (reduce=False: the per-sample partials
     (B,C,C) / (B,heads) instead, for the caller to pass to reduce_parts).  dM=None with d_out, v (B*N, C) in `dtype`: dM is formed in
     the kernel (fold_bwd_forms_dm)."""
@@ -1594,6 +1596,7 @@ def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True, d_out=Non
         a.W2, a.dWo, a.dtemp = _p(W2), _p(dWo), _p(dtemp)
         a.B, a.C, a.heads, a.nsplit, a.dM_nsplit = B, C, heads, nsplit, 0
         a.DO, a.lddo, a.V, a.ldv, a.N = _p(d_out), d_out.stride(0), _p(v), v.stride(0), N
+        a.dm_scale = _p(dm_scale)
         _lib.check(lib.mphsir_spectral_fold_bwd(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold_bwd")
         _acct("spectral_fold_bwd", 4.0 * B * C * C * hd + 2.0 * B * N * C * C, 3.0 * B * C * C * 4 + 2.0 * B * N * C * d_out.element_size())
         _acct("spectral_fold_bwd:dm", 0.0, 0.0)
@@ -1612,6 +1615,7 @@ def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True, d_out=Non
     a.Gpart, a.Spart, a.temperature, a.Wo, a.dM = _p(gp), _p(sp), _p(temperature), _p(Wo), _p(dM)
     a.W2, a.dWo, a.dtemp = _p(W2), _p(dWo), _p(dtemp)
     a.B, a.C, a.heads, a.nsplit, a.dM_nsplit = B, C, heads, nsplit, dm_nsplit
+    a.dm_scale = _p(dm_scale)
     _lib.check(lib.mphsir_spectral_fold_bwd(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold_bwd")
     _acct("spectral_fold_bwd", 4.0 * B * C * C * hd, 3.0 * B * C * C * 4)
     if not reduce:
