@@ -318,6 +318,16 @@ typedef struct mphsir_mlp_wgrad_args {
 int mphsir_gated_mlp_wgrad(const mphsir_mlp_wgrad_args* a, int dtype, void* stream);
 int mphsir_gated_mlp_wgrad_fits(int32_t C, int32_t chunks_per_wg, int dtype);
 
+/* The depthwise / gate middle of the GDFN backward in one launch (mphsir_dwconv_gate_bwd + mphsir_dwconv3x3_bwd): from T = project_in(LN(x))
+ * [B*H*W][2*HP], the taps w9 fp32 [9][ldw >= 2*HP] and dU [B*H*W][HP] (= dY W_out) it recomputes [x1 | x2] = dwconv3x3(T) on every tile's
+ * one-pixel halo, forms [d x1 | d x2] there (never written to HBM), and emits U = gelu(x1) x2 [B*H*W][HP] (for d project_out), dT =
+ * dwconv3x3^T([d x1 | d x2]) [B*H*W][2*HP] and the tap-gradient partials [nblk][9][2*HP] (one per tile range; nblk x HP/16 workgroups).
+ * round_mid != 0 (tests): [d x1 | d x2] rounded to the storage type as the two-launch path stores it -> U and dT bitwise that path's.
+ * 16-bit dtypes, H % 8 == 0, W % 16 == 0, HP % 16 == 0.  Reference: FFN / FeedForward.forward net/MP_HSIR.py:259-265 == :385-391. */
+int mphsir_gdfn_dw_bwd(const void* T, const float* w9, int64_t ldw, const void* dU, void* U, void* dT, float* partial, int32_t nblk,
+                       int32_t B, int32_t H, int32_t W, int32_t HP, int32_t round_mid, int dtype, void* stream);
+int mphsir_gdfn_dw_bwd_fits(int32_t H, int32_t W, int32_t HP, int dtype);
+
 /* ---- backward of the window-attention side of a PGSSTB block --------------------------------------
  * mphsir_combine_bwd: backward of mphsir_gemm_tok epi 2 (y = R + keep*(SA*gate[win] + acc), net/MP_HSIR.py
  *   :715-718,:153): dOut = keep*dY (written only if keep != NULL), dSA = dOut*gate[win],

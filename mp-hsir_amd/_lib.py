@@ -183,6 +183,8 @@ _SYMBOLS = {
     "mphsir_dwconv_gate": (c_int, [ctypes.POINTER(GateArgs), c_int, c_void_p]),
     "mphsir_dwconv_gate_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_dwconv_gate_bwd_fits": (c_int, [c_int32, c_int32, c_int32, c_int]),
+    "mphsir_gdfn_dw_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    "mphsir_gdfn_dw_bwd_fits": (c_int, [c_int32, c_int32, c_int32, c_int]),
     "mphsir_gdfn_fused": (c_int, [ctypes.POINTER(GdfnArgs), c_int, c_void_p]),
     "mphsir_gdfn_fused_fits": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int]),
     "mphsir_gdfn_fused_tile_width": (c_int, [c_int32]),

@@ -410,11 +410,21 @@ class _GdfnRes(torch.autograd.Function):
         t4 = t.reshape(B, H, W, 2 * HP)
         with ops.reduce_scope(leaf=True):
             du = ops.gemm_tok(dy, pf["w_outT"])                                 # (M,HP)
-            u, dtdw = ops.dwconv_gate_bwd(t, pf["w9"], du, B, H, W)             # the depthwise conv is recomputed inside
-            d_out_w = ops.gemm_tn_blocks(dy, u, [(0, D)], ncols=hid).reshape(D, hid, 1, 1)
-            dtdw4 = dtdw.reshape(B, H, W, 2 * HP)
-            dt_, d_dw = ops.dwconv3x3_bwd(t4, dtdw4, pf["w9"], col_ranges=[(0, hid), (HP, hid)])
-            dt_, d_dw = dt_.reshape(-1, 2 * HP), d_dw.reshape(2 * hid, 1, 3, 3)
+            if ops.gdfn_dw_bwd_fits(H, W, HP, a2.dtype):
+                # gate backward + depthwise backward in ONE launch: the conv is recomputed on every tile's halo, [d x1 | d x2] (2 HP values per
+                # token) is neither written nor read back
+                u, dt_, dwp = ops.gdfn_dw_bwd(t, pf["w9"], du, B, H, W)
+                d_out_w = ops.gemm_tn_blocks(dy, u, [(0, D)], ncols=hid).reshape(D, hid, 1, 1)
+                d_dw = torch.empty((2 * hid, 9), dtype=torch.float32, device=t.device)
+                ops.reduce_block(dwp, 0, 9, 0, hid, d_dw[:hid], transpose=True)
+                ops.reduce_block(dwp, 0, 9, HP, hid, d_dw[hid:], transpose=True)
+                d_dw = d_dw.reshape(2 * hid, 1, 3, 3)
+            else:
+                u, dtdw = ops.dwconv_gate_bwd(t, pf["w9"], du, B, H, W)             # the depthwise conv is recomputed inside
+                d_out_w = ops.gemm_tn_blocks(dy, u, [(0, D)], ncols=hid).reshape(D, hid, 1, 1)
+                dtdw4 = dtdw.reshape(B, H, W, 2 * HP)
+                dt_, d_dw = ops.dwconv3x3_bwd(t4, dtdw4, pf["w9"], col_ranges=[(0, hid), (HP, hid)])
+                dt_, d_dw = dt_.reshape(-1, 2 * HP), d_dw.reshape(2 * hid, 1, 3, 3)
             lw, lb = ln.pair()
             if ops.ln_bwd_win_dxn_fits(a2.shape[0], D, a2.dtype):        # project_in's data gradient formed inside the LayerNorm-backward launch
                 da, dlw, dlb, xn = ops.ln_bwd_tok_dxn(a2, dt_, pf["w_inT"], dy, lw, lb)

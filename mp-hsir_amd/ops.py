@@ -1576,6 +1576,36 @@ def fold_bwd_forms_dm(N, C, heads, dtype):
     return dtype in _HALF and 0 < N <= FOLD_BWD_DM_MAX_TOKENS and N % 64 == 0 and (C // heads) in (32, 48, 64)      # (96-wide heads: the token tiles do not fit beside the 150 KB the kernel already takes)
 
 
+GDFN_DW_BWD = os.environ.get("MPHSIR_GDFN_DW_BWD", "1") == "1"      # gate backward + depthwise backward of the GDFN in one launch (0: two)
+GDFN_DW_BWD_WGS = int(os.environ.get("MPHSIR_GDFN_DW_BWD_WGS", "2048"))      # four rounds of resident workgroups (measured: 88 ranges x 22 slabs 333 us, 16 ranges 425)
+
+
+def gdfn_dw_bwd_fits(H, W, HP, dtype):
+    return GDFN_DW_BWD and dtype in _HALF and bool(_lib.load().mphsir_gdfn_dw_bwd_fits(H, W, HP, _DT[dtype]))
+
+
+def gdfn_dw_bwd(t, w9, du, B, H, W, nblk=None, round_mid=False):
+    """t (M, 2HP) = project_in(LN(x)), du (M, HP) contiguous, w9 fp32 [9][2HP] -> (u (M, HP), dt (M, 2HP), tap-gradient partials
+    (nblk, 9, 2HP)): the conv is recomputed on every tile's halo, [d x1 | d x2] stays on the chip (include/mphsir.h)."""
+    lib = _lib.load()
+    _check(t, w9, du)
+    M, HP = du.shape
+    assert t.shape == (M, 2 * HP) and t.is_contiguous() and du.is_contiguous() and M == B * H * W and w9.shape == (9, 2 * HP) and w9.stride(1) == 1
+    nslab = HP // 16
+    tiles = B * (H // 8) * (W // 16)
+    if nblk is None:
+        nblk = max(1, min(tiles, GDFN_DW_BWD_WGS // nslab))
+        if nblk >= 8:
+            nblk = nblk // 8 * 8
+    u = torch.empty((M, HP), dtype=t.dtype, device=t.device)
+    dt = torch.empty((M, 2 * HP), dtype=t.dtype, device=t.device)
+    part = torch.empty((nblk, 9, 2 * HP), dtype=torch.float32, device=t.device)
+    _lib.check(lib.mphsir_gdfn_dw_bwd(_p(t), _p(w9), w9.stride(0), _p(du), _p(u), _p(dt), _p(part), nblk, B, H, W, HP, int(round_mid),
+                                      _DT[t.dtype], _stream(t)), "gdfn_dw_bwd")
+    _acct("gdfn_gate_bwd", M * HP * (40.0 + 72.0), (2.0 * 1.9 + 1.4 + 1.0 + 2.0) * M * HP * t.element_size())
+    return u, dt, part
+
+
 def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True, d_out=None, v=None, dm_scale=None):
     """-> W2 (B,2C,2C) in `dtype`, dWo (C,C) fp32, dtemp (heads,) fp32 (reduce=False: the per-sample partials
     (B,C,C) / (B,heads) instead, for the caller to pass to reduce_parts).  dM=None with d_out, v (B*N, C) in `dtype`: dM is formed in

@@ -1016,6 +1016,54 @@ def check_ln_bwd_win_dxn(dev, dtype, C=64, shape=(2, 16, 16), shift=4):
     return res
 
 
+def check_gdfn_dw_bwd(dev, dtype, shape=(2, 16, 32), hid=85, nblk=None):
+    """mphsir_gdfn_dw_bwd (the GDFN's gate backward + depthwise backward in one launch, [d x1 | d x2] on the chip) against
+    mphsir_dwconv_gate_bwd + mphsir_dwconv3x3_bwd on the same operands: with the pair's rounding switched on (round_mid) u and dt are
+    BITWISE equal and the tap gradients agree to fp32 summation order; the product form is no further from fp64 than the pair."""
+    _use(dev)
+    from mp_hsir_amd import ops
+    B, H, W = shape
+    M = B * H * W
+    HP = ops.round_up(hid, 32)
+    assert ops.gdfn_dw_bwd_fits(H, W, HP, dtype)
+    t = rnd((M, 2 * HP), 941, dtype)
+    du = rnd((M, HP), 942, dtype)
+    w9 = torch.zeros((9, 2 * HP), dtype=torch.float32, device=dev)
+    w9[:, :hid], w9[:, HP:HP + hid] = rnd((9, hid), 943, scale=1 / 3), rnd((9, hid), 944, scale=1 / 3)
+    u_ref, dtdw = ops.dwconv_gate_bwd(t, w9, du, B, H, W)
+    with ops.reduce_scope():
+        dt_ref, dw_ref = ops.dwconv3x3_bwd(t.reshape(B, H, W, 2 * HP), dtdw.reshape(B, H, W, 2 * HP), w9, col_ranges=[(0, hid), (HP, hid)])
+    dt_ref = dt_ref.reshape(M, 2 * HP)
+
+    def taps(part):
+        out = torch.empty((2 * hid, 9), dtype=torch.float32, device=dev)
+        with ops.reduce_scope():
+            ops.reduce_block(part, 0, 9, 0, hid, out[:hid], transpose=True)
+            ops.reduce_block(part, 0, 9, HP, hid, out[hid:], transpose=True)
+        return out
+    res = {}
+    for nb in ([nblk] if nblk else [None, 1, 3]):
+        u, dt, part = ops.gdfn_dw_bwd(t, w9, du, B, H, W, nblk=nb, round_mid=True)
+        assert torch.equal(u, u_ref), ("u", nb, rel_l2(u, u_ref))
+        assert torch.equal(dt, dt_ref), ("dt", nb, rel_l2(dt, dt_ref))
+        res["dw_round_%s" % nb] = rel_l2(taps(part), dw_ref)
+        assert res["dw_round_%s" % nb] < 1e-5, res
+    u, dt, part = ops.gdfn_dw_bwd(t, w9, du, B, H, W, nblk=nblk)
+    dw = taps(part)
+    # fp64 on the same operands
+    t64 = t.double().cpu().reshape(B, H, W, 2 * HP).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wk = w9.double().cpu().t().reshape(2 * HP, 1, 3, 3).clone().requires_grad_(True)
+    x = torch.nn.functional.conv2d(t64, wk, padding=1, groups=2 * HP)
+    uu = torch.nn.functional.gelu(x[:, :HP]) * x[:, HP:]
+    (uu * du.double().cpu().reshape(B, H, W, HP).permute(0, 3, 1, 2)).sum().backward()
+    dt64 = t64.grad.permute(0, 2, 3, 1).reshape(M, 2 * HP)
+    dw64 = torch.cat([wk.grad.reshape(2 * HP, 9)[:hid], wk.grad.reshape(2 * HP, 9)[HP:HP + hid]])
+    res.update(u=rel_l2(u, uu.detach().permute(0, 2, 3, 1).reshape(M, HP)), dt=rel_l2(dt, dt64), dt_pair=rel_l2(dt_ref, dt64), dw=rel_l2(dw, dw64), dw_pair=rel_l2(dw_ref, dw64))
+    tol = TOL[dtype]
+    assert res["u"] < tol and res["dt"] < tol and res["dw"] < tol and res["dt"] <= res["dt_pair"] * 1.05 and res["dw"] <= res["dw_pair"] * 1.05 + 1e-6, res
+    return res
+
+
 def check_ln_bwd_tok_dxn(dev, dtype, C=64, K=384, M=256):
     """mphsir_ln_bwd_tok_dxn (token order, any K % 32 == 0, LN(x) as a second output) against gemm_tok + ln_bwd_tok on the same operands"""
     _use(dev)

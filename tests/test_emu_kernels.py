@@ -229,6 +229,11 @@ def test_ln_bwd_win_with_the_dxn_gemm_inside(dtype, C, shape, shift):
     print(K.check_ln_bwd_win_dxn("cpu", dtype, C, shape, shift))
 
 
+@pytest.mark.parametrize("dtype,shape,hid", [(torch.bfloat16, (2, 8, 16), 85), (torch.float16, (1, 16, 32), 40), (torch.bfloat16, (1, 8, 32), 170)])
+def test_gdfn_gate_and_depthwise_backward_in_one_launch(dtype, shape, hid):
+    print(K.check_gdfn_dw_bwd("cpu", dtype, shape, hid))
+
+
 @pytest.mark.parametrize("dtype,C,Kd,M", [(torch.bfloat16, 64, 384, 128), (torch.float16, 128, 704, 64), (torch.bfloat16, 256, 160, 64), (torch.bfloat16, 96, 96, 64)])
 def test_ln_bwd_tok_with_the_conv_gradient_inside(dtype, C, Kd, M):
     print(K.check_ln_bwd_tok_dxn("cpu", dtype, C, Kd, M))

@@ -340,6 +340,16 @@ def test_ln_bwd_win_with_the_dxn_gemm_inside(dtype, C, shape, shift):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape,hid", [((4, 64, 64), 340), ((2, 64, 64), 170), ((3, 32, 32), 680), ((2, 32, 32), 340), ((1, 64, 64), 255), ((2, 16, 32), 510), ((1, 8, 16), 85)])
+def test_gdfn_gate_and_depthwise_backward_in_one_launch(dtype, shape, hid):
+    print(K.check_gdfn_dw_bwd("cuda", dtype, shape, hid))
+
+
+def test_gdfn_dw_bwd_at_the_training_shape():
+    print(K.check_gdfn_dw_bwd("cuda", torch.bfloat16, (32, 64, 64), 340, nblk=16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("C,Kd,M", [(128, 704, 131072), (64, 384, 131072), (256, 1408, 32768), (128, 384, 131072), (256, 768, 32768), (192, 1024, 4096), (96, 512, 65536)])
 def test_ln_bwd_tok_with_the_conv_gradient_inside(dtype, C, Kd, M):
     print(K.check_ln_bwd_tok_dxn("cuda", dtype, C, Kd, M))
