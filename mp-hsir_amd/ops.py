@@ -1576,7 +1576,7 @@ def fold_bwd_forms_dm(N, C, heads, dtype):
     return dtype in _HALF and 0 < N <= FOLD_BWD_DM_MAX_TOKENS and N % 64 == 0 and (C // heads) in (32, 48, 64)      # (96-wide heads: the token tiles do not fit beside the 150 KB the kernel already takes)
 
 
-GDFN_DW_BWD = os.environ.get("MPHSIR_GDFN_DW_BWD", "1") == "1"      # gate backward + depthwise backward of the GDFN in one launch (0: two)
+GDFN_DW_BWD = os.environ.get("MPHSIR_GDFN_DW_BWD", "0") == "1"      # gate backward + depthwise backward of the GDFN in one launch: correct, 1 GB per step less traffic, but level in A/B and +50 us in the serial trace (803 against 751 us for the four GDFNs): OFF
 GDFN_DW_BWD_WGS = int(os.environ.get("MPHSIR_GDFN_DW_BWD_WGS", "2048"))      # four rounds of resident workgroups (measured: 88 ranges x 22 slabs 333 us, 16 ranges 425)
 
 
