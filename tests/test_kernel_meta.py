@@ -37,7 +37,7 @@ KNOWN = [
     (r"qkv_dwconv_gram_rows_kernelIDF16[b_]Li256ELi32E", 25),            # C = 256 row form (fusion2): 1 launch per step
     (r"qkv_dwconv_gram_rows_kernelIDF16[b_]Li128ELi64ELb0ELb1ELb0E", 14),  # the shader-clock-stamped diagnostic build
     (r"dwconv_gram2_kernelIDF16[b_]Li128ELi(32|64)E", 32),               # cross attention of TVSP level 2: 1 launch per step
-    (r"gated_mlp_bwd2_kernelIDF16[b_]Li256ELi(1ELi8|2ELi4)E", 105),
+    (r"gated_mlp_bwd2_kernelIDF16[b_]Li256ELi(1ELi8|2ELi4)E", 140),
     (r"ln_bwd_win_dxn_kernelIDF16_Li256E", 9),                               # fp16 at C = 256 (no shipped configuration trains that width in fp16)      # forms the host does not choose at C = 256 (tests only)
 ]
 
