@@ -537,6 +537,19 @@ int mphsir_tvsp_text_map_bwd(const float* dtext, const float* clip, float* part,
 int mphsir_resize_bilinear(const void* X, void* Y, int32_t B, int32_t h, int32_t w, int32_t H, int32_t W, int32_t C, int32_t backward,
                            int dtype, void* stream);
 
+/* ---- the two ends of MP_HSIR_Net.forward (net/MP_HSIR.py:822-844) and the task-prompt algebra, one launch each -------------
+ * mphsir_nchw_to_cl:      Y [B][HW][Cp] (dtype) = X [B][C][HW] fp32 with channels C..Cp-1 zero -- `inp_img` as the patch embedding's
+ *   channels-last, 32-padded input (:824); also the backward of the output head (d conv_out from d restored).  Cp <= 252.
+ * mphsir_cl_to_nchw_add:  O [B][C][HW] fp32 = (float) Y [B][HW][ldy] (dtype, first C channels) + R [B][C][HW] fp32 (R may be NULL)
+ *   -- `self.output(...) + inp_img` (:842-843).
+ * mphsir_task_weights:    w [B][T] fp32 = the mean of the one-hot rows of ids [B][n] (int64 task ids; Text_Prompt.forward :519-523).
+ * mphsir_mix_rows:        O [I][D] = scale * A Bm, A [I][J] (transA: stored [J][I]), Bm [J][D], fp32 -- the task-weighted means
+ *   (w.unsqueeze(-1) * table).mean(1) of :527 / TVSP :574 (scale 1/T) and their gradient d table = w^T dO / T.                */
+int mphsir_nchw_to_cl(const float* X, void* Y, int32_t B, int32_t C, int64_t HW, int32_t Cp, int dtype, void* stream);
+int mphsir_cl_to_nchw_add(const void* Y, int64_t ldy, const float* R, float* O, int32_t B, int32_t C, int64_t HW, int dtype, void* stream);
+int mphsir_task_weights(const int64_t* ids, float* w, int32_t B, int32_t n, int32_t T, void* stream);
+int mphsir_mix_rows(const float* A, const float* Bm, float* O, int32_t I, int32_t J, int32_t D, float scale, int32_t transA, void* stream);
+
 /* ---- fused AdamW over the flat parameter arena ---------------------------------------------------
  * One decoupled-weight-decay Adam step on n contiguous fp32 parameters (n % 4 == 0) with gradient g,
  * moments m, v; g is multiplied by grad_scale first (1/world_size after a sum all-reduce).
@@ -630,6 +643,7 @@ int mphsir_l1_clamp_loss(const float* y, const float* clean, float* grad, float*
 #define MPHSIR_K_L1_LOSS 28
 #define MPHSIR_K_GATED_MLP_WGRAD 29
 #define MPHSIR_K_SPECTRAL_DQKV_BWD 30
+#define MPHSIR_K_LAYOUT 31
 #define MPHSIR_K_COUNT 32
 int mphsir_prof_enable(int kid);   /* kid < 0 disables */
 int mphsir_prof_read(int* launches, float* total_ms);

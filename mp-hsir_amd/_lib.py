@@ -228,6 +228,10 @@ _SYMBOLS = {
     "mphsir_gemm_tn_group": (c_int, [ctypes.POINTER(TnProblem), c_int32, c_int32, c_int, c_void_p]),
     "mphsir_pack_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "mphsir_multi_copy": (c_int, [c_void_p, c_int32, c_int64, c_void_p]),
+    "mphsir_nchw_to_cl": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int32, c_int, c_void_p]),
+    "mphsir_cl_to_nchw_add": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_int, c_void_p]),
+    "mphsir_task_weights": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "mphsir_mix_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, ctypes.c_float, c_int32, c_void_p]),
     "mphsir_l1_clamp_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
 }
 

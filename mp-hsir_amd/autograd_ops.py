@@ -596,8 +596,7 @@ def tvsp(mod, x, clip_prompt, prompt_weights):
     text[b,i,j,d] = L[b,d] * clip[floor(i*B/ps), floor(j*512/ps)]."""
     B, H, W, D = x.shape
     ps, dt, dev = mod.prompt_size, x.dtype, x.device
-    learn = mod.text_prompt_learnable[0, :, :, 0, 0]                                   # (T,D)
-    L = (prompt_weights.to(torch.float32).unsqueeze(-1) * learn.unsqueeze(0)).mean(dim=1)      # (B,D)
+    L = mix_rows(prompt_weights, mod.text_prompt_learnable)                            # (B,D) = (w[..., None] * learnable (T,D)).mean(1)
     text = _TextMap.apply(L, clip_prompt, ps)                                          # fp32: see _CrossChannelAttnRes
     vis1 = mod.visual_prompt[0].permute(1, 2, 0).to(dt).contiguous().reshape(ps * ps, D)      # the one visual prompt map (ref :578 expands it to B copies)
     ct = mod.cross_transformer
@@ -611,7 +610,8 @@ def tvsp(mod, x, clip_prompt, prompt_weights):
     return conv3x3(y, mod.conv_last)
 
 
-def prompt_fusion(mod, x, prompt):
+def prompt_fusion(mod, x, prompt, out=None):
+    """out: an uninitialised (B,H,W,out_dim) channel slice of a wider buffer the result is written into (see shuffle_join)"""
     t = torch.cat([x, prompt], dim=-1)
     B, H, W, D = t.shape
     tb = mod.transformer
@@ -622,7 +622,7 @@ def prompt_fusion(mod, x, prompt):
         a = _SelfChannelAttnRes.apply(at, tb.norm1, (B, H, W), t.reshape(-1, D), tb.norm1.body.weight, tb.norm1.body.bias,
                                       at.qkv.weight, at.qkv_dwconv.weight, at.project_out.weight, at.temperature)
     y = _gdfn_res_ag(tb.ffn, tb.norm2, a, B, H, W).reshape(B, H, W, D)
-    return conv1x1(y, mod.conv)
+    return conv1x1(y, mod.conv, out=out)
 
 
 # ---- plain convs / resamplers ----------------------------------------------------------------------
@@ -654,13 +654,16 @@ def _row_major(t):
 
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, conv):
+    def forward(ctx, x, w, conv, out=None):
         N, K = w.shape[0], w.shape[1]
         pk = _packed_conv1x1(conv, w, x.dtype)
         ctx.save_for_backward(x, w)
         ctx.conv = conv
-        y = ops.gemm_tok(x.reshape(-1, K), pk["w"])
-        return y.reshape(*x.shape[:-1], N)
+        if out is not None:       # a channel slice of a wider row-major buffer: written through its row pitch
+            assert out.shape == (*x.shape[:-1], N) and out.dtype == x.dtype and out.stride(-1) == 1
+            out = out.view(-1, N)
+        y = ops.gemm_tok(x.reshape(-1, K), pk["w"], out=out)
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
@@ -676,39 +679,42 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             with ops.reduce_scope(leaf=True):          # w is a leaf: the sum joins the deferred parameter-gradient sums
                 dw = ops.gemm_tn(dy2, x2).reshape(w.shape)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def conv1x1(x, conv):
+def conv1x1(x, conv, out=None):
     """bias-free 1x1 conv / Linear on channels-last data; `conv` is the nn.Conv2d holder (its packed weights are cached on it)."""
-    return _Conv1x1.apply(x, conv.weight, conv)
+    return _Conv1x1.apply(x, conv.weight, conv, out)
 
 
 class _Conv3x3(torch.autograd.Function):
     """dense 3x3 conv as an implicit GEMM on the HIP kernel (forward, input gradient) + im2col/gemm_tn (weights)."""
 
     @staticmethod
-    def forward(ctx, x, w, conv):
+    def forward(ctx, x, w, conv, keep_pad=False):
+        """x with Cin channels, or already zero-padded to round_up(Cin, 32) (input_head).  keep_pad: the output keeps its round_up(Cout, 32)
+        channels (the padded ones are zero: zero weight rows) for a consumer that reads the first Cout through the row pitch (output_head)."""
         Cout, Cin = w.shape[0], w.shape[1]
         Cp = ops.round_up(Cin, 32)
-        xp = x.contiguous() if Cp == Cin else F.pad(x, (0, Cp - Cin)).contiguous()
+        assert x.shape[-1] in (Cin, Cp)
+        xp = x.contiguous() if x.shape[-1] == Cp else F.pad(x, (0, Cp - Cin)).contiguous()
         pk = _packed_conv3x3(conv, w, x.dtype)
         y = ops.conv3x3_tok(xp, pk["fwd"])
         ctx.save_for_backward(xp, w)
-        ctx.conv = conv
-        return y if y.shape[-1] == Cout else y[..., :Cout].contiguous()
+        ctx.conv, ctx.xc = conv, x.shape[-1]
+        return y if keep_pad or y.shape[-1] == Cout else y[..., :Cout].contiguous()
 
     @staticmethod
     def backward(ctx, dy):
         xp, w = ctx.saved_tensors
         Cout, Cin = w.shape[0], w.shape[1]
         Cp, Co32 = xp.shape[-1], ops.round_up(Cout, 32)
-        dyp = dy.contiguous() if Co32 == Cout else F.pad(dy, (0, Co32 - Cout)).contiguous()
+        dyp = dy.contiguous() if dy.shape[-1] == Co32 else F.pad(dy[..., :Cout], (0, Co32 - Cout)).contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
             pk = _packed_conv3x3(ctx.conv, w, dy.dtype)
             dx = ops.conv3x3_tok(dyp, pk["bwd"])
-            dx = dx if dx.shape[-1] == Cin else dx[..., :Cin].contiguous()
+            dx = dx if dx.shape[-1] == ctx.xc else dx[..., :ctx.xc].contiguous()
         if ctx.needs_input_grad[1]:
             if dyp.dtype in (torch.bfloat16, torch.float16):      # the gather happens inside the token-reduction GEMM; the
                 with ops.reduce_scope(leaf=True):                 # ordered sum writes the (Cout, Cin, 3, 3) layout (w is a leaf)
@@ -716,17 +722,108 @@ class _Conv3x3(torch.autograd.Function):
             else:
                 g = ops.gemm_tn(dyp.reshape(-1, Co32), ops.im2col3x3(xp))[:Cout]
                 dw = g.reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def conv3x3(x, conv):
+def conv3x3(x, conv, keep_pad=False):
     """dense 3x3, stride 1, zero padding, no bias on channels-last data; `conv` is the nn.Conv2d holder."""
-    return _Conv3x3.apply(x, conv.weight, conv)
+    return _Conv3x3.apply(x, conv.weight, conv, keep_pad)
+
+
+class _InputHead(torch.autograd.Function):
+    """inp_img (B,C,H,W) fp32 -> channels-last, compute dtype, channels zero-padded to a multiple of 32 (ref :824 + the patch embedding's
+    input layout): one launch for .to / permute / contiguous / pad"""
+
+    @staticmethod
+    def forward(ctx, inp, dt):
+        ctx.c = inp.shape[1]
+        return ops.nchw_to_cl(inp.contiguous(), dt, ops.round_up(inp.shape[1], 32))
+
+    @staticmethod
+    def backward(ctx, d):
+        return (ops.cl_to_nchw_add(d.contiguous(), ctx.c) if ctx.needs_input_grad[0] else None), None
+
+
+def input_head(inp, dt):
+    if inp.dtype != torch.float32 or ops.round_up(inp.shape[1], 32) > 252:
+        return inp.to(dt).permute(0, 2, 3, 1).contiguous()
+    return _InputHead.apply(inp, dt)
+
+
+class _OutputHead(torch.autograd.Function):
+    """restored = output_conv(...) + inp_img (ref :842-843): y (B,H,W,Cy) channels-last with the conv's padded channels kept, inp (B,C,H,W)
+    fp32 -> (B,C,H,W) fp32.  One launch each way (slice / permute / .to / add, and pad / permute / .to in the backward)."""
+
+    @staticmethod
+    def forward(ctx, y, inp):
+        ctx.meta = (y.dtype, ops.round_up(inp.shape[1], 32))      # the width the conv's backward reads (its own output pad is a multiple of 16)
+        return ops.cl_to_nchw_add(y, inp.shape[1], inp.contiguous())
+
+    @staticmethod
+    def backward(ctx, d):
+        dt, cy = ctx.meta
+        return ops.nchw_to_cl(d.contiguous(), dt, cy), (d if ctx.needs_input_grad[1] else None)
+
+
+def output_head(r, conv, inp):
+    """conv3x3(r, conv).permute(0,3,1,2).to(inp.dtype) + inp"""
+    if inp.dtype != torch.float32 or ops.round_up(conv.weight.shape[0], 32) > 252:
+        return conv3x3(r, conv).permute(0, 3, 1, 2).to(inp.dtype) + inp
+    return _OutputHead.apply(conv3x3(r, conv, keep_pad=True), inp)
+
+
+class _MixRows(torch.autograd.Function):
+    """(w.unsqueeze(-1) * table).mean(1) for task weights w (B,T) and a table parameter holding (T,D) values in any singleton-padded shape
+    (ref :527, TVSP :574): one launch, and ONE for the table's gradient w^T dO / T, handed back in the parameter's own shape (the
+    select / slice backward chain of indexing the parameter first was 2 launches per index)."""
+
+    @staticmethod
+    def forward(ctx, w, table):
+        T = w.shape[1]
+        ctx.save_for_backward(w)
+        ctx.tshape = table.shape
+        return ops.mix_rows(w, table.reshape(T, -1).contiguous(), 1.0 / T)
+
+    @staticmethod
+    def backward(ctx, d):
+        (w,) = ctx.saved_tensors
+        assert not ctx.needs_input_grad[0]
+        return None, ops.mix_rows(w, d.contiguous(), 1.0 / w.shape[1], transA=True).reshape(ctx.tshape)
+
+
+def mix_rows(w, table):
+    return _MixRows.apply(w.to(torch.float32).contiguous(), table)
 
 
 def pixel_unshuffle2(x):
     B, H, W, Cc = x.shape
     return x.reshape(B, H // 2, 2, W // 2, 2, Cc).permute(0, 1, 3, 5, 2, 4).reshape(B, H // 2, W // 2, Cc * 4)
+
+
+class _ShuffleJoin(torch.autograd.Function):
+    """cat([pixel_shuffle2(c), f], -1) where f already IS the right half of `buf` (its producer wrote it there through the row pitch):
+    the shuffle writes the left half and the buffer is the result -- no cat launch, the decoder's concatenations (ref :838, :843)."""
+
+    @staticmethod
+    def forward(ctx, c, f, buf):
+        B, H, W, C4 = c.shape
+        Cl = C4 // 4
+        Ct = buf.shape[-1]
+        assert buf.is_contiguous() and buf.shape[:3] == (B, 2 * H, 2 * W) and f.shape == (B, 2 * H, 2 * W, Ct - Cl) and f.dtype == buf.dtype == c.dtype
+        assert f.data_ptr() == buf.data_ptr() + Cl * buf.element_size() and f.stride() == buf.stride(), "f is not the right half of buf"
+        dst = buf[..., :Cl].unflatten(1, (H, 2)).unflatten(3, (W, 2))                     # (B,H,2,W,2,Cl) view of the left half
+        dst.copy_(c.reshape(B, H, W, Cl, 2, 2).permute(0, 1, 4, 2, 5, 3))               # one strided copy launch
+        ctx.cl = Cl
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, d):
+        Cl = ctx.cl
+        return pixel_unshuffle2(d[..., :Cl]), d[..., Cl:], None
+
+
+def shuffle_join(c, f, buf):
+    return _ShuffleJoin.apply(c, f, buf)
 
 
 def pixel_shuffle2(x):

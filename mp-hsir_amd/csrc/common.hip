@@ -94,7 +94,7 @@ int mphsir_device_arch(char* buf, int n) {
 }
 
 const char* mphsir_kernel_name(int kid) {
-    static const char* names[] = {"gemm_tok", "win_attn", "dwconv_gram", "spectral_fold", "gated_mlp", "dwconv_gate", "flat_adamw", "dwconv3x3", "dwconv3x3_wgrad", "gated_mlp_bwd", "combine_bwd", "win_attn_bwd", "ln_bwd_win", "gemm_tn", "gdfn_gate_bwd", "spectral_fold_bwd", "pg_gate_bwd", "conv3x3_tok", "im2col3x3", "reduce_parts", "pack_gather", "layernorm_tok", "pg_gate", "resample", "qkv_dwconv_gram", "gdfn_fused", "dwconv3x3_bwd", "multi_copy", "l1_clamp_loss", "gated_mlp_wgrad", "spectral_dqkv_bwd"};
+    static const char* names[] = {"gemm_tok", "win_attn", "dwconv_gram", "spectral_fold", "gated_mlp", "dwconv_gate", "flat_adamw", "dwconv3x3", "dwconv3x3_wgrad", "gated_mlp_bwd", "combine_bwd", "win_attn_bwd", "ln_bwd_win", "gemm_tn", "gdfn_gate_bwd", "spectral_fold_bwd", "pg_gate_bwd", "conv3x3_tok", "im2col3x3", "reduce_parts", "pack_gather", "layernorm_tok", "pg_gate", "resample", "qkv_dwconv_gram", "gdfn_fused", "dwconv3x3_bwd", "multi_copy", "l1_clamp_loss", "gated_mlp_wgrad", "spectral_dqkv_bwd", "layout"};
     return (kid >= 0 && kid < (int)(sizeof(names) / sizeof(names[0]))) ? names[kid] : "?";
 }
 

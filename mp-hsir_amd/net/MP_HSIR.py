@@ -205,7 +205,7 @@ class BaseBlock(nn.Module):                                                     
         n = len(self.blocks)
         # (no-grad forward only: 512x512 cube 6.99 -> 6.88 ms, batch 16 3.37 -> 3.33 ms; in training the separate add costs nothing
         # measurable -- 21.39 / 21.64 against 21.45 / 21.68 ms fused, two A/B pairs -- and the graph stays as it was)
-        if not ops.BASE_SKIP_FUSED or n == 0 or torch.is_grad_enabled():
+        if not ops.BASE_SKIP_FUSED or n == 0 or (torch.is_grad_enabled() and not ops.BASE_SKIP_TRAIN):
             for blk in self.blocks:
                 y = blk(y)
             return y + x
@@ -354,10 +354,10 @@ class Text_Prompt(nn.Module):                                                   
         if table is None:
             table = self._on_device[x.device] = self.clip_prompt.to(x.device)
         if de_class.dim() > 1:
-            w = F.one_hot(de_class, T).float().mean(dim=1)      # training path: mean of one-hots (:519-523)
+            w = ops.task_weights(de_class.contiguous(), T)      # training path: mean of one-hots (:519-523)
         else:
             w = F.one_hot(de_class, T)                           # test path: int64 one-hot (:525)
-        clip = (w.unsqueeze(-1) * table.unsqueeze(0)).mean(dim=1)
+        clip = AG.mix_rows(w, table)                             # (w.unsqueeze(-1) * table).mean(1)  (:527)
         return clip, w
 
     def get_clip_prompt(self):
@@ -386,8 +386,8 @@ class PromptFusion(nn.Module):                                                  
         self.transformer = TransformerBlock(dim, head, ffn_expansion_factor, bias, "WithBias")
         self.conv = nn.Conv2d(dim, out_dim, 1, bias=bias)
 
-    def forward(self, x, prompt):
-        return AG.prompt_fusion(self, x, prompt)
+    def forward(self, x, prompt, out=None):
+        return AG.prompt_fusion(self, x, prompt, out)
 
 
 class OverlapPatchEmbed(nn.Module):                                                # ref :454-463
@@ -475,23 +475,25 @@ class MP_HSIR_Net(nn.Module):                                                   
         dt = self._dtype()
         self._draw_drop_path(inp_img.shape[0], inp_img.device)
         clip, w = self.text_prompt(inp_img, task_id)
-        x_in = inp_img.to(dt).permute(0, 2, 3, 1).contiguous()                     # channels-last from here on
+        x_in = AG.input_head(inp_img, dt)                                          # channels-last (and 32-padded) from here on
         e1 = self.encoder_level1(AG.conv3x3(x_in, self.patch_embed.proj))
         # the prompt branch of each level (ref :827, :835 -- there in program order behind the stages below) is forked where its input
         # exists and joined where the decoder of that level reads it: a parallel branch of the captured graph (inference only,
         # see ops.PROMPT_SIDE)
         fork = ops.PROMPT_SIDE and not torch.is_grad_enabled()
+        # the decoder's concatenations [pixel_shuffle(up(.)) | fusion(.)] (ref :838, :843): each producer writes its half of one buffer
+        cat1 = e1.new_empty((*e1.shape[:3], 2 * e1.shape[3]))
         with ops.side_stream(e1, fork, "prompt1", track=False) as br1:
-            f1 = self.fusion1(e1, self.prompt1(e1, clip, w))
+            f1 = self.fusion1(e1, self.prompt1(e1, clip, w), out=cat1[..., e1.shape[3]:])
         e2 = self.encoder_level2(AG.pixel_unshuffle2(AG.conv3x3(e1, self.down1_2.body[0])))
+        cat2 = e2.new_empty((*e2.shape[:3], 2 * e2.shape[3]))
         with ops.side_stream(e2, fork, "prompt2", track=False) as br2:
-            f2 = self.fusion2(e2, self.prompt2(e2, clip, w))
+            f2 = self.fusion2(e2, self.prompt2(e2, clip, w), out=cat2[..., e2.shape[3]:])
         lat = self.latent(AG.pixel_unshuffle2(AG.conv3x3(e2, self.down2_3.body[0])))
-        d2_in = AG.pixel_shuffle2(AG.conv3x3(lat, self.up3_2.body[0]))
+        up2 = AG.conv3x3(lat, self.up3_2.body[0])
         br2.join(f2)
-        d2 = self.decoder_level2(AG.conv1x1(torch.cat([d2_in, f2], -1), self.reduce_chan_level2))
-        d1_in = AG.pixel_shuffle2(AG.conv3x3(d2, self.up2_1.body[0]))
+        d2 = self.decoder_level2(AG.conv1x1(AG.shuffle_join(up2, f2, cat2), self.reduce_chan_level2))
+        up1 = AG.conv3x3(d2, self.up2_1.body[0])
         br1.join(f1)
-        r = self.refinement(self.decoder_level1(torch.cat([d1_in, f1], -1)))
-        out = AG.conv3x3(r, self.output).permute(0, 3, 1, 2).to(inp_img.dtype) + inp_img
-        return out
+        r = self.refinement(self.decoder_level1(AG.shuffle_join(up1, f1, cat1)))
+        return AG.output_head(r, self.output, inp_img)

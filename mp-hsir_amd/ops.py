@@ -648,6 +648,58 @@ def resize_bilinear(x, H, W, backward=False):
     return y
 
 
+def nchw_to_cl(x, dtype, cp):
+    """x (B,C,H,W) fp32 -> (B,H,W,cp) channels-last in `dtype`, channels C..cp-1 zero: `inp_img` as the patch embedding reads it,
+    and the gradient of the output head (one launch for .to / permute / contiguous / pad)."""
+    lib = _lib.load()
+    _check(x)
+    B, C, H, W = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32 and cp >= C
+    y = torch.empty((B, H, W, cp), dtype=dtype, device=x.device)
+    _lib.check(lib.mphsir_nchw_to_cl(_p(x), _p(y), B, C, H * W, cp, _DT[dtype], _stream(x)), "nchw_to_cl")
+    _acct("layout", 0.0, x.numel() * 4.0 + y.numel() * y.element_size())
+    return y
+
+
+def cl_to_nchw_add(y, C, res=None):
+    """y (B,H,W,Cy) channels-last, Cy >= C -> (B,C,H,W) fp32 = float(y[..., :C]) + res: the output head `self.output(...) + inp_img`
+    (one launch for slice / permute / .to / add)."""
+    lib = _lib.load()
+    _check(y, res)
+    B, H, W, Cy = y.shape
+    assert y.is_contiguous() and Cy >= C
+    if res is not None:
+        assert res.shape == (B, C, H, W) and res.dtype == torch.float32 and res.is_contiguous()
+    o = torch.empty((B, C, H, W), dtype=torch.float32, device=y.device)
+    _lib.check(lib.mphsir_cl_to_nchw_add(_p(y), Cy, _p(res), _p(o), B, C, H * W, _DT[y.dtype], _stream(y)), "cl_to_nchw_add")
+    _acct("layout", 0.0, o.numel() * (8.0 if res is not None else 4.0) + B * H * W * C * y.element_size())
+    return o
+
+
+def task_weights(ids, T):
+    """ids (B,n) int64 task ids -> (B,T) fp32: the mean of each sample's one-hot rows (Text_Prompt.forward's training path)"""
+    lib = _lib.load()
+    _check(ids)
+    assert ids.dim() == 2 and ids.dtype == torch.int64 and ids.is_contiguous()
+    B, n = ids.shape
+    w = torch.empty((B, T), dtype=torch.float32, device=ids.device)
+    _lib.check(lib.mphsir_task_weights(_p(ids), _p(w), B, n, T, _stream(ids)), "task_weights")
+    return w
+
+
+def mix_rows(A, Bm, scale, transA=False):
+    """scale * A @ Bm in fp32 for the few-row matrices of the task prompts: A (I,J) -- or stored (J,I) with transA -- , Bm (J,D)"""
+    lib = _lib.load()
+    _check(A, Bm)
+    assert A.dtype == Bm.dtype == torch.float32 and A.is_contiguous() and Bm.is_contiguous() and A.dim() == Bm.dim() == 2
+    I, J = (A.shape[1], A.shape[0]) if transA else A.shape
+    assert Bm.shape[0] == J
+    D = Bm.shape[1]
+    o = torch.empty((I, D), dtype=torch.float32, device=A.device)
+    _lib.check(lib.mphsir_mix_rows(_p(A), _p(Bm), _p(o), I, J, D, float(scale), 1 if transA else 0, _stream(A)), "mix_rows")
+    return o
+
+
 def round_up(n, m):
     return (n + m - 1) // m * m
 
@@ -671,6 +723,7 @@ def pack_gated_mlp(fc1_w, fc1_b, fc2_w, dtype):
 
 
 BASE_SKIP_FUSED = os.environ.get("MPHSIR_BASE_SKIP_FUSED", "1") == "1"     # BaseBlock's `+ x` inside its last gated-MLP launch (6 launches fewer per forward)
+BASE_SKIP_TRAIN = os.environ.get("MPHSIR_BASE_SKIP_TRAIN", "1") == "1"     # ... in training passes too
 # hidden split of the gated MLP kernels for small launches (< 256 token tiles at C >= 192: the latent level): 0 = off, else the number of
 # workgroups per token tile is chosen so that about 256 workgroups exist
 MLP_HSPLIT = os.environ.get("MPHSIR_MLP_HSPLIT", "1") == "1"

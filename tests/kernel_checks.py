@@ -1275,6 +1275,47 @@ def check_loss_scaler(dev):
     assert float(sc[0]) == 1024.0 * 2 * 0.5 * 2 and float(sc[3]) == 4.0
 
 
+def check_heads(dev, dtype, B=3, C=31, H=24, W=20, T=6, n=2):
+    """heads.hip against the framework expressions they replace (net/MP_HSIR.py:519-527, :824, :842-843): the layout kernels BITWISE
+    (one rounding each, the same one), the task-prompt algebra to fp32 rounding, forward and backward through the autograd wrappers."""
+    _use(dev)
+    import torch.nn.functional as F
+    from mp_hsir_amd import ops
+    from mp_hsir_amd import autograd_ops as AG
+    inp = rnd((B, C, H, W), 511)
+    cp = ops.round_up(C, 32)
+    x = ops.nchw_to_cl(inp, dtype, cp)
+    ref = F.pad(inp.to(dtype).permute(0, 2, 3, 1), (0, cp - C)).contiguous()
+    assert x.shape == ref.shape and torch.equal(x, ref)
+    y = rnd((B, H, W, cp), 512, dtype)
+    o = ops.cl_to_nchw_add(y, C, inp)
+    assert torch.equal(o, y[..., :C].permute(0, 3, 1, 2).to(torch.float32) + inp)
+    assert torch.equal(ops.cl_to_nchw_add(y, C), y[..., :C].permute(0, 3, 1, 2).to(torch.float32).contiguous())
+    # autograd: d(output head) = the layout kernel on the incoming gradient; the padded channels get zeros
+    yg = y.clone().requires_grad_(True)
+    g = rnd((B, C, H, W), 513)
+    AG._OutputHead.apply(yg, inp).backward(g)
+    assert torch.equal(yg.grad, F.pad(g.to(dtype).permute(0, 2, 3, 1), (0, cp - C)).contiguous())
+    ig = inp.clone().requires_grad_(True)
+    gx = rnd((B, H, W, cp), 514, dtype)
+    AG._InputHead.apply(ig, dtype).backward(gx)
+    assert torch.equal(ig.grad, gx[..., :C].permute(0, 3, 1, 2).to(torch.float32).contiguous())
+    # task weights + weighted means
+    ids = torch.randint(0, T, (B, n), generator=torch.Generator().manual_seed(515)).to(dev)
+    w = ops.task_weights(ids, T)
+    wr = F.one_hot(ids, T).float().mean(dim=1)
+    assert torch.equal(w, wr)
+    table = rnd((1, T, 40, 1, 1), 516).requires_grad_(True)          # text_prompt_learnable's shape
+    L = AG.mix_rows(w, table)
+    tr = table.detach().clone().requires_grad_(True)
+    Lr = (wr.unsqueeze(-1) * tr[0, :, :, 0, 0].unsqueeze(0)).mean(dim=1)
+    assert rel_l2(L, Lr.detach()) < 1e-6
+    dL = rnd(L.shape, 517)
+    L.backward(dL)
+    Lr.backward(dL)
+    assert table.grad.shape == table.shape and rel_l2(table.grad, tr.grad) < 1e-6
+
+
 def check_resamplers(dev, dtype, B=3, ps=16, D=32, H=40, W=24):
     """mphsir_tvsp_text_map (+bwd) against the reference's own expression (broadcast multiply + F.interpolate nearest,
     net/MP_HSIR.py:575-577) and mphsir_resize_bilinear (+bwd) against F.interpolate(bilinear) (:580), fp64 autograd."""

@@ -296,6 +296,12 @@ def test_resamplers(dtype):
     K.check_resamplers("cpu", dtype, B=1, ps=4, D=16, H=48, W=64)       # ratios 12 and 16: the backward's gather bounds
 
 
+@pytest.mark.parametrize("dtype", K.DTYPES)
+def test_heads(dtype):
+    K.check_heads("cpu", dtype)
+    K.check_heads("cpu", dtype, B=1, C=40, H=9, W=7, T=7, n=1)          # ragged pixel tiles, a second channel pad
+
+
 def test_win_attn_bwd_head_split():
     K.check_win_attn_bwd_head_split("cpu", torch.bfloat16)
 

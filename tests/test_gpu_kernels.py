@@ -415,6 +415,13 @@ def test_resamplers(dtype):
     K.check_resamplers("cuda", dtype, B=1, ps=4, D=32, H=48, W=64)          # ratios 12 and 16: the backward's gather bounds
 
 
+@pytest.mark.parametrize("dtype", K.DTYPES + [F16])
+def test_heads(dtype):
+    K.check_heads("cuda", dtype)
+    K.check_heads("cuda", dtype, B=32, C=31, H=64, W=64)
+    K.check_heads("cuda", dtype, B=1, C=172, H=40, W=36, T=7, n=1)       # the remote-sensing cube's channel count; ragged pixel tiles
+
+
 def test_win_attn_bwd_head_split():
     K.check_win_attn_bwd_head_split("cuda", torch.bfloat16)
     K.check_win_attn_bwd_head_split("cuda", torch.float16, C=256, heads=8, shape=(4, 16, 16))

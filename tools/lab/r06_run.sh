@@ -1,5 +1,8 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "gated_mlp" > gpurun_out/r06q_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r06q_tests.log
-tail -2 gpurun_out/r06q_tests.log
-F="--no-cpu-baseline --no-extra --no-spectral --no-roofline --steps 40 --warmup 5"
-for i in 1 2 3; do echo "$(python bench.py $F 2>/dev/null | tail -1 | cut -c50-140)"; done
+timeout 1500 python3 -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "heads or resamplers or conv" > gpurun_out/r06c_tests.log 2>&1; tail -3 gpurun_out/r06c_tests.log
+timeout 2400 python3 -m pytest tests/test_gpu_model.py -x -q -m gpu > gpurun_out/r06c_model.log 2>&1; tail -3 gpurun_out/r06c_model.log
+B="python3 bench.py --warmup 5 --no-cpu-baseline --no-roofline --no-spectral --no-extra --steps 60"
+for i in 1 2 3; do
+  $B 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+done
+python3 tools/diag/glue_sites.py 2>&1 | head -3
