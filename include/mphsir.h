@@ -365,21 +365,25 @@ int mphsir_ln_bwd_win(const void* X, const void* dXNw, const void* dRes, const f
 /* The same with the d_xn GEMM inside: d_xn = dQKV WqkvT^T is formed per window on the matrix cores (dQKV [B*nW*64][3C] in window-token
  * order as mphsir_win_attn_bwd writes it, WqkvT = the [C][3C] weight mphsir_gemm_tok would take for that data gradient) and fed to the
  * LayerNorm backward in LDS: replaces mphsir_gemm_tok + mphsir_ln_bwd_win (autograd of net/MP_HSIR.py:667 norm1 and :193-196 qkv);
- * d_xn never reaches HBM.  dX = dRes + LN_backward(d_xn) in image order; part [B*nW][2][C] as mphsir_ln_bwd_win.  16-bit dtypes. */
-int mphsir_ln_bwd_win_dxn(const void* X, const void* dQKV, const void* WqkvT, const void* dRes, const float* ln_w, void* dX, float* part,
-                          int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
+ * d_xn never reaches HBM.  dX = dRes + dRes2 + LN_backward(d_xn) in image order (dRes, dRes2 optional: dRes2 is the gradient arriving over
+ * the skip of the enclosing BaseBlock, net/MP_HSIR.py:760, when this block is its first); part [B*nW][2][C] as mphsir_ln_bwd_win.  16-bit dtypes. */
+int mphsir_ln_bwd_win_dxn(const void* X, const void* dQKV, const void* WqkvT, const void* dRes, const void* dRes2, const float* ln_w, void* dX,
+                          float* part, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream);
 int mphsir_ln_bwd_win_dxn_fits(int32_t C, int dtype);
 /* ... and in plain token order for the prompt modules' pre-norm 1x1 convs (autograd of `self.ffn(self.norm2(x))` / `self.attn(self.norm1(x))`,
  * net/MP_HSIR.py:286,476-477 with :256,:303): d_xn = dY WT^T with dY [M][K] (the gradient of the 1x1 conv's output, K = its output
- * channels, K % 32 == 0), WT [C][K] = the conv weight transposed; dX = dRes + LN_backward(d_xn); XN (optional, needs ln_b) = LN(X), the
- * operand of the conv's weight gradient; part [M/64][2][C].  M % 64 == 0; (C, dtype) as mphsir_ln_bwd_win_dxn_fits.                 */
+ * channels, K % 32 == 0), WT [C][K] = the conv weight transposed; dX = dRes + LN_backward(d_xn) (dRes optional); XN (optional, needs
+ * ln_b) = LN(X), the operand of the conv's weight gradient; part [M/64][2][C].  M % 64 == 0; (C, dtype) as mphsir_ln_bwd_win_dxn_fits.
+ * x_f32 != 0: X and dX are fp32 rows while dY / WT / dRes / XN stay `dtype` (TVSP's norm11 on the fp32 text map, net/MP_HSIR.py:282 with
+ * :575-577 -- the reference's autocast keeps that LayerNorm in fp32 too); C <= 192.                                                  */
 int mphsir_ln_bwd_tok_dxn(const void* X, const void* dY, const void* WT, const void* dRes, const float* ln_w, const float* ln_b, void* dX,
-                          void* XN, float* part, int64_t M, int32_t C, int32_t K, int dtype, void* stream);
+                          void* XN, float* part, int64_t M, int32_t C, int32_t K, int32_t x_f32, int dtype, void* stream);
 
 /* ---- stand-alone LayerNorm over channels (SURVEY 8b `layernorm_nhwc`; net/MP_HSIR.py:341-370) ---------------------------
  * Y[m][:] = LN(X[m][:]) * ln_w + ln_b, biased variance, eps 1e-5, statistics in fp32.  X and Y may have different element
- * types (x_dtype / y_dtype): TVSP's norm11 (:282) reads the fp32 rank-one text map and writes the compute dtype.        */
-int mphsir_layernorm_tok(const void* X, int x_dtype, const float* ln_w, const float* ln_b, void* Y, int y_dtype,
+ * types (x_dtype / y_dtype): TVSP's norm11 (:282) reads the fp32 rank-one text map and writes the compute dtype.
+ * Xcopy (optional, [M][C] in y_dtype): X cast to the output type by the same pass -- the residual operand of that block (:282).  */
+int mphsir_layernorm_tok(const void* X, int x_dtype, const float* ln_w, const float* ln_b, void* Y, void* Xcopy, int y_dtype,
                          int64_t M, int32_t C, void* stream);
 
 /* ---- backward of the two small per-sample / per-window stages -----------------------------------------

@@ -168,7 +168,7 @@ _SYMBOLS = {
     "mphsir_tvsp_text_map": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mphsir_tvsp_text_map_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "mphsir_resize_bilinear": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
-    "mphsir_layernorm_tok": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int32, c_void_p]),
+    "mphsir_layernorm_tok": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int32, c_void_p]),
     "mphsir_win_attn_fwd": (c_int, [ctypes.POINTER(WinAttnArgs), c_int, c_void_p]),
     "mphsir_win_attn_hdp": (c_int, [c_int, c_int]),
     "mphsir_pg_gate_fwd": (c_int, [ctypes.POINTER(PgFwdArgs), c_void_p]),
@@ -204,9 +204,9 @@ _SYMBOLS = {
     "mphsir_win_attn_bwd": (c_int, [ctypes.POINTER(WinAttnBwdArgs), c_int, c_void_p]),
     "mphsir_win_attn_bwd_fits": (c_int, [c_int32, c_int32, c_int]),
     "mphsir_ln_bwd_win": (c_int, [c_void_p] * 6 + [c_int32] * 5 + [c_void_p, c_void_p, c_int32, c_int, c_void_p]),
-    "mphsir_ln_bwd_win_dxn": (c_int, [c_void_p] * 7 + [c_int32] * 5 + [c_int, c_void_p]),
+    "mphsir_ln_bwd_win_dxn": (c_int, [c_void_p] * 8 + [c_int32] * 5 + [c_int, c_void_p]),
     "mphsir_ln_bwd_win_dxn_fits": (c_int, [c_int32, c_int]),
-    "mphsir_ln_bwd_tok_dxn": (c_int, [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_int, c_void_p]),
+    "mphsir_ln_bwd_tok_dxn": (c_int, [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_gemm_tn": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                c_int32, c_int32, c_int32, c_int, c_void_p]),
     "mphsir_spectral_fold_bwd": (c_int, [ctypes.POINTER(FoldBwdArgs), c_int, c_void_p]),

@@ -8,16 +8,42 @@ import torch.nn.functional as F
 from . import ops
 
 
+class SkipGrad:
+    """One BaseBlock's skip gradient on its way from the backward of the last block (where `+ x` was added, ref :760) to the backward of
+    the first block (whose input x is): the first block's final launch adds it to dx, and autograd sees no second gradient for x."""
+
+    def __init__(self):
+        self.dz = None
+
+    def take(self):
+        dz, self.dz = self.dz, None
+        return dz
+
+
+def _skip_put(skip, dz, needed):
+    """the res-gradient a last block returns: handed to the holder when there is one"""
+    if not needed:
+        return None
+    if skip is not None and skip[2]:
+        skip[0].dz = dz
+        return None
+    return dz
+
+
+def _skip_take(skip):
+    return skip[0].take() if (skip is not None and skip[1]) else None
+
+
 class _GatedMlp(torch.autograd.Function):
     """z = y + keep*mlp(LN2(y)): HIP forward and HIP data-gradient; the parameter gradients are the
     token-reduction GEMMs / column sums of the three matrices the backward kernel writes."""
 
     @staticmethod
-    def forward(ctx, blk, k2, y, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, res=None):
+    def forward(ctx, blk, k2, y, ln_w, ln_b, fc1_w, fc1_b, fc2_w, fc2_b, res=None, skip=None):
         """res: optional second residual (the input of the enclosing BaseBlock, ref :727-761), added by the same launch"""
         B, H, W, Cc = y.shape
         pk = blk.packed(y.dtype)
-        ctx.blk, ctx.k2 = blk, k2
+        ctx.blk, ctx.k2, ctx.skip = blk, k2, skip
         ctx.save_for_backward(y)
         z = ops.gated_mlp_fwd(y.reshape(-1, Cc), pk["ln2"][0], pk["ln2"][1], pk["W1"], pk["b1"], pk["W2"], pk["b2"],
                               keep=k2, rows_per_batch=H * W, res=None if res is None else res.reshape(-1, Cc))
@@ -26,7 +52,7 @@ class _GatedMlp(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         (y,) = ctx.saved_tensors
-        return (None, None) + _gated_mlp_backward(ctx.blk, ctx.k2, y, dz) + (dz if ctx.needs_input_grad[9] else None,)
+        return (None, None) + _gated_mlp_backward(ctx.blk, ctx.k2, y, dz) + (_skip_put(ctx.skip, dz, ctx.needs_input_grad[9]), None)
 
 
 def _gated_mlp_backward(blk, k2, y, dz):
@@ -213,8 +239,9 @@ def _pgsstb_attn_forward(blk, k1, x, fuse=False):
     return y.reshape(B, H, W, Cc), saved
 
 
-def _pgsstb_attn_backward(blk, k1, saved, dy):
-    """backward of the first residual branch: (dx, d norm1.weight, d norm1.bias, d qkv.weight, d qkv.bias, d proj.weight, d proj.bias,
+def _pgsstb_attn_backward(blk, k1, saved, dy, extra=None):
+    """extra: a gradient of x from outside the block (SkipGrad), added to dx by the last launch.
+    backward of the first residual branch: (dx, d norm1.weight, d norm1.bias, d qkv.weight, d qkv.bias, d proj.weight, d proj.bias,
     d rpb table, d temperature, d spectral qkv, d spectral dw, d project_out, *d prompt-gate parameters (_PG_KEYS))"""
     x, sa, gate, mu, oattn, t, v, gp, spart, Mb, MbT = saved[:11]
     qk = saved[11] if len(saved) > 11 else None
@@ -276,9 +303,11 @@ def _pgsstb_attn_backward(blk, k1, saved, dy):
         # was built and measured slower in round 4 -- four barriers and an fp32 staging tile per GEMM tile against a 2 C per token
         # round trip -- and removed in round 5.)
         if ops.ln_bwd_win_dxn_fits(M, Cc, dt):      # d_xn = dqkv Wqkv formed inside the LayerNorm-backward launch
-            dx, part = ops.ln_bwd_win_dxn(x, dqkv, pk["wqkvT"], dy, pk["ln1"][0], shift)
+            dx, part = ops.ln_bwd_win_dxn(x, dqkv, pk["wqkvT"], dy, pk["ln1"][0], shift, dres2=None if extra is None else extra.contiguous())
         else:
             dx, part = ops.ln_bwd_win(x, ops.gemm_tok(dqkv, pk["wqkvT"]), dy, pk["ln1"][0], shift)
+            if extra is not None:
+                dx = dx + extra
         dln = ops.reduce_parts(part)
         drpb = ops.reduce_parts(drpb)
     d_sdw = _join_taps(dwq, dwk, dwv).reshape(3 * Cc, 1, 3, 3)
@@ -292,15 +321,15 @@ class _PgsstbAttn(torch.autograd.Function):
     """First residual branch of a PGSSTB block: HIP forward (5 launches) and HIP backward."""
 
     @staticmethod
-    def forward(ctx, blk, k1, x, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, rpb, s_temp, s_qkv, s_dw, s_out, *pg):
+    def forward(ctx, blk, k1, skip, x, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, rpb, s_temp, s_qkv, s_dw, s_out, *pg):
         y, saved = _pgsstb_attn_forward(blk, k1, x)
-        ctx.blk, ctx.k1 = blk, k1
+        ctx.blk, ctx.k1, ctx.skip = blk, k1, skip
         ctx.save_for_backward(*saved)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        return (None, None) + _pgsstb_attn_backward(ctx.blk, ctx.k1, ctx.saved_tensors, dy)
+        return (None, None, None) + _pgsstb_attn_backward(ctx.blk, ctx.k1, ctx.saved_tensors, dy, extra=_skip_take(ctx.skip))
 
 
 _N_ATTN_PARAMS = 11 + len(_PG_KEYS)
@@ -312,7 +341,7 @@ class _Pgsstb(torch.autograd.Function):
     for the backward.  The backward is the two halves' backward, in sequence."""
 
     @staticmethod
-    def forward(ctx, blk, k1, k2, res, x, *params):
+    def forward(ctx, blk, k1, k2, res, skip, x, *params):
         B, H, W, Cc = x.shape
         _, saved = _pgsstb_attn_forward(blk, k1, x, fuse=True)
         pk = blk.packed(x.dtype)
@@ -320,16 +349,17 @@ class _Pgsstb(torch.autograd.Function):
                                  res=None if res is None else res.reshape(-1, Cc),
                                  branch=dict(v=saved[6], Mb=saved[9], sa=saved[1].reshape(-1, Cc), gate=saved[2], keep=k1,
                                              geom=(H, W, blk.shift_size), want_y=True))
-        ctx.blk, ctx.k1, ctx.k2 = blk, k1, k2
+        ctx.blk, ctx.k1, ctx.k2, ctx.skip = blk, k1, k2, skip
         ctx.save_for_backward(y.reshape(B, H, W, Cc), *saved)
         return z.reshape(B, H, W, Cc)
 
     @staticmethod
     def backward(ctx, dz):
         y, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        d_res = _skip_put(ctx.skip, dz, ctx.needs_input_grad[3])       # (before the take: a one-block BaseBlock is first and last)
         gm = _gated_mlp_backward(ctx.blk, ctx.k2, y, dz)
-        ga = _pgsstb_attn_backward(ctx.blk, ctx.k1, saved, gm[0])
-        return (None, None, None, dz if ctx.needs_input_grad[3] else None) + ga + gm[1:]
+        ga = _pgsstb_attn_backward(ctx.blk, ctx.k1, saved, gm[0], extra=_skip_take(ctx.skip))
+        return (None, None, None, d_res, None) + ga + gm[1:]
 
 
 def _join_taps(*dw):
@@ -352,9 +382,9 @@ def getattr_path(mod, dotted):
     return mod
 
 
-def pgsstb(blk, x, k1, k2, res=None):
+def pgsstb(blk, x, k1, k2, res=None, skip=None):
     """One PGSSTB block (ref :662-723): attention-side residual branch, then the gated-MLP residual branch (+ res: the skip of the
-    enclosing BaseBlock when this is its last block)."""
+    enclosing BaseBlock when this is its last block; skip: see SkipGrad)."""
     a, sp, pgm = blk.attn, blk.gobal_spectral_attn, blk.local_spectral_attn
     m = blk.mlp
     B, H, W, Cc = x.shape
@@ -371,9 +401,9 @@ def pgsstb(blk, x, k1, k2, res=None):
                        a.relative_position_bias_table, sp.temperature, sp.qkv.weight, sp.qkv_dwconv.weight,
                        sp.project_out.weight, *[getattr_path(pgm, k) for k in _PG_KEYS])
         if fuse:
-            return _Pgsstb.apply(blk, k1, k2, res, x, *attn_params, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
-        y = _PgsstbAttn.apply(blk, k1, x, *attn_params)
-    return _GatedMlp.apply(blk, k2, y, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, res)
+            return _Pgsstb.apply(blk, k1, k2, res, skip, x, *attn_params, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+        y = _PgsstbAttn.apply(blk, k1, skip, x, *attn_params)
+    return _GatedMlp.apply(blk, k2, y, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, res, skip)
 
 
 # ---- GDFN / channel attention sub-chains ------------------------------------------------------------
@@ -512,26 +542,27 @@ class _CrossChannelAttnRes(torch.autograd.Function):
     the depthwise / Gram kernel; the backward sums d t_kv over the batch first and runs the kv / norm12 backward on ps*ps tokens."""
 
     @staticmethod
-    def forward(ctx, ct, geom, dt, text32, vis1, n11w, n11b, n12w, n12b, w_q, w_kv, w_qdw, w_kvdw, w_out, temp):
+    def forward(ctx, ct, geom, dt, text32, vis1, vis1_f32, visual_prompt, n11w, n11b, n12w, n12b, w_q, w_kv, w_qdw, w_kvdw, w_out, temp):
+        """vis1: TVSP.packed()'s token view of `visual_prompt` (the parameter itself is the autograd input)"""
         B, H, W = geom
         D = text32.shape[1]
         pa = ct.attn.packed(dt)
         lw, lb = ct.norm11.pair()
-        xq = ops.layernorm_tok(text32, lw, lb, dt)
+        xq, text_c = ops.layernorm_tok(text32, lw, lb, dt, want_cast=True)      # + the text map in the compute dtype: the residual operand
         tq = ops.gemm_tok(xq, pa["wq"])
         tkv = ops.gemm_tok(vis1, pa["wkv"], ln=ct.norm12.pair()).repeat(B, 1)      # (B ps ps, 2D): the same rows for every sample
         w9 = pa["w9"]
         v, gp, sp, _ = ops.dwconv_gram(tq, tkv[:, :D], tkv[:, D:], w9[:, :D], w9[:, D:2 * D], w9[:, 2 * D:], 3 * D,
                                        B, H, W, D, ct.attn.num_heads)
         Mb, MbT, gp, sp = ops.spectral_fold(gp, sp, pa["temp"], pa["wo"], dt, transposed=True)
-        a = ops.gemm_tok(v, Mb, epi=1, res=text32.to(dt))
+        a = ops.gemm_tok(v, Mb, epi=1, res=text_c)
         ctx.ct, ctx.geom = ct, geom
-        ctx.save_for_backward(text32, vis1, xq, tq, tkv, v, gp, sp, Mb, MbT)
+        ctx.save_for_backward(text32, vis1, xq, tq, tkv, v, gp, sp, Mb, MbT, vis1_f32)
         return a
 
     @staticmethod
     def backward(ctx, da):
-        text32, vis1, xq, tq, tkv, v, gp, sp, Mb, MbT = ctx.saved_tensors
+        text32, vis1, xq, tq, tkv, v, gp, sp, Mb, MbT, vis1_f32 = ctx.saved_tensors
         ct, (B, H, W) = ctx.ct, ctx.geom
         attn = ct.attn
         D = text32.shape[1]
@@ -551,15 +582,26 @@ class _CrossChannelAttnRes(torch.autograd.Function):
                 dkv = torch.cat([dtk, dtv], dim=-1).reshape(M, 2 * D)
             n11w, n11b = ct.norm11.pair()
             n12w, n12b = ct.norm12.pair()
-            # norm11 backward in fp32 on the fp32 text map (see the class docstring); dres = the residual path of `a`
-            dtext, d11w, d11b, _ = ops.ln_bwd_tok(text32, ops.gemm_tok(dtq2, pa["wqT"]).float(), da.float(), n11w, n11b)
+            # norm11 backward in fp32 on the fp32 text map (see the class docstring); dres = the residual path of `a`.  Where the kernel covers
+            # the width, the q conv's data gradient is formed inside the launch (fp32 rows of x, 16-bit dtq / weights / da)
+            if ops.ln_bwd_tok_dxn_f32_fits(M, D, dtq2.dtype):
+                dtext, d11w, d11b, _ = ops.ln_bwd_tok_dxn(text32, dtq2, pa["wqT"], da, n11w, n11b, want_xn=False)
+            else:
+                dtext, d11w, d11b, _ = ops.ln_bwd_tok(text32, ops.gemm_tok(dtq2, pa["wqT"]).float(), da.float(), n11w, n11b)
             # the kv side is batch-invariant up to t_kv: its gradient is summed over the batch (fp32 accumulation) and everything behind it
             # -- the 1x1 conv's data gradient, norm12's backward, both parameter gradients -- runs on the ps*ps tokens of the one map
             dkv1 = dkv.reshape(B, H * W, 2 * D).sum(dim=0)
-            dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis1, ops.gemm_tok(dkv1, pa["wkvT"]), torch.zeros_like(vis1), n12w, n12b)
+            if ops.ln_bwd_tok_dxn_f32_fits(vis1.shape[0], D, vis1.dtype) and vis1.shape[0] % 64 == 0:
+                # fp32 rows of the parameter: its gradient comes out in fp32, the type it is accumulated in
+                dvis, d12w, d12b, xv = ops.ln_bwd_tok_dxn(vis1_f32, dkv1, pa["wkvT"], None, n12w, n12b)
+            elif ops.ln_bwd_win_dxn_fits(vis1.shape[0], D, vis1.dtype) and vis1.shape[0] % 64 == 0:
+                dvis, d12w, d12b, xv = ops.ln_bwd_tok_dxn(vis1, dkv1, pa["wkvT"], None, n12w, n12b)
+            else:
+                dvis, d12w, d12b, xv = ops.ln_bwd_tok(vis1, ops.gemm_tok(dkv1, pa["wkvT"]), torch.zeros_like(vis1), n12w, n12b)
             d_wq = ops.gemm_tn(dtq2, xq).reshape(D, D, 1, 1)
             d_wkv = ops.gemm_tn(dkv1, xv).reshape(2 * D, D, 1, 1)
-        return (None, None, None, dtext, dvis, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.reshape(D, 1, 3, 3),
+        d_prompt = dvis.t().reshape(1, D, H, W)               # (ps*ps, D) tokens -> the parameter's (1, D, ps, ps), a view
+        return (None, None, None, dtext, None, None, d_prompt, d11w, d11b, d12w, d12b, d_wq, d_wkv, dwq.reshape(D, 1, 3, 3),
                 _join_taps(dwk, dwv).reshape(2 * D, 1, 3, 3), dwo.reshape(D, D, 1, 1), dtemp.reshape(-1, 1, 1))
 
 
@@ -591,28 +633,47 @@ class _Bilinear(torch.autograd.Function):
         return ops.resize_bilinear(dy.contiguous(), ctx.hw[0], ctx.hw[1], backward=True), None, None
 
 
-def tvsp(mod, x, clip_prompt, prompt_weights):
+def tvsp(mod, x, clip_prompt, prompt_weights, out=None):
     """TVSP.forward (ref :572-583) with the batch-coupling broadcast of SURVEY Q1 made explicit:
-    text[b,i,j,d] = L[b,d] * clip[floor(i*B/ps), floor(j*512/ps)]."""
+    text[b,i,j,d] = L[b,d] * clip[floor(i*B/ps), floor(j*512/ps)].  out: see conv3x3."""
     B, H, W, D = x.shape
     ps, dt, dev = mod.prompt_size, x.dtype, x.device
     L = mix_rows(prompt_weights, mod.text_prompt_learnable)                            # (B,D) = (w[..., None] * learnable (T,D)).mean(1)
     text = _TextMap.apply(L, clip_prompt, ps)                                          # fp32: see _CrossChannelAttnRes
-    vis1 = mod.visual_prompt[0].permute(1, 2, 0).to(dt).contiguous().reshape(ps * ps, D)      # the one visual prompt map (ref :578 expands it to B copies)
+    pm = mod.packed(dt)                                     # vis1: the one visual prompt map as tokens (ref :578 expands it to B copies)
     ct = mod.cross_transformer
     at = ct.attn
-    a = _CrossChannelAttnRes.apply(ct, (B, ps, ps), dt, text.reshape(-1, D), vis1, ct.norm11.body.weight,
+    a = _CrossChannelAttnRes.apply(ct, (B, ps, ps), dt, text.reshape(-1, D), pm["vis1"], pm["vis1_f32"], mod.visual_prompt, ct.norm11.body.weight,
                                    ct.norm11.body.bias, ct.norm12.body.weight, ct.norm12.body.bias, at.q.weight, at.kv.weight,
                                    at.q_dwconv.weight, at.kv_dwconv.weight, at.project_out.weight, at.temperature)
     y = _gdfn_res_ag(ct.ffn, ct.norm2, a, B, ps, ps).reshape(B, ps, ps, D)
     if (H, W) != (ps, ps):                                                             # ref :580
         y = _Bilinear.apply(y, H, W)
-    return conv3x3(y, mod.conv_last)
+    return conv3x3(y, mod.conv_last, out=out)
 
 
-def prompt_fusion(mod, x, prompt, out=None):
-    """out: an uninitialised (B,H,W,out_dim) channel slice of a wider buffer the result is written into (see shuffle_join)"""
-    t = torch.cat([x, prompt], dim=-1)
+class _JoinLeft(torch.autograd.Function):
+    """cat([x, p], -1) where p already IS the right half of `buf` (TVSP's last conv wrote it there): x is copied into the left half and the
+    buffer is the result -- half the bytes of the cat launch (ref :596)."""
+
+    @staticmethod
+    def forward(ctx, x, p, buf):
+        C = x.shape[-1]
+        assert buf.is_contiguous() and buf.shape[:3] == x.shape[:3] and p.shape == (*x.shape[:3], buf.shape[-1] - C) and p.dtype == buf.dtype == x.dtype
+        assert p.data_ptr() == buf.data_ptr() + C * buf.element_size() and p.stride() == buf.stride(), "p is not the right half of buf"
+        buf[..., :C].copy_(x)
+        ctx.c = C
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[..., :ctx.c], d[..., ctx.c:], None
+
+
+def prompt_fusion(mod, x, prompt, out=None, joined=None):
+    """out: an uninitialised (B,H,W,out_dim) channel slice of a wider buffer the result is written into (see shuffle_join);
+    joined: the (B,H,W,2C) buffer whose right half `prompt` is (TVSP wrote it there, see _JoinLeft), else the two are concatenated"""
+    t = torch.cat([x, prompt], dim=-1) if joined is None else _JoinLeft.apply(x, prompt, joined)
     B, H, W, D = t.shape
     tb = mod.transformer
     at = tb.attn
@@ -691,17 +752,21 @@ class _Conv3x3(torch.autograd.Function):
     """dense 3x3 conv as an implicit GEMM on the HIP kernel (forward, input gradient) + im2col/gemm_tn (weights)."""
 
     @staticmethod
-    def forward(ctx, x, w, conv, keep_pad=False):
-        """x with Cin channels, or already zero-padded to round_up(Cin, 32) (input_head).  keep_pad: the output keeps its round_up(Cout, 32)
-        channels (the padded ones are zero: zero weight rows) for a consumer that reads the first Cout through the row pitch (output_head)."""
+    def forward(ctx, x, w, conv, keep_pad=False, out=None):
+        """x with Cin channels, or already zero-padded to round_up(Cin, 32) (input_head).  keep_pad: the output keeps its round_up(Cout, 16)
+        channels (the padded ones are zero: zero weight rows) for a consumer that reads the first Cout through the row pitch (output_head).
+        out: an uninitialised (B,H,W,Cout) channel slice of a wider buffer the result is written into (Cout % 16 == 0)."""
         Cout, Cin = w.shape[0], w.shape[1]
         Cp = ops.round_up(Cin, 32)
         assert x.shape[-1] in (Cin, Cp)
         xp = x.contiguous() if x.shape[-1] == Cp else F.pad(x, (0, Cp - Cin)).contiguous()
         pk = _packed_conv3x3(conv, w, x.dtype)
-        y = ops.conv3x3_tok(xp, pk["fwd"])
+        assert out is None or Cout % 16 == 0
+        y = ops.conv3x3_tok(xp, pk["fwd"], out=out)
         ctx.save_for_backward(xp, w)
         ctx.conv, ctx.xc = conv, x.shape[-1]
+        if out is not None:
+            return y.view(y.shape)
         return y if keep_pad or y.shape[-1] == Cout else y[..., :Cout].contiguous()
 
     @staticmethod
@@ -709,7 +774,10 @@ class _Conv3x3(torch.autograd.Function):
         xp, w = ctx.saved_tensors
         Cout, Cin = w.shape[0], w.shape[1]
         Cp, Co32 = xp.shape[-1], ops.round_up(Cout, 32)
-        dyp = dy.contiguous() if dy.shape[-1] == Co32 else F.pad(dy[..., :Cout], (0, Co32 - Cout)).contiguous()
+        if dy.shape[-1] == Co32:      # (a channel slice of a wider gradient -- the split of a concatenation -- is read in place through its row pitch)
+            dyp = dy if ops.pixel_pitch(dy) is not None else dy.contiguous()
+        else:
+            dyp = F.pad(dy[..., :Cout], (0, Co32 - Cout)).contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
             pk = _packed_conv3x3(ctx.conv, w, dy.dtype)
@@ -722,12 +790,12 @@ class _Conv3x3(torch.autograd.Function):
             else:
                 g = ops.gemm_tn(dyp.reshape(-1, Co32), ops.im2col3x3(xp))[:Cout]
                 dw = g.reshape(Cout, 9, Cp)[:, :, :Cin].permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
-def conv3x3(x, conv, keep_pad=False):
+def conv3x3(x, conv, keep_pad=False, out=None):
     """dense 3x3, stride 1, zero padding, no bias on channels-last data; `conv` is the nn.Conv2d holder."""
-    return _Conv3x3.apply(x, conv.weight, conv, keep_pad)
+    return _Conv3x3.apply(x, conv.weight, conv, keep_pad, out)
 
 
 class _InputHead(torch.autograd.Function):

@@ -13,12 +13,38 @@ namespace mphsir {
 
 template <class TI, class TO>
 __global__ __launch_bounds__(256) void layernorm_tok_kernel(const TI* __restrict__ X, const float* __restrict__ w,
-                                                            const float* __restrict__ b, TO* __restrict__ Y, long M, int C) {
-    // 4 adjacent lanes per token, 64 tokens per workgroup; element-wise (strided by 4) so any C % 4 == 0 works
+                                                            const float* __restrict__ b, TO* __restrict__ Y, TO* __restrict__ Xc, long M, int C) {
+    // 4 adjacent lanes per token, 64 tokens per workgroup.  C % 16 == 0: each lane walks the row in 4-element vectors (a quad reads 16
+    // consecutive elements per step); else element-wise (strided by 4) so any C % 4 == 0 works.  Xc (optional): the input cast to TO.
     const int tid = threadIdx.x, q = tid & 3;
-    const long t = (long)blockIdx.x * 64 + (tid >> 2);
-    if (t >= M) return;              // whole lane quads leave together (the shuffles below stay inside a quad)
+    const long t0 = (long)blockIdx.x * 64 + (tid >> 2);
+    const bool live = t0 < M;        // rows past the end redo the last row and store nothing (every lane reaches the shuffles)
+    const long t = live ? t0 : M - 1;
     const TI* x = X + t * C;
+    TO* y = Y + t * C;
+    if (C % 16 == 0) {
+        float s = 0.f;
+        for (int c = 4 * q; c < C; c += 16) { const f32x4 v = load4<TI>(x + c); s += (v[0] + v[1]) + (v[2] + v[3]); }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)C;
+        float d2 = 0.f;
+        for (int c = 4 * q; c < C; c += 16) {
+            const f32x4 v = load4<TI>(x + c);
+            for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; d2 += d * d; }
+        }
+        d2 += __shfl_xor(d2, 1);
+        d2 += __shfl_xor(d2, 2);
+        const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
+        for (int c = 4 * q; c < C; c += 16) {
+            const f32x4 v = load4<TI>(x + c), wv = load4<float>(w + c), bv = load4<float>(b + c);
+            f32x4 o;
+            for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * wv[e] + bv[e];
+            if (live) store4<TO>(y + c, o);
+            if (live && Xc) store4<TO>(Xc + t * C + c, v);
+        }
+        return;
+    }
     float s = 0.f;
     for (int c = q; c < C; c += 4) s += to_f32(x[c]);
     s += __shfl_xor(s, 1);
@@ -29,25 +55,28 @@ __global__ __launch_bounds__(256) void layernorm_tok_kernel(const TI* __restrict
     d2 += __shfl_xor(d2, 1);
     d2 += __shfl_xor(d2, 2);
     const float rstd = rsqrtf(d2 / (float)C + 1e-5f);
-    TO* y = Y + t * C;
-    for (int c = q; c < C; c += 4) y[c] = from_f32<TO>((to_f32(x[c]) - mean) * rstd * w[c] + b[c]);
+    for (int c = q; c < C; c += 4) {
+        if (live) y[c] = from_f32<TO>((to_f32(x[c]) - mean) * rstd * w[c] + b[c]);
+        if (live && Xc) Xc[t * C + c] = from_f32<TO>(to_f32(x[c]));
+    }
 }
 
 }  // namespace mphsir
 
-extern "C" int mphsir_layernorm_tok(const void* X, int x_dtype, const float* ln_w, const float* ln_b, void* Y, int y_dtype,
+extern "C" int mphsir_layernorm_tok(const void* X, int x_dtype, const float* ln_w, const float* ln_b, void* Y, void* Xcopy, int y_dtype,
                                     int64_t M, int32_t C, void* stream) {
     using namespace mphsir;
     clear_error();
     MPHSIR_REQUIRE(X && ln_w && ln_b && Y, "layernorm_tok: null pointer");
     MPHSIR_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "layernorm_tok: M > 0 and C %% 4 == 0 required");
+    MPHSIR_REQUIRE(C % 16 != 0 || (aligned16(X) && aligned16(Y) && aligned16(Xcopy) && aligned16(ln_w) && aligned16(ln_b)), "layernorm_tok: 16-byte alignment required");
     MPHSIR_REQUIRE(MPHSIR_DTYPE_OK(x_dtype) && MPHSIR_DTYPE_OK(y_dtype), "layernorm_tok: dtype unsupported");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((M + 63) / 64)), block(256);
 #define MPHSIR_LN_CASE(xi, TI, yo, TO)                                                                          \
     if (x_dtype == xi && y_dtype == yo) {                                                                      \
         MPHSIR_LAUNCH(MPHSIR_K_LAYERNORM, (layernorm_tok_kernel<TI, TO>), grid, block, 0, s,                    \
-                      reinterpret_cast<const TI*>(X), ln_w, ln_b, reinterpret_cast<TO*>(Y), (long)M, (int)C);   \
+                      reinterpret_cast<const TI*>(X), ln_w, ln_b, reinterpret_cast<TO*>(Y), reinterpret_cast<TO*>(Xcopy), (long)M, (int)C); \
         return MPHSIR_OK;                                                                                      \
     }
     MPHSIR_LN_CASE(MPHSIR_F32, float, MPHSIR_F32, float)

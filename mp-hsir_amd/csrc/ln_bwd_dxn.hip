@@ -27,6 +27,24 @@ struct LnDxnDev {
     int K;                       // reduction width of the GEMM (3C for the window attention's qkv; 2 HP / 3 D for the prompt modules), % 32 == 0
     int linear;                  // 1: rows in plain token order (the prompt modules' LayerNorms): row = 64 blockIdx + t, no window gather
     const float* ln_b; void* XN; // optional (linear form): also emit LN(x), the operand of the 1x1 conv's weight gradient
+    const void* dRes2;           // optional: a second residual gradient added to dX (the skip of the enclosing BaseBlock, whose backward ends here)
+};
+
+// 8 consecutive channels of a token row of X / dX: the 16-bit types hold them packed (one 16-byte vector), fp32 rows (the text map of TVSP's
+// norm11, which the reference's autocast keeps in fp32 too) as two
+template <class TX> struct Row8 {
+    Vec16<TX> v;
+    __device__ __forceinline__ void load(const TX* p) { v = load16<TX>(p); }
+    __device__ __forceinline__ void store(TX* p) const { store16<TX>(p, v); }
+    __device__ __forceinline__ float get(int e) const { return v.get(e); }
+    __device__ __forceinline__ void set(int e, float x) { v.set(e, x); }
+};
+template <> struct Row8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
+    __device__ __forceinline__ float get(int e) const { return e < 4 ? a[e] : b[e - 4]; }
+    __device__ __forceinline__ void set(int e, float x) { if (e < 4) a[e] = x; else b[e - 4] = x; }
 };
 
 template <class T, int C> struct LnDxnCfg {
@@ -43,8 +61,9 @@ template <class T, int C> struct LnDxnCfg {
     static_assert(C % 32 == 0 && bytes <= 160 * 1024, "shape");
 };
 
-template <class T, int C>
+template <class T, int C, bool XF = false>     // XF: X and dX are fp32 (dY, W, d_res, XN stay T)
 __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
+    typedef typename std::conditional<XF, float, T>::type TX;
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
     typedef LnDxnCfg<T, C> CF;
@@ -55,10 +74,11 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
     float* Fs = reinterpret_cast<float*>(smem_v);                      // [64][LDF] d_xn, then d_xn * xhat
     T* Ws = reinterpret_cast<T*>(Fs + CF::f_floats);                   // [C][LDW]  rows of Wqkv^T, one K group
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
-    const T* X = reinterpret_cast<const T*>(a.X);
-    const T* dRes = reinterpret_cast<const T*>(a.dRes);
+    const TX* X = reinterpret_cast<const TX*>(a.X);
+    const T* dRes = reinterpret_cast<const T*>(a.dRes);         // (may be null: no residual path)
+    const T* dRes2 = reinterpret_cast<const T*>(a.dRes2);
     const T* WT = reinterpret_cast<const T*>(a.WT);
-    T* dX = reinterpret_cast<T*>(a.dX);
+    TX* dX = reinterpret_cast<TX*>(a.dX);
     const int t = tid >> 2, q = tid & 3;
     // token t of this window in image order (cyclic shift + window partition as address arithmetic, net/MP_HSIR.py:672-677)
     const int nwx = a.W >> 3, nW = (a.H >> 3) * nwx;
@@ -68,11 +88,12 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
 
     // ---- the lane's share of the token row (x, d_res): requested now, used after the GEMM
     constexpr bool DR_LATE = C >= 256;       // wide rows: d_res is requested after the GEMM (32 registers fewer held across it: no spills)
-    Vec16<T> xv[MAXV], dr[MAXV];
+    Row8<TX> xv[MAXV];
+    Vec16<T> dr[MAXV];
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
-        xv[k] = load16<T>(X + pix * C + (q + 4 * k) * VEC);
-        if (!DR_LATE) dr[k] = load16<T>(dRes + pix * C + (q + 4 * k) * VEC);
+        xv[k].load(X + pix * C + (q + 4 * k) * VEC);
+        if (!DR_LATE && dRes) dr[k] = load16<T>(dRes + pix * C + (q + 4 * k) * VEC);
     }
 
     // ---- (a) d_xn = dQKV Wqkv: wave wv owns window rows 16 wv .. 16 wv + 15
@@ -126,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
     __syncthreads();
 
     // ---- (b) LayerNorm backward on the tile (ln_bwd_win_kernel's arithmetic, d_xn read from the fp32 tile)
-    if (DR_LATE) {
+    if (DR_LATE && dRes) {
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) dr[k] = load16<T>(dRes + pix * C + (q + 4 * k) * VEC);
     }
@@ -157,12 +178,17 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
         const int c0 = (q + 4 * k) * VEC;
-        Vec16<T> o;
+        Row8<TX> o;
+        Vec16<T> r2;
+        if (dRes2) r2 = load16<T>(dRes2 + pix * C + c0);
         for (int e = 0; e < VEC; ++e) {
             const float dxn = Fs[t * LDF + c0 + e], xh = (xv[k].get(e) - mean) * rstd;
-            o.set(e, dr[k].get(e) + rstd * (dxn * a.ln_w[c0 + e] - s1 - xh * s2));
+            float v = rstd * (dxn * a.ln_w[c0 + e] - s1 - xh * s2);
+            if (dRes) v += dr[k].get(e);
+            if (dRes2) v += r2.get(e);
+            o.set(e, v);
         }
-        store16<T>(dX + pix * C + c0, o);
+        o.store(dX + pix * C + c0);
         if (a.XN) {
             Vec16<T> n;
             for (int e = 0; e < VEC; ++e) n.set(e, (xv[k].get(e) - mean) * rstd * a.ln_w[c0 + e] + a.ln_b[c0 + e]);
@@ -191,22 +217,24 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
 }
 
 template <class T> struct LnDxnShapes {
-    static int run(const LnDxnDev& d, int C, hipStream_t s) {
+    static int run(const LnDxnDev& d, int C, bool xf, hipStream_t s) {
         const int nblk = d.linear ? d.B : d.B * (d.H / 8) * (d.W / 8);      // linear: B = number of 64-row blocks
-#define MPHSIR_LD_CASE(c)                                                                                                 \
-    if (C == c) {                                                                                                          \
+#define MPHSIR_LD_CASE(c, XF)                                                                                             \
+    if (C == c && xf == XF) {                                                                                              \
         constexpr size_t shmem = LnDxnCfg<T, c>::bytes;                                                                     \
-        allow_big_lds(ln_bwd_win_dxn_kernel<T, c>, shmem);                                                                  \
-        MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_dxn_kernel<T, c>), dim3(nblk), dim3(256), shmem, s, d);              \
+        allow_big_lds(ln_bwd_win_dxn_kernel<T, c, XF>, shmem);                                                              \
+        MPHSIR_LAUNCH(MPHSIR_K_LN_BWD_WIN, (ln_bwd_win_dxn_kernel<T, c, XF>), dim3(nblk), dim3(256), shmem, s, d);          \
         return MPHSIR_OK;                                                                                                  \
     }
-        MPHSIR_LD_CASE(32) MPHSIR_LD_CASE(64) MPHSIR_LD_CASE(96) MPHSIR_LD_CASE(128) MPHSIR_LD_CASE(192) MPHSIR_LD_CASE(256)
+        MPHSIR_LD_CASE(32, false) MPHSIR_LD_CASE(64, false) MPHSIR_LD_CASE(96, false) MPHSIR_LD_CASE(128, false) MPHSIR_LD_CASE(192, false)
+        MPHSIR_LD_CASE(256, false)
+        MPHSIR_LD_CASE(32, true) MPHSIR_LD_CASE(64, true) MPHSIR_LD_CASE(96, true) MPHSIR_LD_CASE(128, true) MPHSIR_LD_CASE(192, true)
 #undef MPHSIR_LD_CASE
         return MPHSIR_EINVAL;
     }
 };
 template <> struct LnDxnShapes<float> {
-    static int run(const LnDxnDev&, int, hipStream_t) { return MPHSIR_EINVAL; }
+    static int run(const LnDxnDev&, int, bool, hipStream_t) { return MPHSIR_EINVAL; }
 };
 
 }  // namespace mphsir
@@ -215,28 +243,30 @@ extern "C" int mphsir_ln_bwd_win_dxn_fits(int32_t C, int dtype) {
     return ((dtype == MPHSIR_BF16 || dtype == MPHSIR_F16) && (C == 32 || C == 64 || C == 96 || C == 128 || C == 192 || C == 256)) ? 1 : 0;      /* (C = 384: 90 spilled registers -- the remote-sensing latent level keeps the two launches) */
 }
 
-extern "C" int mphsir_ln_bwd_win_dxn(const void* X, const void* dQKV, const void* WqkvT, const void* dRes, const float* ln_w, void* dX, float* part,
-                                     int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream) {
+extern "C" int mphsir_ln_bwd_win_dxn(const void* X, const void* dQKV, const void* WqkvT, const void* dRes, const void* dRes2, const float* ln_w, void* dX,
+                                     float* part, int32_t B, int32_t H, int32_t W, int32_t C, int32_t shift, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
-    MPHSIR_REQUIRE(X && dQKV && WqkvT && dRes && ln_w && dX && part, "ln_bwd_win_dxn: null pointer");
+    MPHSIR_REQUIRE(X && dQKV && WqkvT && ln_w && dX && part, "ln_bwd_win_dxn: null pointer");
     MPHSIR_REQUIRE(mphsir_ln_bwd_win_dxn_fits(C, dtype), "ln_bwd_win_dxn: (C=%d, dtype=%d) not covered (16-bit types; ask mphsir_ln_bwd_win_dxn_fits)", C, dtype);
     MPHSIR_REQUIRE(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && (shift == 0 || shift == 4), "ln_bwd_win_dxn: bad geometry");
-    MPHSIR_REQUIRE(aligned16(X) && aligned16(dQKV) && aligned16(WqkvT) && aligned16(dRes) && aligned16(dX), "ln_bwd_win_dxn: 16-byte alignment required");
-    LnDxnDev d{X, dQKV, WqkvT, dRes, ln_w, dX, part, B, H, W, shift, 3 * C, 0, nullptr, nullptr};
+    MPHSIR_REQUIRE(aligned16(X) && aligned16(dQKV) && aligned16(WqkvT) && aligned16(dRes) && aligned16(dRes2) && aligned16(dX),
+                   "ln_bwd_win_dxn: 16-byte alignment required");
+    LnDxnDev d{X, dQKV, WqkvT, dRes, ln_w, dX, part, B, H, W, shift, 3 * C, 0, nullptr, nullptr, dRes2};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return MPHSIR_DISPATCH_T(dtype, (LnDxnShapes<T_>::run(d, C, s)));
+    return MPHSIR_DISPATCH_T(dtype, (LnDxnShapes<T_>::run(d, C, false, s)));
 }
 
 extern "C" int mphsir_ln_bwd_tok_dxn(const void* X, const void* dY, const void* WT, const void* dRes, const float* ln_w, const float* ln_b, void* dX,
-                                     void* XN, float* part, int64_t M, int32_t C, int32_t K, int dtype, void* stream) {
+                                     void* XN, float* part, int64_t M, int32_t C, int32_t K, int32_t x_f32, int dtype, void* stream) {
     using namespace mphsir;
     clear_error();
-    MPHSIR_REQUIRE(X && dY && WT && dRes && ln_w && dX && part && (!XN || ln_b), "ln_bwd_tok_dxn: null pointer (XN needs ln_b)");
-    MPHSIR_REQUIRE(mphsir_ln_bwd_win_dxn_fits(C, dtype), "ln_bwd_tok_dxn: (C=%d, dtype=%d) not covered (16-bit types; ask mphsir_ln_bwd_win_dxn_fits)", C, dtype);
+    MPHSIR_REQUIRE(X && dY && WT && ln_w && dX && part && (!XN || ln_b), "ln_bwd_tok_dxn: null pointer (XN needs ln_b)");
+    MPHSIR_REQUIRE(mphsir_ln_bwd_win_dxn_fits(C, dtype) && (!x_f32 || C <= 192),
+                   "ln_bwd_tok_dxn: (C=%d, dtype=%d, x_f32=%d) not covered (16-bit types; ask mphsir_ln_bwd_win_dxn_fits; fp32 rows: C <= 192)", C, dtype, x_f32);
     MPHSIR_REQUIRE(M > 0 && M % 64 == 0 && K > 0 && K % 32 == 0, "ln_bwd_tok_dxn: M %% 64 == 0 and K %% 32 == 0 required (M=%ld, K=%d)", (long)M, K);
-    MPHSIR_REQUIRE(aligned16(X) && aligned16(dY) && aligned16(WT) && aligned16(dRes) && aligned16(dX) && (!XN || aligned16(XN)), "ln_bwd_tok_dxn: 16-byte alignment required");
-    LnDxnDev d{X, dY, WT, dRes, ln_w, dX, part, (int)(M / 64), 8, 8, 0, K, 1, ln_b, XN};
+    MPHSIR_REQUIRE(aligned16(X) && aligned16(dY) && aligned16(WT) && aligned16(dRes) && aligned16(dX) && aligned16(XN), "ln_bwd_tok_dxn: 16-byte alignment required");
+    LnDxnDev d{X, dY, WT, dRes, ln_w, dX, part, (int)(M / 64), 8, 8, 0, K, 1, ln_b, XN, nullptr};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return MPHSIR_DISPATCH_T(dtype, (LnDxnShapes<T_>::run(d, C, s)));
+    return MPHSIR_DISPATCH_T(dtype, (LnDxnShapes<T_>::run(d, C, x_f32 != 0, s)));
 }

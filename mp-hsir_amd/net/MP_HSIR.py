@@ -186,10 +186,11 @@ class PGSSTB(nn.Module):                                                        
         m = torch.empty((2, B), dtype=torch.float32, device=device).bernoulli_(keep) / keep
         return m[0].contiguous(), m[1].contiguous()
 
-    def forward(self, x, text_prompt=None, res=None):
-        """x: channels-last (B,H,W,C) in the compute dtype; res: a second residual added to the output by the last launch"""
+    def forward(self, x, text_prompt=None, res=None, skip=None):
+        """x: channels-last (B,H,W,C) in the compute dtype; res: a second residual added to the output by the last launch;
+        skip: (AG.SkipGrad, is first block, is last block) of the enclosing BaseBlock, see there"""
         k1, k2 = self.drop_path_factors(x.shape[0], x.device)
-        return AG.pgsstb(self, x, k1, k2, res)
+        return AG.pgsstb(self, x, k1, k2, res, skip)
 
 
 class BaseBlock(nn.Module):                                                        # ref :727-761
@@ -209,8 +210,12 @@ class BaseBlock(nn.Module):                                                     
             for blk in self.blocks:
                 y = blk(y)
             return y + x
+        # training: the gradient arriving over the skip is handed from the last block's backward to the first block's, whose final launch
+        # adds it (AG.SkipGrad) -- otherwise autograd sums the two gradients of x with a launch of its own
+        hold = AG.SkipGrad() if (ops.BASE_SKIP_BWD and torch.is_grad_enabled() and x.requires_grad) else None
         for i, blk in enumerate(self.blocks):
-            y = blk(y, res=x if i == n - 1 else None)          # the skip `+ x` (ref :760) rides in the last block's gated-MLP launch
+            y = blk(y, res=x if i == n - 1 else None,           # the skip `+ x` (ref :760) rides in the last block's gated-MLP launch
+                    skip=None if hold is None else (hold, i == 0, i == n - 1))
         return y
 
 
@@ -374,10 +379,19 @@ class TVSP(nn.Module):                                                          
         self.text_prompt_learnable = nn.Parameter(torch.randn(1, task_classes, prompt_dim, 1, 1))
         self.cross_transformer = CrossTransformer(prompt_dim, 2, 2.66, False, "WithBias")
         self.conv_last = nn.Conv2d(prompt_dim, out_dim, 3, padding=1, bias=False)
+        self._cache = _Cache()
 
-    def forward(self, x, clip_prompt=None, prompt_weights=None):
-        """x: channels-last (B,H,W,D) (only its shape is used, as in the reference)."""
-        return AG.tvsp(self, x, clip_prompt, prompt_weights)
+    def packed(self, dtype):
+        """vis1: the one visual prompt map as tokens (ps*ps, D) in the compute dtype (a pure layout change of a parameter: under the engine's
+        PackPlan it rides in the per-step weight gather instead of two launches per forward)"""
+        ps, D = self.prompt_size, self.prompt_dim
+        return self._cache.get([self.visual_prompt], dtype,
+                               lambda: dict(vis1=self.visual_prompt[0].permute(1, 2, 0).to(ops.cdt(dtype)).contiguous().reshape(ps * ps, D),
+                                            vis1_f32=self.visual_prompt[0].permute(1, 2, 0).float().contiguous().reshape(ps * ps, D)))
+
+    def forward(self, x, clip_prompt=None, prompt_weights=None, out=None):
+        """x: channels-last (B,H,W,D) (only its shape is used, as in the reference).  out: see AG.conv3x3."""
+        return AG.tvsp(self, x, clip_prompt, prompt_weights, out)
 
 
 class PromptFusion(nn.Module):                                                     # ref :587-599
@@ -386,8 +400,8 @@ class PromptFusion(nn.Module):                                                  
         self.transformer = TransformerBlock(dim, head, ffn_expansion_factor, bias, "WithBias")
         self.conv = nn.Conv2d(dim, out_dim, 1, bias=bias)
 
-    def forward(self, x, prompt, out=None):
-        return AG.prompt_fusion(self, x, prompt, out)
+    def forward(self, x, prompt, out=None, joined=None):
+        return AG.prompt_fusion(self, x, prompt, out, joined)
 
 
 class OverlapPatchEmbed(nn.Module):                                                # ref :454-463
@@ -482,13 +496,16 @@ class MP_HSIR_Net(nn.Module):                                                   
         # see ops.PROMPT_SIDE)
         fork = ops.PROMPT_SIDE and not torch.is_grad_enabled()
         # the decoder's concatenations [pixel_shuffle(up(.)) | fusion(.)] (ref :838, :843): each producer writes its half of one buffer
-        cat1 = e1.new_empty((*e1.shape[:3], 2 * e1.shape[3]))
+        # ... and so do the prompt fusions' inputs [e | prompt] (ref :596): TVSP's last conv writes the right half, e is copied into the left
+        C1 = e1.shape[3]
+        cat1, pf1 = e1.new_empty((*e1.shape[:3], 2 * C1)), e1.new_empty((*e1.shape[:3], 2 * C1))
         with ops.side_stream(e1, fork, "prompt1", track=False) as br1:
-            f1 = self.fusion1(e1, self.prompt1(e1, clip, w), out=cat1[..., e1.shape[3]:])
+            f1 = self.fusion1(e1, self.prompt1(e1, clip, w, out=pf1[..., C1:]), out=cat1[..., C1:], joined=pf1)
         e2 = self.encoder_level2(AG.pixel_unshuffle2(AG.conv3x3(e1, self.down1_2.body[0])))
-        cat2 = e2.new_empty((*e2.shape[:3], 2 * e2.shape[3]))
+        C2 = e2.shape[3]
+        cat2, pf2 = e2.new_empty((*e2.shape[:3], 2 * C2)), e2.new_empty((*e2.shape[:3], 2 * C2))
         with ops.side_stream(e2, fork, "prompt2", track=False) as br2:
-            f2 = self.fusion2(e2, self.prompt2(e2, clip, w), out=cat2[..., e2.shape[3]:])
+            f2 = self.fusion2(e2, self.prompt2(e2, clip, w, out=pf2[..., C2:]), out=cat2[..., C2:], joined=pf2)
         lat = self.latent(AG.pixel_unshuffle2(AG.conv3x3(e2, self.down2_3.body[0])))
         up2 = AG.conv3x3(lat, self.up3_2.body[0])
         br2.join(f2)

@@ -596,16 +596,17 @@ def gemm_tok(x, w, bias=None, ln=None, epi=0, res=None, sa=None, gate=None, keep
 
 
 
-def layernorm_tok(x, ln_w, ln_b, out_dtype):
-    """x (M,C) contiguous, fp32 or compute dtype -> LN(x) in out_dtype (statistics in fp32)."""
+def layernorm_tok(x, ln_w, ln_b, out_dtype, want_cast=False):
+    """x (M,C) contiguous, fp32 or compute dtype -> LN(x) in out_dtype (statistics in fp32); want_cast: -> (LN(x), x cast to out_dtype)."""
     lib = _lib.load()
     _check(x, ln_w, ln_b)
     M, C = x.shape
     assert x.is_contiguous()
     y = torch.empty((M, C), dtype=out_dtype, device=x.device)
-    _lib.check(lib.mphsir_layernorm_tok(_p(x), _DT[x.dtype], _p(ln_w), _p(ln_b), _p(y), _DT[out_dtype], M, C, _stream(x)), "layernorm_tok")
-    _acct("layernorm_tok", 8.0 * M * C, M * C * (x.element_size() + y.element_size()))
-    return y
+    xc = torch.empty((M, C), dtype=out_dtype, device=x.device) if want_cast else None
+    _lib.check(lib.mphsir_layernorm_tok(_p(x), _DT[x.dtype], _p(ln_w), _p(ln_b), _p(y), _p(xc), _DT[out_dtype], M, C, _stream(x)), "layernorm_tok")
+    _acct("layernorm_tok", 8.0 * M * C, M * C * (x.element_size() + y.element_size() * (2 if want_cast else 1)))
+    return (y, xc) if want_cast else y
 
 
 def tvsp_text_map(L, clip, ps):
@@ -724,6 +725,7 @@ def pack_gated_mlp(fc1_w, fc1_b, fc2_w, dtype):
 
 BASE_SKIP_FUSED = os.environ.get("MPHSIR_BASE_SKIP_FUSED", "1") == "1"     # BaseBlock's `+ x` inside its last gated-MLP launch (6 launches fewer per forward)
 BASE_SKIP_TRAIN = os.environ.get("MPHSIR_BASE_SKIP_TRAIN", "1") == "1"     # ... in training passes too
+BASE_SKIP_BWD = os.environ.get("MPHSIR_BASE_SKIP_BWD", "1") == "1"         # ... and the skip's gradient added by the first block's last backward launch
 # hidden split of the gated MLP kernels for small launches (< 256 token tiles at C >= 192: the latent level): 0 = off, else the number of
 # workgroups per token tile is chosen so that about 256 workgroups exist
 MLP_HSPLIT = os.environ.get("MPHSIR_MLP_HSPLIT", "1") == "1"
@@ -1458,36 +1460,45 @@ def ln_bwd_win_dxn_fits(M, C, dtype):
             and bool(_lib.load().mphsir_ln_bwd_win_dxn_fits(C, _DT[dtype])))
 
 
-def ln_bwd_win_dxn(x, dqkv, wqkvT, dres, ln_w, shift):
-    """dx = dres + LN_backward(dqkv wqkvT^T) with the token GEMM inside the launch (dqkv (M, 3C) in window-token order, wqkvT (C, 3C))
-    -> (dx (B,H,W,C), part (B*nW,2,C))."""
+def ln_bwd_win_dxn(x, dqkv, wqkvT, dres, ln_w, shift, dres2=None):
+    """dx = dres + [dres2 +] LN_backward(dqkv wqkvT^T) with the token GEMM inside the launch (dqkv (M, 3C) in window-token order, wqkvT (C, 3C))
+    -> (dx (B,H,W,C), part (B*nW,2,C)).  dres2: a second residual gradient in image order (the skip of the enclosing BaseBlock)."""
     lib = _lib.load()
-    _check(x, dqkv, wqkvT, dres, ln_w)
+    _check(x, dqkv, wqkvT, dres, ln_w, dres2)
     B, H, W, C = x.shape
     assert x.is_contiguous() and dqkv.is_contiguous() and dres.is_contiguous() and wqkvT.is_contiguous()
     assert dqkv.shape == (B * H * W, 3 * C) and wqkvT.shape == (C, 3 * C) and wqkvT.dtype == x.dtype
+    assert dres2 is None or (dres2.is_contiguous() and dres2.shape == x.shape and dres2.dtype == x.dtype)
     dx = torch.empty_like(x)
     part = torch.empty((B * H * W // 64, 2, C), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mphsir_ln_bwd_win_dxn(_p(x), _p(dqkv), _p(wqkvT), _p(dres), _p(ln_w), _p(dx), _p(part), B, H, W, C, shift,
+    _lib.check(lib.mphsir_ln_bwd_win_dxn(_p(x), _p(dqkv), _p(wqkvT), _p(dres), _p(dres2), _p(ln_w), _p(dx), _p(part), B, H, W, C, shift,
                                          _DT[x.dtype], _stream(x)), "ln_bwd_win_dxn")
     _acct("ln_bwd_win", 10.0 * x.numel() + 6.0 * x.numel() * C, 6.0 * x.numel() * x.element_size())
     _acct("ln_bwd_win:dxn", 0.0, 0.0)
     return dx, part
 
 
-def ln_bwd_tok_dxn(x2, dy, wT, dres, ln_w, ln_b):
+def ln_bwd_tok_dxn_f32_fits(M, C, dtype):
+    """... with fp32 x rows and 16-bit dy / weights (TVSP's norm11)"""
+    return ln_bwd_win_dxn_fits(M, C, dtype) and C <= 192
+
+
+def ln_bwd_tok_dxn(x2, dy, wT, dres, ln_w, ln_b, want_xn=True):
     """ln_bwd_tok with the 1x1 conv's data gradient inside: d_xn = dy wT^T (dy (M, K), wT (C, K)) is formed per 64 rows on the matrix cores
-    -> (dx = dres + LN_backward(d_xn), d ln weight, d ln bias, LN(x)) for x2 (M, C), M % 64 == 0."""
+    -> (dx = dres + LN_backward(d_xn), d ln weight, d ln bias, LN(x)) for x2 (M, C), M % 64 == 0.  dres may be None (no residual path);
+    x2 may be fp32 while dy / wT / dres are a 16-bit type (dx then fp32 too; LN(x), if wanted, in the 16-bit type)."""
     lib = _lib.load()
     _check(x2, dy, wT, dres, ln_w, ln_b)
     M, C = x2.shape
     K = dy.shape[1]
-    assert x2.is_contiguous() and dy.is_contiguous() and dres.is_contiguous() and wT.is_contiguous() and M % 64 == 0 and K % 32 == 0
-    assert dy.shape == (M, K) and wT.shape == (C, K) and wT.dtype == x2.dtype and dy.dtype == x2.dtype
-    dx, xn = torch.empty_like(x2), torch.empty_like(x2)
+    xf = x2.dtype == torch.float32 and dy.dtype != torch.float32
+    assert x2.is_contiguous() and dy.is_contiguous() and (dres is None or dres.is_contiguous()) and wT.is_contiguous() and M % 64 == 0 and K % 32 == 0
+    assert dy.shape == (M, K) and wT.shape == (C, K) and wT.dtype == dy.dtype and (xf or dy.dtype == x2.dtype) and (dres is None or dres.dtype == dy.dtype)
+    dx = torch.empty_like(x2)
+    xn = torch.empty((M, C), dtype=dy.dtype, device=x2.device) if want_xn else None
     part = torch.empty((M // 64, 2, C), dtype=torch.float32, device=x2.device)
-    _lib.check(lib.mphsir_ln_bwd_tok_dxn(_p(x2), _p(dy), _p(wT), _p(dres), _p(ln_w), _p(ln_b), _p(dx), _p(xn), _p(part), M, C, K,
-                                         _DT[x2.dtype], _stream(x2)), "ln_bwd_tok_dxn")
+    _lib.check(lib.mphsir_ln_bwd_tok_dxn(_p(x2), _p(dy), _p(wT), _p(dres), _p(ln_w), _p(ln_b), _p(dx), _p(xn), _p(part), M, C, K, 1 if xf else 0,
+                                         _DT[dy.dtype], _stream(x2)), "ln_bwd_tok_dxn")
     _acct("ln_bwd_win", 12.0 * x2.numel() + 2.0 * M * C * K, (5.0 * C + K) * M * x2.element_size())
     _acct("ln_bwd_win:dxn", 0.0, 0.0)
     g = reduce_parts(part)
@@ -1756,15 +1767,28 @@ def pack_conv3x3(w, dtype, flip_transpose=False):
     return out.reshape(Np, 9 * Cp)
 
 
-def conv3x3_tok(x, wp):
-    """x (B,H,W,Cp) channels-last with Cp % 32 == 0; wp from pack_conv3x3 -> (B,H,W,Np)."""
+def pixel_pitch(t):
+    """row pitch (elements) of a channels-last (B,H,W,C) view whose pixels are equally spaced rows -- a contiguous tensor or a channel slice
+    of one -- else None"""
+    B, H, W, C = t.shape
+    ld = t.stride(2)
+    ok = t.stride(3) == 1 and ld >= C and t.stride(1) == W * ld and t.stride(0) == H * W * ld and (ld * t.element_size()) % 16 == 0 and t.data_ptr() % 16 == 0
+    return ld if ok else None
+
+
+def conv3x3_tok(x, wp, out=None):
+    """x (B,H,W,Cp) channels-last with Cp % 32 == 0 (contiguous, or a channel slice of a wider buffer read through its row pitch); wp from
+    pack_conv3x3 -> (B,H,W,Np), written into `out` (same kind of view) when given."""
     lib = _lib.load()
-    _check(x, wp)
+    _check(x, wp, out)
     B, H, W, Cp = x.shape
     Np = wp.shape[0]
-    assert x.is_contiguous() and wp.shape[1] == 9 * Cp and wp.dtype == x.dtype
-    y = torch.empty((B, H, W, Np), dtype=x.dtype, device=x.device)
-    _lib.check(lib.mphsir_conv3x3_tok(_p(x), Cp, _p(wp), _p(y), Np, B, H, W, Cp, Np, _DT[x.dtype], _stream(x)), "conv3x3_tok")
+    ldx = pixel_pitch(x)
+    assert ldx is not None and wp.shape[1] == 9 * Cp and wp.dtype == x.dtype
+    y = out if out is not None else torch.empty((B, H, W, Np), dtype=x.dtype, device=x.device)
+    ldy = pixel_pitch(y)
+    assert ldy is not None and y.shape == (B, H, W, Np) and y.dtype == x.dtype
+    _lib.check(lib.mphsir_conv3x3_tok(_p(x), ldx, _p(wp), _p(y), ldy, B, H, W, Cp, Np, _DT[x.dtype], _stream(x)), "conv3x3_tok")
     _acct("conv3x3_tok", 18.0 * B * H * W * Cp * Np, (B * H * W * (Cp + Np) + wp.numel()) * x.element_size())
     return y
 

@@ -1013,6 +1013,12 @@ def check_ln_bwd_win_dxn(dev, dtype, C=64, shape=(2, 16, 16), shift=4):
     tol = TOL[dtype]
     assert res["dx"] < tol and res["dgamma"] < tol and res["dbeta"] < tol, res
     assert res["dx"] <= res["dx_pair"] * 1.05 + 1e-7 and res["dgamma"] <= res["dgamma_pair"] * 1.05 + 1e-6 and res["dbeta"] <= res["dbeta_pair"] * 1.05 + 1e-6, res
+    # a second residual gradient (the BaseBlock skip's): the same launch adds it; the LayerNorm partials do not move
+    dres2 = rnd((B, H, W, C), 926, dtype)
+    dx_c, part_c = ops.ln_bwd_win_dxn(x, dqkv, wT, dres, ln_w, shift, dres2=dres2)
+    assert torch.equal(part_c, part_b)
+    res["dx_skip"] = rel_l2(dx_c, dx64 + dres2.double().cpu())
+    assert res["dx_skip"] < tol, res
     return res
 
 
@@ -1087,6 +1093,23 @@ def check_ln_bwd_tok_dxn(dev, dtype, C=64, K=384, M=256):
         res[name] = (rel_l2(pa, w), rel_l2(pb, w))
         assert res[name][1] < TOL[dtype] and res[name][1] <= res[name][0] * 1.05 + 1e-6, res
     assert rel_l2(b[3], a[3].double().cpu()) < TOL[dtype] / 4      # LN(x): the same formula (the compiler contracts its fmas differently in the two kernels)
+    # no residual path (TVSP's norm12 on the batch-invariant prompt map), LN(x) not wanted
+    with ops.reduce_scope():
+        c = ops.ln_bwd_tok_dxn(x, dy, wT, None, ln_w, ln_b, want_xn=False)
+    assert c[3] is None and rel_l2(c[0], xr.grad) < TOL[dtype] and torch.equal(c[1], b[1]) and torch.equal(c[2], b[2])
+    # fp32 rows of x with 16-bit dy / weights / d_res (TVSP's norm11 on the fp32 text map): against the fp32 LayerNorm backward on d_xn
+    # formed in fp64 from the same 16-bit operands
+    if C <= 192:
+        assert ops.ln_bwd_tok_dxn_f32_fits(M, C, dtype)
+        x32 = rnd((M, C), 937)
+        with ops.reduce_scope():
+            d = ops.ln_bwd_tok_dxn(x32, dy, wT, dres, ln_w, ln_b, want_xn=False)
+        assert d[0].dtype == torch.float32
+        xr2 = x32.double().cpu().clone().requires_grad_(True)
+        lw2, lb2 = ln_w.double().cpu().clone().requires_grad_(True), ln_b.double().cpu().clone().requires_grad_(True)
+        (torch.nn.functional.layer_norm(xr2, (C,), lw2, lb2, 1e-5) * dxn).sum().backward()
+        res["f32_rows"] = (rel_l2(d[0], xr2.grad + dres.double().cpu()), rel_l2(d[1], lw2.grad), rel_l2(d[2], lb2.grad))
+        assert max(res["f32_rows"]) < 2e-5, res           # fp32 arithmetic on exactly representable operands: fp32 rounding only
     return res
 
 
@@ -1273,6 +1296,21 @@ def check_loss_scaler(dev):
         assert rel_l2(p, ref.detach()) < 2e-6, (step, rel_l2(p, ref.detach()))
     # steps 0,1 good -> x2 after the second; step 2 overflow -> /2; steps 3,4 good -> x2
     assert float(sc[0]) == 1024.0 * 2 * 0.5 * 2 and float(sc[3]) == 4.0
+
+
+def check_layernorm_tok(dev, dtype, M=200, C=64):
+    """mphsir_layernorm_tok (TVSP's norm11, net/MP_HSIR.py:282: fp32 rows in, compute dtype out) against F.layer_norm in fp64; the optional
+    cast copy of the input BITWISE against .to(dtype); the vector form (C % 16 == 0) and the element-wise form (C % 4 == 0)"""
+    _use(dev)
+    from mp_hsir_amd import ops
+    lw, lb = (1 + 0.2 * rnd((C,), 521)).contiguous(), (0.1 * rnd((C,), 522)).contiguous()
+    for src in (torch.float32, dtype):
+        x = rnd((M, C), 523, src)
+        y, xc = ops.layernorm_tok(x, lw, lb, dtype, want_cast=True)
+        want = torch.nn.functional.layer_norm(x.double().cpu(), (C,), lw.double().cpu(), lb.double().cpu(), 1e-5)
+        assert y.dtype == dtype and rel_l2(y, want) < TOL[dtype]
+        assert torch.equal(xc, x.to(dtype))
+        assert torch.equal(ops.layernorm_tok(x, lw, lb, dtype), y)
 
 
 def check_heads(dev, dtype, B=3, C=31, H=24, W=20, T=6, n=2):

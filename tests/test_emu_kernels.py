@@ -297,6 +297,12 @@ def test_resamplers(dtype):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES)
+def test_layernorm_tok(dtype):
+    K.check_layernorm_tok("cpu", dtype)
+    K.check_layernorm_tok("cpu", dtype, M=70, C=20)          # element-wise form, a ragged last workgroup
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES)
 def test_heads(dtype):
     K.check_heads("cpu", dtype)
     K.check_heads("cpu", dtype, B=1, C=40, H=9, W=7, T=7, n=1)          # ragged pixel tiles, a second channel pad

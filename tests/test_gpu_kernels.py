@@ -416,6 +416,14 @@ def test_resamplers(dtype):
 
 
 @pytest.mark.parametrize("dtype", K.DTYPES + [F16])
+def test_layernorm_tok(dtype):
+    K.check_layernorm_tok("cuda", dtype)
+    K.check_layernorm_tok("cuda", dtype, M=131072, C=64)
+    K.check_layernorm_tok("cuda", dtype, M=4099, C=192)
+    K.check_layernorm_tok("cuda", dtype, M=70, C=20)
+
+
+@pytest.mark.parametrize("dtype", K.DTYPES + [F16])
 def test_heads(dtype):
     K.check_heads("cuda", dtype)
     K.check_heads("cuda", dtype, B=32, C=31, H=64, W=64)
