@@ -1023,6 +1023,16 @@ def check_ln_bwd_win_dxn(dev, dtype, C=64, shape=(2, 16, 16), shift=4):
 
 
 def check_gdfn_dw_bwd(dev, dtype, shape=(2, 16, 32), hid=85, nblk=None):
+    """(the product switch is off by default since the end of round 6 -- level in the step -- and turned on for the check)"""
+    from mp_hsir_amd import ops
+    old, ops.GDFN_DW_BWD = ops.GDFN_DW_BWD, True
+    try:
+        return _check_gdfn_dw_bwd(dev, dtype, shape, hid, nblk)
+    finally:
+        ops.GDFN_DW_BWD = old
+
+
+def _check_gdfn_dw_bwd(dev, dtype, shape, hid, nblk):
     """mphsir_gdfn_dw_bwd (the GDFN's gate backward + depthwise backward in one launch, [d x1 | d x2] on the chip) against
     mphsir_dwconv_gate_bwd + mphsir_dwconv3x3_bwd on the same operands: with the pair's rounding switched on (round_mid) u and dt are
     BITWISE equal and the tap gradients agree to fp32 summation order; the product form is no further from fp64 than the pair."""
