@@ -344,6 +344,22 @@ class DataParallelEngine:
             else:
                 loss.backward()
 
+    def _loss_backward(self, restored, clean):
+        """loss + backward pass -> the (unscaled) loss.  With the reference's own loss (l1_after_clamp, train.py:58-61) the loss kernel's
+        gradient starts the backward pass at `restored` directly: `loss.backward()` would first build a ones_like tensor and scale the
+        gradient by it (two launches; with the fp16 loss scale three)."""
+        if (self.loss_fn is l1_after_clamp and restored.dtype == torch.float32 and clean.dtype == torch.float32
+                and restored.shape == clean.shape and restored.requires_grad):
+            loss, g = ops.l1_clamp_loss_grad(restored.detach(), clean)
+            if self._use_scaler(restored.device):
+                g.mul_(self.scaler[0])
+            with ops.deferred_reductions():
+                restored.backward(g)
+            return loss
+        loss = self.loss_fn(restored, clean)
+        self._backward(loss)
+        return loss
+
     def _optimizer_step(self, lr, hyper=None):
         """AdamW over the arenas (1/world folded in); fp16 path: non-finite check + unscale + skip + scale update"""
         gs = 1.0 / self.world
@@ -404,13 +420,12 @@ class DataParallelEngine:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 restored = self.net(self._sx, self._sp)
-                loss = self.loss_fn(restored, self._sc)
                 overlap = self.world > 1 and getattr(self, "_overlap", False)
                 if overlap:
                     self._remaining = [b[2] for b in self.buckets]
                     self._bucket_order, self._capturing = [], True
                 try:
-                    self._backward(loss)
+                    loss = self._loss_backward(restored, self._sc)
                 finally:
                     self._capturing = False
                 for bi in range(len(self.buckets)):
@@ -518,8 +533,7 @@ class DataParallelEngine:
         if not first and self.world > 1 and not self.use_graph:
             self._remaining = [b[2] for b in self.buckets]
         restored = self.net(degraded, prompt)
-        loss = self.loss_fn(restored, clean)
-        self._backward(loss)
+        loss = self._loss_backward(restored, clean)
         if not first and (self.world == 1 or self.use_graph):
             for bi in range(len(self.buckets)):
                 self._gather_bucket(bi)

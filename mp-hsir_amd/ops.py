@@ -546,6 +546,22 @@ def l1_clamp_loss(y, clean):
     return _L1ClampLoss.apply(y, clean)
 
 
+def l1_clamp_loss_grad(y, clean):
+    """(mean |clamp(y, 0, 1) - clean|, its gradient w.r.t. y) from one pass, outside autograd: for a caller that starts the backward pass
+    at y itself (engine.DataParallelEngine: `y.backward(g)` instead of `loss.backward()`, whose ones_like + scale launches it saves)"""
+    lib = _lib.load()
+    _check(y, clean)
+    y, clean = y.contiguous(), clean.contiguous()
+    assert y.dtype == torch.float32 and clean.dtype == torch.float32 and y.shape == clean.shape
+    n = y.numel()
+    nblk = max(1, min(1024, (n + 1023) // 1024))
+    g = torch.empty_like(y)
+    part = torch.empty((nblk, 1), dtype=torch.float32, device=y.device)
+    _lib.check(lib.mphsir_l1_clamp_loss(_p(y), _p(clean), _p(g), _p(part), n, nblk, _stream(y)), "l1_clamp_loss")
+    _acct("l1_clamp_loss", 4.0 * n, 12.0 * n)
+    return reduce_parts(part, immediate=True).reshape(()), g
+
+
 def _rows(t):
     """(rows, ld) of a 2-D view whose last dim is contiguous."""
     assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D view"
