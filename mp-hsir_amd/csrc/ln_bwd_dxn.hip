@@ -56,13 +56,17 @@ template <class T, int C> struct LnDxnCfg {
     static constexpr int LDW = 32 * KGC + PAD, LDF = C + 1;
     static constexpr int MAXV = C / 32;                               // 16-byte vectors of a token row per lane (4 lanes per token)
     static constexpr size_t f_floats = ((size_t)64 * LDF + 3) & ~(size_t)3;
-    static constexpr size_t bytes = f_floats * 4 + (size_t)C * LDW * sizeof(T);
+    // the weight stage is dead when the fp32 tile is written (one barrier between them): they share the LDS, and the workgroup's footprint is
+    // the larger of the two -- 33 KB at C = 128 instead of 62: three workgroups per CU (148 registers) where there were two
+    static constexpr size_t w_bytes = (size_t)C * LDW * sizeof(T);
+    static constexpr size_t bytes = f_floats * 4 > w_bytes ? f_floats * 4 : w_bytes;
+    static constexpr int MINWG = C <= 128 ? 3 : 2;                    // workgroups per CU the register budget is held to
     static constexpr int NWV = (C * KGC * 4 + 255) / 256;             // 16-byte weight vectors per thread and stage
     static_assert(C % 32 == 0 && bytes <= 160 * 1024, "shape");
 };
 
 template <class T, int C, bool XF = false>     // XF: X and dX are fp32 (dY, W, d_res, XN stay T)
-__global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
+__global__ __launch_bounds__(256, (LnDxnCfg<T, C>::MINWG)) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
     typedef typename std::conditional<XF, float, T>::type TX;
     typedef ElemTraits<T> TR;
     typedef typename TR::frag_t frag_t;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
     static_assert(sizeof(T) == 2, "16-bit types only");
     HIP_DYNAMIC_SHARED(f32x4, smem_v)
     float* Fs = reinterpret_cast<float*>(smem_v);                      // [64][LDF] d_xn, then d_xn * xhat
-    T* Ws = reinterpret_cast<T*>(Fs + CF::f_floats);                   // [C][LDW]  rows of Wqkv^T, one K group
+    T* Ws = reinterpret_cast<T*>(smem_v);                              // [C][LDW]  rows of Wqkv^T, one K group (the same LDS, before the tile exists)
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id_uniform();
     const TX* X = reinterpret_cast<const TX*>(a.X);
     const T* dRes = reinterpret_cast<const T*>(a.dRes);         // (may be null: no residual path)
@@ -137,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_win_dxn_kernel(LnDxnDev a) {
                 for (int nb = 0; nb < NB; ++nb) mma(acc[nb], load_frag<T>(Ws, LDW, nb * 16, kc * 32), xf[kc]);
             }
     }
+    __syncthreads();                                       // every wave has read the last weight group: the tile takes its place
     {
         float* frow = Fs + (wv * 16 + (lane & 15)) * LDF + (lane >> 4) * 4;
 #pragma unroll
