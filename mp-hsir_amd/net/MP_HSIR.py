@@ -204,8 +204,8 @@ class BaseBlock(nn.Module):                                                     
     def forward(self, x, text_prompt=None):
         y = x
         n = len(self.blocks)
-        # (no-grad forward only: 512x512 cube 6.99 -> 6.88 ms, batch 16 3.37 -> 3.33 ms; in training the separate add costs nothing
-        # measurable -- 21.39 / 21.64 against 21.45 / 21.68 ms fused, two A/B pairs -- and the graph stays as it was)
+        # (no-grad forward: 512x512 cube 6.99 -> 6.88 ms, batch 16 3.37 -> 3.33 ms; training, round 6: 19.22 -> 19.18 ms for the forward
+        # half, A/B by MPHSIR_BASE_SKIP_TRAIN -- six adds of 5-19 us that the serial trace of the step shows one for one)
         if not ops.BASE_SKIP_FUSED or n == 0 or (torch.is_grad_enabled() and not ops.BASE_SKIP_TRAIN):
             for blk in self.blocks:
                 y = blk(y)
