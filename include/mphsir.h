@@ -407,6 +407,9 @@ typedef struct mphsir_fold_bwd_args {
     const void* DO; int64_t lddo; const void* V; int64_t ldv; int32_t N;
     const float* dm_scale;      /* optional [B]: dM_b (given or formed) is multiplied by dm_scale[b] -- the DropPath factor, when d_out is handed over
                                    as the block's incoming gradient without it */
+    int32_t w2_blocks;          /* != 0: only the entries mphsir_spectral_dqkv_bwd reads are written -- per head the columns [h hd, (h+1) hd) and
+                                   [C + h hd, C + (h+1) hd) of its q and k rows (W2_b is zero elsewhere; 0 writes the zeros too, for the token GEMM
+                                   [dq | dk] = [q | k] W2_b^T of the unfused path): 2 hd / 2C of the stores */
 } mphsir_fold_bwd_args;
 int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype, void* stream);
 typedef struct mphsir_pg_bwd_args {

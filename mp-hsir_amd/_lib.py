@@ -117,7 +117,8 @@ class FoldBwdArgs(_Args):
     """mirror of struct mphsir_fold_bwd_args"""
     _fields_ = _SZ + [(n, c_void_p) for n in ("Gpart", "Spart", "temperature", "Wo", "dM", "W2", "dWo", "dtemp")] + \
                [(n, c_int32) for n in ("B", "C", "heads", "nsplit", "dM_nsplit")] + \
-               [("DO", c_void_p), ("lddo", c_int64), ("V", c_void_p), ("ldv", c_int64), ("N", c_int32), ("dm_scale", c_void_p)]
+               [("DO", c_void_p), ("lddo", c_int64), ("V", c_void_p), ("ldv", c_int64), ("N", c_int32), ("dm_scale", c_void_p),
+                ("w2_blocks", c_int32)]
 
 
 class PgBwdArgs(_Args):

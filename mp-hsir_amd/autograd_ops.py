@@ -99,17 +99,20 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
     M = B * N
     dt = v.dtype
     temp32, wo32 = temperature.detach().reshape(heads).float().contiguous(), wo.detach().reshape(C, C).float().contiguous()
-    if ops.fold_bwd_forms_dm(N, C, heads, dt):
-        # small images (the lower pyramid levels): dM = d_out^T v is formed INSIDE the fold backward -- one launch fewer on the chain
-        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temp32, wo32, None, dt, reduce=False, d_out=d_out.reshape(M, C), v=v.reshape(M, C), dm_scale=keep)
-    else:
-        dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), reduce=False)    # (B, splits, C, C) fp32 partials: summed by the fold backward as it stages them
-        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temp32, wo32, dM, dt, reduce=False, dm_scale=keep)
-    # q, k of the forward: either kept by it (qk) or recomputed by the depthwise kernel; when q|k|v are adjacent channel
-    # slices of one tensor (self-attention) every depthwise pass runs once over the joint channel range.
     joint = (t_q.data_ptr() + C * t_q.element_size() == t_k.data_ptr() and t_k.data_ptr() + C * t_k.element_size() == t_v.data_ptr()
              and t_q.stride() == t_k.stride() == t_v.stride() and w9q.data_ptr() + 4 * C == w9k.data_ptr()
              and w9k.data_ptr() + 4 * C == w9v.data_ptr())
+    fused = joint and t_q.stride(2) == 3 * C and w9q.stride(0) == 3 * C and ops.spectral_dqkv_bwd_fits(C, heads, H, W, dt)
+    # (the fused launch reads only each head's own column blocks of W2: the fold backward then writes nothing else -- 2 hd of 2C columns)
+    if ops.fold_bwd_forms_dm(N, C, heads, dt):
+        # small images (the lower pyramid levels): dM = d_out^T v is formed INSIDE the fold backward -- one launch fewer on the chain
+        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temp32, wo32, None, dt, reduce=False, d_out=d_out.reshape(M, C), v=v.reshape(M, C), dm_scale=keep,
+                                                   w2_blocks=fused)
+    else:
+        dM = ops.gemm_tn(d_out.reshape(B, N, C), v.reshape(B, N, C), reduce=False)    # (B, splits, C, C) fp32 partials: summed by the fold backward as it stages them
+        W2, dwo_p, dtemp_p = ops.spectral_fold_bwd(gp, sp, temp32, wo32, dM, dt, reduce=False, dm_scale=keep, w2_blocks=fused)
+    # q, k of the forward: either kept by it (qk) or recomputed by the depthwise kernel; when q|k|v are adjacent channel
+    # slices of one tensor (self-attention) every depthwise pass runs once over the joint channel range.
     if qk is not None:
         pass                                                    # kept by the forward (dwconv_gram keep_qk)
     elif joint:
@@ -118,7 +121,7 @@ def channel_attention_bwd(d_out, t_q, t_k, t_v, w9q, w9k, w9v, v, gp, sp, Mb, Mb
         qk = torch.empty((B, H, W, 2 * C), dtype=dt, device=v.device)      # depthwise outputs go straight into the halves of [q | k]
         ops.dwconv3x3(t_q, w9q, out=qk[..., :C])
         ops.dwconv3x3(t_k, w9k, out=qk[..., C:])
-    if joint and t_q.stride(2) == 3 * C and w9q.stride(0) == 3 * C and ops.spectral_dqkv_bwd_fits(C, heads, H, W, dt):
+    if fused:
         # ONE launch from the fold backward's matrix to dt: dv = d_out M_b and [dq | dk] = [q | k] W2^T are formed per halo tile on the
         # matrix cores and fed to the depthwise backward in LDS -- [dq | dk | dv] (3C per token) is neither written nor read back
         dwo, dtemp = ops.reduce_parts(dwo_p), ops.reduce_parts(dtemp_p)

@@ -24,6 +24,7 @@ struct FoldBwdDev {
     const void* DO; long lddo; const void* V; long ldv; int N;      // N > 0 (16-bit types, small images): dM is not read but FORMED here -- dM_b =
                                                                       // d_out_b^T v_b over the sample's N tokens (rows b N .. of DO [.][lddo], V [.][ldv])
     void* W2;                   // [B][2C][2C] compute dtype
+    int w2_blocks;              // only the head's own column blocks are written (what spectral_dqkv_bwd reads)
     float* dWo;                 // [B][C][C] fp32 per-sample partial (column block of this head written by its WG)
     float* dtemp;               // [B][HEADS]
     int B, C, HD;
@@ -37,6 +38,41 @@ struct FoldBwdDev {
 // fp32 and every sum has a fixed order: bitwise reproducible.
 constexpr int FB_THREADS = 1024, FB_WAVES = FB_THREADS / 64;   // only B*heads (64..256) workgroups exist: make each one wide
 __host__ __device__ constexpr int fb_co(int hd) { return hd > 64 ? 32 : 128; }     // rows per chunk = 16 per wave (LDS budget at head_dim 96)
+// tokens per stage of the in-kernel dM: as many as the LDS holds beside the fp32 tiles -- a stage costs one exposed round trip to L2 / HBM
+// (one tile in flight: the 128-register budget of a 1024-thread workgroup has no room for a deeper prefetch), so fewer, larger stages
+__host__ __device__ constexpr int fb_tk(int hd) { return hd == 48 ? 128 : 64; }      // (head_dim 32 at 128 / 256 tokens per stage: 10 / 18 spilled registers)
+
+// W2_b rows of one head: q rows h HD + i and k rows C + h HD + j (see the file header).  16-byte stores: a thread builds VEC consecutive
+// columns of a row (element-wise 2-byte stores made this phase 5-10 us of the launch).  blocks: only the row's two column blocks of this
+// head -- [h HD, (h+1) HD) and [C + h HD, C + (h+1) HD) -- the rest of W2_b is zero and the fused backward never reads it.
+// (Not inlined: inside the kernel it cost the 32-wide heads two spilled registers at the 128 a 1024-thread workgroup has.)
+template <class T>
+__device__ __attribute__((noinline)) void fold_bwd_write_w2(T* W2, int blocks, const float* D, const float* sq, const float* dn, const float* rq, const float* rk,
+                                               int HD, int LD, int C, int h, int tid) {
+    constexpr int VEC = Vec16<T>::N;
+    const int C2 = 2 * C, hg = HD / VEC, gpr = blocks ? 2 * hg : C2 / VEC;      // column groups per row
+    // entry (row r of the head's q rows [k rows: kside], column col) of W2_b
+    auto entry = [&](int r, int col, bool kside) __attribute__((always_inline)) -> float {
+        const int cq = col - h * HD, ck = col - C - h * HD;              // position inside the head's q-column / k-column block
+        if (!kside) {
+            if (cq == r) return sq[r] > 1e-24f ? dn[r] * rq[r] : 0.f;                      // 2 * dsq = dnq / nq
+            return (ck >= 0 && ck < HD) ? D[r * LD + ck] : 0.f;                            // dG[i][j]
+        }
+        if (ck == r) return sq[HD + r] > 1e-24f ? dn[HD + r] * rk[r] : 0.f;
+        return (cq >= 0 && cq < HD) ? D[cq * LD + r] : 0.f;                                // Nq^T
+    };
+#pragma unroll 1
+    for (int o = tid; o < 2 * HD * gpr; o += FB_THREADS) {
+        const int rr = o / gpr, g = o % gpr;
+        const bool kside = rr >= HD;
+        const int r = kside ? rr - HD : rr;
+        const int c0g = blocks ? (g < hg ? h * HD + g * VEC : C + h * HD + (g - hg) * VEC) : g * VEC;
+        Vec16<T> ov;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) ov.set(e, entry(r, c0g + e, kside));
+        store16<T>(W2 + (long)((kside ? C : 0) + h * HD + r) * C2 + c0g, ov);
+    }
+}
 
 template <class T, int HDT>      // HDT > 0: the head width as a compile-time constant (loops over it unroll), 0: runtime
 __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDev a) {
@@ -53,7 +89,7 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
     float* dn = sq + 2 * HD;                          // [2*HD] d nq | d nk
     float* red = dn + 2 * HD;                         // [HD] per-row d temperature terms
     // in-kernel dM (a.N > 0): token tiles of d_out[:, c0 .. c0 + FB_CO) and v[:, head] in the storage type, 64 tokens per stage
-    constexpr int FB_TK = 64, FB_PAD = 8;
+    constexpr int FB_TK = fb_tk(HDT > 0 ? HDT : 64), FB_PAD = 8, FB_NR = FB_TK / 64;
     const int LDD = FB_CO + FB_PAD, LDV = HD + FB_PAD;
     T* Dt = reinterpret_cast<T*>(red + ((HD + 3) & ~3));          // [FB_TK][LDD]
     T* Vt = Dt + FB_TK * LDD;                                      // [FB_TK][LDV]
@@ -130,16 +166,22 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
                 f32x4 accM[TPWM];
 #pragma unroll
                 for (int q = 0; q < TPWM; ++q) accM[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                Vec16<T> dreg, vreg;
+                Vec16<T> dreg[FB_NR], vreg;
+                // d_out: 64 token rows x FB_CO / 8 vectors = the 1024 threads, FB_NR times; v: FB_TK rows x HD / 8 vectors <= 1024
                 const int dtok = tid / dvr, dcol = (tid % dvr) * 8, vtok = tid / vvr, vcol = (tid % vvr) * 8;
-                const bool don = tid < FB_TK * dvr, von = tid < FB_TK * vvr;
+                const bool von = tid < FB_TK * vvr;
                 auto tload = [&](int t0) __attribute__((always_inline)) {
-                    if (don) { if (dcol < cw && t0 + dtok < a.N) dreg = load16<T>(DOb + (long)(t0 + dtok) * a.lddo + dcol); else dreg = Vec16<T>{}; }
+#pragma unroll
+                    for (int r = 0; r < FB_NR; ++r) {
+                        const int tk = t0 + r * 64 + dtok;
+                        if (dcol < cw && tk < a.N) dreg[r] = load16<T>(DOb + (long)tk * a.lddo + dcol); else dreg[r] = Vec16<T>{};
+                    }
                     if (von) { if (t0 + vtok < a.N) vreg = load16<T>(Vb + (long)(t0 + vtok) * a.ldv + vcol); else vreg = Vec16<T>{}; }
                 };
                 tload(0);
                 for (int t0 = 0; t0 < a.N; t0 += FB_TK) {
-                    if (don) store16<T>(Dt + dtok * LDD + dcol, dreg);
+#pragma unroll
+                    for (int r = 0; r < FB_NR; ++r) store16<T>(Dt + (r * 64 + dtok) * LDD + dcol, dreg[r]);
                     if (von) store16<T>(Vt + vtok * LDV + vcol, vreg);
                     __syncthreads();
                     if (t0 + FB_TK < a.N) tload(t0 + FB_TK);
@@ -279,31 +321,7 @@ __global__ __launch_bounds__(FB_THREADS) void spectral_fold_bwd_kernel(FoldBwdDe
         D[i * LD + j] *= rq[i] * rk[j];
     }
     __syncthreads();
-    // W2_b rows of this head: q rows hHD+i and k rows C+hHD+j, all 2C columns
-    T* W2 = reinterpret_cast<T*>(a.W2) + (long)b * 4 * C * C;
-    const int C2 = 2 * C;
-    for (int o = tid; o < HD * C2; o += FB_THREADS) {
-        const int i = o / C2, col = o % C2;           // q-gradient row
-        float v = 0.f;
-        if (col < C) {
-            if (col == h * HD + i) v = sq[i] > 1e-24f ? dn[i] * rq[i] : 0.f;          // 2 * dsq = dnq / nq
-        } else {
-            const int cp = col - C - h * HD;
-            if (cp >= 0 && cp < HD) v = D[i * LD + cp];                               // dG[i][j]
-        }
-        W2[(long)(h * HD + i) * C2 + col] = from_f32<T>(v);
-    }
-    for (int o = tid; o < HD * C2; o += FB_THREADS) {
-        const int j = o / C2, col = o % C2;           // k-gradient row
-        float v = 0.f;
-        if (col < C) {
-            const int ci = col - h * HD;
-            if (ci >= 0 && ci < HD) v = D[ci * LD + j];                               // Nq^T
-        } else if (col == C + h * HD + j) {
-            v = sq[HD + j] > 1e-24f ? dn[HD + j] * rk[j] : 0.f;
-        }
-        W2[(long)(C + h * HD + j) * C2 + col] = from_f32<T>(v);
-    }
+    fold_bwd_write_w2<T>(reinterpret_cast<T*>(a.W2) + (long)b * 4 * C * C, a.w2_blocks, D, sq, dn, rq, rk, HD, LD, C, h, tid);
 }
 
 }  // namespace mphsir
@@ -317,14 +335,14 @@ extern "C" int mphsir_spectral_fold_bwd(const mphsir_fold_bwd_args* a, int dtype
     MPHSIR_REQUIRE(a->B > 0 && a->heads > 0 && a->C % a->heads == 0 && a->nsplit > 0, "spectral_fold_bwd: bad shape");
     const int HD = a->C / a->heads;
     MPHSIR_REQUIRE(HD <= 96, "spectral_fold_bwd: head_dim %d > 96", HD);
-    FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->dM_nsplit, a->dm_scale, a->DO, (long)a->lddo, a->V, (long)a->ldv, a->N, a->W2, a->dWo, a->dtemp, a->B, a->C, HD};
+    FoldBwdDev d{a->Gpart, a->Spart, a->nsplit, a->temperature, a->Wo, a->dM, a->dM_nsplit, a->dm_scale, a->DO, (long)a->lddo, a->V, (long)a->ldv, a->N, a->W2, a->w2_blocks, a->dWo, a->dtemp, a->B, a->C, HD};
     if (a->N > 0)
         MPHSIR_REQUIRE(dtype != MPHSIR_F32 && (HD == 32 || HD == 48 || HD == 64) && a->DO && a->V && aligned16(a->DO) && aligned16(a->V) &&
                            (a->lddo * 2) % 16 == 0 && (a->ldv * 2) % 16 == 0 && a->lddo >= a->C && a->ldv >= a->C,
                        "spectral_fold_bwd: forming dM in the kernel (N > 0) needs a 16-bit type, a head width of 32 / 48 / 64 and 16-byte aligned DO / V rows");
     MPHSIR_REQUIRE(HD % 16 == 0, "spectral_fold_bwd: head_dim %d must be a multiple of 16", HD);
     const size_t shmem = ((3 * (size_t)HD + 2 * fb_co(HD)) * (HD + 8) + 9 * (size_t)HD + 4) * sizeof(float) +
-                         (a->N > 0 ? (size_t)64 * (fb_co(HD) + 8 + HD + 8) * 2 : 0);
+                         (a->N > 0 ? (size_t)fb_tk(HD) * (fb_co(HD) + 8 + HD + 8) * 2 : 0);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define MPHSIR_FB_LAUNCH(T_, HD_)                                                                                                       \
     do {                                                                                                                              \

@@ -1686,7 +1686,7 @@ def gdfn_dw_bwd(t, w9, du, B, H, W, nblk=None, round_mid=False):
     return u, dt, part
 
 
-def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True, d_out=None, v=None, dm_scale=None):
+def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True, d_out=None, v=None, dm_scale=None, w2_blocks=False):
     """-> W2 (B,2C,2C) in `dtype`, dWo (C,C) fp32, dtemp (heads,) fp32 (reduce=False: the per-sample partials
     (B,C,C) / (B,heads) instead, for the caller to pass to reduce_parts).  dM=None with d_out, v (B*N, C) in `dtype`: dM is formed in
     the kernel (fold_bwd_forms_dm)."""
@@ -1707,6 +1707,7 @@ def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True, d_out=Non
         a.B, a.C, a.heads, a.nsplit, a.dM_nsplit = B, C, heads, nsplit, 0
         a.DO, a.lddo, a.V, a.ldv, a.N = _p(d_out), d_out.stride(0), _p(v), v.stride(0), N
         a.dm_scale = _p(dm_scale)
+        a.w2_blocks = 1 if w2_blocks else 0
         _lib.check(lib.mphsir_spectral_fold_bwd(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold_bwd")
         _acct("spectral_fold_bwd", 4.0 * B * C * C * hd + 2.0 * B * N * C * C, 3.0 * B * C * C * 4 + 2.0 * B * N * C * d_out.element_size())
         _acct("spectral_fold_bwd:dm", 0.0, 0.0)
@@ -1726,6 +1727,7 @@ def spectral_fold_bwd(gp, sp, temperature, Wo, dM, dtype, reduce=True, d_out=Non
     a.W2, a.dWo, a.dtemp = _p(W2), _p(dWo), _p(dtemp)
     a.B, a.C, a.heads, a.nsplit, a.dM_nsplit = B, C, heads, nsplit, dm_nsplit
     a.dm_scale = _p(dm_scale)
+    a.w2_blocks = 1 if w2_blocks else 0
     _lib.check(lib.mphsir_spectral_fold_bwd(ctypes.byref(a), _DT[dtype], _stream(gp)), "spectral_fold_bwd")
     _acct("spectral_fold_bwd", 4.0 * B * C * C * hd, 3.0 * B * C * C * 4)
     if not reduce:

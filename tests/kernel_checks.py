@@ -1146,6 +1146,20 @@ def check_fold_bwd_forms_dm(dev, dtype, C=64, heads=2, B=3, N=256):
         tol = 1e-5 if x.dtype == torch.float32 else 4e-3
         res[name] = (rel_l2(y, x.double().cpu()), rel_l2(y, z.double().cpu()))
         assert res[name][0] < tol and res[name][1] < tol, res
+    # w2_blocks: only each head's own column blocks of its q / k rows are written (what the fused backward reads) -- those entries are
+    # BITWISE the dense call's, everything outside them is left alone (here: the NaN the buffer was filled with is not visible in W2's
+    # blocks, and the dense W2 is zero outside them)
+    for kw in (dict(dM=dm), dict(dM=None, d_out=d_out, v=v)):
+        dM_ = kw.pop("dM")
+        dense = ops.spectral_fold_bwd(gp, sp, temp, wo, dM_, dtype, reduce=False, **kw)
+        blk = ops.spectral_fold_bwd(gp, sp, temp, wo, dM_, dtype, reduce=False, w2_blocks=True, **kw)
+        mask = torch.zeros((2 * C, 2 * C), dtype=torch.bool, device=dense[0].device)
+        for h in range(heads):
+            for r0 in (h * hd, C + h * hd):
+                mask[r0:r0 + hd, h * hd:(h + 1) * hd] = True
+                mask[r0:r0 + hd, C + h * hd:C + (h + 1) * hd] = True
+        assert torch.equal(blk[0][:, mask], dense[0][:, mask]) and float(dense[0][:, ~mask].float().abs().max()) == 0.0
+        assert torch.equal(blk[1], dense[1]) and torch.equal(blk[2], dense[2])
     return res
 
 
